@@ -1,0 +1,121 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the SELD hot path.
+// Wave size is 64 everywhere; nothing here compiles for any other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define PSELD_WAVE 64
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// ---- status codes returned by every extern "C" entry point -----------------------------------
+enum {
+    PSELD_OK = 0,
+    PSELD_ERR_BAD_ARG = -1,
+    PSELD_ERR_UNSUPPORTED = -2,
+    PSELD_ERR_HIP = -3,
+};
+enum { PSELD_F32 = 0, PSELD_BF16 = 1 };
+
+void pseld_set_error(const char* fmt, ...);
+
+#define PSELD_CHECK_ARG(cond, ...)                                                               \
+    do {                                                                                         \
+        if (!(cond)) {                                                                           \
+            pseld_set_error(__VA_ARGS__);                                                        \
+            return PSELD_ERR_BAD_ARG;                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define PSELD_LAUNCH_CHECK(name)                                                                 \
+    do {                                                                                         \
+        hipError_t e__ = hipGetLastError();                                                      \
+        if (e__ != hipSuccess) {                                                                 \
+            pseld_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));              \
+            return PSELD_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+static inline int pseld_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- element conversion -------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 8-element vector of T (16 B for bf16, 32 B for f32): the unit every kernel moves.
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    f32x4 lo, hi;
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? lo[i] : hi[i - 4]; }
+    __device__ __forceinline__ void set(int i, float v) { if (i < 4) lo[i] = v; else hi[i - 4] = v; }
+};
+template <> struct Vec8<bf16_t> {
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&out)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&out)[8]) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { out[i] = a[i]; out[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&out)[8]) {
+    bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&in)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&in)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = in[i]; b[i] = in[4 + i]; }
+    *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&in)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)in[i];
+    *(bf16x8*)p = a;
+}
+
+// ---- wave-level reductions (64 lanes) -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over an aligned group of G lanes (G power of two <= 64)
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact-erf GELU and its derivative (reference: nn.GELU default, model_utilities.py:145-166)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

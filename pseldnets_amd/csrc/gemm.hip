@@ -1,0 +1,438 @@
+// MFMA GEMM for the Swin/HTS-AT linear layers (forward, input-gradient, weight-gradient) on gfx950.
+//
+// Replaces the nn.Linear / Conv2d-as-GEMM calls of the reference hot path and their autograd:
+//   htsat.py:112-145 (qkv, proj), model_utilities.py:159-171 (Mlp fc1/fc2), htsat.py:290-311 (PatchMerging
+//   reduction), model_utilities.py:205-213 (PatchEmbed proj), accdoa.py:230 (tscam_conv).
+//
+// One kernel template, three operand layouts (all row-major, leading dimensions in elements):
+//   TA=0,TB=0  C[M,N] = A[M,K] * B[N,K]^T          forward  (x @ W^T)
+//   TA=0,TB=1  C[M,N] = A[M,K] * B[K,N]            dX = dY @ W
+//   TA=1,TB=1  C[M,N] = A[K,M]^T * B[K,N]          dW = dY^T @ X   (split-K over the token dimension,
+//                                                  fp32 partial slabs reduced by splitk_reduce)
+// Element type T is bf16 (v_mfma_f32_32x32x16_bf16) or f32 (v_mfma_f32_32x32x2_f32, exact f32 FMA chain,
+// used as the parity mode); both share one fragment layout: lane (r = l&31, h = l>>5) holds the 8
+// contraction elements k = 16*kk + 8*h + j of row/column r, so every loader is dtype-agnostic.
+//
+// Workgroup = 4 waves, each owning a 64x96 output tile (2x3 MFMA tiles, 96 accumulator VGPRs):
+//   WM=4,WN=1 -> 256x96 block tile (N == 96-ish layers), WM=2,WN=2 -> 128x192.
+// K is consumed in 128-byte slices (64 bf16 / 32 f32) staged HBM -> registers -> LDS with the next slice's
+// loads in flight during the MFMAs. Non-transposed LDS rows are 128 B + 16 B pad (conflict-free
+// ds_read_b128 over a 16-lane group); transposed operands keep their [k][m] image and are read with
+// ds_read_b64_tr_b16 (bf16) so no transpose pass ever runs.
+//
+// Roofline: MFMA-bound for C >= 384 layers; stage-0/1 layers (K = 96/192) are HBM-bound (72-150 flop/B).
+#include "common.h"
+
+namespace {
+
+constexpr int GEMM_THREADS = 256;
+constexpr int ROWB = 144;  // bytes per non-transposed LDS row: 128 B of K + 16 B pad
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_RESID = 2, EPI_MULGELUGRAD = 4, EPI_ACCUM = 8 };
+enum { PRO_NONE = 0, PRO_GELU_A = 1, PRO_GELU_B = 2 };
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;      // [N]
+    const void* resid;      // [M, ldr] (T)
+    const float* rowscale;  // [ceil(M / rows_per_scale)] or null
+    const void* aux;        // [M, ldaux] (T): pre-activation for EPI_MULGELUGRAD
+    int M, N, K;
+    int lda, ldb, ldc, ldr, ldaux;
+    int rows_per_scale;
+    int kchunk;             // contraction elements per split (multiple of BK); == K when no split
+    long slab_stride;       // elements between split-K output slabs
+    int epi, pro;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int BK = 64;
+    static constexpr int KSTEPS = 4;
+    using Frag = bf16x8;
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct FragF32 { float v[8]; };
+template <> struct Mma<float> {
+    static constexpr int BK = 32;
+    static constexpr int KSTEPS = 2;
+    using Frag = FragF32;
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
+
+// ---- fragment loaders ------------------------------------------------------------------------------
+// Non-transposed image: [rows][ROWB bytes]; lane reads 8 consecutive k of its row.
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag ld_frag_n(const char* tile, int row, int kk, int h);
+template <>
+__device__ __forceinline__ bf16x8 ld_frag_n<bf16_t>(const char* tile, int row, int kk, int h) {
+    return *(const bf16x8*)(tile + row * ROWB + (kk * 16 + 8 * h) * 2);
+}
+template <>
+__device__ __forceinline__ FragF32 ld_frag_n<float>(const char* tile, int row, int kk, int h) {
+    const f32x4* p = (const f32x4*)(tile + row * ROWB + (kk * 16 + 8 * h) * 4);
+    const f32x4 a = p[0], b = p[1];
+    FragF32 f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+    return f;
+}
+// Transposed image: [k rows][strideB bytes], columns = the operand's row/column index.
+// bf16: two ds_read_b64_tr_b16, each delivering 4 consecutive k of this lane's column. Within a 16-lane
+// group, lane 4q+p supplies the address of k-row q, columns 4p..4p+3 of the group's 16-column block.
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag ld_frag_t(const char* tile, int strideB, int col0, int kk, int lane);
+template <>
+__device__ __forceinline__ bf16x8 ld_frag_t<bf16_t>(const char* tile, int strideB, int col0, int kk, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3, h = lane >> 5, gsel = (lane >> 4) & 1;
+    const char* addr = tile + (kk * 16 + 8 * h + q) * strideB + (col0 + 16 * gsel + 4 * p) * 2;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 4 * strideB));
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    short8v s;
+    s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3];
+    s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, s);
+}
+template <>
+__device__ __forceinline__ FragF32 ld_frag_t<float>(const char* tile, int strideB, int col0, int kk, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    FragF32 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = *(const float*)(tile + (kk * 16 + 8 * h + j) * strideB + (col0 + r) * 4);
+    return f;
+}
+
+// transposed-image row stride in bytes: X columns of T, forced to 64 (mod 128) so the four k-rows a
+// 32-lane half reads with ds_read_b64_tr_b16 fall in four different 64-byte bank groups.
+template <typename T, int X> struct TStride {
+    static constexpr int raw = X * (int)sizeof(T);
+    static constexpr int value = (raw % 128 == 64) ? raw : raw + 64;
+};
+
+__device__ __forceinline__ f32x4 gelu4_bf16(f32x4 v) {
+    // v carries 8 packed bf16; apply exact GELU elementwise
+    bf16x8 x = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (bf16_t)gelu_f((float)x[i]);
+    return __builtin_bit_cast(f32x4, x);
+}
+__device__ __forceinline__ f32x4 gelu4_f32(f32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
+    return v;
+}
+template <typename T> __device__ __forceinline__ f32x4 gelu_chunk(f32x4 v);
+template <> __device__ __forceinline__ f32x4 gelu_chunk<bf16_t>(f32x4 v) { return gelu4_bf16(v); }
+template <> __device__ __forceinline__ f32x4 gelu_chunk<float>(f32x4 v) { return gelu4_f32(v); }
+
+// ---- the kernel ---------------------------------------------------------------------------------------
+template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
+    constexpr int BM = WM * 64, BN = WN * 96;
+    constexpr int BK = Mma<T>::BK, KSTEPS = Mma<T>::KSTEPS;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int EPC = 16 / ES;  // elements per 16-byte chunk
+    constexpr int A_STRIDE = TA ? TStride<T, BM>::value : ROWB;
+    constexpr int B_STRIDE = TB ? TStride<T, BN>::value : ROWB;
+    constexpr int A_BYTES = TA ? BK * A_STRIDE : BM * ROWB;
+    constexpr int B_BYTES = TB ? BK * B_STRIDE : BN * ROWB;
+    constexpr int NCH_A = BM / 32, NCH_B = BN / 32;  // 16-byte chunks per thread per K slice
+    constexpr int A_CPR = TA ? BM / EPC : 8;         // chunks per image row
+    constexpr int B_CPR = TB ? BN / EPC : 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    const char* Ag = (const char*)g.A;
+    const char* Bg = (const char*)g.B;
+
+    f32x4 ra[NCH_A], rb[NCH_B];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NCH_A; ++i) {
+            const int c = tid + GEMM_THREADS * i;
+            const int row = c / A_CPR, cb = c % A_CPR;
+            bool ok;
+            long off;
+            if (TA) {  // image row = contraction index, chunk runs along M
+                ok = (k0 + row < kend) && (m0 + cb * EPC < g.M);
+                off = ((long)(k0 + row) * g.lda + m0 + cb * EPC) * ES;
+            } else {
+                ok = (m0 + row < g.M) && (k0 + cb * EPC < kend);
+                off = ((long)(m0 + row) * g.lda + k0 + cb * EPC) * ES;
+            }
+            ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH_B; ++i) {
+            const int c = tid + GEMM_THREADS * i;
+            const int row = c / B_CPR, cb = c % B_CPR;
+            bool ok;
+            long off;
+            if (TB) {
+                ok = (k0 + row < kend) && (n0 + cb * EPC < g.N);
+                off = ((long)(k0 + row) * g.ldb + n0 + cb * EPC) * ES;
+            } else {
+                ok = (n0 + row < g.N) && (k0 + cb * EPC < kend);
+                off = ((long)(n0 + row) * g.ldb + k0 + cb * EPC) * ES;
+            }
+            rb[i] = ok ? *(const f32x4*)(Bg + off) : zero4;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH_A; ++i) {
+            const int c = tid + GEMM_THREADS * i;
+            const int row = c / A_CPR, cb = c % A_CPR;
+            f32x4 v = ra[i];
+            if (g.pro & PRO_GELU_A) v = gelu_chunk<T>(v);
+            *(f32x4*)(As + row * A_STRIDE + cb * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH_B; ++i) {
+            const int c = tid + GEMM_THREADS * i;
+            const int row = c / B_CPR, cb = c % B_CPR;
+            f32x4 v = rb[i];
+            if (g.pro & PRO_GELU_B) v = gelu_chunk<T>(v);
+            *(f32x4*)(Bs + row * B_STRIDE + cb * 16) = v;
+        }
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    if (kbeg < kend) load_regs(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+        store_lds();
+        __syncthreads();
+        if (k0 + BK < kend) load_regs(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            if (k0 + kk * 16 < kend) {  // uniform: skip MFMA steps that are pure K padding
+                typename Mma<T>::Frag fa[2], fb[3];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int base = wm * 64 + mi * 32;
+                    fa[mi] = TA ? ld_frag_t<T>(As, A_STRIDE, base, kk, lane) : ld_frag_n<T>(As, base + r, kk, h);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 3; ++ni) {
+                    const int base = wn * 96 + ni * 32;
+                    fb[ni] = TB ? ld_frag_t<T>(Bs, B_STRIDE, base, kk, lane) : ld_frag_n<T>(Bs, base + r, kk, h);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 3; ++ni) Mma<T>::mma(fa[mi], fb[ni], acc[mi][ni]);
+            }
+        }
+    }
+
+    // ---- epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+    OutT* Cg = (OutT*)g.C + (long)blockIdx.z * g.slab_stride;
+    const T* Rg = (const T*)g.resid;
+    const T* Ug = (const T*)g.aux;
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni) {
+        const int n = n0 + wn * 96 + ni * 32 + r;
+        if (n >= g.N) continue;
+        const float bv = (g.epi & EPI_BIAS) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[mi][ni][e] + bv;
+                if (g.rowscale) v *= g.rowscale[m / g.rows_per_scale];
+                if (g.epi & EPI_MULGELUGRAD) v *= gelu_grad_f(to_f32<T>(Ug[(long)m * g.ldaux + n]));
+                if (g.epi & EPI_RESID) v += to_f32<T>(Rg[(long)m * g.ldr + n]);
+                OutT* dst = Cg + (long)m * g.ldc + n;
+                if (g.epi & EPI_ACCUM) v += to_f32<OutT>(*dst);
+                *dst = from_f32<OutT>(v);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 96, BK = Mma<T>::BK;
+    constexpr int A_STRIDE = TA ? TStride<T, BM>::value : ROWB;
+    constexpr int B_STRIDE = TB ? TStride<T, BN>::value : ROWB;
+    constexpr int A_BYTES = TA ? BK * A_STRIDE : BM * ROWB;
+    constexpr int B_BYTES = TB ? BK * B_STRIDE : BN * ROWB;
+    dim3 grid(pseld_cdiv(g.N, BN), pseld_cdiv(g.M, BM), splits);
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(GEMM_THREADS), A_BYTES + B_BYTES, stream, g);
+    PSELD_LAUNCH_CHECK("gemm");
+    return PSELD_OK;
+}
+
+template <typename T, typename OutT, bool TA, bool TB>
+int dispatch_tile(const GemmArgs& g, int splits, hipStream_t stream) {
+    // 256x96 when one 96-column tile covers N (or N is not worth a 192 tile), else 128x192
+    if (g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288))
+        return launch_gemm<T, OutT, 4, 1, TA, TB>(g, splits, stream);
+    return launch_gemm<T, OutT, 2, 2, TA, TB>(g, splits, stream);
+}
+
+// ---- split-K slab reduction: out[i] (+)= sum_s slabs[s][i] ----------------------------------------------
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits,
+                                     long slab_stride, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[z * slab_stride + i];
+    out[i] = s;
+}
+
+// ---- column sums (bias gradients): out[n] = sum_m X[m, n] * rowscale ------------------------------------
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ X, float* __restrict__ part, int M, int N, int ld,
+                                      int rows_per_block) {
+    // block handles rows [blockIdx.y*rows_per_block, ...), 64 columns starting at blockIdx.x*64
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int mbeg = blockIdx.y * rows_per_block;
+    const int mend = min(M, mbeg + rows_per_block);
+    float s = 0.f;
+    if (n < N)
+        for (int m = mbeg + w; m < mend; m += 4) s += to_f32<T>(X[(long)m * ld + n]);
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+}  // namespace
+
+static size_t g_ws_need = 0;
+
+// C[M,N] = op(A) op(B) with fused prologue/epilogue; see include/pseld_hip.h for the contract.
+extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B, void* C, int M, int N,
+                          int K, int lda, int ldb, int ldc, const float* bias, const void* resid, int ldr,
+                          const float* rowscale, int rows_per_scale, const void* aux, int ldaux, int epi, int pro,
+                          void* stream) {
+    PSELD_CHECK_ARG(A && B && C, "gemm: null operand");
+    PSELD_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape %dx%dx%d", M, N, K);
+    PSELD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && K % 8 == 0, "gemm: lda/ldb/K must be multiples of 8 (%d,%d,%d)",
+                    lda, ldb, K);
+    PSELD_CHECK_ARG(!(trans_a && !trans_b), "gemm: layout A^T*B^T is not built");
+    PSELD_CHECK_ARG(!trans_a, "gemm: use pseld_gemm_wgrad for the split-K weight-gradient layout");
+    PSELD_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm: EPI_BIAS without bias");
+    PSELD_CHECK_ARG(!(epi & EPI_RESID) || resid, "gemm: EPI_RESID without resid");
+    PSELD_CHECK_ARG(!(epi & EPI_MULGELUGRAD) || aux, "gemm: EPI_MULGELUGRAD without aux");
+    PSELD_CHECK_ARG(!trans_b || N % 8 == 0, "gemm: N must be a multiple of 8 when B is [K,N]");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid; g.rowscale = rowscale; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux;
+    g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    g.kchunk = K; g.slab_stride = 0; g.epi = epi; g.pro = pro;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PSELD_BF16) {
+        return trans_b ? dispatch_tile<bf16_t, bf16_t, false, true>(g, 1, s)
+                       : dispatch_tile<bf16_t, bf16_t, false, false>(g, 1, s);
+    } else if (dtype == PSELD_F32) {
+        return trans_b ? dispatch_tile<float, float, false, true>(g, 1, s)
+                       : dispatch_tile<float, float, false, false>(g, 1, s);
+    }
+    pseld_set_error("gemm: unknown dtype %d", dtype);
+    return PSELD_ERR_BAD_ARG;
+}
+
+// Weight gradient dW[N,K] (fp32) = dY[Mtok,N]^T @ X[Mtok,K], optionally with GELU applied to X on load
+// (dW2 = dY^T gelu(u)). Split over the token dimension into `splits` fp32 slabs in `workspace`
+// (needs splits*N*K floats), then reduced into dW (overwrite, or accumulate when `accumulate`).
+extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
+    // aim for >= ~1024 workgroups, at least 2048 tokens per split
+    const int tiles = pseld_cdiv(N, 96) * pseld_cdiv(K, 96);
+    int splits = pseld_cdiv(1024, tiles);
+    const int max_splits = pseld_cdiv(Mtok, 2048);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits_out) *splits_out = splits;
+    return (long)splits * N * K * (long)sizeof(float);
+}
+
+extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, int Mtok, int N, int K, int lddy,
+                                int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
+                                long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(dY && X && dW && workspace, "gemm_wgrad: null pointer");
+    PSELD_CHECK_ARG(Mtok > 0 && N > 0 && K > 0, "gemm_wgrad: bad shape");
+    PSELD_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && K % 8 == 0 && Mtok % 8 == 0,
+                    "gemm_wgrad: Mtok/N/K/ld must be multiples of 8 (%d,%d,%d,%d,%d)", Mtok, N, K, lddy, ldx);
+    PSELD_CHECK_ARG(lddw == K, "gemm_wgrad: dW must be dense [N,K]");
+    int splits = 1;
+    const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, &splits);
+    PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dY; g.B = X; g.C = workspace;
+    g.M = N; g.N = K; g.K = Mtok; g.lda = lddy; g.ldb = ldx; g.ldc = K;
+    g.rows_per_scale = 1;
+    const int bk = (dtype == PSELD_BF16) ? 64 : 32;
+    int kchunk = pseld_cdiv(Mtok, splits);
+    kchunk = pseld_cdiv(kchunk, bk) * bk;
+    splits = pseld_cdiv(Mtok, kchunk);
+    g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = gelu_on_x ? PRO_GELU_B : PRO_NONE;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true>(g, splits, s);
+    else if (dtype == PSELD_F32) rc = dispatch_tile<float, float, true, true>(g, splits, s);
+    else { pseld_set_error("gemm_wgrad: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
+    if (rc != PSELD_OK) return rc;
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, workspace, dW, n, splits,
+                       g.slab_stride, accumulate);
+    PSELD_LAUNCH_CHECK("splitk_reduce");
+    return PSELD_OK;
+}
+
+// out[n] (fp32) = sum_m X[m,n]; two deterministic passes through `workspace` (>= blocks*N floats).
+extern "C" long pseld_colsum_workspace(int M, int N) {
+    const int rows_per_block = 1024;
+    return (long)pseld_cdiv(M, rows_per_block) * N * (long)sizeof(float);
+}
+extern "C" int pseld_colsum(int dtype, const void* X, float* out, int M, int N, int ld, int accumulate,
+                            float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(X && out && workspace, "colsum: null pointer");
+    const int rows_per_block = 1024;
+    const int nb = pseld_cdiv(M, rows_per_block);
+    PSELD_CHECK_ARG(workspace_bytes >= (long)nb * N * 4, "colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(pseld_cdiv(N, 64), nb);
+    if (dtype == PSELD_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, workspace, M, N, ld, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)X, workspace, M, N, ld, rows_per_block);
+    PSELD_LAUNCH_CHECK("colsum_partial");
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pseld_cdiv(N, 256)), dim3(256), 0, s, workspace, out, (long)N, nb, (long)N, accumulate);
+    PSELD_LAUNCH_CHECK("colsum_reduce");
+    return PSELD_OK;
+}

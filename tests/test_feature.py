@@ -1,0 +1,78 @@
+"""K1 feature kernel vs the CPU oracle (oracle/feature.py). Tolerances: log-mel in dB 2e-3 abs (1e-3 rel of the
+~20-80 dB range is far looser; fp32 FFT round-off gives ~1e-5), intensity-vector mel 1e-4 abs (values in [-1, 1])."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import feature as of
+
+CFG = {'data': {'nfft': 1024, 'hoplen': 240, 'window': 'hann', 'n_mels': 64, 'sample_rate': 24000,
+                'audio_feature': 'logmelIV'}}
+
+
+def _wave(B, C, L, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = 0.1 * torch.randn(B, C, L, generator=g)
+    t = torch.arange(L) / 24000.0
+    x[:, 0] += 0.05 * torch.sin(2 * np.pi * 440.0 * t)      # a tone so some bins dominate
+    x[:, 1] += 0.03 * torch.sin(2 * np.pi * 3000.0 * t + 0.3)
+    return x
+
+
+def test_oracle_matches_independent_f64_restatement():
+    x = _wave(2, 4, 9600, seed=1)
+    a = of.logmel_iv(x).numpy()
+    b = of.logmel_iv_f64(x.numpy())
+    assert a.shape == (2, 7, 41, 64)
+    assert np.abs(a[:, :4] - b[:, :4]).max() < 5e-4     # dB
+    assert np.abs(a[:, 4:] - b[:, 4:]).max() < 5e-6
+
+
+def test_oracle_rejects_bad_rank():
+    with pytest.raises(ValueError):
+        of.logmel_iv(torch.zeros(4, 4800))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(1, 4800), (3, 24000), (2, 240000)])
+def test_logmel_iv_kernel_matches_oracle(dev, B, L):
+    from pseldnets_amd.utils.config import get_afextractor
+    x = _wave(B, 4, L, seed=B)
+    ref = of.logmel_iv(x)
+    ext = get_afextractor(CFG).to(dev)
+    out = ext(x.to(dev)).cpu()
+    assert out.shape == ref.shape == (B, 7, 1 + L // 240, 64)
+    err_db = (out[:, :4] - ref[:, :4]).abs().max().item()
+    err_iv = (out[:, 4:] - ref[:, 4:]).abs().max().item()
+    print(f"logmel max|d| = {err_db:.3e} dB, iv max|d| = {err_iv:.3e}")
+    assert err_db < 2e-3
+    assert err_iv < 1e-4
+
+
+@pytest.mark.gpu
+def test_logmel_only_and_edge_cases(dev):
+    from pseldnets_amd.utils.feature import Logmel_Extractor, LogmelIV_Extractor
+    x = _wave(2, 1, 7200, seed=5)
+    ext = Logmel_Extractor(CFG).to(dev)
+    out = ext(x.to(dev)).cpu()
+    ref = of.logmel(x)
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-3
+    # silence: every bin clamps to amin -> exactly -100 dB, IV = 0
+    z = torch.zeros(1, 4, 4800, device=dev)
+    o = LogmelIV_Extractor(CFG).to(dev)(z).cpu()
+    assert torch.all(o[:, :4] == -100.0) and torch.all(o[:, 4:] == 0.0)
+    with pytest.raises(ValueError):
+        ext(torch.zeros(4, 4800, device=dev))
+
+
+@pytest.mark.gpu
+def test_chunked_equals_whole_clip_chunks(dev):
+    """A 60 s clip is 6 independent 10 s chunks: feature(chunked) has 6x1001 frames."""
+    from pseldnets_amd.utils.feature import LogmelIV_Extractor
+    x = _wave(1, 4, 48000, seed=9)
+    ext = LogmelIV_Extractor(CFG).to(dev)
+    chunks = x.reshape(1, 4, 2, 24000).permute(0, 2, 1, 3).reshape(2, 4, 24000).contiguous()
+    out = ext(chunks.to(dev)).cpu()
+    ref = of.logmel_iv(chunks)
+    assert (out[:, :4] - ref[:, :4]).abs().max().item() < 2e-3

@@ -1,0 +1,103 @@
+"""MFMA GEMM (csrc/gemm.hip) vs torch CPU fp64 matmul of the same (rounded) operands.
+f32 mode: exact-f32 MFMA chain -> 2e-5 rel of |a||b| sum; bf16 mode: operands are bf16-rounded identically on
+both sides, accumulation is f32, output rounded to bf16 -> 1e-2 rel."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(*shape, generator=g)).to(dtype)
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.2e-2
+
+
+def _check(name, got, ref, dtype, denom=None):
+    got = got.double().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() if denom is None else denom
+    rel = err / max(scale, 1e-30)
+    print(f"{name}: max|d|={err:.3e} rel={rel:.3e}")
+    assert rel < _tol(dtype), name
+
+
+SHAPES = [(256, 96, 96), (300, 288, 96), (1000, 192, 384), (512, 1536, 4608), (130, 48, 112), (4096, 768, 3072)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_fwd(dev, dtype, M, N, K):
+    from pseldnets_amd import ops
+    x, w = _mk((M, K), dtype, 1), _mk((N, K), dtype, 2, 0.1)
+    b = _mk((N,), torch.float32, 3)
+    y = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev))
+    ref = x.double() @ w.double().t() + b.double()
+    _check(f"fwd {M}x{N}x{K}", y, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_fwd_fused_epilogues(dev, dtype):
+    from pseldnets_amd import ops
+    M, N, K, L = 512, 96, 384, 128
+    x, w = _mk((M, K), dtype, 1), _mk((N, K), dtype, 2, 0.1)
+    b, r = _mk((N,), torch.float32, 3), _mk((M, N), dtype, 4)
+    s = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 0.0])
+    y = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), resid=r.to(dev), rowscale=s.to(dev), rows_per_scale=L,
+                       gelu_in=True)
+    gx = torch.nn.functional.gelu(x.double()).to(dtype).double() if dtype == torch.bfloat16 else torch.nn.functional.gelu(x.double())
+    ref = r.double() + s.double().repeat_interleave(L)[:, None] * (gx @ w.double().t() + b.double())
+    _check("fwd gelu_in+bias+rowscale+resid", y, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_dgrad(dev, dtype, M, N, K):
+    from pseldnets_amd import ops
+    dy, w = _mk((M, N), dtype, 5), _mk((N, K), dtype, 6, 0.1)
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev))
+    ref = dy.double() @ w.double()
+    _check(f"dgrad {M}x{N}x{K}", dx, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_dgrad_gelu_grad(dev, dtype):
+    from pseldnets_amd import ops
+    M, N, K = 384, 96, 384
+    dy, w, u = _mk((M, N), dtype, 5), _mk((N, K), dtype, 6, 0.1), _mk((M, K), dtype, 7)
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev), gelu_grad_of=u.to(dev))
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    ref = (dy.double() @ w.double()) * ud.grad
+    _check("dgrad*gelu'", dx, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4096, 96, 96), (8192, 288, 96), (4096, 384, 1536), (2048, 1536, 4608), (1024, 48, 112)])
+def test_linear_wgrad(dev, dtype, M, N, K):
+    from pseldnets_amd import ops
+    dy, x = _mk((M, N), dtype, 8, 0.1), _mk((M, K), dtype, 9)
+    dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dy.to(dev), x.to(dev), dw)
+    ref = dy.double().t() @ x.double()
+    _check(f"wgrad {M}x{N}x{K}", dw, ref, torch.float32 if dtype == torch.float32 else dtype)
+    db = torch.empty(N, dtype=torch.float32, device=dev)
+    ops.colsum(dy.to(dev), db)
+    _check("colsum", db, dy.double().sum(0), torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_wgrad_gelu_on_x_and_accumulate(dev, dtype):
+    from pseldnets_amd import ops
+    M, N, K = 4096, 96, 384
+    dy, u = _mk((M, N), dtype, 8, 0.1), _mk((M, K), dtype, 9)
+    dw = torch.ones(N, K, dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dy.to(dev), u.to(dev), dw, gelu_on_x=True, accumulate=True)
+    g = torch.nn.functional.gelu(u.double())
+    if dtype == torch.bfloat16:
+        g = g.to(dtype).double()
+    ref = 1.0 + dy.double().t() @ g
+    _check("wgrad gelu_on_x + accumulate", dw, ref, dtype)
