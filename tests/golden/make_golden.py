@@ -1,0 +1,261 @@
+"""Generates the golden fixtures in this directory by IMPORTING THE REFERENCE (/root/reference/src) in the
+build container (CPU, torch 2.10). Run:  python tests/golden/make_golden.py
+Only inputs that are closed-form functions (oracle/synth.py, oracle/htsat.py:formula_*) are used, so the
+fixtures store expected outputs (and small explicit inputs for the losses), never reference source.
+
+Known deviation recorded here: torch 2.10's CPU batch-norm backward returns wrong weight/bias gradients when its
+input is channels-last-strided and the incoming gradient is contiguous — exactly what the reference's in-place
+`x[..., [nch]] = self.scalar[nch](x[..., [nch]])` (models/accdoa.py:224-227) produces. Finite differences of the
+reference's own forward confirm the analytic value (see `bn_fd_check` in htsat_tiny.npz). Reference-autograd
+gradients of `scalar.*` are therefore NOT stored; every other parameter gradient is.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from tests.golden import _ref_import as R  # noqa: E402
+
+R.install()
+import loss.accdoa  # noqa: E402
+import loss.einv2  # noqa: E402
+import loss.multi_accdoa  # noqa: E402
+from data.components.sampler import UserDistributedBatchSampler  # noqa: E402
+from models import accdoa, einv2, multi_accdoa  # noqa: E402
+import utils.feature as ref_feature  # noqa: E402
+
+from oracle import htsat as oh  # noqa: E402
+from oracle import synth  # noqa: E402
+
+torch.set_num_threads(8)
+CFG = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'), adapt=dict())
+TINY = dict(embed_dim=48, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), drop_path_rate=0.0)
+FULL = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.1)
+
+
+def ref_kwargs(c):
+    return dict(spec_size=256, patch_size=4, patch_stride=[4, 4], embed_dim=c['embed_dim'], depths=list(c['depths']),
+                num_heads=list(c['num_heads']), window_size=8, mlp_ratio=4, qkv_bias=True, drop_rate=0.,
+                attn_drop_rate=0., drop_path_rate=c['drop_path_rate'], ape=False, patch_norm=True, norm_before_mlp='ln')
+
+
+def load_formula(net, kind, C, cfg):
+    sd = oh.formula_state(kind, C, 7, cfg)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(('relative_position_index' in k) or ('attn_mask' in k) for k in missing), missing
+    return sd
+
+
+def slices(t, n=16):
+    f = t.detach().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return f[idx].numpy(), idx.numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KB')
+
+
+def gen_feature():
+    x = synth.formula_wave(1, 4, 4800)
+    ext = ref_feature.LogmelIV_Extractor({'data': dict(CFG['data'])})
+    lm = ref_feature.Logmel_Extractor({'data': dict(CFG['data'])})
+    with torch.no_grad():
+        y = ext(x)
+        y1 = lm(x[:, :1])
+        # one full 10 s chunk: keep a strided sample + checksums
+        xl = synth.formula_wave(1, 4, 240000)
+        yl = ext(xl)
+    samp, idx = slices(yl, 4096)
+    save('feature.npz', small_out=y.numpy(), small_logmel_ch0=y1.numpy(), chunk_sample=samp, chunk_index=idx,
+         chunk_shape=np.array(yl.shape), chunk_abs_sum_per_channel=yl.abs().sum(dim=(0, 2, 3)).numpy())
+
+
+def gen_htsat_tiny():
+    C = 3
+    out = {}
+    x = oh.formula_features(2)
+    # --- multi-ACCDOA: eval forward, train forward + ADPIT loss + backward, running stats --------------------
+    net = multi_accdoa.HTSAT(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    load_formula(net, 'multi_accdoa', C, TINY)
+    net.eval()
+    with torch.no_grad():
+        out['maccdoa_eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net.train()
+    pred = net(x.clone())
+    lab = synth.formula_adpit_label(2, 100, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab})
+    ld['loss_all'].backward()
+    out['maccdoa_train'] = pred['multi_accdoa'].detach().numpy()
+    out['maccdoa_loss'] = ld['loss_all'].item()
+    names, norms, heads = [], [], []
+    for n, p in net.named_parameters():
+        if n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    sd = net.state_dict()
+    out['running_mean'] = torch.stack([sd[f'scalar.{c}.running_mean'] for c in range(7)]).numpy()
+    out['running_var'] = torch.stack([sd[f'scalar.{c}.running_var'] for c in range(7)]).numpy()
+    # finite-difference evidence for the BN-parameter gradients (float64 reference forward)
+    net64 = multi_accdoa.HTSAT(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY)).double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in oh.formula_state('multi_accdoa', C, 7, TINY).items()}, strict=False)
+    net64.train()
+    lossf = loss.multi_accdoa.Losses('mse', 'loss_all')
+
+    def L():
+        return lossf(net64(x.double().clone()), {'adpit_label': lab.double()})['loss_all'].item()
+    fd = []
+    h = 1e-5
+    with torch.no_grad():
+        for (c, kind, j) in [(0, 'bias', 3), (5, 'bias', 7), (2, 'weight', 11), (6, 'weight', 40)]:
+            prm = getattr(net64.scalar[c], kind)
+            prm[j] += h; lp = L(); prm[j] -= 2 * h; lm = L(); prm[j] += h
+            fd.append((c, 0 if kind == 'bias' else 1, j, (lp - lm) / (2 * h)))
+    out['bn_fd_check'] = np.array(fd)
+    # --- ACCDOA head on the same encoder ---------------------------------------------------------------------
+    net = accdoa.HTSAT(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    load_formula(net, 'accdoa', C, TINY)
+    net.eval()
+    with torch.no_grad():
+        out['accdoa_eval'] = net(x.clone())['accdoa'].numpy()
+    # --- EINV2 dual branch + tPIT ----------------------------------------------------------------------------
+    net = einv2.HTSAT(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    load_formula(net, 'einv2', C, TINY)
+    net.train()
+    pred = net(x.clone())
+    sed_l, doa_l = synth.formula_einv2_label(2, 100, C)
+    ld = loss.einv2.Losses_pit({'sed': 'bce', 'doa': 'mse'}, 'loss_all', 'tPIT', 0.5)(pred, {'sed_label': sed_l, 'doa_label': doa_l})
+    ld['loss_all'].backward()
+    out['einv2_sed'] = pred['sed'].detach().numpy()
+    out['einv2_doa'] = pred['doa'].detach().numpy()
+    out['einv2_losses'] = np.array([ld['loss_all'].item(), ld['loss_sed'].item(), ld['loss_doa'].item()])
+    names, norms = [], []
+    for n, p in net.named_parameters():
+        if n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item())
+    out['einv2_grad_names'] = np.array(names)
+    out['einv2_grad_norms'] = np.array(norms)
+    # --- SEDDOA single branch -------------------------------------------------------------------------------
+    net = einv2.HTSAT_SEDDOA(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    load_formula(net, 'seddoa', C, TINY)
+    net.eval()
+    with torch.no_grad():
+        p = net(x.clone())
+    out['seddoa_sed'] = p['sed'].numpy(); out['seddoa_doa'] = p['doa'].numpy()
+    save('htsat_tiny.npz', **out)
+
+
+def gen_htsat_full():
+    C = 170
+    out = {}
+    x = oh.formula_features(1)
+    net = multi_accdoa.HTSAT(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(FULL))
+    load_formula(net, 'multi_accdoa', C, FULL)
+    out['n_params'] = sum(p.numel() for p in net.parameters())
+    net.eval()
+    with torch.no_grad():
+        y = net(x.clone())['multi_accdoa']
+    out['maccdoa_sample'], out['maccdoa_index'] = slices(y, 2048)
+    out['maccdoa_norm'] = y.norm().item()
+    out['maccdoa_frame0'] = y[0, 0].numpy()
+    net = einv2.HTSAT(CFG, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(FULL))
+    load_formula(net, 'einv2', C, FULL)
+    net.eval()
+    with torch.no_grad():
+        p = net(x.clone())
+    out['einv2_sed_sample'], out['einv2_sed_index'] = slices(p['sed'], 2048)
+    out['einv2_doa'] = p['doa'].numpy()
+    save('htsat_full.npz', **out)
+
+
+def gen_losses():
+    out = {}
+    B, T, C = 2, 100, 5
+    pred = synth.formula_pred((B, T, 9 * C), 0.3).requires_grad_(True)
+    lab = synth.formula_adpit_label(B, T, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')({'multi_accdoa': pred}, {'adpit_label': lab})
+    ld['loss_all'].backward()
+    out['adpit_loss'] = ld['loss_all'].item(); out['adpit_grad'] = pred.grad.numpy().copy()
+    # ties: all-zero labels -> every candidate equal -> index 0
+    pz = synth.formula_pred((1, 4, 9 * C), 0.9)
+    out['adpit_zero_label_loss'] = loss.multi_accdoa.Losses('mse', 'loss_all')({'multi_accdoa': pz}, {'adpit_label': torch.zeros(1, 4, 6, 4, C)})['loss_all'].item()
+    pa = synth.formula_pred((B, T, 3 * C), 1.1).requires_grad_(True)
+    la = synth.formula_accdoa_label(B, T, C)
+    ld = loss.accdoa.Losses('mse', 'loss_all')({'accdoa': pa}, {'accdoa_label': la})
+    ld['loss_all'].backward()
+    out['mse_loss'] = ld['loss_all'].item(); out['mse_grad'] = pa.grad.numpy().copy()
+    sed = synth.formula_pred((B, T, 3, C), 0.5, 2.0).requires_grad_(True)
+    doa = torch.tanh(synth.formula_pred((B, T, 3, 3), 0.8)).requires_grad_(True)
+    sl, dl = synth.formula_einv2_label(B, T, C)
+    ld = loss.einv2.Losses_pit({'sed': 'bce', 'doa': 'mse'}, 'loss_all', 'tPIT', 0.5)({'sed': sed, 'doa': doa}, {'sed_label': sl, 'doa_label': dl})
+    ld['loss_all'].backward()
+    out['tpit_losses'] = np.array([ld['loss_all'].item(), ld['loss_sed'].item(), ld['loss_doa'].item()])
+    out['tpit_grad_sed'] = sed.grad.numpy().copy(); out['tpit_grad_doa'] = doa.grad.numpy().copy()
+    sed2 = sed.detach().clone().requires_grad_(True); doa2 = doa.detach().clone().requires_grad_(True)
+    for method in ('mACCDOA_pit', 'ACCDOA', 'both'):
+        ld = loss.einv2.Losses_agg_pit('mse', 'loss_all', 0.5, method)({'sed': sed2, 'doa': doa2}, {'sed_label': sl, 'doa_label': dl})
+        out[f'agg_{method}'] = float(ld['loss_all'])
+    save('losses.npz', **out)
+
+
+def gen_optim():
+    """One clip(1.0) + AdamW(lr 1e-4) step exactly as Lightning would run it (torch.nn.utils.clip_grad_norm_,
+    torch.optim.AdamW defaults) on formula parameters/gradients."""
+    shapes = {'a.weight': (48, 112), 'a.bias': (48,), 'b.weight': (7, 3, 5)}
+    ps = [torch.nn.Parameter(oh.formula_tensor(k, s)) for k, s in shapes.items()]
+    opt = torch.optim.AdamW(ps, lr=1e-4, amsgrad=False)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.1)
+    outs, norms, lrs = [], [], []
+    for it in range(5):
+        for i, (k, s) in enumerate(shapes.items()):
+            ps[i].grad = 3.0 * oh.formula_tensor(k + f'.g{it}', s)
+        norms.append(torch.nn.utils.clip_grad_norm_(ps, 1.0).item())
+        lrs.append(opt.param_groups[0]['lr'])
+        opt.step()
+        sched.step()          # used here as "one epoch per step" to exercise the schedule
+        outs.append(torch.cat([p.detach().reshape(-1) for p in ps]).numpy().copy())
+    save('optim.npz', params_after=np.stack(outs), grad_norms=np.array(norms), lrs=np.array(lrs))
+
+
+def gen_sampler():
+    out = {}
+    for (n, b, world, seed) in [(100, 8, 1, 2024), (100, 8, 2, 2024), (64, 8, 4, 7), (37, 5, 2, 2023)]:
+        for rank in range(world):
+            class FakeDist:
+                pass
+            import torch.distributed as dist
+            real = (dist.is_initialized, dist.get_rank, dist.get_world_size)
+            dist.is_initialized = lambda: True
+            dist.get_rank = lambda r=rank: r
+            dist.get_world_size = lambda w=world: w
+            import data.components.sampler as smod
+            smod.dist = dist
+            try:
+                s = UserDistributedBatchSampler(n, b, seed=seed)
+                it = iter(s)
+                batches = [next(it).copy() for _ in range(len(s) + 2)]  # copy: the sampler yields views it later reshuffles in place
+            finally:
+                dist.is_initialized, dist.get_rank, dist.get_world_size = real
+            out[f'n{n}_b{b}_w{world}_s{seed}_r{rank}'] = np.stack(batches)
+    save('sampler.npz', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler']
+    if 'feature' in which: gen_feature()
+    if 'tiny' in which: gen_htsat_tiny()
+    if 'full' in which: gen_htsat_full()
+    if 'losses' in which: gen_losses()
+    if 'optim' in which: gen_optim()
+    if 'sampler' in which: gen_sampler()

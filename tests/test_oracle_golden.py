@@ -1,0 +1,178 @@
+"""Pins the CPU oracle (oracle/) to golden vectors produced by importing the REFERENCE in the build container
+(tests/golden/make_golden.py). Tolerance 2e-5 abs unless noted (same op order, fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import feature as of
+from oracle import htsat as oh
+from oracle import losses as ol
+from oracle import optim as oo
+from oracle import synth
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+TINY = dict(embed_dim=48, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), drop_path_rate=0.0)
+FULL = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.1)
+
+
+def gold(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def close(a, b, tol=2e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    d = np.abs(a - b).max()
+    assert d < tol, d
+
+
+def test_feature_golden():
+    g = gold('feature.npz')
+    x = synth.formula_wave(1, 4, 4800)
+    y = of.logmel_iv(x)
+    close(y[:, :4], g['small_out'][:, :4], 2e-4)      # dB
+    close(y[:, 4:], g['small_out'][:, 4:], 2e-6)
+    close(of.logmel(x[:, :1]), g['small_logmel_ch0'], 2e-4)
+    yl = of.logmel_iv(synth.formula_wave(1, 4, 240000))
+    assert tuple(yl.shape) == tuple(g['chunk_shape']) == (1, 7, 1001, 64)
+    close(yl.reshape(-1)[torch.from_numpy(g['chunk_index'])], g['chunk_sample'], 2e-4)
+
+
+def test_htsat_tiny_forward_golden():
+    g = gold('htsat_tiny.npz')
+    x = oh.formula_features(2)
+    with torch.no_grad():
+        sd = oh.formula_state('multi_accdoa', 3, 7, TINY)
+        close(oh.accdoa_htsat_forward(x.clone(), sd, TINY, key='multi_accdoa')['multi_accdoa'], g['maccdoa_eval'])
+        sd = oh.formula_state('accdoa', 3, 7, TINY)
+        close(oh.accdoa_htsat_forward(x.clone(), sd, TINY)['accdoa'], g['accdoa_eval'])
+        sd = oh.formula_state('seddoa', 3, 7, TINY)
+        p = oh.seddoa_htsat_forward(x.clone(), sd, TINY)
+        close(p['sed'], g['seddoa_sed'], 1e-4)
+        close(p['doa'], g['seddoa_doa'])
+
+
+def test_htsat_tiny_train_step_golden():
+    g = gold('htsat_tiny.npz')
+    x = oh.formula_features(2)
+    sd = oh.formula_state('multi_accdoa', 3, 7, TINY)
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    upd = {}
+    pred = oh.accdoa_htsat_forward(x.clone(), p, TINY, training=True, bn_update=upd, key='multi_accdoa')
+    close(pred['multi_accdoa'], g['maccdoa_train'])
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3)})
+    assert abs(ld['loss_all'].item() - float(g['maccdoa_loss'])) < 1e-6
+    ld['loss_all'].backward()
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= 2e-4 * max(norm, 1e-3), n
+        k = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:k].numpy() - head[:k]).max() <= 2e-4 * max(np.abs(head).max(), 1e-4) + 1e-7, n
+    close(torch.stack([upd[f'scalar.{c}.running_mean'] for c in range(7)]), g['running_mean'], 1e-4)
+    close(torch.stack([upd[f'scalar.{c}.running_var'] for c in range(7)]), g['running_var'], 1e-3)
+    # BN-parameter gradients: the reference's autograd is wrong under torch 2.10 CPU (see make_golden.py);
+    # the golden is the finite difference of the reference's own float64 forward.
+    for c, is_w, j, fd in g['bn_fd_check']:
+        name = f"scalar.{int(c)}.{'weight' if is_w else 'bias'}"
+        got = p[name].grad[int(j)].item()
+        assert abs(got - fd) <= 2e-3 * max(abs(fd), 1e-3), (name, got, fd)
+
+
+def test_einv2_tiny_golden():
+    g = gold('htsat_tiny.npz')
+    x = oh.formula_features(2)
+    sd = oh.formula_state('einv2', 3, 7, TINY)
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    pred = oh.einv2_htsat_forward(x.clone(), p, TINY, training=True)
+    close(pred['sed'], g['einv2_sed'], 1e-4)
+    close(pred['doa'], g['einv2_doa'])
+    sl, dl = synth.formula_einv2_label(2, 100, 3)
+    ld = ol.tpit(pred, {'sed_label': sl, 'doa_label': dl})
+    got = np.array([ld['loss_all'].item(), ld['loss_sed'].item(), ld['loss_doa'].item()])
+    assert np.abs(got - g['einv2_losses']).max() < 2e-6
+    ld['loss_all'].backward()
+    for n, norm in zip(g['einv2_grad_names'], g['einv2_grad_norms']):
+        assert abs(p[str(n)].grad.norm().item() - norm) <= 3e-4 * max(norm, 1e-3), n
+
+
+def test_htsat_full_size_golden():
+    g = gold('htsat_full.npz')
+    x = oh.formula_features(1)
+    sd = oh.formula_state('multi_accdoa', 170, 7, FULL)
+    n_params = sum(v.numel() for k, v in sd.items() if 'running' not in k and 'num_batches' not in k)
+    assert n_params == int(g['n_params']) == 34596242
+    with torch.no_grad():
+        y = oh.accdoa_htsat_forward(x.clone(), sd, FULL, key='multi_accdoa')['multi_accdoa']
+    assert tuple(y.shape) == (1, 100, 1530)
+    close(y.reshape(-1)[torch.from_numpy(g['maccdoa_index'])], g['maccdoa_sample'], 5e-5)
+    close(y[0, 0], g['maccdoa_frame0'], 5e-5)
+    assert abs(y.norm().item() - float(g['maccdoa_norm'])) < 1e-3
+    sd = oh.formula_state('einv2', 170, 7, FULL)
+    with torch.no_grad():
+        p = oh.einv2_htsat_forward(x.clone(), sd, FULL)
+    close(p['sed'].reshape(-1)[torch.from_numpy(g['einv2_sed_index'])], g['einv2_sed_sample'], 2e-4)
+    close(p['doa'], g['einv2_doa'], 5e-5)
+
+
+def test_pool_matrix_is_the_interpolate_mean_map():
+    P = oh.pool_matrix()
+    assert P.shape == (100, 32)
+    assert torch.allclose(P.sum(1), torch.ones(100), atol=1e-6)
+    assert (P != 0).sum(1).max().item() <= 3
+    assert abs(P[50, 15].item() - 0.71875) < 1e-6 and abs(P[50, 16].item() - 0.28125) < 1e-6
+
+
+def test_losses_golden():
+    g = gold('losses.npz')
+    B, T, C = 2, 100, 5
+    pred = synth.formula_pred((B, T, 9 * C), 0.3).requires_grad_(True)
+    ld = ol.adpit({'multi_accdoa': pred}, {'adpit_label': synth.formula_adpit_label(B, T, C)})
+    assert abs(ld['loss_all'].item() - float(g['adpit_loss'])) < 1e-7
+    ld['loss_all'].backward()
+    close(pred.grad, g['adpit_grad'], 1e-8)
+    pz = synth.formula_pred((1, 4, 9 * C), 0.9)
+    z = ol.adpit({'multi_accdoa': pz}, {'adpit_label': torch.zeros(1, 4, 6, 4, C)})['loss_all'].item()
+    assert abs(z - float(g['adpit_zero_label_loss'])) < 1e-7
+    pa = synth.formula_pred((B, T, 3 * C), 1.1).requires_grad_(True)
+    ld = ol.mse_accdoa({'accdoa': pa}, {'accdoa_label': synth.formula_accdoa_label(B, T, C)})
+    assert abs(ld['loss_all'].item() - float(g['mse_loss'])) < 1e-7
+    ld['loss_all'].backward()
+    close(pa.grad, g['mse_grad'], 1e-8)
+    sed = synth.formula_pred((B, T, 3, C), 0.5, 2.0).requires_grad_(True)
+    doa = torch.tanh(synth.formula_pred((B, T, 3, 3), 0.8)).detach().requires_grad_(True)
+    sl, dl = synth.formula_einv2_label(B, T, C)
+    ld = ol.tpit({'sed': sed, 'doa': doa}, {'sed_label': sl, 'doa_label': dl})
+    got = np.array([ld['loss_all'].item(), ld['loss_sed'].item(), ld['loss_doa'].item()])
+    assert np.abs(got - g['tpit_losses']).max() < 1e-6
+    ld['loss_all'].backward()
+    close(sed.grad, g['tpit_grad_sed'], 1e-8)
+    close(doa.grad, g['tpit_grad_doa'], 1e-8)
+    for method in ('mACCDOA_pit', 'ACCDOA', 'both'):
+        v = ol.agg_pit({'sed': sed.detach(), 'doa': doa.detach()}, {'sed_label': sl, 'doa_label': dl}, 0.5, method)['loss_all']
+        assert abs(float(v) - float(g[f'agg_{method}'])) < 1e-6, method
+
+
+def test_optimizer_golden():
+    g = gold('optim.npz')
+    shapes = {'a.weight': (48, 112), 'a.bias': (48,), 'b.weight': (7, 3, 5)}
+    ps = [oh.formula_tensor(k, s) for k, s in shapes.items()]
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    for it in range(5):
+        grads = [3.0 * oh.formula_tensor(k + f'.g{it}', s) for k, s in shapes.items()]
+        lr = oo.step_lr(1e-4, it, 2, 0.1)
+        assert abs(lr - g['lrs'][it]) < 1e-12
+        total = oo.adamw_step(ps, grads, m, v, it + 1, lr)
+        assert abs(total.item() - g['grad_norms'][it]) < 1e-3
+        flat = torch.cat([p.reshape(-1) for p in ps]).numpy()
+        assert np.abs(flat - g['params_after'][it]).max() < 2e-7
+
+
+def test_sampler_golden():
+    g = gold('sampler.npz')
+    for key in g.files:
+        n, b, w, s, r = [int(t[1:]) for t in key.split('_')]
+        want = g[key]
+        got = oo.distributed_batches(n, b, w, r, seed=s, n_batches=want.shape[0])
+        assert np.array_equal(np.stack(got), want), key
