@@ -54,6 +54,79 @@ long pseld_colsum_workspace(int M, int N);
 int pseld_colsum(int dtype, const void* X, float* out, int M, int N, int ld, int accumulate, float* workspace,
                  long workspace_bytes, void* stream);
 
+/* ---- LayerNorm (plain, and the 2x2 patch-merging gather form) -----------------------------------------------
+ * htsat.py:234,261,525 (norm1/norm2/final norm), model_utilities.py:212 (PatchEmbed.norm), htsat.py:290-311
+ * (PatchMerging: merge_res = side of the INPUT token grid; rows are [B*(res/2)^2, C=4*Cs]). gamma/beta fp32. */
+int pseld_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, long M, int C, int merge_res, float eps, void* stream);
+long pseld_layernorm_bwd_workspace(long M, int C);
+int pseld_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const void* dres, void* dx,
+                        float* dgamma, float* dbeta, long M, int C, int merge_res, float eps, int accumulate,
+                        float* workspace, long workspace_bytes, void* stream);
+
+/* ---- the 7 "scalar" BatchNorm2d(mel) + pad + time->frequency fold + 4x4 patch extraction ----------------------
+ * models/accdoa.py:223-227 (in-place per-channel BN), htsat.py:493-511 (reshape_wav2img), im2col of
+ * model_utilities.py:209 (PatchEmbed.proj). stats: sums f32[3*Cin*F] = interleaved (sum x, sum x^2)[Cin*F] then,
+ * if centered, sum (x-mean)^2 [Cin*F]; the first 2*Cin*F floats are what sync-BN all-reduces
+ * (configs/trainer/gpu.yaml:9). finalize: scale_shift / mean_rstd f32[Cin*F][2]; running stats updated in place. */
+long pseld_bn_scalar_workspace(int B, int Cin, int T);
+int pseld_bn_scalar_stats(const float* feat, float* sums, int B, int Cin, int T, int F, int centered, float* workspace,
+                          long workspace_bytes, void* stream);
+int pseld_bn_scalar_finalize(float* sums, float count, int centered, const float* weight, const float* bias,
+                             float* running_mean, float* running_var, long long* num_batches, float* mean_rstd,
+                             float* scale_shift, int Cin, int F, float momentum, float eps, int training, void* stream);
+int pseld_bn_fold_patchify(int dtype, const float* feat, const float* scale_shift, void* A, int B, int Cin, int c_first,
+                           int Cuse, int T, void* stream);
+long pseld_bn_scalar_bwd_workspace(int B, int Cuse);
+int pseld_bn_scalar_bwd(int dtype, const float* feat, const float* mean_rstd, const void* dA, float* dweight,
+                        float* dbias, int B, int Cin, int c_first, int Cuse, int T, int accumulate, float* workspace,
+                        long workspace_bytes, void* stream);
+/* DropPath backward factor per sample (model_utilities.py:216-232): y = x * scale[i / elems_per_scale] */
+int pseld_rowscale(int dtype, const void* x, const float* scale, void* y, long n, long elems_per_scale, void* stream);
+
+/* ---- (shifted-)window attention ----------------------------------------------------------------------------------
+ * htsat.py:23-50 (partition/reverse), :239-260 (roll), :118-138 (WindowAttention core), :203-222 (mask).
+ * qkv [B, res*res, 3C] -> out [B, res*res, C], both in natural token order; 8x8 windows, head_dim 8..32.
+ * bias_table f32[225, heads]. Backward adds d(bias_table) (deterministic up to fp32 atomic order). */
+int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, int B, int res, int C,
+                          int heads, int shift, void* stream);
+long pseld_window_attn_bwd_workspace(int heads);
+int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* dout, void* dqkv,
+                          float* dbias_table, int B, int res, int C, int heads, int shift, int accumulate,
+                          float* workspace, long workspace_bytes, void* stream);
+
+/* ---- output head ---------------------------------------------------------------------------------------------------
+ * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):
+ * tok [B,64,C] -> A [B*32, C*6] (k = c*6 + cf*3 + dt, matching the conv weight's [D, C, 2, 3] flattening).
+ * accdoa.py:231-242: z [B*32, ldz] -> y f32[B, n_out, D] through the fixed interpolate/crop/mean map given in
+ * compact form (row f uses taps w[f][0..2] at inputs i0[f]..i0[f]+2), then tanh (act_tanh) or identity. */
+int pseld_head_im2col(int dtype, const void* tok, void* A, int B, int C, void* stream);
+int pseld_head_col2im(int dtype, const void* dA, void* dtok, int B, int C, void* stream);
+int pseld_head_pool_fwd(int dtype, const void* z, float* y, const int* i0, const float* w, int B, int D, int ldz,
+                        int n_out, int n_in, int act_tanh, void* stream);
+int pseld_head_pool_bwd(int dtype, const float* dy, const float* y, void* dz, const int* t_cnt, const int* t_f,
+                        const float* t_w, int B, int D, int ldz, int n_out, int n_in, int act_tanh, int max_taps,
+                        void* stream);
+
+/* ---- losses (value + gradient in one pass; fp32) ------------------------------------------------------------------
+ * loss/multi_accdoa.py:16-105 ADPIT: pred [rows=B*T, 9, C] (row stride ldp), label [rows, 6, 4, C];
+ * loss/accdoa.py:15-22 MSE; loss/einv2.py:59-116 tPIT (bce + mse, beta): loss_out[0..2] = all, sed, doa. */
+int pseld_adpit_loss(const float* pred, const float* label, float* dpred, float* loss_out, long rows, int C, int ldp,
+                     float* workspace, long workspace_bytes, void* stream);
+int pseld_mse_loss(const float* pred, const float* target, float* dpred, float* loss_out, long n, float* workspace,
+                   long workspace_bytes, void* stream);
+int pseld_tpit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label, float* dsed,
+                    float* ddoa, float* loss_out, long rows, int C, float beta, float* workspace, long workspace_bytes,
+                    void* stream);
+
+/* ---- optimiser: clip_grad_norm_(max_norm) + AdamW over one flat fp32 arena --------------------------------------
+ * models/components/model_module.py:128-146 (AdamW, torch defaults), configs/trainer/default.yaml:26 (clip 1.0). */
+int pseld_grad_norm(const float* g, long n, float* norm_out, float* workspace, long workspace_bytes, void* stream);
+int pseld_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* grad_norm,
+                     float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void* stream);
+int pseld_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

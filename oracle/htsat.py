@@ -89,21 +89,46 @@ def fold_to_image(x, spec_size=256, mel_bins=64):
     return x.permute(0, 1, 3, 2, 4).reshape(B, C, ratio * Fq, spec_size)
 
 
-def window_attention(xw, sd, pre, heads, mask, rel_index):
-    """htsat.py:112-145 on windows xw [nWin_total, N, C]."""
-    Bw, N, C = xw.shape
+def attention_core(qkv, table, heads, mask, rel_index):
+    """htsat.py:124-138 after the qkv Linear and before proj: qkv [nWin_total, N, 3C] -> [nWin_total, N, C]."""
+    Bw, N, C3 = qkv.shape
+    C = C3 // 3
     hd = C // heads
-    qkv = F.linear(xw, sd[pre + 'qkv.weight'], sd[pre + 'qkv.bias']).view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = qkv.view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
     attn = q @ k.transpose(-2, -1)
-    bias = sd[pre + 'relative_position_bias_table'][rel_index.reshape(-1)].view(N, N, heads).permute(2, 0, 1)
+    bias = table[rel_index.reshape(-1)].view(N, N, heads).permute(2, 0, 1)
     attn = attn + bias.unsqueeze(0)
     if mask is not None:
         nW = mask.shape[0]
         attn = (attn.view(Bw // nW, nW, heads, N, N) + mask[None, :, None]).view(-1, heads, N, N)
     attn = attn.softmax(dim=-1)
-    out = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
+    return (attn @ v).transpose(1, 2).reshape(Bw, N, C)
+
+
+def window_attention(xw, sd, pre, heads, mask, rel_index):
+    """htsat.py:112-145 on windows xw [nWin_total, N, C]."""
+    qkv = F.linear(xw, sd[pre + 'qkv.weight'], sd[pre + 'qkv.bias'])
+    out = attention_core(qkv, sd[pre + 'relative_position_bias_table'], heads, mask, rel_index)
     return F.linear(out, sd[pre + 'proj.weight'], sd[pre + 'proj.bias'])
+
+
+def to_windows(x, res, ws, shift):
+    """htsat.py:239-246: [B, res*res, C] natural order -> (shifted) windows [B*nW, ws*ws, C]."""
+    B, L, C = x.shape
+    y = x.view(B, res, res, C)
+    if shift > 0:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    return y.view(B, res // ws, ws, res // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+
+
+def from_windows(w, B, res, ws, shift):
+    """htsat.py:252-260: inverse of to_windows."""
+    C = w.shape[-1]
+    y = w.view(B, res // ws, res // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, res, res, C)
+    if shift > 0:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    return y.reshape(B, res * res, C)
 
 
 def swin_block(x, sd, pre, res, heads, ws, shift, rel_index, keep=None):

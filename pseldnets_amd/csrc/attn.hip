@@ -1,0 +1,559 @@
+// Swin (shifted-)window attention, forward and backward, for 8x8 windows with head_dim <= 32 on gfx950.
+//
+// Replaces (reference, /root/reference/src/models/components/htsat.py): window_partition/window_reverse :23-50,
+// the cyclic torch.roll(+-shift) :239-242,:257-260, WindowAttention.forward :118-138 (q*scale, q@k^T,
+// + relative_position_bias_table[relative_position_index], + attn_mask {0,-100}, softmax, @v, head merge) and
+// the autograd of all of it. qkv / out stay in NATURAL token order [B, res*res, 3C] / [B, res*res, C]: roll,
+// partition and reverse are folded into the window->token address map, the mask and the relative-position index
+// are recomputed from coordinates, and the [B*nW, h, 64, 64] score tensor never exists in HBM.
+//
+// One workgroup (4 waves) = one window x one group of 4 heads, one head per wave. The window's q|k|v (|dO) rows
+// are staged once into LDS with coalesced 16-byte loads; each wave then runs on MFMA 32x32 tiles:
+//   S^T = K Q^T (lane = query, so the softmax reduction is in-register + one cross-half shuffle),
+//   O   = P V with the S^T accumulators re-used directly as the A operand (no LDS round trip) and V read
+//         through ds_read_b64_tr_b16.
+// Backward recomputes P in both orientations (S^T for dQ and the bias gradient, S for dV/dK) so that no
+// accumulator tile ever needs a transpose; d(bias table) is summed in registers across all windows a workgroup
+// walks and flushed with one fp32 atomic tile per head per workgroup.
+// T = bf16 (v_mfma_f32_32x32x16_bf16) or f32 (v_mfma_f32_32x32x2_f32, parity mode) share every loader.
+//
+// Roofline: HBM-bound (reads 3C, writes C per token; ~100 flop/B at head_dim 24).
+#include "common.h"
+
+namespace {
+
+constexpr int HG = 4;  // heads per workgroup = waves per workgroup
+
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+
+template <typename T> struct AMma;
+template <> struct AMma<bf16_t> {
+    using Frag = bf16x8;
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ Frag keep_if(const Frag& f, bool live) {
+        f32x4 v = __builtin_bit_cast(f32x4, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = live ? v[i] : 0.f;
+        return __builtin_bit_cast(Frag, v);
+    }
+    static __device__ __forceinline__ Frag from_acc(const f32x16& a, int s) {
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (bf16_t)a[8 * s + j];
+        return f;
+    }
+    // 8 consecutive elements of one LDS row
+    static __device__ __forceinline__ Frag ld_row(const char* p) { return *(const bf16x8*)p; }
+    // element j = M[row0 + 8*(j>>2) + 4*h2 + (j&3)][col0 + (lane&31)]  (the k-order of an accumulator operand)
+    static __device__ __forceinline__ Frag ld_cols(const char* base, int strideB, int row0, int col0, int lane) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, gsel = (lane >> 4) & 1, h2 = lane >> 5;
+        const char* addr = base + (row0 + 4 * h2 + q) * strideB + (col0 + 16 * gsel + 4 * p) * 2;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 8 * strideB));
+        short8v s;
+        s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3];
+        s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, s);
+    }
+};
+struct AFragF32 { float v[8]; };
+template <> struct AMma<float> {
+    using Frag = AFragF32;
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ Frag keep_if(Frag f, bool live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.v[i] = live ? f.v[i] : 0.f;
+        return f;
+    }
+    static __device__ __forceinline__ Frag from_acc(const f32x16& a, int s) {
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = a[8 * s + j];
+        return f;
+    }
+    static __device__ __forceinline__ Frag ld_row(const char* p) {
+        const f32x4 a = ((const f32x4*)p)[0], b = ((const f32x4*)p)[1];
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+        return f;
+    }
+    static __device__ __forceinline__ Frag ld_cols(const char* base, int strideB, int row0, int col0, int lane) {
+        const int r = lane & 31, h2 = lane >> 5;
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            f.v[j] = *(const float*)(base + (row0 + 8 * (j >> 2) + 4 * h2 + (j & 3)) * strideB + (col0 + r) * 4);
+        return f;
+    }
+};
+
+struct AttnArgs {
+    const void* qkv;   // [B, L, 3C]
+    void* out;         // fwd: [B, L, C]
+    const void* dout;  // bwd: [B, L, C]
+    void* dqkv;        // bwd: [B, L, 3C]
+    const float* bias_table;  // [225, heads]
+    float* dbias_acc;         // bwd: [heads, 64(query), 64(key)] fp32, atomically accumulated
+    int B, res, C, heads, hd, shift;
+    int n_win_total;          // B * (res/8)^2
+    float scale;
+};
+
+// token index (natural order) of window slot t of window `w` of a res x res grid, plus its mask region label
+__device__ __forceinline__ void window_token(const AttnArgs& a, int wi, int t, long& tok, int& label) {
+    const int nwr = a.res >> 3;
+    const int nW = nwr * nwr;
+    const int b = wi / nW, w = wi - b * nW;
+    const int wy = w / nwr, wx = w - wy * nwr;
+    const int hs = wy * 8 + (t >> 3), ws = wx * 8 + (t & 7);
+    int oh = hs + a.shift, ow = ws + a.shift;
+    if (oh >= a.res) oh -= a.res;
+    if (ow >= a.res) ow -= a.res;
+    tok = (long)b * a.res * a.res + (long)oh * a.res + ow;
+    if (a.shift > 0) {
+        const int rh = hs < a.res - 8 ? 0 : (hs < a.res - a.shift ? 1 : 2);
+        const int rw = ws < a.res - 8 ? 0 : (ws < a.res - a.shift ? 1 : 2);
+        label = 3 * rh + rw;
+    } else {
+        label = 0;
+    }
+}
+
+__device__ __forceinline__ int rel_index(int qi, int ki) {
+    return ((qi >> 3) - (ki >> 3) + 7) * 15 + ((qi & 7) - (ki & 7) + 7);
+}
+
+// row held by accumulator register e of a 32x32 tile for lane half h2
+__device__ __forceinline__ int acc_row(int e, int h2) { return (e & 3) + 8 * (e >> 2) + 4 * h2; }
+
+// Cooperative copy of `nseg` column segments (each seg_elems wide, at global column gcol[s], LDS column lcol[s])
+// for the 64 tokens of a window between global rows and the LDS tile.
+template <typename T, bool TO_LDS>
+__device__ __forceinline__ void window_copy(char* tile, int strideB, T* gbase, int gld, int gcol, int lcol,
+                                            int seg_elems, const long* toks) {
+    const int cps = seg_elems >> 3;  // 8-element chunks per token
+    for (int c = threadIdx.x; c < 64 * cps; c += 256) {
+        const int t = c / cps, k = c - t * cps;
+        T* g = gbase + toks[t] * gld + gcol + k * 8;
+        char* l = tile + t * strideB + (lcol + k * 8) * (int)sizeof(T);
+        if constexpr (TO_LDS) {
+            if (sizeof(T) == 2) *(f32x4*)l = *(const f32x4*)g;
+            else { ((f32x4*)l)[0] = ((const f32x4*)g)[0]; ((f32x4*)l)[1] = ((const f32x4*)g)[1]; }
+        } else {
+            if (sizeof(T) == 2) *(f32x4*)g = *(const f32x4*)l;
+            else { ((f32x4*)g)[0] = ((const f32x4*)l)[0]; ((f32x4*)g)[1] = ((const f32x4*)l)[1]; }
+        }
+    }
+}
+
+// S-type product: acc[ta][tb] = sum_dims A[row][dim] * B[col][dim] for two 64-row LDS operands at column
+// offsets ca / cb (both "row-major, dims contiguous"). KS = number of 16-wide dim steps.
+template <typename T>
+__device__ __forceinline__ void qk_product(f32x16 (&acc)[2][2], const char* tile, int strideB, int ca, int cb, int hd,
+                                           int lane) {
+    using M = AMma<T>;
+    const int r = lane & 31, h2 = lane >> 5;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ta][tb][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = 16 * kk + 8 * h2;
+        typename M::Frag fa[2], fb[2];
+        // dims >= hd belong to the neighbouring head (or the row pad): read them anyway (in-bounds) and select
+        // zero, which keeps this loop branch-free
+        const bool live = d0 < hd;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[t] = M::ld_row(tile + (t * 32 + r) * strideB + (ca + d0) * (int)sizeof(T));
+            fb[t] = M::ld_row(tile + (t * 32 + r) * strideB + (cb + d0) * (int)sizeof(T));
+            fa[t] = M::keep_if(fa[t], live);
+            fb[t] = M::keep_if(fb[t], live);
+        }
+        if (16 * kk < hd) {
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) M::mma(fa[ta], fb[tb], acc[ta][tb]);
+        }
+    }
+}
+
+// Z = X^T * Bm : X given as accumulator tiles x[tr][tc] (rows tr*32.., cols tc*32..), Bm an LDS matrix
+// [64 rows][cols at col0..]; result z[tc] (rows = X's columns) [32 x 32(d)].
+template <typename T>
+__device__ __forceinline__ void xt_product(f32x16 (&z)[2], const f32x16 (&x)[2][2], const char* tile, int strideB,
+                                           int col0, int lane) {
+    using M = AMma<T>;
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[tc][e] = 0.f;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const typename M::Frag fb = M::ld_cols(tile, strideB, tr * 32 + 16 * s, col0, lane);
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) M::mma(M::from_acc(x[tr][tc], s), fb, z[tc]);
+        }
+}
+
+// store a [64 tokens][hd] result held as z[t] (row = token t*32 + acc_row, col = lane&31 = d) into LDS columns
+template <typename T>
+__device__ __forceinline__ void store_rows(char* tile, int strideB, int col0, const f32x16 (&z)[2], float mul, int hd,
+                                           int lane) {
+    const int d = lane & 31, h2 = lane >> 5;
+    if (d < hd) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                *(T*)(tile + (t * 32 + acc_row(e, h2)) * strideB + (col0 + d) * (int)sizeof(T)) = from_f32<T>(z[t][e] * mul);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hd = a.hd;
+    const int GW = HG * hd;                              // columns per q/k/v segment in the tile
+    const int strideB = 3 * GW * (int)sizeof(T) + 16;
+    char* tile = smem;
+    float* btab = (float*)(smem + 64 * strideB);          // [HG][225]
+    long* toks = (long*)(btab + HG * 225);                // [64]
+    int* labels = (int*)(toks + 64);                      // [64]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hg = blockIdx.y, wi = blockIdx.x;
+    const int head = hg * HG + wave;
+    const int heads_here = min(HG, a.heads - hg * HG);
+    const int r = lane & 31, h2 = lane >> 5;
+
+    if (threadIdx.x < 64) {
+        long tk; int lb;
+        window_token(a, wi, threadIdx.x, tk, lb);
+        toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
+    }
+    for (int i = threadIdx.x; i < heads_here * 225; i += 256) {
+        const int hh = i / 225, idx = i - hh * 225;
+        btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh];
+    }
+    __syncthreads();
+    const T* qkv = (const T*)a.qkv;
+    for (int sel = 0; sel < 3; ++sel)
+        window_copy<const T, true>(tile, strideB, qkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
+    __syncthreads();
+
+    if (head < a.heads) {
+        const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd;
+        f32x16 st[2][2];  // S^T tiles: [key tile][query tile]
+        qk_product<T>(st, tile, strideB, ck, cq, hd, lane);
+        const float* bt = btab + wave * 225;
+        float inv_l[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qi = qt * 32 + r;
+            const int ql = labels[qi];
+            const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
+            const int* labh = labels + 4 * h2;
+            float m = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    // key = kt*32 + (e&3) + 8*(e>>2) + 4*h2: its (y, x) = (kt*4 + (e>>2), (e&3) + 4*h2), so the
+                    // table index is a per-lane base minus a compile-time constant (one address register)
+                    float s = st[kt][qt][e] * a.scale + btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))];
+                    s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;   // labels are all 0 when shift == 0
+                    st[kt][qt][e] = s;
+                    m = fmaxf(m, s);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = __expf(st[kt][qt][e] - m);
+                    st[kt][qt][e] = p;
+                    l += p;
+                }
+            l += __shfl_xor(l, 32, 64);
+            inv_l[qt] = 1.f / l;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[kt][qt][e] *= inv_l[qt];
+        }
+        f32x16 o[2];
+        xt_product<T>(o, st, tile, strideB, cv, lane);     // O[query][d] = sum_key P^T[key][query] V[key][d]
+        store_rows<T>(tile, strideB, cq, o, 1.f, hd, lane);  // into this head's (dead) q columns
+    }
+    __syncthreads();
+    window_copy<T, false>(tile, strideB, (T*)a.out, a.C, hg * GW, 0, heads_here * hd, toks);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hd = a.hd;
+    const int GW = HG * hd;
+    const int strideB = 4 * GW * (int)sizeof(T) + 16;    // q | k | v | dO
+    char* tile = smem;
+    float* btab = (float*)(smem + 64 * strideB);          // [HG][225]
+    float* stat = btab + HG * 225;                        // [HG][64][3]: m, 1/l, delta
+    long* toks = (long*)(stat + HG * 64 * 3);
+    int* labels = (int*)(toks + 64);
+    const int dq_strideB = GW * (int)sizeof(T) + 16;
+    char* dqt = (char*)(labels + 64);                     // [64][GW] side tile for dQ
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hg = blockIdx.y;
+    const int head = hg * HG + wave;
+    const int heads_here = min(HG, a.heads - hg * HG);
+    const int r = lane & 31, h2 = lane >> 5;
+    const bool active = head < a.heads;
+
+    for (int i = threadIdx.x; i < heads_here * 225; i += 256) {
+        const int hh = i / 225, idx = i - hh * 225;
+        btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh];
+    }
+    f32x16 dsum[2][2];  // sum over windows of dS^T [key tile][query tile]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dsum[x][y][e] = 0.f;
+
+    const T* qkv = (const T*)a.qkv;
+    const T* dout = (const T*)a.dout;
+    const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd, cdo = 3 * GW + wave * hd;
+    const float* bt = btab + wave * 225;
+    float* st_w = stat + wave * 64 * 3;
+
+    for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x) {
+        __syncthreads();  // previous iteration's stores out of the tile are done
+        if (threadIdx.x < 64) {
+            long tk; int lb;
+            window_token(a, wi, threadIdx.x, tk, lb);
+            toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
+        }
+        __syncthreads();
+        for (int sel = 0; sel < 3; ++sel)
+            window_copy<const T, true>(tile, strideB, qkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
+        window_copy<const T, true>(tile, strideB, dout, a.C, hg * GW, 3 * GW, heads_here * hd, toks);
+        __syncthreads();
+
+        if (active) {
+            {
+                // ---- transposed orientation: rows = keys, lane = query ------------------------------------
+                f32x16 pt[2][2], dpt[2][2];
+                qk_product<T>(pt, tile, strideB, ck, cq, hd, lane);     // S^T = K Q^T
+                qk_product<T>(dpt, tile, strideB, cv, cdo, hd, lane);   // dP^T = V dO^T
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int qi = qt * 32 + r;
+                    const int ql = labels[qi];
+                    const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
+                    const int* labh = labels + 4 * h2;
+                    float m = -1e30f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float s = pt[kt][qt][e] * a.scale + btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))];
+                            s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;   // labels are all 0 when shift == 0
+                            pt[kt][qt][e] = s;
+                            m = fmaxf(m, s);
+                        }
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    float l = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = __expf(pt[kt][qt][e] - m);
+                            pt[kt][qt][e] = p;
+                            l += p;
+                        }
+                    l += __shfl_xor(l, 32, 64);
+                    const float il = 1.f / l;
+                    float delta = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            pt[kt][qt][e] *= il;
+                            delta += pt[kt][qt][e] * dpt[kt][qt][e];
+                        }
+                    delta += __shfl_xor(delta, 32, 64);
+                    if (h2 == 0) { st_w[qi * 3 + 0] = m; st_w[qi * 3 + 1] = il; st_w[qi * 3 + 2] = delta; }
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float ds = pt[kt][qt][e] * (dpt[kt][qt][e] - delta);
+                            dpt[kt][qt][e] = ds;               // dS^T
+                            dsum[kt][qt][e] += ds;
+                        }
+                }
+                f32x16 dq[2];
+                xt_product<T>(dq, dpt, tile, strideB, ck, lane);    // dQ[query][d] = sum_key dS^T[key][query] K[key][d]
+                store_rows<T>(dqt, dq_strideB, cq, dq, a.scale, hd, lane);   // side tile: q is still needed below
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the two orientations' live ranges apart
+            {
+                // ---- natural orientation: rows = queries, lane = key -----------------------------------------
+                f32x16 p[2][2], dp[2][2];
+                qk_product<T>(p, tile, strideB, cq, ck, hd, lane);      // S = Q K^T
+                qk_product<T>(dp, tile, strideB, cdo, cv, hd, lane);    // dP = dO V^T
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int ki = kt * 32 + r;
+                    const int kl = labels[ki];
+                    const float* btk = bt + 112 + 4 * h2 - (ki >> 3) * 15 - (ki & 7);
+                    const int* labh = labels + 4 * h2;
+                    const float* sth = st_w + 12 * h2;
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            // query = qt*32 + (e&3) + 8*(e>>2) + 4*h2 -> (y, x) = (qt*4 + (e>>2), (e&3) + 4*h2)
+                            const int qc = qt * 32 + (e & 3) + 8 * (e >> 2);
+                            float s = p[qt][kt][e] * a.scale + btk[(qt * 4 + (e >> 2)) * 15 + (e & 3)];
+                            s -= (labh[qc] != kl) ? 100.f : 0.f;
+                            const float pv = __expf(s - sth[qc * 3 + 0]) * sth[qc * 3 + 1];
+                            p[qt][kt][e] = pv;
+                            dp[qt][kt][e] = pv * (dp[qt][kt][e] - sth[qc * 3 + 2]);   // dS
+                        }
+                }
+                // v and k are dead once S, dP (above) and dQ (first half) exist: overwrite them in place
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 g[2];
+                xt_product<T>(g, p, tile, strideB, cdo, lane);      // dV[key][d] = sum_query P[query][key] dO[query][d]
+                store_rows<T>(tile, strideB, cv, g, 1.f, hd, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                xt_product<T>(g, dp, tile, strideB, cq, lane);      // dK[key][d] = sum_query dS[query][key] Q[query][d]
+                store_rows<T>(tile, strideB, ck, g, a.scale, hd, lane);
+            }
+        }
+        __syncthreads();
+        window_copy<T, false>(dqt, dq_strideB, (T*)a.dqkv, 3 * a.C, hg * GW, 0, heads_here * hd, toks);
+        for (int sel = 1; sel < 3; ++sel)
+            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
+    }
+    // flush d(bias) partial sums: dbias_acc[head][query][key] += dsum
+    if (active) {
+        float* dst = a.dbias_acc + (long)head * 4096;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    atomicAdd(dst + (qt * 32 + r) * 64 + kt * 32 + acc_row(e, h2), dsum[kt][qt][e]);
+    }
+}
+
+// dtable[idx][h] (+)= sum over (q,k) with rel_index(q,k) == idx of acc[h][q][k]
+__global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __restrict__ dtable, int heads, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 225 * heads) return;
+    const int idx = i / heads, h = i - idx * heads;
+    const int dy = idx / 15 - 7, dx = idx % 15 - 7;
+    float s = 0.f;
+    for (int qy = 0; qy < 8; ++qy) {
+        const int ky = qy - dy;
+        if (ky < 0 || ky > 7) continue;
+        for (int qx = 0; qx < 8; ++qx) {
+            const int kx = qx - dx;
+            if (kx < 0 || kx > 7) continue;
+            s += acc[(long)h * 4096 + (qy * 8 + qx) * 64 + ky * 8 + kx];
+        }
+    }
+    dtable[i] = accumulate ? dtable[i] + s : s;
+}
+
+template <typename T> size_t fwd_lds(int hd) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
+template <typename T> size_t bwd_lds(int hd) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + HG * 64 * 3 * 4 + 64 * 8 + 64 * 4 + 64 * (HG * hd * sizeof(T) + 16); }
+
+int check_args(const char* who, int B, int res, int C, int heads, int shift) {
+    PSELD_CHECK_ARG(B > 0 && res >= 8 && res % 8 == 0, "%s: grid side must be a multiple of 8 (got %d)", who, res);
+    PSELD_CHECK_ARG(heads > 0 && C % heads == 0, "%s: C %% heads != 0", who);
+    const int hd = C / heads;
+    PSELD_CHECK_ARG(hd % 8 == 0 && hd >= 8 && hd <= 32, "%s: head_dim must be 8..32 and a multiple of 8 (got %d)", who, hd);
+    PSELD_CHECK_ARG(shift == 0 || (shift == 4 && res > 8), "%s: shift must be 0 or 4 (and res > 8)", who);
+    return PSELD_OK;
+}
+
+}  // namespace
+
+extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, int B, int res,
+                                     int C, int heads, int shift, void* stream) {
+    PSELD_CHECK_ARG(qkv && bias_table && out, "window_attn_fwd: null pointer");
+    int rc = check_args("window_attn_fwd", B, res, C, heads, shift);
+    if (rc) return rc;
+    AttnArgs a; memset(&a, 0, sizeof(a));
+    a.qkv = qkv; a.out = out; a.bias_table = bias_table; a.B = B; a.res = res; a.C = C; a.heads = heads;
+    a.hd = C / heads; a.shift = shift; a.n_win_total = B * (res / 8) * (res / 8);
+    a.scale = 1.0f / sqrtf((float)a.hd);
+    dim3 grid(a.n_win_total, pseld_cdiv(heads, HG));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PSELD_BF16) {
+        hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), fwd_lds<bf16_t>(a.hd), s, a);
+    } else if (dtype == PSELD_F32) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), fwd_lds<float>(a.hd), s, a);
+    } else { pseld_set_error("window_attn_fwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    PSELD_LAUNCH_CHECK("window_attn_fwd");
+    return PSELD_OK;
+}
+
+extern "C" long pseld_window_attn_bwd_workspace(int heads) { return (long)heads * 4096 * (long)sizeof(float); }
+
+// dqkv [B,L,3C] from dout [B,L,C]; dbias_table f32[225, heads] (+)=. workspace: pseld_window_attn_bwd_workspace bytes.
+extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* dout, void* dqkv,
+                                     float* dbias_table, int B, int res, int C, int heads, int shift, int accumulate,
+                                     float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(qkv && bias_table && dout && dqkv && dbias_table && workspace, "window_attn_bwd: null pointer");
+    int rc = check_args("window_attn_bwd", B, res, C, heads, shift);
+    if (rc) return rc;
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_window_attn_bwd_workspace(heads), "window_attn_bwd: workspace too small");
+    AttnArgs a; memset(&a, 0, sizeof(a));
+    a.qkv = qkv; a.dout = dout; a.dqkv = dqkv; a.bias_table = bias_table; a.dbias_acc = workspace;
+    a.B = B; a.res = res; a.C = C; a.heads = heads; a.hd = C / heads; a.shift = shift;
+    a.n_win_total = B * (res / 8) * (res / 8);
+    a.scale = 1.0f / sqrtf((float)a.hd);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)heads * 4096 * sizeof(float), s) != hipSuccess) {
+        pseld_set_error("window_attn_bwd: memset failed"); return PSELD_ERR_HIP;
+    }
+    const int nhg = pseld_cdiv(heads, HG);
+    int slots = a.n_win_total < 768 ? a.n_win_total : 768;
+    dim3 grid(slots, nhg);
+    if (dtype == PSELD_BF16) {
+        hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, dim3(256), bwd_lds<bf16_t>(a.hd), s, a);
+    } else if (dtype == PSELD_F32) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, dim3(256), bwd_lds<float>(a.hd), s, a);
+    } else { pseld_set_error("window_attn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    PSELD_LAUNCH_CHECK("window_attn_bwd");
+    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);
+    PSELD_LAUNCH_CHECK("bias_table_grad");
+    return PSELD_OK;
+}

@@ -341,8 +341,9 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
                           void* stream) {
     PSELD_CHECK_ARG(A && B && C, "gemm: null operand");
     PSELD_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape %dx%dx%d", M, N, K);
-    PSELD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && K % 8 == 0, "gemm: lda/ldb/K must be multiples of 8 (%d,%d,%d)",
-                    lda, ldb, K);
+    PSELD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 (%d,%d)", lda, ldb);
+    // K %% 8 != 0 is allowed only for B = [K,N] (rows >= K are zero-filled) with A rows padded (finite) to 8
+    PSELD_CHECK_ARG(K % 8 == 0 || (trans_b && lda >= (K + 7) / 8 * 8), "gemm: K=%d must be a multiple of 8", K);
     PSELD_CHECK_ARG(!(trans_a && !trans_b), "gemm: layout A^T*B^T is not built");
     PSELD_CHECK_ARG(!trans_a, "gemm: use pseld_gemm_wgrad for the split-K weight-gradient layout");
     PSELD_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm: EPI_BIAS without bias");
@@ -385,8 +386,9 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
                                 long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(dY && X && dW && workspace, "gemm_wgrad: null pointer");
     PSELD_CHECK_ARG(Mtok > 0 && N > 0 && K > 0, "gemm_wgrad: bad shape");
-    PSELD_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && K % 8 == 0 && Mtok % 8 == 0,
-                    "gemm_wgrad: Mtok/N/K/ld must be multiples of 8 (%d,%d,%d,%d,%d)", Mtok, N, K, lddy, ldx);
+    PSELD_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && K % 8 == 0,
+                    "gemm_wgrad: K/ld must be multiples of 8 (%d,%d,%d)", K, lddy, ldx);
+    PSELD_CHECK_ARG(N % 8 == 0 || lddy >= (N + 7) / 8 * 8, "gemm_wgrad: N=%d needs dY rows padded to 8", N);
     PSELD_CHECK_ARG(lddw == K, "gemm_wgrad: dW must be dense [N,K]");
     int splits = 1;
     const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, &splits);

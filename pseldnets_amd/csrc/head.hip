@@ -1,0 +1,420 @@
+// HTS-AT output head around the tscam GEMM, the SELD losses, and the fused clip + AdamW step.
+//
+// Replaces (reference, /root/reference/src):
+//   models/components/htsat.py:526-534 (tokens -> [B, C, SF=2, 32] feature map) and the im2col of
+//   models/accdoa.py:230 tscam_conv Conv2d(C -> D, (2, 3), padding (0, 1));
+//   models/accdoa.py:231-242: flatten/permute, interpolate(x32, bilinear), crop 1000, reshape(100, 10).mean, tanh
+//   — the interpolate∘crop∘mean chain is one fixed sparse [100 x 32] linear map (<= 3 taps per row), so the
+//   [B, 1024, D] up-sampled tensor is never materialised;
+//   loss/multi_accdoa.py:16-105 (ADPIT), loss/accdoa.py:15-22 (MSE), loss/einv2.py:59-116 (track-wise PIT);
+//   torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW as driven by models/components/model_module.py:128-146
+//   and configs/trainer/default.yaml:26.
+// All HBM-bound streaming kernels; losses and optimiser state are fp32.
+#include "common.h"
+
+void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
+                        hipStream_t stream);
+
+namespace {
+
+// ---- head im2col: A[(b, tt)][c*6 + cf*3 + dt] = tok[b][ (2*g + cf)*8 + w ][c], tt + dt - 1 = 8*g + w ------------
+template <typename T>
+__global__ void head_im2col_kernel(const T* __restrict__ tok, T* __restrict__ A, int B, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, tt, c)
+    const long total = (long)B * 32 * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int tt = (int)((i / C) % 32);
+    const long b = i / ((long)C * 32);
+    T* dst = A + (b * 32 + tt) * (long)(C * 6) + c * 6;
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int ts = tt + dt - 1;
+            T v = from_f32<T>(0.f);
+            if (ts >= 0 && ts < 32) v = tok[(b * 64 + (2 * (ts >> 3) + cf) * 8 + (ts & 7)) * C + c];
+            dst[cf * 3 + dt] = v;
+        }
+}
+// transpose of the above (gather form): dtok[b][n][c] = sum_dt dA[(b, ts - dt + 1)][c*6 + cf*3 + dt]
+template <typename T>
+__global__ void head_col2im_kernel(const T* __restrict__ dA, T* __restrict__ dtok, int B, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, n, c)
+    const long total = (long)B * 64 * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int n = (int)((i / C) % 64);
+    const long b = i / ((long)C * 64);
+    const int hh = n >> 3, w = n & 7, g = hh >> 1, cf = hh & 1;
+    const int ts = 8 * g + w;
+    float s = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        const int tt = ts - dt + 1;
+        if (tt >= 0 && tt < 32) s += to_f32<T>(dA[(b * 32 + tt) * (long)(C * 6) + c * 6 + cf * 3 + dt]);
+    }
+    dtok[i] = from_f32<T>(s);
+}
+
+// ---- pooled output: y[b][f][d] = act( sum_j w[f][j] * z[b][i0[f] + j][d] ) -------------------------------------
+template <typename T>
+__global__ void head_pool_fwd_kernel(const T* __restrict__ z, float* __restrict__ y, const int* __restrict__ i0,
+                                     const float* __restrict__ w, int B, int D, int ldz, int n_out, int n_in, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, f, d)
+    const long total = (long)B * n_out * D;
+    if (i >= total) return;
+    const int d = (int)(i % D);
+    const int f = (int)((i / D) % n_out);
+    const long b = i / ((long)D * n_out);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tt = i0[f] + j;
+        if (tt < n_in) s += w[f * 3 + j] * to_f32<T>(z[(b * n_in + tt) * ldz + d]);
+    }
+    y[i] = act ? tanhf(s) : s;
+}
+// dz[b][tt][d] = sum over taps (f, wgt) of column tt: wgt * dy[b][f][d] * act'(y[b][f][d]); pad columns zeroed
+template <typename T>
+__global__ void head_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* __restrict__ dz,
+                                     const int* __restrict__ t_cnt, const int* __restrict__ t_f,
+                                     const float* __restrict__ t_w, int B, int D, int ldz, int n_out, int n_in, int act,
+                                     int max_taps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, tt, dcol < ldz)
+    const long total = (long)B * n_in * ldz;
+    if (i >= total) return;
+    const int d = (int)(i % ldz);
+    const int tt = (int)((i / ldz) % n_in);
+    const long b = i / ((long)ldz * n_in);
+    float s = 0.f;
+    if (d < D) {
+        const int cnt = t_cnt[tt];
+        for (int k = 0; k < cnt; ++k) {
+            const int f = t_f[tt * max_taps + k];
+            const long o = (b * n_out + f) * D + d;
+            float g = dy[o];
+            if (act) { const float yv = y[o]; g *= (1.f - yv * yv); }
+            s += t_w[tt * max_taps + k] * g;
+        }
+    }
+    dz[i] = from_f32<T>(s);
+}
+
+// ---- ADPIT loss (forward value + gradient in one pass) --------------------------------------------------------
+// pred [B*T, 9, C] (row stride ldp), label [B*T, 6, 4, C]; one thread per (row, class).
+__global__ __launch_bounds__(256) void adpit_kernel(const float* __restrict__ pred, const float* __restrict__ label,
+                                                    float* __restrict__ dpred, float* __restrict__ partial, long rows,
+                                                    int C, int ldp, float inv_count) {
+    __shared__ float red[4];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float lossv = 0.f;
+    if (i < rows * C) {
+        const int c = (int)(i % C);
+        const long row = i / C;
+        float p[9], t[6][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p[k] = pred[row * ldp + k * C + c];
+#pragma unroll
+        for (int tr = 0; tr < 6; ++tr) {
+            const float* l = label + ((row * 6 + tr) * 4) * C + c;
+            const float act = l[0];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) t[tr][ax] = act * l[(ax + 1) * C];
+        }
+        // slots (track 0..2) x axis; candidate = arrangement + pad, written exactly as the reference sums them
+        static const int ARR[13][3] = {{0, 0, 0}, {1, 1, 2}, {1, 2, 1}, {1, 2, 2}, {2, 1, 1}, {2, 1, 2}, {2, 2, 1},
+                                       {3, 4, 5}, {3, 5, 4}, {4, 3, 5}, {4, 5, 3}, {5, 3, 4}, {5, 4, 3}};
+        float best = 0.f;
+        int bi = 0;
+        float tgt_best[9];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            float tg[9];
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const float aaa = t[0][ax];
+                    const float bbb = t[s < 2 ? 1 : 2][ax];      // B0 B0 B1
+                    const float ccc = t[3 + s][ax];              // C0 C1 C2
+                    const float pad = (k == 0) ? (bbb + ccc) : (k < 7 ? (aaa + ccc) : (aaa + bbb));
+                    const float v = t[ARR[k][s]][ax] + pad;
+                    tg[s * 3 + ax] = v;
+                    const float d = p[s * 3 + ax] - v;
+                    acc += d * d;
+                }
+            const float m = acc / 9.f;
+            if (k == 0 || m < best) {
+                best = m; bi = k;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) tgt_best[q] = tg[q];
+            }
+        }
+        (void)bi;
+        lossv = best;
+        const float gs = 2.f / 9.f * inv_count;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dpred[row * ldp + k * C + c] = gs * (p[k] - tgt_best[k]);
+    }
+    lossv = wave_sum(lossv);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lossv;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                  float* __restrict__ dpred, float* __restrict__ partial, long n,
+                                                  float inv_count) {
+    __shared__ float red[4];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    if (i < n) {
+        const float d = pred[i] - target[i];
+        l = d * d;
+        dpred[i] = 2.f * d * inv_count;
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void scalar_finish_kernel(const float* __restrict__ partial, int n, float scale, float* out) {
+    // single block; deterministic tree over the per-block partials
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// ---- track-wise PIT (EINV2): one thread per (b, t) ---------------------------------------------------------
+// sed logits [rows, 3, C], doa [rows, 3, 3], labels same shapes. out3 = mean over rows of (all, sed, doa).
+__global__ __launch_bounds__(256) void tpit_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
+                                                   const float* __restrict__ sed_l, const float* __restrict__ doa_l,
+                                                   float* __restrict__ dsed, float* __restrict__ ddoa,
+                                                   float* __restrict__ partial, long rows, int C, float beta, float inv_rows) {
+    __shared__ float red[3][4];
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float l_all = 0.f, l_sed = 0.f, l_doa = 0.f;
+    if (row < rows) {
+        // pairwise costs: bce[i][j] = mean_c BCE(sed[i], label[j]); mse[i][j] = mean_xyz (doa[i]-label[j])^2
+        float bce[3][3], mse[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { bce[i][j] = 0.f; mse[i][j] = 0.f; }
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float x = sed[(row * 3 + i) * C + c];
+                const float sp = fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));   // softplus(x) = BCE(x, 0)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bce[i][j] += sp - x * sed_l[(row * 3 + j) * C + c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { const float d = doa[(row * 3 + i) * 3 + a] - doa_l[(row * 3 + j) * 3 + a]; s += d * d; }
+                mse[i][j] = s;
+            }
+        static const int PERM[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+        float best = 0.f, bs = 0.f, bd = 0.f;
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float ls = (bce[0][PERM[k][0]] + bce[1][PERM[k][1]] + bce[2][PERM[k][2]]) / (3.f * C);
+            const float ld = (mse[0][PERM[k][0]] + mse[1][PERM[k][1]] + mse[2][PERM[k][2]]) / 9.f;
+            const float tot = beta * ls + (1.f - beta) * ld;
+            if (k == 0 || tot < best) { best = tot; bs = ls; bd = ld; bi = k; }
+        }
+        l_all = best; l_sed = bs; l_doa = bd;
+        const float gs = beta * inv_rows / (3.f * C), gd = (1.f - beta) * inv_rows * 2.f / 9.f;
+        for (int i = 0; i < 3; ++i) {
+            const int j = PERM[bi][i];
+            for (int c = 0; c < C; ++c) {
+                const float x = sed[(row * 3 + i) * C + c];
+                const float sg = 1.f / (1.f + __expf(-x));
+                dsed[(row * 3 + i) * C + c] = gs * (sg - sed_l[(row * 3 + j) * C + c]);
+            }
+            for (int a = 0; a < 3; ++a)
+                ddoa[(row * 3 + i) * 3 + a] = gd * (doa[(row * 3 + i) * 3 + a] - doa_l[(row * 3 + j) * 3 + a]);
+        }
+    }
+    l_all = wave_sum(l_all); l_sed = wave_sum(l_sed); l_doa = wave_sum(l_doa);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l_all; red[1][threadIdx.x >> 6] = l_sed; red[2][threadIdx.x >> 6] = l_doa; }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[(long)threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// ---- optimiser -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = g[i]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void norm_finish_kernel(const float* __restrict__ partial, int n, float* out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = sqrtf(red[0]);
+}
+// p, m, v fp32 in place; optional shadow copy of the new weights in bf16. grad_norm is a DEVICE scalar (the
+// global L2 norm, possibly all-reduced); clip coefficient = min(1, max_norm / (norm + 1e-6)) as clip_grad_norm_.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ shadow, long n, const float* __restrict__ grad_norm, float max_norm,
+                             float grad_scale, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float coef = grad_scale;
+    if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (grad_norm[0] * grad_scale + 1e-6f));
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = (bf16_t)pi;
+}
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (bf16_t)x[i];
+}
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)                                              \
+    if (dtype == PSELD_BF16) { CALL_BF16; } else if (dtype == PSELD_F32) { CALL_F32; }           \
+    else { pseld_set_error("%s: unknown dtype %d", who, dtype); return PSELD_ERR_BAD_ARG; }
+
+}  // namespace
+
+extern "C" int pseld_head_im2col(int dtype, const void* tok, void* A, int B, int C, void* stream) {
+    PSELD_CHECK_ARG(tok && A && B > 0 && C > 0, "head_im2col: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * 32 * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_im2col_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)tok, (bf16_t*)A, B, C),
+               hipLaunchKernelGGL(head_im2col_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const float*)tok, (float*)A, B, C), "head_im2col");
+    PSELD_LAUNCH_CHECK("head_im2col");
+    return PSELD_OK;
+}
+extern "C" int pseld_head_col2im(int dtype, const void* dA, void* dtok, int B, int C, void* stream) {
+    PSELD_CHECK_ARG(dA && dtok && B > 0 && C > 0, "head_col2im: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * 64 * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_col2im_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)dA, (bf16_t*)dtok, B, C),
+               hipLaunchKernelGGL(head_col2im_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const float*)dA, (float*)dtok, B, C), "head_col2im");
+    PSELD_LAUNCH_CHECK("head_col2im");
+    return PSELD_OK;
+}
+extern "C" int pseld_head_pool_fwd(int dtype, const void* z, float* y, const int* i0, const float* w, int B, int D, int ldz,
+                                   int n_out, int n_in, int act_tanh, void* stream) {
+    PSELD_CHECK_ARG(z && y && i0 && w && B > 0 && D > 0 && ldz >= D, "head_pool_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * n_out * D;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_fwd_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh),
+               hipLaunchKernelGGL(head_pool_fwd_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const float*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh), "head_pool_fwd");
+    PSELD_LAUNCH_CHECK("head_pool_fwd");
+    return PSELD_OK;
+}
+extern "C" int pseld_head_pool_bwd(int dtype, const float* dy, const float* y, void* dz, const int* t_cnt, const int* t_f,
+                                   const float* t_w, int B, int D, int ldz, int n_out, int n_in, int act_tanh, int max_taps,
+                                   void* stream) {
+    PSELD_CHECK_ARG(dy && y && dz && t_cnt && t_f && t_w && ldz >= D, "head_pool_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * n_in * ldz;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, dy, y, (bf16_t*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps),
+               hipLaunchKernelGGL(head_pool_bwd_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, dy, y, (float*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps), "head_pool_bwd");
+    PSELD_LAUNCH_CHECK("head_pool_bwd");
+    return PSELD_OK;
+}
+
+// loss_out[0] = ADPIT loss (mean over B*T*C of the class-wise minimum); dpred = d loss / d pred (same layout as pred).
+// workspace >= ceil(rows*C/256) floats.
+extern "C" int pseld_adpit_loss(const float* pred, const float* label, float* dpred, float* loss_out, long rows, int C,
+                                int ldp, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(pred && label && dpred && loss_out && workspace && rows > 0 && C > 0 && ldp >= 9 * C, "adpit_loss: bad arguments");
+    const int nb = pseld_cdiv(rows * C, 256);
+    PSELD_CHECK_ARG(workspace_bytes >= (long)nb * 4, "adpit_loss: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const float inv = 1.f / ((float)rows * (float)C);
+    hipLaunchKernelGGL(adpit_kernel, dim3(nb), dim3(256), 0, s, pred, label, dpred, workspace, rows, C, ldp, inv);
+    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, workspace, nb, inv, loss_out);
+    PSELD_LAUNCH_CHECK("adpit_loss");
+    return PSELD_OK;
+}
+extern "C" int pseld_mse_loss(const float* pred, const float* target, float* dpred, float* loss_out, long n,
+                              float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(pred && target && dpred && loss_out && workspace && n > 0, "mse_loss: bad arguments");
+    const int nb = pseld_cdiv(n, 256);
+    PSELD_CHECK_ARG(workspace_bytes >= (long)nb * 4, "mse_loss: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const float inv = 1.f / (float)n;
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, s, pred, target, dpred, workspace, n, inv);
+    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, workspace, nb, inv, loss_out);
+    PSELD_LAUNCH_CHECK("mse_loss");
+    return PSELD_OK;
+}
+// loss_out[0..2] = (loss_all, loss_sed, loss_doa) means over rows = B*T. workspace >= 3*ceil(rows/256) floats.
+extern "C" int pseld_tpit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label,
+                               float* dsed, float* ddoa, float* loss_out, long rows, int C, float beta, float* workspace,
+                               long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(sed && doa && sed_label && doa_label && dsed && ddoa && loss_out && workspace && rows > 0, "tpit_loss: bad arguments");
+    const int nb = pseld_cdiv(rows, 256);
+    PSELD_CHECK_ARG(workspace_bytes >= (long)nb * 12, "tpit_loss: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const float inv = 1.f / (float)rows;
+    hipLaunchKernelGGL(tpit_kernel, dim3(nb), dim3(256), 0, s, sed, doa, sed_label, doa_label, dsed, ddoa, workspace, rows, C, beta, inv);
+    for (int k = 0; k < 3; ++k)
+        hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, workspace + (long)k * nb, nb, inv, loss_out + k);
+    PSELD_LAUNCH_CHECK("tpit_loss");
+    return PSELD_OK;
+}
+
+// norm_out[0] = ||g||_2 (device scalar). workspace >= 1024 floats.
+extern "C" int pseld_grad_norm(const float* g, long n, float* norm_out, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(g && norm_out && workspace && n > 0 && workspace_bytes >= 1024 * 4, "grad_norm: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = pseld_cdiv(n, 256 * 16);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, g, n, workspace);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, workspace, nb, norm_out);
+    PSELD_LAUNCH_CHECK("grad_norm");
+    return PSELD_OK;
+}
+// One fused clip + AdamW step over a flat parameter arena (step is 1-based). shadow_bf16 may be null.
+extern "C" int pseld_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n,
+                                const float* grad_norm, float max_norm, float grad_scale, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, void* stream) {
+    PSELD_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad arguments");
+    PSELD_CHECK_ARG(max_norm <= 0.f || grad_norm, "adamw_step: clipping needs the device grad norm");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n,
+                       grad_norm, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    PSELD_LAUNCH_CHECK("adamw_step");
+    return PSELD_OK;
+}
+extern "C" int pseld_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+    PSELD_CHECK_ARG(x && y && n > 0, "cast: bad arguments");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    PSELD_LAUNCH_CHECK("cast_f32_to_bf16");
+    return PSELD_OK;
+}

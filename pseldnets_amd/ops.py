@@ -104,3 +104,256 @@ def colsum(x, out, accumulate=False):
                         _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_colsum")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LayerNorm
+def layernorm_fwd(x, gamma, beta, merge_res=0, eps=1e-5, out_rows=None):
+    """x [M, C] -> LN(x); merge mode: x is the token grid [B*res*res, Cs], output rows [B*(res/2)^2, 4*Cs]."""
+    _chk(x, gamma, beta)
+    if merge_res:
+        Cs = x.shape[1]
+        M, C = x.shape[0] // 4, 4 * Cs
+    else:
+        M, C = x.shape
+    y = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    rc = _lib.lib().pseld_layernorm_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y),
+                                        None, None, M, C, merge_res, eps, _lib.stream_ptr())
+    _lib.check(rc, "pseld_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, gamma, dgamma, dbeta, dres=None, merge_res=0, eps=1e-5, accumulate=False):
+    """Returns dx (same geometry as x). dgamma/dbeta (fp32) are overwritten or accumulated."""
+    _chk(dy, x, gamma, dgamma, dbeta, dres)
+    M, C = dy.shape
+    L = _lib.lib()
+    need = L.pseld_layernorm_bwd_workspace(M, C)
+    ws = workspace(need, dy.device)
+    dx = torch.empty_like(x)
+    rc = L.pseld_layernorm_bwd(dtype_code(dy), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx),
+                               _lib.ptr(dgamma), _lib.ptr(dbeta), M, C, merge_res, eps, int(accumulate), _lib.ptr(ws),
+                               ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_layernorm_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scalar BatchNorm + fold + patchify
+def bn_scalar_stats(feat, centered=True):
+    """feat f32[B, Cin, T, 64] -> sums f32[3*Cin*64] (see header)."""
+    _chk(feat)
+    B, Cin, T, F = feat.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_bn_scalar_workspace(B, Cin, T), feat.device)
+    sums = torch.zeros(3 * Cin * F, dtype=torch.float32, device=feat.device)
+    rc = L.pseld_bn_scalar_stats(_lib.ptr(feat), _lib.ptr(sums), B, Cin, T, F, int(centered), _lib.ptr(ws),
+                                 ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_bn_scalar_stats")
+    return sums
+
+
+def bn_scalar_finalize(sums, count, centered, weight, bias, running_mean, running_var, num_batches, training,
+                       momentum=0.1, eps=1e-5):
+    """weight/bias/running_* f32[Cin*64] (contiguous over channels), num_batches int64[Cin]."""
+    Cin = weight.numel() // 64
+    mean_rstd = torch.empty(Cin * 64 * 2, dtype=torch.float32, device=weight.device)
+    scale_shift = torch.empty(Cin * 64 * 2, dtype=torch.float32, device=weight.device)
+    rc = _lib.lib().pseld_bn_scalar_finalize(_lib.ptr(sums), float(count), int(centered), _lib.ptr(weight), _lib.ptr(bias),
+                                             _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches),
+                                             _lib.ptr(mean_rstd), _lib.ptr(scale_shift), Cin, 64, momentum, eps,
+                                             int(training), _lib.stream_ptr())
+    _lib.check(rc, "pseld_bn_scalar_finalize")
+    return mean_rstd, scale_shift
+
+
+def bn_fold_patchify(feat, scale_shift, dtype, c_first=0, c_use=None):
+    _chk(feat, scale_shift)
+    B, Cin, T, F = feat.shape
+    c_use = Cin if c_use is None else c_use
+    A = torch.empty((B * 4096, c_use * 16), dtype=dtype, device=feat.device)
+    rc = _lib.lib().pseld_bn_fold_patchify(_DT[dtype], _lib.ptr(feat), _lib.ptr(scale_shift), _lib.ptr(A), B, Cin, c_first,
+                                           c_use, T, _lib.stream_ptr())
+    _lib.check(rc, "pseld_bn_fold_patchify")
+    return A
+
+
+def bn_scalar_bwd(feat, mean_rstd, dA, dweight, dbias, c_first=0, accumulate=False):
+    _chk(feat, mean_rstd, dA, dweight, dbias)
+    B, Cin, T, F = feat.shape
+    c_use = dA.shape[1] // 16
+    L = _lib.lib()
+    ws = workspace(L.pseld_bn_scalar_bwd_workspace(B, c_use), feat.device)
+    rc = L.pseld_bn_scalar_bwd(dtype_code(dA), _lib.ptr(feat), _lib.ptr(mean_rstd), _lib.ptr(dA), _lib.ptr(dweight),
+                               _lib.ptr(dbias), B, Cin, c_first, c_use, T, int(accumulate), _lib.ptr(ws), ws.numel() * 4,
+                               _lib.stream_ptr())
+    _lib.check(rc, "pseld_bn_scalar_bwd")
+
+
+def rowscale(x, scale, elems_per_scale):
+    _chk(x, scale)
+    y = torch.empty_like(x)
+    rc = _lib.lib().pseld_rowscale(dtype_code(x), _lib.ptr(x), _lib.ptr(scale), _lib.ptr(y), x.numel(), elems_per_scale,
+                                   _lib.stream_ptr())
+    _lib.check(rc, "pseld_rowscale")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# window attention
+def window_attn_fwd(qkv, bias_table, B, res, heads, shift):
+    _chk(qkv, bias_table)
+    C = qkv.shape[1] // 3
+    out = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
+    rc = _lib.lib().pseld_window_attn_fwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(out), B, res, C,
+                                          heads, shift, _lib.stream_ptr())
+    _lib.check(rc, "pseld_window_attn_fwd")
+    return out
+
+
+def window_attn_bwd(qkv, bias_table, dout, dbias_table, B, res, heads, shift, accumulate=False):
+    _chk(qkv, bias_table, dout, dbias_table)
+    C = qkv.shape[1] // 3
+    L = _lib.lib()
+    ws = workspace(L.pseld_window_attn_bwd_workspace(heads), qkv.device)
+    dqkv = torch.empty_like(qkv)
+    rc = L.pseld_window_attn_bwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(dout), _lib.ptr(dqkv),
+                                 _lib.ptr(dbias_table), B, res, C, heads, shift, int(accumulate), _lib.ptr(ws),
+                                 ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_window_attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------------------
+# head
+def pool_taps(n_in=32, ratio=32, n_keep=1000, group=10):
+    """The interpolate(x`ratio`, bilinear, align_corners=False) -> crop -> mean(group) chain of
+    models/accdoa.py:236-240 as a sparse [n_keep/group, n_in] map in both compact forms the kernels take."""
+    n_out = n_keep // group
+    P = [[0.0] * n_in for _ in range(n_out)]
+    for o in range(n_keep):
+        src = (o + 0.5) / ratio - 0.5
+        src = max(src, 0.0)
+        i0 = min(int(src), n_in - 1)
+        i1 = min(i0 + 1, n_in - 1)
+        l1 = src - i0
+        P[o // group][i0] += (1.0 - l1) / group
+        P[o // group][i1] += l1 / group
+    i0s, ws = [], []
+    for f in range(n_out):
+        nz = [i for i, v in enumerate(P[f]) if v != 0.0]
+        a = nz[0]
+        assert nz[-1] - a <= 2
+        i0s.append(a)
+        ws.extend([P[f][a + j] if a + j < n_in else 0.0 for j in range(3)])
+    max_taps = max(sum(1 for f in range(n_out) if P[f][t] != 0.0) for t in range(n_in))
+    t_cnt, t_f, t_w = [], [], []
+    for t in range(n_in):
+        fs = [f for f in range(n_out) if P[f][t] != 0.0]
+        t_cnt.append(len(fs))
+        t_f.extend(fs + [0] * (max_taps - len(fs)))
+        t_w.extend([P[f][t] for f in fs] + [0.0] * (max_taps - len(fs)))
+    return dict(n_in=n_in, n_out=n_out, max_taps=max_taps, dense=torch.tensor(P, dtype=torch.float32),
+                i0=torch.tensor(i0s, dtype=torch.int32), w=torch.tensor(ws, dtype=torch.float32),
+                t_cnt=torch.tensor(t_cnt, dtype=torch.int32), t_f=torch.tensor(t_f, dtype=torch.int32),
+                t_w=torch.tensor(t_w, dtype=torch.float32))
+
+
+def head_im2col(tok, B):
+    _chk(tok)
+    C = tok.shape[1]
+    A = torch.empty((B * 32, C * 6), dtype=tok.dtype, device=tok.device)
+    _lib.check(_lib.lib().pseld_head_im2col(dtype_code(tok), _lib.ptr(tok), _lib.ptr(A), B, C, _lib.stream_ptr()), "pseld_head_im2col")
+    return A
+
+
+def head_col2im(dA, B):
+    _chk(dA)
+    C = dA.shape[1] // 6
+    dtok = torch.empty((B * 64, C), dtype=dA.dtype, device=dA.device)
+    _lib.check(_lib.lib().pseld_head_col2im(dtype_code(dA), _lib.ptr(dA), _lib.ptr(dtok), B, C, _lib.stream_ptr()), "pseld_head_col2im")
+    return dtok
+
+
+def head_pool_fwd(z, taps, B, D, act_tanh):
+    _chk(z)
+    y = torch.empty((B, taps['n_out'], D), dtype=torch.float32, device=z.device)
+    rc = _lib.lib().pseld_head_pool_fwd(dtype_code(z), _lib.ptr(z), _lib.ptr(y), _lib.ptr(taps['i0']), _lib.ptr(taps['w']), B, D,
+                                        z.stride(0), taps['n_out'], taps['n_in'], int(act_tanh), _lib.stream_ptr())
+    _lib.check(rc, "pseld_head_pool_fwd")
+    return y
+
+
+def head_pool_bwd(dy, y, taps, B, D, ldz, dtype, act_tanh):
+    _chk(dy, y)
+    dz = torch.empty((B * taps['n_in'], ldz), dtype=dtype, device=dy.device)
+    rc = _lib.lib().pseld_head_pool_bwd(_DT[dtype], _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dz), _lib.ptr(taps['t_cnt']),
+                                        _lib.ptr(taps['t_f']), _lib.ptr(taps['t_w']), B, D, ldz, taps['n_out'], taps['n_in'],
+                                        int(act_tanh), taps['max_taps'], _lib.stream_ptr())
+    _lib.check(rc, "pseld_head_pool_bwd")
+    return dz
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses and optimiser
+def adpit_loss(pred, label):
+    """pred f32[B, T, 9*C], label f32[B, T, 6, 4, C] -> (loss f32[1], dpred like pred)."""
+    _chk(pred, label)
+    B, T = pred.shape[:2]
+    C = label.shape[-1]
+    rows = B * T
+    ws = workspace(((rows * C + 255) // 256) * 4, pred.device)
+    dpred = torch.empty_like(pred)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    rc = _lib.lib().pseld_adpit_loss(_lib.ptr(pred), _lib.ptr(label), _lib.ptr(dpred), _lib.ptr(loss), rows, C, pred.stride(1),
+                                     _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_adpit_loss")
+    return loss, dpred
+
+
+def mse_loss(pred, target):
+    _chk(pred, target)
+    n = pred.numel()
+    ws = workspace(((n + 255) // 256) * 4, pred.device)
+    dpred = torch.empty_like(pred)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    rc = _lib.lib().pseld_mse_loss(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(dpred), _lib.ptr(loss), n, _lib.ptr(ws),
+                                   ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_mse_loss")
+    return loss, dpred
+
+
+def tpit_loss(sed, doa, sed_label, doa_label, beta):
+    _chk(sed, doa, sed_label, doa_label)
+    B, T, _, C = sed.shape
+    rows = B * T
+    ws = workspace(((rows + 255) // 256) * 12, sed.device)
+    dsed, ddoa = torch.empty_like(sed), torch.empty_like(doa)
+    loss = torch.empty(3, dtype=torch.float32, device=sed.device)
+    rc = _lib.lib().pseld_tpit_loss(_lib.ptr(sed), _lib.ptr(doa), _lib.ptr(sed_label), _lib.ptr(doa_label), _lib.ptr(dsed),
+                                    _lib.ptr(ddoa), _lib.ptr(loss), rows, C, beta, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_tpit_loss")
+    return loss, dsed, ddoa
+
+
+def grad_norm(g, out=None):
+    _chk(g)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=g.device)
+    ws = workspace(4096, g.device)
+    _lib.check(_lib.lib().pseld_grad_norm(_lib.ptr(g), g.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "pseld_grad_norm")
+    return out
+
+
+def adamw_step(p, g, m, v, step, lr, grad_norm_t=None, max_norm=0.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8,
+               weight_decay=0.01, shadow=None):
+    _chk(p, g, m, v, grad_norm_t, shadow)
+    rc = _lib.lib().pseld_adamw_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(shadow), p.numel(),
+                                     _lib.ptr(grad_norm_t), max_norm, grad_scale, lr, betas[0], betas[1], eps, weight_decay,
+                                     step, _lib.stream_ptr())
+    _lib.check(rc, "pseld_adamw_step")
+
+
+def cast_bf16(x, y):
+    _chk(x, y)
+    _lib.check(_lib.lib().pseld_cast_f32_to_bf16(_lib.ptr(x), _lib.ptr(y), x.numel(), _lib.stream_ptr()), "pseld_cast_f32_to_bf16")

@@ -1,0 +1,225 @@
+"""Per-kernel parity of the HIP ops (through the C ABI) against the CPU oracle on seeded inputs.
+Tolerances (max-abs error relative to the reference tensor's max-abs): f32 mode 2e-5 (exact-f32 MFMA, fp32
+reductions in a different order), bf16 mode 2e-2 (inputs are bf16-rounded identically on both sides; outputs are
+rounded to bf16)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import htsat as oh
+from oracle import losses as ol
+from oracle import optim as oo
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(*shape, generator=g)).to(dtype)
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+def check(name, got, ref, t):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    err = (got - ref).abs().max().item()
+    rel = err / max(ref.abs().max().item(), 1e-30)
+    print(f"{name}: max|d|={err:.3e} rel={rel:.3e}")
+    assert rel < t, name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(300, 96), (257, 192), (100, 384), (70, 768), (33, 1536), (64, 48)])
+def test_layernorm(dev, dtype, M, C):
+    from pseldnets_amd import ops
+    x, g, b, dy = rnd((M, C), 1, dtype), 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3), rnd((M, C), 4, dtype)
+    dres = rnd((M, C), 5, dtype)
+    y = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev))
+    xr = x.double().requires_grad_(True); gr = g.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    check("ln fwd", y, yr, tol(dtype))
+    yr.backward(dy.double())
+    dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), dg, db, dres=dres.to(dev))
+    check("ln dx", dx, xr.grad + dres.double(), tol(dtype))
+    check("ln dgamma", dg, gr.grad, 1e-4 if dtype == torch.float32 else tol(dtype))
+    check("ln dbeta", db, br.grad, 1e-4 if dtype == torch.float32 else tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,res,Cs", [(2, 16, 48), (1, 32, 96), (3, 8, 384)])
+def test_patch_merge_layernorm(dev, dtype, B, res, Cs):
+    from pseldnets_amd import ops
+    x = rnd((B * res * res, Cs), 1, dtype)
+    C = 4 * Cs
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    M = B * (res // 2) ** 2
+    dy = rnd((M, C), 4, dtype)
+    y = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), merge_res=res)
+    xr = x.double().requires_grad_(True)
+    xg = xr.view(B, res, res, Cs)
+    cat = torch.cat([xg[:, 0::2, 0::2], xg[:, 1::2, 0::2], xg[:, 0::2, 1::2], xg[:, 1::2, 1::2]], -1).reshape(M, C)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.layer_norm(cat, (C,), gr, br, 1e-5)
+    check("merge-ln fwd", y, yr, tol(dtype))
+    yr.backward(dy.double())
+    dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), dg, db, merge_res=res)
+    check("merge-ln dx", dx, xr.grad, tol(dtype))
+    check("merge-ln dgamma", dg, gr.grad, 1e-4 if dtype == torch.float32 else tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,c_first,c_use", [(2, 1001, 0, 7), (3, 1001, 0, 4), (1, 501, 0, 7)])
+def test_scalar_bn_fold_patchify(dev, dtype, B, T, c_first, c_use):
+    from pseldnets_amd import ops
+    Cin = 7
+    feat = oh.formula_features(B, T)
+    sd = oh.formula_state('accdoa', 3, Cin, dict(embed_dim=48, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16)))
+    w = torch.stack([sd[f'scalar.{c}.weight'] for c in range(Cin)]).reshape(-1)
+    b = torch.stack([sd[f'scalar.{c}.bias'] for c in range(Cin)]).reshape(-1)
+    rm = torch.stack([sd[f'scalar.{c}.running_mean'] for c in range(Cin)]).reshape(-1).to(dev)
+    rv = torch.stack([sd[f'scalar.{c}.running_var'] for c in range(Cin)]).reshape(-1).to(dev)
+    nb = torch.zeros(Cin, dtype=torch.long, device=dev)
+    featd = feat.to(dev)
+    sums = ops.bn_scalar_stats(featd, centered=True)
+    mean_rstd, scale_shift = ops.bn_scalar_finalize(sums, B * T, True, w.to(dev), b.to(dev), rm, rv, nb, True)
+    A = ops.bn_fold_patchify(featd, scale_shift, dtype, c_first, c_use)
+    # oracle
+    p = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    upd = {}
+    xn = oh.scalar_batchnorm(feat.double(), p, True, update=upd)
+    img = oh.fold_to_image(xn)[:, c_first:c_first + c_use]
+    cols = F.unfold(img, kernel_size=4, stride=4).transpose(1, 2).reshape(B * 4096, c_use * 16)
+    check("patchify", A, cols, 1e-5 if dtype == torch.float32 else 1e-2)
+    check("running_mean", rm, torch.stack([upd[f'scalar.{c}.running_mean'] for c in range(Cin)]).reshape(-1), 1e-5)
+    check("running_var", rv, torch.stack([upd[f'scalar.{c}.running_var'] for c in range(Cin)]).reshape(-1), 1e-5)
+    assert nb.tolist() == [1] * Cin
+    # backward: BN parameter gradients from a patch-matrix gradient
+    dA = rnd((B * 4096, c_use * 16), 7, dtype)
+    cols.backward(dA.double())
+    dw = torch.zeros(Cin * 64, device=dev); dbias = torch.zeros(Cin * 64, device=dev)
+    ops.bn_scalar_bwd(featd, mean_rstd, dA.to(dev), dw, dbias, c_first)
+    dw_ref = torch.stack([p[f'scalar.{c}.weight'].grad if p[f'scalar.{c}.weight'].grad is not None else torch.zeros(64, dtype=torch.double) for c in range(Cin)]).reshape(-1)
+    db_ref = torch.stack([p[f'scalar.{c}.bias'].grad if p[f'scalar.{c}.bias'].grad is not None else torch.zeros(64, dtype=torch.double) for c in range(Cin)]).reshape(-1)
+    check("bn dweight", dw, dw_ref, 1e-4 if dtype == torch.float32 else 1e-2)
+    check("bn dbias", dbias, db_ref, 1e-4 if dtype == torch.float32 else 1e-2)
+    # eval mode uses the running statistics
+    mr2, ss2 = ops.bn_scalar_finalize(sums, B * T, True, w.to(dev), b.to(dev), rm, rv, nb, False)
+    A2 = ops.bn_fold_patchify(featd, ss2, torch.float32, 0, Cin)
+    sd_eval = dict(sd)
+    for c in range(Cin):
+        sd_eval[f'scalar.{c}.running_mean'] = rm[c * 64:(c + 1) * 64].cpu()
+        sd_eval[f'scalar.{c}.running_var'] = rv[c * 64:(c + 1) * 64].cpu()
+    img2 = oh.fold_to_image(oh.scalar_batchnorm(feat, sd_eval, False))
+    check("patchify eval", A2, F.unfold(img2, kernel_size=4, stride=4).transpose(1, 2).reshape(B * 4096, Cin * 16), 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,res,C,heads,shift", [(2, 16, 48, 2, 0), (2, 16, 48, 2, 4), (1, 64, 96, 4, 4), (3, 8, 768, 32, 0),
+                                                 (2, 16, 384, 16, 4), (1, 32, 192, 8, 4), (2, 16, 64, 2, 4)])
+def test_window_attention(dev, dtype, B, res, C, heads, shift):
+    from pseldnets_amd import ops
+    L = res * res
+    qkv = rnd((B * L, 3 * C), 1, dtype)
+    table = 0.5 * rnd((225, heads), 2)
+    dout = rnd((B * L, C), 3, dtype)
+    out = ops.window_attn_fwd(qkv.to(dev), table.to(dev), B, res, heads, shift)
+    q = qkv.double().requires_grad_(True)
+    tb = table.double().requires_grad_(True)
+    mask = oh.shifted_window_mask(res, res, 8, shift).double() if shift else None
+    w = oh.to_windows(q.view(B, L, 3 * C), res, 8, shift)
+    o = oh.attention_core(w, tb, heads, mask, oh.relative_position_index(8))
+    ref = oh.from_windows(o, B, res, 8, shift).reshape(B * L, C)
+    check(f"attn fwd res{res} C{C} h{heads} s{shift}", out, ref, tol(dtype))
+    ref.backward(dout.double())
+    dtab = torch.zeros(225, heads, device=dev)
+    dqkv = ops.window_attn_bwd(qkv.to(dev), table.to(dev), dout.to(dev), dtab, B, res, heads, shift)
+    check("attn dqkv", dqkv, q.grad, tol(dtype) * (1 if dtype == torch.float32 else 2))
+    check("attn dbias_table", dtab, tb.grad, 1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C,D", [(2, 384, 27), (1, 768, 1530)])
+def test_head(dev, dtype, B, C, D):
+    from pseldnets_amd import ops
+    taps = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in ops.pool_taps().items()}
+    tok = rnd((B * 64, C), 1, dtype)
+    Dp = (D + 7) // 8 * 8
+    W = torch.zeros(Dp, C * 6, dtype=dtype); W[:D] = rnd((D, C * 6), 2, dtype, 0.02)
+    bias = torch.zeros(Dp); bias[:D] = 0.1 * rnd((D,), 3)
+    A = ops.head_im2col(tok.to(dev), B)
+    z = torch.zeros(B * 32, Dp, dtype=dtype, device=dev)
+    ops.linear_fwd(A, W.to(dev), bias.to(dev), out=z)
+    y = ops.head_pool_fwd(z, taps, B, D, True)
+    # oracle: tokens -> map -> conv -> interpolate/mean -> tanh (final LN excluded here: identity weights)
+    t = tok.double().requires_grad_(True)
+    x = t.view(B, 64, C).permute(0, 2, 1).reshape(B, C, 8, 8)
+    fmap = x.reshape(B, C, 4, 2, 8).permute(0, 1, 3, 2, 4).reshape(B, C, 2, 32)
+    Wc = W[:D].double().view(D, C, 2, 3).requires_grad_(True)
+    yr = torch.tanh(oh.head(fmap, Wc, bias[:D].double()))
+    check("head fwd", y, yr, 1e-5 if dtype == torch.float32 else 2e-2)
+    dy = rnd((B, 100, D), 4)
+    yr.backward(dy.double())
+    dz = ops.head_pool_bwd(dy.to(dev), y, taps, B, D, Dp, dtype, True)
+    dA = ops.linear_dgrad(dz, W.to(dev))
+    dtok = ops.head_col2im(dA, B)
+    check("head dtok", dtok, t.grad, 1e-4 if dtype == torch.float32 else 3e-2)
+    dW = torch.zeros(Dp, C * 6, device=dev)
+    ops.linear_wgrad(dz, A, dW)
+    check("head dW", dW[:D], Wc.grad.reshape(D, C * 6), 1e-4 if dtype == torch.float32 else 3e-2)
+    assert torch.all(dW[D:] == 0)
+
+
+def test_adpit_and_mse_and_tpit_losses(dev):
+    from pseldnets_amd import ops
+    B, T, C = 3, 100, 13
+    pred = synth.formula_pred((B, T, 9 * C), 0.3)
+    lab = synth.formula_adpit_label(B, T, C)
+    loss, dp = ops.adpit_loss(pred.to(dev), lab.to(dev))
+    pr = pred.clone().requires_grad_(True)
+    ref = ol.adpit({'multi_accdoa': pr}, {'adpit_label': lab})['loss_all']
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    check("adpit grad", dp, pr.grad, 1e-5)
+    pa, la = synth.formula_pred((B, T, 3 * C), 1.1), synth.formula_accdoa_label(B, T, C)
+    loss, dp = ops.mse_loss(pa.to(dev), la.to(dev))
+    pr = pa.clone().requires_grad_(True)
+    ref = ol.mse_accdoa({'accdoa': pr}, {'accdoa_label': la})['loss_all']
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    check("mse grad", dp, pr.grad, 1e-5)
+    sed = synth.formula_pred((B, T, 3, C), 0.5, 2.0)
+    doa = torch.tanh(synth.formula_pred((B, T, 3, 3), 0.8))
+    sl, dl = synth.formula_einv2_label(B, T, C)
+    loss3, dsed, ddoa = ops.tpit_loss(sed.to(dev), doa.to(dev), sl.to(dev), dl.to(dev), 0.5)
+    sr, dr = sed.clone().requires_grad_(True), doa.clone().requires_grad_(True)
+    ld = ol.tpit({'sed': sr, 'doa': dr}, {'sed_label': sl, 'doa_label': dl})
+    ld['loss_all'].backward()
+    ref3 = torch.stack([ld['loss_all'], ld['loss_sed'], ld['loss_doa']]).detach()
+    assert (loss3.cpu() - ref3).abs().max().item() < 2e-6
+    check("tpit dsed", dsed, sr.grad, 1e-4)
+    check("tpit ddoa", ddoa, dr.grad, 1e-4)
+
+
+def test_clip_adamw_matches_oracle(dev):
+    from pseldnets_amd import ops
+    n = 100003
+    p0, g = rnd((n,), 1), 3.0 * rnd((n,), 2)
+    p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    pr, mr, vr = [p0.clone()], [torch.zeros(n)], [torch.zeros(n)]
+    for step in range(1, 4):
+        gs = g * step
+        nrm = ops.grad_norm(gs.to(dev))
+        ops.adamw_step(p, gs.to(dev), m, v, step, 1e-3, grad_norm_t=nrm, max_norm=1.0, shadow=shadow)
+        total = oo.adamw_step(pr, [gs.clone()], mr, vr, step, 1e-3)
+        assert abs(nrm.item() - total.item()) < 1e-3 * total.item()
+    check("adamw p", p, pr[0], 1e-6)
+    check("adamw m", m, mr[0], 1e-5)
+    check("adamw shadow", shadow, pr[0].to(torch.bfloat16), 1e-6)
