@@ -1,0 +1,90 @@
+"""ACCDOA networks on MI355X — mirror of the reference's `models/accdoa.py` registry module (HTSAT :107-246).
+Constructor signature, forward contract ({'accdoa': f32[B, 100, 3*C]}) and state-dict keys are the reference's;
+the arithmetic is the HIP path (components/htsat.py). CRNN / ConvConformer / PASST backbones of the reference
+registry are not built on this path yet and raise NotImplementedError."""
+import torch
+
+from .components.htsat import SwinEncoder, TscamHead
+from .components.seld_net import HTSATNetBase
+
+
+class HTSAT(HTSATNetBase):
+    out_key = 'accdoa'
+    tracks_axes = 3
+
+    def __init__(self, cfg, num_classes, in_channels=7, audioset_pretrain=True,
+                 pretrained_path='ckpts/HTSAT-fullset-imagenet-768d-32000hz.ckpt', **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self._init_common(cfg, in_channels)
+        self.enc = SwinEncoder(self.arena, 'encoder.', in_channels, mel_bins=self.mel_bins, **kwargs)
+        self.head = TscamHead(self.arena, 'tscam_conv.', self.enc.num_features, num_classes * self.tracks_axes, True)
+        self._finish_init()
+        if pretrained_path:
+            self.load_ckpts(pretrained_path, audioset_pretrain)
+
+    def load_ckpts(self, pretrained_path, audioset_pretrain=True):
+        """accdoa.py:172-202: AudioSet HTS-AT checkpoints (1-channel patch-embed replicated / in_channels, bn0 copied
+        into every scalar) or PSELDNets checkpoints (heads skipped)."""
+        ck = torch.load(pretrained_path, map_location='cpu')['state_dict']
+        own = self.state_dict()
+        if audioset_pretrain:
+            ck = {k.replace('sed_model.', ''): v for k, v in ck.items()}
+            for key in own:
+                if not key.startswith('encoder.'):
+                    continue
+                src = key[len('encoder.'):]
+                if src == 'patch_embed.proj.weight':
+                    own[key].copy_(ck[src].repeat(1, self.in_channels, 1, 1) / self.in_channels)
+                elif src in ck and 'tscam_conv' not in src and 'head' not in src:
+                    own[key].copy_(ck[src])
+            for c in range(self.in_channels):
+                for leaf in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                    own[f'scalar.{c}.{leaf}'].copy_(ck[f'bn0.{leaf}'])
+        else:
+            ck = {k.replace('net.', '').replace('_orig_mod.', ''): v for k, v in ck.items()}
+            for key in own:
+                if key.startswith(('fc.', 'head.', 'tscam_conv.')) or key not in ck:
+                    continue
+                own[key].copy_(ck[key])
+        self.shadow_trusted = False
+
+    # -- the two halves the autograd node and the fused step share ------------------------------------------------
+    def _forward_impl(self, x, training):
+        B = x.shape[0]
+        dt = self.compute_dtype
+        mean_rstd, scale_shift = self._bn_front(x, training)
+        drop = self._drop_scales(B, self.enc, x.device, training)
+        tok, s_patch = self.enc.forward_patch(x, scale_shift, dt)
+        s_layers = []
+        for li in range(self.enc.nl):
+            tok, s = self.enc.forward_layer(li, tok, B, drop)
+            s_layers.append(s)
+        xn, s_fin = self.enc.forward_final(tok)
+        y, s_head = self.head.forward(xn, B)
+        return y, dict(feat=x, mean_rstd=mean_rstd, patch=s_patch, layers=s_layers, fin=s_fin, head=s_head, B=B)
+
+    def _backward_impl(self, saved, douts):
+        dy = douts[0] if isinstance(douts, (tuple, list)) else douts
+        B, dt = saved['B'], self.compute_dtype
+        dxn = self.head.backward(dy, saved['head'], B, dt)
+        dx = self.enc.backward_final(dxn, saved['fin'])
+        for li in reversed(range(self.enc.nl)):
+            dx = self.enc.backward_layer(li, dx, saved['layers'][li], B)
+        dw, db = self._bn_grads()
+        self.enc.backward_patch(dx, saved['patch'], saved['feat'], saved['mean_rstd'], dw, db, accumulate_bn=False)
+
+    def forward(self, x):
+        """
+        x: (batch_size, num_channels, time_frames, mel_bins) features of 10-second chunks
+        """
+        return {self.out_key: self._run(x)}
+
+
+class _NotBuilt:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("this backbone of the reference registry is not built on the MI355X path yet "
+                                  "(SURVEY.md §8 rows a16/a17); use backbone=HTSAT")
+
+
+CRNN = ConvConformer = PASST = _NotBuilt

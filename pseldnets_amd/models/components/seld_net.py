@@ -1,0 +1,206 @@
+"""Shared machinery of the HTS-AT SELD networks: reference-named module tree over a flat parameter arena, the
+per-input-channel "scalar" BatchNorm front (models/accdoa.py:223-227), autograd glue, and the fused
+clip+AdamW step. Concrete networks (models/accdoa.py, multi_accdoa.py, einv2.py mirrors) only declare their
+encoders and heads."""
+import torch
+import torch.nn as nn
+
+from ... import _lib, ops
+from .arena import ParamArena
+from .htsat import default_init
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state-dict keys."""
+
+
+def _attach(root, dotted, tensor, is_param):
+    parts = dotted.split('.')
+    node = root
+    for part in parts[:-1]:
+        if not hasattr(node, part):
+            node.add_module(part, _Node())
+        node = getattr(node, part)
+    if is_param:
+        node.register_parameter(parts[-1], nn.Parameter(tensor))
+    else:
+        node.register_buffer(parts[-1], tensor)
+
+
+def _get(root, dotted):
+    obj = root
+    for part in dotted.split('.'):
+        obj = getattr(obj, part)
+    return obj
+
+
+class _NetFn(torch.autograd.Function):
+    """Whole-network autograd node: forward runs the HIP forward, backward the hand-written HIP backward, which
+    deposits every parameter gradient in the arena; the per-parameter views are handed back to autograd."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        outs, saved = net._forward_impl(x, net.training)
+        ctx.net, ctx.saved_state = net, saved
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        net = ctx.net
+        net._backward_impl(ctx.saved_state, douts)
+        grads = tuple(net.arena.g(n).clone() for n in net.arena.entries)
+        return (None, None) + grads
+
+
+class HTSATNetBase(nn.Module):
+    compute_dtype = torch.float32       # float32 = parity mode; bfloat16 = throughput mode
+
+    def _init_common(self, cfg, in_channels):
+        data = cfg.data if hasattr(cfg, 'data') else cfg['data']
+        get = (lambda k: getattr(data, k)) if not isinstance(data, dict) else (lambda k: data[k])
+        self.mel_bins = get('n_mels')
+        self.label_res = 0.1
+        self.output_frames = None
+        self.tgt_output_frames = int(10 / 0.1)
+        self.pred_res = int(get('sample_rate') / get('hoplen') * self.label_res)
+        self.in_channels = in_channels
+        self.arena = ParamArena()
+        for c in range(in_channels):
+            self.arena.add(f'scalar.{c}.weight', (self.mel_bins,))
+        for c in range(in_channels):
+            self.arena.add(f'scalar.{c}.bias', (self.mel_bins,))
+        self._materialized_on = None
+        self.sync_bn_group = None         # set to a torch.distributed group for sync-BN (configs/trainer/gpu.yaml:9)
+        self.shadow_trusted = False
+        self.bn_momentum, self.bn_eps = 0.1, 1e-5
+
+    def _finish_init(self):
+        """Create the reference-named parameter/buffer tree (CPU tensors until the first forward on a GPU)."""
+        for name in self.arena.entries:
+            _attach(self, name, default_init(name, self.arena.offsets[name][1]), True)
+        for enc in self._encoders():
+            for name, t in enc.static_buffers().items():
+                _attach(self, name, t, False)
+        C = self.in_channels
+        self._rm = torch.zeros(C, self.mel_bins)
+        self._rv = torch.ones(C, self.mel_bins)
+        self._nbt = torch.zeros(C, dtype=torch.long)
+        for c in range(C):
+            _attach(self, f'scalar.{c}.running_mean', self._rm[c], False)
+            _attach(self, f'scalar.{c}.running_var', self._rv[c], False)
+            _attach(self, f'scalar.{c}.num_batches_tracked', self._nbt[c], False)
+
+    def _encoders(self):
+        return [v for v in vars(self).values() if hasattr(v, 'static_buffers')]
+
+    # -- device placement ------------------------------------------------------------------------------------
+    def _materialize(self, device):
+        if self._materialized_on == device:
+            return
+        _lib.require_gpu()
+        init = {n: _get(self, n).detach().to(device=device, dtype=torch.float32) for n in self.arena.entries}
+        self.arena.materialize(device, init)
+        for n in self.arena.entries:
+            _get(self, n).data = self.arena.p(n)
+        C = self.in_channels
+        rm = torch.stack([_get(self, f'scalar.{c}.running_mean').detach().float() for c in range(C)]).to(device)
+        rv = torch.stack([_get(self, f'scalar.{c}.running_var').detach().float() for c in range(C)]).to(device)
+        nbt = torch.stack([_get(self, f'scalar.{c}.num_batches_tracked').detach() for c in range(C)]).to(device)
+        self._rm, self._rv, self._nbt = rm.contiguous(), rv.contiguous(), nbt.contiguous()
+        for c in range(C):
+            node = _get(self, f'scalar.{c}')
+            node._buffers['running_mean'] = self._rm[c]
+            node._buffers['running_var'] = self._rv[c]
+            node._buffers['num_batches_tracked'] = self._nbt[c]
+        self._materialized_on = device
+        self.shadow_trusted = False
+
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda() re-create tensors: drop the arena binding, it is rebuilt on the next forward
+        self._materialized_on = None
+        return super()._apply(fn, *a, **k)
+
+    # -- the BN front shared by every HTS-AT variant -----------------------------------------------------------
+    def _bn_front(self, feat, training):
+        a, C = self.arena, self.in_channels
+        n = C * self.mel_bins
+        w = a.flat[a.offsets['scalar.0.weight'][0]: a.offsets['scalar.0.weight'][0] + n]
+        b = a.flat[a.offsets['scalar.0.bias'][0]: a.offsets['scalar.0.bias'][0] + n]
+        B, _, T, _ = feat.shape
+        count = float(B * T)
+        sums, centered = None, False
+        if training:
+            group = self.sync_bn_group
+            centered = group is None
+            sums = ops.bn_scalar_stats(feat, centered=centered)
+            if group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(sums[:2 * n], group=group)
+                count *= dist.get_world_size(group)
+        mean_rstd, scale_shift = ops.bn_scalar_finalize(sums, count, centered, w, b, self._rm.view(-1), self._rv.view(-1),
+                                                       self._nbt, training, self.bn_momentum, self.bn_eps)
+        return mean_rstd, scale_shift
+
+    def _bn_grads(self):
+        a, n = self.arena, self.in_channels * self.mel_bins
+        ow, ob = a.offsets['scalar.0.weight'][0], a.offsets['scalar.0.bias'][0]
+        return a.grad[ow:ow + n], a.grad[ob:ob + n]
+
+    def _check_input(self, x):
+        if x.ndim != 4:
+            raise ValueError("x shape must be (batch_size, num_channels, time_frames, mel_bins)")
+        if not x.is_cuda:
+            raise _lib.PseldError("network input must live on the MI355X (no CPU fallback)")
+        B, C, T, F = x.shape
+        if self.output_frames is None:
+            self.output_frames = int(T // self.pred_res)
+        if self.output_frames < self.tgt_output_frames:
+            raise NotImplementedError('5-second clip pairing (models/accdoa.py:214-219) is not built on the MI355X path')
+        elif self.output_frames > self.tgt_output_frames:
+            raise NotImplementedError('output_frames > tgt_output_frames is not implemented')
+        if C != self.in_channels or F != self.mel_bins:
+            raise ValueError(f"expected [B, {self.in_channels}, T, {self.mel_bins}] features, got {tuple(x.shape)}")
+
+    def _drop_scales(self, B, enc, device, training):
+        """Per-sample DropPath factors (model_utilities.py:216-232): 0 or 1/keep for every (block, branch)."""
+        if not training or enc.cfg['drop_path_rate'] <= 0:
+            return None
+        keep = 1.0 - torch.tensor(enc.rates, device=device, dtype=torch.float32).view(-1, 1, 1)
+        u = torch.rand(len(enc.rates), 2, B, device=device)
+        return (torch.floor(keep + u) / keep).contiguous()
+
+    def _run(self, x):
+        self._check_input(x)
+        self._materialize(x.device)
+        if not self.shadow_trusted:
+            self.arena.shadow_valid = False
+        x = x.contiguous().float()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = [_get(self, n) for n in self.arena.entries]
+            return _NetFn.apply(self, x, *params)
+        outs, _ = self._forward_impl(x, self.training)
+        return outs
+
+    # -- fused optimiser over the arena ------------------------------------------------------------------------
+    def zero_grad_arena(self):
+        self.arena.grad.zero_()
+
+    def fused_adamw_step(self, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0,
+                         grad_norm=None):
+        """clip_grad_norm_(max_norm) + AdamW over the whole arena in two kernels; refreshes the bf16 shadow."""
+        a = self.arena
+        a.ensure_opt_state()
+        a.step += 1
+        if max_norm and grad_norm is None:
+            grad_norm = ops.grad_norm(a.grad)
+        shadow = None
+        if self.compute_dtype == torch.bfloat16:
+            if a.shadow is None:
+                a.shadow = torch.empty(a.size, dtype=torch.bfloat16, device=a.flat.device)
+            shadow = a.shadow
+        ops.adamw_step(a.flat, a.grad, a.m, a.v, a.step, lr, grad_norm_t=grad_norm, max_norm=max_norm or 0.0,
+                       grad_scale=grad_scale, betas=betas, eps=eps, weight_decay=weight_decay, shadow=shadow)
+        if shadow is not None:
+            a.shadow_valid = True
+            self.shadow_trusted = True
+        return grad_norm

@@ -1,0 +1,11 @@
+"""Multi-ACCDOA networks on MI355X — mirror of the reference's `models/multi_accdoa.py` (HTSAT :29-44):
+the ACCDOA net with a 3 tracks x 3 axes x C head and output key 'multi_accdoa'."""
+from . import accdoa
+
+
+class HTSAT(accdoa.HTSAT):
+    out_key = 'multi_accdoa'
+    tracks_axes = 9
+
+
+CRNN = ConvConformer = PASST = accdoa._NotBuilt
