@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Headline benchmark: train clips/sec (60 s x 4-ch FOA @ 24 kHz) of HTS-AT mACCDOA, bf16, on N MI355X.
+
+One step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  32 clips/GPU = 192 ten-second chunks -> fused STFT/log-mel/IV -> scalar BN -> HTS-AT (Swin) -> mACCDOA head ->
+  ADPIT loss -> hand-written backward -> (bucketed RCCL all-reduce) -> clip(1.0) -> AdamW.
+Contract: python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run, one rank per GPU).
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CLIP_SECONDS, CHUNKS_PER_CLIP, FS, CLASSES = 60, 6, 24000, 170
+GFLOP_PER_CHUNK_TRAIN = 37.61       # 37.026 (net fwd+bwd) + 0.583 (features)
+PEAK_BF16_TFLOPS = 2516.6           # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_cfg():
+    return AttrDict(data=AttrDict(n_mels=64, sample_rate=FS, hoplen=240, nfft=1024, window='hann',
+                                  audio_feature='logmelIV'), adapt=AttrDict())
+
+
+def synthetic_batch(clips, device, seed):
+    """wave = 0.1*N(0,1) f32[clips, 4, 1 440 000] chunked as segment_index(chunklen=hoplen=10 s)
+    would (6 full chunks per clip); adpit_label: track A0 only, act ~ Bernoulli(0.02), unit DOA."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    chunks = clips * CHUNKS_PER_CLIP
+    wave = 0.1 * torch.randn(clips, 4, CHUNKS_PER_CLIP, 10 * FS, generator=g, device=device)
+    wave = wave.permute(0, 2, 1, 3).reshape(chunks, 4, 10 * FS).contiguous()
+    act = (torch.rand(chunks, 100, CLASSES, generator=g, device=device) < 0.02).float()
+    doa = torch.randn(chunks, 100, 3, CLASSES, generator=g, device=device)
+    doa = doa / doa.norm(dim=2, keepdim=True).clamp_min(1e-6)
+    label = torch.zeros(chunks, 100, 6, 4, CLASSES, device=device)
+    label[:, :, 0, 0] = act
+    label[:, :, 0, 1:] = doa * act.unsqueeze(2)
+    return wave, {'adpit_label': label}
+
+
+class KernelTimer:
+    """HIP-event timing of every C-ABI launch on the stream it is enqueued on (torch's current stream)."""
+
+    def __init__(self, lib):
+        self.lib, self.records, self.on = lib, [], False
+        self._orig = {}
+
+    def install(self, names):
+        for n in names:
+            fn = getattr(self.lib, n)
+            self._orig[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n):
+                if not self.on:
+                    return _fn(*a)
+                s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = _fn(*a)
+                e.record()
+                self.records.append((_n, a, s, e))
+                return rc
+            setattr(self.lib, n, wrapped)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for n, a, s, e in self.records:
+            key = n
+            flops = 0.0
+            if n == 'pseld_gemm':
+                key = 'gemm_kernel(fwd/dgrad)'
+                flops = 2.0 * a[6] * a[7] * a[8]
+            elif n == 'pseld_gemm_wgrad':
+                key = 'gemm_kernel(wgrad)+reduce'
+                flops = 2.0 * a[4] * a[5] * a[6]
+            t = s.elapsed_time(e)
+            d = agg.setdefault(key, [0.0, 0, 0.0])
+            d[0] += t; d[1] += 1; d[2] += flops
+        return agg
+
+
+def cpu_baseline(chunks=4, steps=2):
+    """The CPU oracle (a port: the reference's Python cannot travel) timed on this host: features + HTS-AT mACCDOA
+    fwd + ADPIT + backward + clip + AdamW on `chunks` 10 s chunks, fp32, all host threads."""
+    from oracle import feature as of, htsat as oh, losses as ol, optim as oo
+    torch.manual_seed(0)
+    cfg = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.0)
+    sd = oh.formula_state('multi_accdoa', CLASSES, 7, cfg)
+    names = [k for k, v in sd.items() if v.is_floating_point() and 'running' not in k]
+    m = [torch.zeros_like(sd[n]) for n in names]
+    v = [torch.zeros_like(sd[n]) for n in names]
+    wave = 0.1 * torch.randn(chunks, 4, 10 * FS)
+    label = torch.zeros(chunks, 100, 6, 4, CLASSES)
+    label[:, :, 0, 0] = (torch.rand(chunks, 100, CLASSES) < 0.02).float()
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        p = {k: (t.detach().requires_grad_(True) if k in names else t) for k, t in sd.items()}
+        feat = of.logmel_iv(wave)
+        out = oh.accdoa_htsat_forward(feat, p, cfg, training=True, key='multi_accdoa')
+        loss = ol.adpit(out, {'adpit_label': label})['loss_all']
+        loss.backward()
+        with torch.no_grad():
+            plist = [sd[n] for n in names]
+            oo.adamw_step(plist, [p[n].grad for n in names], m, v, it + 1, 1e-4)
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": round(chunks / CHUNKS_PER_CLIP / t, 4), "unit": "clips/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} timed train steps of {chunks} ten-second chunks (fp32 oracle, "
+            f"features+fwd+bwd+clip+AdamW), best step {t:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--clips', type=int, default=32, help='60 s clips per GPU per step')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        group = dist.group.WORLD
+
+    from pseldnets_amd import _lib
+    from pseldnets_amd.models import multi_accdoa
+    from pseldnets_amd.trainer import FusedTrainer
+    from pseldnets_amd.utils.config import get_afextractor
+
+    cfg = make_cfg()
+    torch.manual_seed(2024)
+    net = multi_accdoa.HTSAT(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/htsat.yaml geometry
+    net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    net.to(device)
+    if world > 1:
+        import torch.distributed as dist
+        for p in net.parameters():            # identical initial weights on every rank
+            dist.broadcast(p.data, 0)
+    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'adpit', lr=1e-4, max_norm=1.0, process_group=group,
+                           sync_bn=False)
+    wave, target = synthetic_batch(args.clips, device, 2024 + rank)
+
+    lib = _lib.lib()
+    timer = None
+    if rank == 0 and not args.no_kernel_timing:
+        timer = KernelTimer(lib)
+        timer.install(_lib.declared_symbols())
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.training_step(wave, target)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.training_step(wave, target)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    clips_per_s = args.clips * world / (elapsed / args.steps)
+    loss_val = float(loss['loss_all'].item())
+
+    out = {
+        "metric": "train clips/sec (60 s 4-ch FOA) HTS-AT mACCDOA", "value": round(clips_per_s, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"HTS-AT mACCDOA {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
+                               f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, ADPIT, clip 1.0, AdamW, "
+                               "drop_path 0.1, BN train mode, no augmentation",
+                   "global_clips": args.clips * world, "parallelism": f"dp{world}"},
+        "loss": round(loss_val, 6),
+    }
+    step_tflops = clips_per_s * CHUNKS_PER_CLIP * GFLOP_PER_CHUNK_TRAIN / 1e3
+    out["roofline_step"] = {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4)}
+    if rank == 0 and timer is not None:
+        # separate instrumented steps: HIP events around every launch on the launch stream
+        timer.on = True
+        for _ in range(2):
+            trainer.training_step(wave, target)
+        agg = timer.summary()
+        timer.on = False
+        total = sum(v[0] for v in agg.values())
+        top = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        gem = [v for k, v in agg.items() if k.startswith('gemm_kernel(fwd')]
+        if gem:
+            tms, n, fl = gem[0]
+            ach = fl / (tms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3,
+                               "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3), 4),
+                               "traffic": None, "kernel": "gemm_kernel<T,WM,WN,TA=0,TB> (forward + input-gradient launches)",
+                               "launches": n // 2, "avg_launch_ms": round(tms / n, 4),
+                               "flops_per_launch_avg": round(fl / n, 1)}
+        out["kernel_time_share"] = {k: {"ms_per_step": round(v[0] / 2, 3), "launches": v[1] // 2,
+                                        "share": round(v[0] / total, 4)} for k, v in top[:10]}
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the checker must never take the measurement down
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

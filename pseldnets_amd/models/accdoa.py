@@ -64,15 +64,25 @@ class HTSAT(HTSATNetBase):
         y, s_head = self.head.forward(xn, B)
         return y, dict(feat=x, mean_rstd=mean_rstd, patch=s_patch, layers=s_layers, fin=s_fin, head=s_head, B=B)
 
-    def _backward_impl(self, saved, douts):
+    def _backward_impl(self, saved, douts, on_range_done=None):
+        """Hand-written backward. `on_range_done(a, b)` is told each arena range [a, b) whose gradients are final,
+        back to front, so the data-parallel loop can all-reduce it while earlier layers are still running."""
         dy = douts[0] if isinstance(douts, (tuple, list)) else douts
         B, dt = saved['B'], self.compute_dtype
+        a = self.arena
         dxn = self.head.backward(dy, saved['head'], B, dt)
         dx = self.enc.backward_final(dxn, saved['fin'])
+        hi = a.size
         for li in reversed(range(self.enc.nl)):
             dx = self.enc.backward_layer(li, dx, saved['layers'][li], B)
+            if on_range_done is not None and li in (3, 2):     # buckets: {stage3+norm+head}, {stage2}, {rest}
+                lo = a.offsets[self.enc.first_param_of_layer(li)][0]
+                on_range_done(lo, hi)
+                hi = lo
         dw, db = self._bn_grads()
         self.enc.backward_patch(dx, saved['patch'], saved['feat'], saved['mean_rstd'], dw, db, accumulate_bn=False)
+        if on_range_done is not None:
+            on_range_done(0, hi)
 
     def forward(self, x):
         """
