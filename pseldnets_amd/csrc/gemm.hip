@@ -23,6 +23,9 @@
 // Roofline: MFMA-bound for C >= 384 layers; stage-0/1 layers (K = 96/192) are HBM-bound (72-150 flop/B).
 #include "common.h"
 
+void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
+                        hipStream_t stream);
+
 namespace {
 
 constexpr int GEMM_THREADS = 256;
@@ -149,6 +152,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
     constexpr int NCH_A = BM / 32, NCH_B = BN / 32;  // 16-byte chunks per thread per K slice
     constexpr int A_CPR = TA ? BM / EPC : 8;         // chunks per image row
     constexpr int B_CPR = TB ? BN / EPC : 8;
+    constexpr bool STAGED = (sizeof(OutT) == 2);      // bf16 output: LDS-staged, 16-byte coalesced epilogue
+    constexpr int CS_STRIDE = BN * 2 + 16;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
@@ -249,33 +254,89 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 3; ++ni) Mma<T>::mma(fa[mi], fb[ni], acc[mi][ni]);
+                    for (int ni = 0; ni < 3; ++ni) {
+                        // STAGED: compute the tile transposed (lane = output row, registers = 4-column groups)
+                        // so the epilogue can move 8-byte row segments instead of single elements
+                        if (STAGED) Mma<T>::mma(fb[ni], fa[mi], acc[mi][ni]);
+                        else Mma<T>::mma(fa[mi], fb[ni], acc[mi][ni]);
+                    }
             }
         }
     }
 
-    // ---- epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
     OutT* Cg = (OutT*)g.C + (long)blockIdx.z * g.slab_stride;
     const T* Rg = (const T*)g.resid;
     const T* Ug = (const T*)g.aux;
+    if constexpr (STAGED) {
+        // ---- bf16 epilogue: tile^T -> LDS (8-byte row segments) -> 16-byte coalesced rows with the fused ops ----
+        __syncthreads();  // every wave is done with the operand images
+        char* Cs = smem;
 #pragma unroll
-    for (int ni = 0; ni < 3; ++ni) {
-        const int n = n0 + wn * 96 + ni * 32 + r;
-        if (n >= g.N) continue;
-        const float bv = (g.epi & EPI_BIAS) ? g.bias[n] : 0.f;
+        for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi) {
+                const int ml = wm * 64 + mi * 32 + r;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                float v = acc[mi][ni][e] + bv;
-                if (g.rowscale) v *= g.rowscale[m / g.rows_per_scale];
-                if (g.epi & EPI_MULGELUGRAD) v *= gelu_grad_f(to_f32<T>(Ug[(long)m * g.ldaux + n]));
-                if (g.epi & EPI_RESID) v += to_f32<T>(Rg[(long)m * g.ldr + n]);
-                OutT* dst = Cg + (long)m * g.ldc + n;
-                if (g.epi & EPI_ACCUM) v += to_f32<OutT>(*dst);
-                *dst = from_f32<OutT>(v);
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * 96 + ni * 32 + 8 * q + 4 * h;
+                    bf16x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[mi][ni][4 * q + j];
+                        if ((g.epi & EPI_BIAS) && n0 + nl + j < g.N) v += g.bias[n0 + nl + j];
+                        pk[j] = (bf16_t)v;
+                    }
+                    *(bf16x4*)(Cs + ml * CS_STRIDE + nl * 2) = pk;
+                }
+            }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        for (int c = tid; c < BM * CPR; c += GEMM_THREADS) {
+            const int row = c / CPR, cb = c - row * CPR;
+            const int m = m0 + row, n = n0 + cb * 8;
+            if (m >= g.M || n >= g.N) continue;
+            float v[8];
+            load8<bf16_t>((const bf16_t*)(Cs + row * CS_STRIDE + cb * 16), v);
+            if (g.rowscale) {
+                const float sc = g.rowscale[m / g.rows_per_scale];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= sc;
+            }
+            if (g.epi & EPI_MULGELUGRAD) {
+                float u[8];
+                load8<bf16_t>((const bf16_t*)Ug + (long)m * g.ldaux + n, u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(u[k]);
+            }
+            if (g.epi & EPI_RESID) {
+                float rr[8];
+                load8<bf16_t>((const bf16_t*)Rg + (long)m * g.ldr + n, rr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+            }
+            store8<bf16_t>((bf16_t*)Cg + (long)m * g.ldc + n, v);
+        }
+    } else {
+        // ---- f32 epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+            const int n = n0 + wn * 96 + ni * 32 + r;
+            if (n >= g.N) continue;
+            const float bv = (g.epi & EPI_BIAS) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (m >= g.M) continue;
+                    float v = acc[mi][ni][e] + bv;
+                    if (g.rowscale) v *= g.rowscale[m / g.rows_per_scale];
+                    if (g.epi & EPI_MULGELUGRAD) v *= gelu_grad_f(to_f32<T>(Ug[(long)m * g.ldaux + n]));
+                    if (g.epi & EPI_RESID) v += to_f32<T>(Rg[(long)m * g.ldr + n]);
+                    OutT* dst = Cg + (long)m * g.ldc + n;
+                    if (g.epi & EPI_ACCUM) v += to_f32<OutT>(*dst);
+                    *dst = from_f32<OutT>(v);
+                }
             }
         }
     }
@@ -288,8 +349,10 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
     constexpr int B_STRIDE = TB ? TStride<T, BN>::value : ROWB;
     constexpr int A_BYTES = TA ? BK * A_STRIDE : BM * ROWB;
     constexpr int B_BYTES = TB ? BK * B_STRIDE : BN * ROWB;
+    constexpr int CS_BYTES = (sizeof(OutT) == 2) ? BM * (BN * 2 + 16) : 0;
+    constexpr int LDS = (A_BYTES + B_BYTES > CS_BYTES) ? (A_BYTES + B_BYTES) : CS_BYTES;
     dim3 grid(pseld_cdiv(g.N, BN), pseld_cdiv(g.M, BM), splits);
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(GEMM_THREADS), A_BYTES + B_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(GEMM_THREADS), LDS, stream, g);
     PSELD_LAUNCH_CHECK("gemm");
     return PSELD_OK;
 }
@@ -350,6 +413,8 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     PSELD_CHECK_ARG(!(epi & EPI_RESID) || resid, "gemm: EPI_RESID without resid");
     PSELD_CHECK_ARG(!(epi & EPI_MULGELUGRAD) || aux, "gemm: EPI_MULGELUGRAD without aux");
     PSELD_CHECK_ARG(!trans_b || N % 8 == 0, "gemm: N must be a multiple of 8 when B is [K,N]");
+    PSELD_CHECK_ARG(dtype != PSELD_BF16 || (N % 8 == 0 && ldc % 8 == 0 && (!resid || ldr % 8 == 0) && (!aux || ldaux % 8 == 0)),
+                    "gemm(bf16): N and ldc/ldr/ldaux must be multiples of 8 (%d,%d)", N, ldc);
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid; g.rowscale = rowscale; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux;
@@ -410,21 +475,20 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     else { pseld_set_error("gemm_wgrad: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
     if (rc != PSELD_OK) return rc;
     const long n = (long)N * K;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, workspace, dW, n, splits,
-                       g.slab_stride, accumulate);
+    pseld_reduce_slabs(workspace, dW, n, splits, g.slab_stride, accumulate, s);
     PSELD_LAUNCH_CHECK("splitk_reduce");
     return PSELD_OK;
 }
 
 // out[n] (fp32) = sum_m X[m,n]; two deterministic passes through `workspace` (>= blocks*N floats).
+static inline int colsum_rows(int M) { int r = pseld_cdiv(M, 256); return r < 1024 ? 1024 : r; }
 extern "C" long pseld_colsum_workspace(int M, int N) {
-    const int rows_per_block = 1024;
-    return (long)pseld_cdiv(M, rows_per_block) * N * (long)sizeof(float);
+    return (long)pseld_cdiv(M, colsum_rows(M)) * N * (long)sizeof(float);
 }
 extern "C" int pseld_colsum(int dtype, const void* X, float* out, int M, int N, int ld, int accumulate,
                             float* workspace, long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(X && out && workspace, "colsum: null pointer");
-    const int rows_per_block = 1024;
+    const int rows_per_block = colsum_rows(M);
     const int nb = pseld_cdiv(M, rows_per_block);
     PSELD_CHECK_ARG(workspace_bytes >= (long)nb * N * 4, "colsum: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -434,7 +498,7 @@ extern "C" int pseld_colsum(int dtype, const void* X, float* out, int M, int N, 
     else
         hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)X, workspace, M, N, ld, rows_per_block);
     PSELD_LAUNCH_CHECK("colsum_partial");
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pseld_cdiv(N, 256)), dim3(256), 0, s, workspace, out, (long)N, nb, (long)N, accumulate);
+    pseld_reduce_slabs(workspace, out, (long)N, nb, (long)N, accumulate, s);
     PSELD_LAUNCH_CHECK("colsum_reduce");
     return PSELD_OK;
 }
