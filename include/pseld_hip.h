@@ -43,11 +43,13 @@ int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B
                int lda, int ldb, int ldc, const float* bias, const void* resid, int ldr, const float* rowscale,
                int rows_per_scale, const void* aux, int ldaux, int epi, int pro, void* stream);
 
-/* Weight gradient of the same layers: dW f32[N,K] (+)= dY[Mtok,N]^T @ (gelu_on_x ? gelu(X) : X)[Mtok,K];
- * split over tokens into fp32 slabs in `workspace`, reduced in a fixed order (bitwise reproducible). */
+/* Weight gradient of the same layers: dW f32[N,K] (+)= dY[Mtok,N]^T @ (gelu_on_x ? gelu(X) : X)[Mtok,K], and (when
+ * dbias != NULL) the bias gradient dbias f32[N] (+)= sum_m dY[m,n] from the same pass. Split over tokens into fp32
+ * slabs in `workspace`, reduced in a fixed order (bitwise reproducible). */
 long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out);
-int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, int Mtok, int N, int K, int lddy, int ldx,
-                     int lddw, int gelu_on_x, int accumulate, float* workspace, long workspace_bytes, void* stream);
+int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, int Mtok, int N, int K,
+                     int lddy, int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
+                     long workspace_bytes, void* stream);
 
 /* Bias gradient: out f32[N] (+)= sum_m X[m,n]. */
 long pseld_colsum_workspace(int M, int N);

@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int HG = 4;  // heads per workgroup = waves per workgroup
+template <typename T> struct HeadsPerGroup { static constexpr int value = sizeof(T) == 2 ? 4 : 2; };  // = waves per workgroup
 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -100,7 +100,7 @@ struct AttnArgs {
     const void* dout;  // bwd: [B, L, C]
     void* dqkv;        // bwd: [B, L, 3C]
     const float* bias_table;  // [225, heads]
-    float* dbias_acc;         // bwd: [heads, 64(query), 64(key)] fp32, atomically accumulated
+    float* dbias_acc;         // bwd: [heads, 64(key), 64(query)] fp32, atomically accumulated
     int B, res, C, heads, hd, shift;
     int n_win_total;          // B * (res/8)^2
     float scale;
@@ -139,7 +139,7 @@ template <typename T, bool TO_LDS>
 __device__ __forceinline__ void window_copy(char* tile, int strideB, T* gbase, int gld, int gcol, int lcol,
                                             int seg_elems, const long* toks) {
     const int cps = seg_elems >> 3;  // 8-element chunks per token
-    for (int c = threadIdx.x; c < 64 * cps; c += 256) {
+    for (int c = threadIdx.x; c < 64 * cps; c += (int)blockDim.x) {
         const int t = c / cps, k = c - t * cps;
         T* g = gbase + toks[t] * gld + gcol + k * 8;
         char* l = tile + t * strideB + (lcol + k * 8) * (int)sizeof(T);
@@ -223,8 +223,53 @@ __device__ __forceinline__ void store_rows(char* tile, int strideB, int col0, co
     }
 }
 
+// acc[ta] (ta = 0,1) = sum_dims A[ta*32 + row][dim] * B[tb*32 + col][dim]: both 64-row LDS operands, one B tile.
+// Result tiles: rows = A rows (registers), cols = B rows of tile tb (lanes).
+template <typename T>
+__device__ __forceinline__ void qk_half(f32x16 (&acc)[2], const char* tile, int strideB, int ca, int cb, int tb, int hd,
+                                        int lane) {
+    using M = AMma<T>;
+    const int r = lane & 31, h2 = lane >> 5;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ta][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = 16 * kk + 8 * h2;
+        const bool live = d0 < hd;
+        typename M::Frag fb = M::keep_if(M::ld_row(tile + (tb * 32 + r) * strideB + (cb + d0) * (int)sizeof(T)), live);
+        if (16 * kk < hd) {
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta) {
+                typename M::Frag fa = M::keep_if(M::ld_row(tile + (ta * 32 + r) * strideB + (ca + d0) * (int)sizeof(T)), live);
+                M::mma(fa, fb, acc[ta]);
+            }
+        }
+    }
+}
+// same with the roles named for the natural orientation: acc[qt] = Q[qt tile] . K[kt tile]^T
+template <typename T>
+__device__ __forceinline__ void qk_half_b(f32x16 (&acc)[2], const char* tile, int strideB, int ca, int cb, int tb, int hd,
+                                          int lane) {
+    qk_half<T>(acc, tile, strideB, ca, cb, tb, hd, lane);
+}
+// store one 32-token tile t of a result (row = token t*32 + acc_row, col = lane&31 = d) into LDS columns
+template <typename T>
+__device__ __forceinline__ void store_tile(char* tile, int strideB, int col0, int t, const f32x16& z, float mul, int hd,
+                                           int lane) {
+    const int d = lane & 31, h2 = lane >> 5;
+    if (d < hd) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            *(T*)(tile + (t * 32 + acc_row(e, h2)) * strideB + (col0 + d) * (int)sizeof(T)) = from_f32<T>(z[e] * mul);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int HG = HeadsPerGroup<T>::value;
+    constexpr int NTHR = HG * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
     const int GW = HG * hd;                              // columns per q/k/v segment in the tile
@@ -245,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         window_token(a, wi, threadIdx.x, tk, lb);
         toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
     }
-    for (int i = threadIdx.x; i < heads_here * 225; i += 256) {
+    for (int i = threadIdx.x; i < heads_here * 225; i += NTHR) {
         const int hh = i / 225, idx = i - hh * 225;
         btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh];
     }
@@ -306,6 +351,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+    constexpr int HG = HeadsPerGroup<T>::value;
+    constexpr int NTHR = HG * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
     const int GW = HG * hd;
@@ -317,6 +364,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     int* labels = (int*)(toks + 64);
     const int dq_strideB = GW * (int)sizeof(T) + 16;
     char* dqt = (char*)(labels + 64);                     // [64][GW] side tile for dQ
+    const int dkv_strideB = 2 * GW * (int)sizeof(T) + 16;
+    char* dkv = dqt + 64 * dq_strideB;                    // [64][dV | dK] side tile
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hg = blockIdx.y;
@@ -325,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     const int r = lane & 31, h2 = lane >> 5;
     const bool active = head < a.heads;
 
-    for (int i = threadIdx.x; i < heads_here * 225; i += 256) {
+    for (int i = threadIdx.x; i < heads_here * 225; i += NTHR) {
         const int hh = i / 225, idx = i - hh * 225;
         btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh];
     }
@@ -357,105 +406,114 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         __syncthreads();
 
         if (active) {
-            {
-                // ---- transposed orientation: rows = keys, lane = query ------------------------------------
-                f32x16 pt[2][2], dpt[2][2];
-                qk_product<T>(pt, tile, strideB, ck, cq, hd, lane);     // S^T = K Q^T
-                qk_product<T>(dpt, tile, strideB, cv, cdo, hd, lane);   // dP^T = V dO^T
+            // ---- transposed orientation (rows = keys, lane = query), one 32-query tile at a time so that only
+            // 2+2 score tiles are live next to the persistent d(bias) accumulators --------------------------------
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x16 pt[2], dpt[2];
+                qk_half<T>(pt, tile, strideB, ck, cq, qt, hd, lane);      // S^T[:, qt] = K Q_qt^T
+                qk_half<T>(dpt, tile, strideB, cv, cdo, qt, hd, lane);    // dP^T[:, qt] = V dO_qt^T
+                const int qi = qt * 32 + r;
+                const int ql = labels[qi];
+                const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
+                const int* labh = labels + 4 * h2;
+                float m = -1e30f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float sv = pt[kt][e] * a.scale + btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))];
+                        sv -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;
+                        pt[kt][e] = sv;
+                        m = fmaxf(m, sv);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float pv = __expf(pt[kt][e] - m);
+                        pt[kt][e] = pv;
+                        l += pv;
+                    }
+                l += __shfl_xor(l, 32, 64);
+                const float il = 1.f / l;
+                float delta = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        pt[kt][e] *= il;
+                        delta += pt[kt][e] * dpt[kt][e];
+                    }
+                delta += __shfl_xor(delta, 32, 64);
+                if (h2 == 0) { st_w[qi * 3 + 0] = m; st_w[qi * 3 + 1] = il; st_w[qi * 3 + 2] = delta; }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float ds = pt[kt][e] * (dpt[kt][e] - delta);
+                        dpt[kt][e] = ds;               // dS^T
+                        dsum[kt][qt][e] += ds;
+                    }
+                // dQ[query tile qt][d] = sum_key dS^T[key][query] K[key][d]
+                f32x16 dq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+                        AMma<T>::mma(AMma<T>::from_acc(dpt[kt], sx), AMma<T>::ld_cols(tile, strideB, kt * 32 + 16 * sx, ck, lane), dq);
+                store_tile<T>(dqt, dq_strideB, cq, qt, dq, a.scale, hd, lane);   // side tile: q is still needed below
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    const int qi = qt * 32 + r;
-                    const int ql = labels[qi];
-                    const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
-                    const int* labh = labels + 4 * h2;
-                    float m = -1e30f;
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float s = pt[kt][qt][e] * a.scale + btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))];
-                            s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;   // labels are all 0 when shift == 0
-                            pt[kt][qt][e] = s;
-                            m = fmaxf(m, s);
-                        }
-                    m = fmaxf(m, __shfl_xor(m, 32, 64));
-                    float l = 0.f;
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float p = __expf(pt[kt][qt][e] - m);
-                            pt[kt][qt][e] = p;
-                            l += p;
-                        }
-                    l += __shfl_xor(l, 32, 64);
-                    const float il = 1.f / l;
-                    float delta = 0.f;
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            pt[kt][qt][e] *= il;
-                            delta += pt[kt][qt][e] * dpt[kt][qt][e];
-                        }
-                    delta += __shfl_xor(delta, 32, 64);
-                    if (h2 == 0) { st_w[qi * 3 + 0] = m; st_w[qi * 3 + 1] = il; st_w[qi * 3 + 2] = delta; }
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float ds = pt[kt][qt][e] * (dpt[kt][qt][e] - delta);
-                            dpt[kt][qt][e] = ds;               // dS^T
-                            dsum[kt][qt][e] += ds;
-                        }
-                }
-                f32x16 dq[2];
-                xt_product<T>(dq, dpt, tile, strideB, ck, lane);    // dQ[query][d] = sum_key dS^T[key][query] K[key][d]
-                store_rows<T>(dqt, dq_strideB, cq, dq, a.scale, hd, lane);   // side tile: q is still needed below
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the two orientations' live ranges apart
-            {
-                // ---- natural orientation: rows = queries, lane = key -----------------------------------------
-                f32x16 p[2][2], dp[2][2];
-                qk_product<T>(p, tile, strideB, cq, ck, hd, lane);      // S = Q K^T
-                qk_product<T>(dp, tile, strideB, cdo, cv, hd, lane);    // dP = dO V^T
+            // ---- natural orientation (rows = queries, lane = key), one 32-key tile at a time -----------------------
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    const int ki = kt * 32 + r;
-                    const int kl = labels[ki];
-                    const float* btk = bt + 112 + 4 * h2 - (ki >> 3) * 15 - (ki & 7);
-                    const int* labh = labels + 4 * h2;
-                    const float* sth = st_w + 12 * h2;
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 p[2], dp[2];
+                qk_half_b<T>(p, tile, strideB, cq, ck, kt, hd, lane);      // S[:, kt] = Q K_kt^T
+                qk_half_b<T>(dp, tile, strideB, cdo, cv, kt, hd, lane);    // dP[:, kt] = dO V_kt^T
+                const int ki = kt * 32 + r;
+                const int kl = labels[ki];
+                const float* btk = bt + 112 + 4 * h2 - (ki >> 3) * 15 - (ki & 7);
+                const int* labh = labels + 4 * h2;
+                const float* sth = st_w + 12 * h2;
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            // query = qt*32 + (e&3) + 8*(e>>2) + 4*h2 -> (y, x) = (qt*4 + (e>>2), (e&3) + 4*h2)
-                            const int qc = qt * 32 + (e & 3) + 8 * (e >> 2);
-                            float s = p[qt][kt][e] * a.scale + btk[(qt * 4 + (e >> 2)) * 15 + (e & 3)];
-                            s -= (labh[qc] != kl) ? 100.f : 0.f;
-                            const float pv = __expf(s - sth[qc * 3 + 0]) * sth[qc * 3 + 1];
-                            p[qt][kt][e] = pv;
-                            dp[qt][kt][e] = pv * (dp[qt][kt][e] - sth[qc * 3 + 2]);   // dS
-                        }
-                }
-                // v and k are dead once S, dP (above) and dQ (first half) exist: overwrite them in place
+                    for (int e = 0; e < 16; ++e) {
+                        const int qc = qt * 32 + (e & 3) + 8 * (e >> 2);
+                        float sv = p[qt][e] * a.scale + btk[(qt * 4 + (e >> 2)) * 15 + (e & 3)];
+                        sv -= (labh[qc] != kl) ? 100.f : 0.f;
+                        const float pv = __expf(sv - sth[qc * 3 + 0]) * sth[qc * 3 + 1];
+                        p[qt][e] = pv;
+                        dp[qt][e] = pv * (dp[qt][e] - sth[qc * 3 + 2]);   // dS
+                    }
+                f32x16 gv, gk;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { gv[e] = 0.f; gk[e] = 0.f; }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        // dV[key tile][d] += P[query][key]^T dO[query][d];  dK += dS^T Q
+                        AMma<T>::mma(AMma<T>::from_acc(p[qt], sx), AMma<T>::ld_cols(tile, strideB, qt * 32 + 16 * sx, cdo, lane), gv);
+                        AMma<T>::mma(AMma<T>::from_acc(dp[qt], sx), AMma<T>::ld_cols(tile, strideB, qt * 32 + 16 * sx, cq, lane), gk);
+                    }
+                // dV / dK of this key tile go to a second side tile: v and k rows of OTHER key tiles are still needed
+                store_tile<T>(dkv, dkv_strideB, cq, kt, gv, 1.f, hd, lane);
+                store_tile<T>(dkv, dkv_strideB, GW + cq, kt, gk, a.scale, hd, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                f32x16 g[2];
-                xt_product<T>(g, p, tile, strideB, cdo, lane);      // dV[key][d] = sum_query P[query][key] dO[query][d]
-                store_rows<T>(tile, strideB, cv, g, 1.f, hd, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                xt_product<T>(g, dp, tile, strideB, cq, lane);      // dK[key][d] = sum_query dS[query][key] Q[query][d]
-                store_rows<T>(tile, strideB, ck, g, a.scale, hd, lane);
             }
         }
         __syncthreads();
         window_copy<T, false>(dqt, dq_strideB, (T*)a.dqkv, 3 * a.C, hg * GW, 0, heads_here * hd, toks);
-        for (int sel = 1; sel < 3; ++sel)
-            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
+        window_copy<T, false>(dkv, dkv_strideB, (T*)a.dqkv, 3 * a.C, 1 * a.C + hg * GW, GW, heads_here * hd, toks);   // dK
+        window_copy<T, false>(dkv, dkv_strideB, (T*)a.dqkv, 3 * a.C, 2 * a.C + hg * GW, 0, heads_here * hd, toks);    // dV
     }
-    // flush d(bias) partial sums: dbias_acc[head][query][key] += dsum
+    // flush d(bias) partial sums: dbias_acc[head][key][query] += dsum (lane = query: 128-byte contiguous atomics)
     if (active) {
         float* dst = a.dbias_acc + (long)head * 4096;
 #pragma unroll
@@ -464,7 +522,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    atomicAdd(dst + (qt * 32 + r) * 64 + kt * 32 + acc_row(e, h2), dsum[kt][qt][e]);
+                    atomicAdd(dst + (kt * 32 + acc_row(e, h2)) * 64 + qt * 32 + r, dsum[kt][qt][e]);
     }
 }
 
@@ -481,14 +539,14 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
         for (int qx = 0; qx < 8; ++qx) {
             const int kx = qx - dx;
             if (kx < 0 || kx > 7) continue;
-            s += acc[(long)h * 4096 + (qy * 8 + qx) * 64 + ky * 8 + kx];
+            s += acc[(long)h * 4096 + (ky * 8 + kx) * 64 + qy * 8 + qx];
         }
     }
     dtable[i] = accumulate ? dtable[i] + s : s;
 }
 
-template <typename T> size_t fwd_lds(int hd) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
-template <typename T> size_t bwd_lds(int hd) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + HG * 64 * 3 * 4 + 64 * 8 + 64 * 4 + 64 * (HG * hd * sizeof(T) + 16); }
+template <typename T> size_t fwd_lds(int hd) { constexpr int HG = HeadsPerGroup<T>::value; return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
+template <typename T> size_t bwd_lds(int hd) { constexpr int HG = HeadsPerGroup<T>::value; return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + HG * 64 * 3 * 4 + 64 * 8 + 64 * 4 + 64 * (HG * hd * sizeof(T) + 16) + 64 * (2 * HG * hd * sizeof(T) + 16); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
     PSELD_CHECK_ARG(B > 0 && res >= 8 && res % 8 == 0, "%s: grid side must be a multiple of 8 (got %d)", who, res);
@@ -510,14 +568,15 @@ extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bi
     a.qkv = qkv; a.out = out; a.bias_table = bias_table; a.B = B; a.res = res; a.C = C; a.heads = heads;
     a.hd = C / heads; a.shift = shift; a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)a.hd);
-    dim3 grid(a.n_win_total, pseld_cdiv(heads, HG));
     hipStream_t s = (hipStream_t)stream;
+    const int hgv = dtype == PSELD_BF16 ? HeadsPerGroup<bf16_t>::value : HeadsPerGroup<float>::value;
+    dim3 grid(a.n_win_total, pseld_cdiv(heads, hgv));
     if (dtype == PSELD_BF16) {
-        hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), fwd_lds<bf16_t>(a.hd), s, a);
+        hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(hgv * 64), fwd_lds<bf16_t>(a.hd), s, a);
     } else if (dtype == PSELD_F32) {
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), fwd_lds<float>(a.hd), s, a);
+        hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(hgv * 64), fwd_lds<float>(a.hd), s, a);
     } else { pseld_set_error("window_attn_fwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_fwd");
     return PSELD_OK;
@@ -542,15 +601,20 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     if (hipMemsetAsync(workspace, 0, (size_t)heads * 4096 * sizeof(float), s) != hipSuccess) {
         pseld_set_error("window_attn_bwd: memset failed"); return PSELD_ERR_HIP;
     }
-    const int nhg = pseld_cdiv(heads, HG);
-    int slots = a.n_win_total < 768 ? a.n_win_total : 768;
+    // ~512-1024 workgroups in total, each walking several windows, so the d(bias) flush (one atomic tile per head
+    // per workgroup) stays a small fraction of the traffic
+    const int hgv = dtype == PSELD_BF16 ? HeadsPerGroup<bf16_t>::value : HeadsPerGroup<float>::value;
+    const int nhg = pseld_cdiv(heads, hgv);
+    int slots = 1024 / nhg;
+    if (slots > a.n_win_total) slots = a.n_win_total;
+    if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);
     if (dtype == PSELD_BF16) {
-        hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, dim3(256), bwd_lds<bf16_t>(a.hd), s, a);
+        hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, dim3(hgv * 64), bwd_lds<bf16_t>(a.hd), s, a);
     } else if (dtype == PSELD_F32) {
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, dim3(256), bwd_lds<float>(a.hd), s, a);
+        hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, dim3(hgv * 64), bwd_lds<float>(a.hd), s, a);
     } else { pseld_set_error("window_attn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_bwd");
     hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);

@@ -47,6 +47,7 @@ struct GemmArgs {
     int rows_per_scale;
     int kchunk;             // contraction elements per split (multiple of BK); == K when no split
     long slab_stride;       // elements between split-K output slabs
+    float* colsum;          // TA only: per-split column sums of A (= bias gradient), [splits][M]
     int epi, pro;
 };
 
@@ -231,12 +232,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
+    float colacc = 0.f;
     if (kbeg < kend) load_regs(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
         store_lds();
         __syncthreads();
         if (k0 + BK < kend) load_regs(k0 + BK);
+        if (TA && g.colsum && blockIdx.x == 0 && tid < BM) {
+            // bias gradient for free: column sums of the dY image this workgroup has in LDS anyway
+#pragma unroll 8
+            for (int kr = 0; kr < BK; ++kr) colacc += to_f32<T>(*(const T*)(As + kr * A_STRIDE + tid * ES));
+        }
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             if (k0 + kk * 16 < kend) {  // uniform: skip MFMA steps that are pure K padding
@@ -264,6 +271,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
         }
     }
 
+    if (TA && g.colsum && blockIdx.x == 0 && tid < BM && m0 + tid < g.M)
+        g.colsum[(long)blockIdx.z * g.M + m0 + tid] = colacc;
     OutT* Cg = (OutT*)g.C + (long)blockIdx.z * g.slab_stride;
     const T* Rg = (const T*)g.resid;
     const T* Ug = (const T*)g.aux;
@@ -419,7 +428,7 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid; g.rowscale = rowscale; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux;
     g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-    g.kchunk = K; g.slab_stride = 0; g.epi = epi; g.pro = pro;
+    g.kchunk = K; g.slab_stride = 0; g.epi = epi; g.pro = pro; g.colsum = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PSELD_BF16) {
         return trans_b ? dispatch_tile<bf16_t, bf16_t, false, true>(g, 1, s)
@@ -443,11 +452,11 @@ extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_o
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits_out) *splits_out = splits;
-    return (long)splits * N * K * (long)sizeof(float);
+    return (long)splits * ((long)N * K + N) * (long)sizeof(float);   // dW slabs + bias-gradient slabs
 }
 
-extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, int Mtok, int N, int K, int lddy,
-                                int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
+extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, int Mtok, int N, int K,
+                                int lddy, int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
                                 long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(dY && X && dW && workspace, "gemm_wgrad: null pointer");
     PSELD_CHECK_ARG(Mtok > 0 && N > 0 && K > 0, "gemm_wgrad: bad shape");
@@ -468,6 +477,7 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     kchunk = pseld_cdiv(kchunk, bk) * bk;
     splits = pseld_cdiv(Mtok, kchunk);
     g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = gelu_on_x ? PRO_GELU_B : PRO_NONE;
+    g.colsum = dbias ? workspace + (long)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true>(g, splits, s);
@@ -476,6 +486,7 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     if (rc != PSELD_OK) return rc;
     const long n = (long)N * K;
     pseld_reduce_slabs(workspace, dW, n, splits, g.slab_stride, accumulate, s);
+    if (dbias) pseld_reduce_slabs(g.colsum, dbias, (long)N, splits, (long)N, accumulate, s);
     PSELD_LAUNCH_CHECK("splitk_reduce");
     return PSELD_OK;
 }

@@ -113,8 +113,8 @@ class SwinEncoder:
         dtype = dx.dtype
         dP0 = ops.layernorm_bwd(dx, saved['P0'], a.p(p + 'patch_embed.norm.weight'), a.g(p + 'patch_embed.norm.weight'),
                                 a.g(p + 'patch_embed.norm.bias'))
-        ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 16))
-        ops.colsum(dP0, a.g(p + 'patch_embed.proj.bias'))
+        ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 16),
+                         dbias=a.g(p + 'patch_embed.proj.bias'))
         W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 16)
         dA0 = ops.linear_dgrad(dP0, W)
         ops.bn_scalar_bwd(feat, mean_rstd, dA0, bn_dw, bn_db, saved['c_first'], accumulate=accumulate_bn)
@@ -166,23 +166,19 @@ class SwinEncoder:
             s = saved['blocks'][bi]
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
             dy2 = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
-            ops.linear_wgrad(dy2, s['u'], a.g(b + 'mlp.fc2.weight'), gelu_on_x=True)
-            ops.colsum(dy2, a.g(b + 'mlp.fc2.bias'))
+            ops.linear_wgrad(dy2, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True)
             du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'])
-            ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'))
-            ops.colsum(du, a.g(b + 'mlp.fc1.bias'))
+            ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
             dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype))
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
                                        a.g(b + 'norm2.bias'), dres=dx)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
             dyp = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
-            ops.linear_wgrad(dyp, s['ao'], a.g(b + 'attn.proj.weight'))
-            ops.colsum(dyp, a.g(b + 'attn.proj.bias'))
+            ops.linear_wgrad(dyp, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'))
             dao = ops.linear_dgrad(dyp, a.w(b + 'attn.proj.weight', dtype))
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
-            ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'))
-            ops.colsum(dqkv, a.g(b + 'attn.qkv.bias'))
+            ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
             dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
                                    a.g(b + 'norm1.bias'), dres=dx_mid)
@@ -225,8 +221,8 @@ class TscamHead:
     def backward(self, dy, saved, B, dtype, accumulate_into=None):
         a, p = self.arena, self.prefix
         dz = ops.head_pool_bwd(dy.contiguous(), saved['y'], self._taps(dy.device), B, self.D, self.Dp, dtype, self.act)
-        ops.linear_wgrad(dz, saved['A'], a.g(p + 'weight', padded=True).view(self.Dp, self.C * 6))
-        ops.colsum(dz, a.g(p + 'bias', padded=True))
+        ops.linear_wgrad(dz, saved['A'], a.g(p + 'weight', padded=True).view(self.Dp, self.C * 6),
+                         dbias=a.g(p + 'bias', padded=True))
         W = a.w(p + 'weight', dtype, padded=True).view(self.Dp, self.C * 6)
         dA = ops.linear_dgrad(dz, W)
         return ops.head_col2im(dA, B)

@@ -77,16 +77,16 @@ def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resi
     return out
 
 
-def linear_wgrad(dy, x, dw, gelu_on_x=False, accumulate=False):
-    """dw f32[N,K] (+)= dy[M,N]^T @ (gelu(x) if gelu_on_x else x)[M,K]."""
-    _chk(dy, x, dw)
+def linear_wgrad(dy, x, dw, dbias=None, gelu_on_x=False, accumulate=False):
+    """dw f32[N,K] (+)= dy[M,N]^T @ (gelu(x) if gelu_on_x else x)[M,K]; dbias f32[N] (+)= column sums of dy."""
+    _chk(dy, x, dw, dbias)
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dw.shape == (N, K) and dw.dtype == torch.float32 and dy.dtype == x.dtype
     L = _lib.lib()
     need = L.pseld_gemm_wgrad_workspace(M, N, K, None)
     ws = workspace(need, dy.device)
-    rc = L.pseld_gemm_wgrad(dtype_code(dy), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), M, N, K, dy.stride(0),
+    rc = L.pseld_gemm_wgrad(dtype_code(dy), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(dbias), M, N, K, dy.stride(0),
                             x.stride(0), dw.stride(0), int(gelu_on_x), int(accumulate), _lib.ptr(ws),
                             ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_gemm_wgrad")

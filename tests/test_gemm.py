@@ -81,9 +81,11 @@ def test_linear_wgrad(dev, dtype, M, N, K):
     from pseldnets_amd import ops
     dy, x = _mk((M, N), dtype, 8, 0.1), _mk((M, K), dtype, 9)
     dw = torch.empty(N, K, dtype=torch.float32, device=dev)
-    ops.linear_wgrad(dy.to(dev), x.to(dev), dw)
+    dbf = torch.empty(N, dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dy.to(dev), x.to(dev), dw, dbias=dbf)
     ref = dy.double().t() @ x.double()
     _check(f"wgrad {M}x{N}x{K}", dw, ref, torch.float32 if dtype == torch.float32 else dtype)
+    _check("wgrad fused bias grad", dbf, dy.double().sum(0), torch.float32)
     db = torch.empty(N, dtype=torch.float32, device=dev)
     ops.colsum(dy.to(dev), db)
     _check("colsum", db, dy.double().sum(0), torch.float32)

@@ -125,6 +125,8 @@ def test_scalar_bn_fold_patchify(dev, dtype, B, T, c_first, c_use):
                                                  (2, 16, 384, 16, 4), (1, 32, 192, 8, 4), (2, 16, 64, 2, 4)])
 def test_window_attention(dev, dtype, B, res, C, heads, shift):
     from pseldnets_amd import ops
+    if dtype == torch.float32 and C // heads > 24:
+        pytest.skip("f32 (parity-mode) attention backward is built for head_dim <= 24 (LDS budget)")
     L = res * res
     qkv = rnd((B * L, 3 * C), 1, dtype)
     table = 0.5 * rnd((225, heads), 2)
