@@ -83,7 +83,7 @@ class KernelTimer:
                 flops = 2.0 * a[6] * a[7] * a[8]
             elif n == 'pseld_gemm_wgrad':
                 key = 'gemm_kernel(wgrad)+reduce'
-                flops = 2.0 * a[4] * a[5] * a[6]
+                flops = 2.0 * a[5] * a[6] * a[7]
             t = s.elapsed_time(e)
             d = agg.setdefault(key, [0.0, 0, 0.0])
             d[0] += t; d[1] += 1; d[2] += flops
