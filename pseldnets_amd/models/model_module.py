@@ -1,0 +1,112 @@
+"""Task logic around the hot path — mirror of the reference's `models/model_module.py` (SELDModelModule.setup :22-45,
+common_step :47-68, training_step :70-81) and `models/components/model_module.py` (standardize :123-126,
+configure_optimizers :128-146, configure_loss :171-175), without Lightning: the object exposes the same hooks and
+can be driven either hook-by-hook (autograd + torch optimiser, as Lightning would) or through `fused_training_step`
+(FusedTrainer: backward, bucketed all-reduce, clip and AdamW inside the MI355X path).
+Validation-epoch aggregation / SELD metrics (model_module.py:83-179) are out of scope."""
+import importlib
+
+import torch
+
+from .. import models
+from ..trainer import FusedTrainer
+from ..utils.config import get_afextractor
+
+ModelMoodule = {            # (sic) the reference's registry name, models/model_module.py:13-17
+    'accdoa': models.accdoa,
+    'einv2': models.einv2,
+    'multi_accdoa': models.multi_accdoa,
+}
+_LOSS_KIND = {'accdoa': 'mse', 'multi_accdoa': 'adpit', 'einv2': 'tpit'}
+
+
+def _get(cfg, dotted, default=None):
+    cur = cfg
+    for part in dotted.split('.'):
+        try:
+            cur = cur[part]
+        except (KeyError, TypeError):
+            return default
+    return cur
+
+
+def instantiate(node):
+    """hydra.utils.instantiate subset: {_target_: 'pkg.mod.Class', **kwargs}. Reference loss targets
+    (`loss.multi_accdoa.Losses`, ...) are mapped onto this package."""
+    kwargs = {k: v for k, v in dict(node).items() if k != '_target_'}
+    target = node['_target_']
+    if target.startswith('loss.'):
+        target = 'pseldnets_amd.' + target
+    mod, cls = target.rsplit('.', 1)
+    return getattr(importlib.import_module(mod), cls)(**kwargs)
+
+
+class SELDModelModule:
+    def __init__(self, cfg, dataset, valid_meta=None, test_meta=None):
+        self.cfg = cfg
+        self.num_classes = dataset.num_classes
+        self.method = _get(cfg, 'model.method')
+        self.net = None
+        self.training = True
+        self.af_extractor = get_afextractor(cfg)
+        self.loss = instantiate(_get(cfg, 'model.loss'))
+        aug = _get(cfg, 'augment.type', [])
+        if aug or _get(cfg, 'augment.AugMix', False):
+            raise NotImplementedError("augmentations are not built on the MI355X path yet (SURVEY.md §8f rank 1): "
+                                      "run with augment.type=[] and AugMix=false")
+        self._trainer = None
+
+    def setup(self, stage='fit', device='cuda'):
+        feature = _get(self.cfg, 'data.audio_feature')
+        in_channels = {'logmelIV': 7, 'salsa': 7, 'salsalite': 7, 'logmelgcc': 10, 'logmel': 1}[feature]
+        kwargs = dict(_get(self.cfg, 'model.kwargs', {}))
+        self.net = vars(ModelMoodule[self.method])[_get(self.cfg, 'model.backbone')](
+            self.cfg, self.num_classes, in_channels, **kwargs)
+        if str(_get(self.cfg, 'trainer.precision', '32-true')).startswith('bf16'):
+            self.net.compute_dtype = torch.bfloat16
+        self.net.to(device)
+        if self.af_extractor is not None:
+            self.af_extractor.to(device)
+        return self
+
+    def standardize(self, batch_x):
+        return self.af_extractor(batch_x) if self.af_extractor is not None else batch_x
+
+    def forward(self, x):
+        return self.net(x)
+
+    def common_step(self, batch_x, batch_y=None):
+        batch_x = self.standardize(batch_x)
+        return self.forward(batch_x), batch_y
+
+    def training_step(self, batch_sample, batch_idx=0):
+        """Reference semantics: returns the scalar to back-propagate (loss_dict[loss.loss_type])."""
+        self.net.train()
+        batch_target = {k: v for k, v in batch_sample.items() if 'data' not in k}
+        pred, target = self.common_step(batch_sample['data'], batch_target)
+        loss_dict = self.loss(pred, target)
+        return loss_dict[self.loss.loss_type]
+
+    def configure_optimizers(self):
+        opt_cfg, sch_cfg = _get(self.cfg, 'model.optimizer'), _get(self.cfg, 'model.lr_scheduler')
+        optimizer = vars(torch.optim)[opt_cfg['method']](self.net.parameters(), **dict(opt_cfg['kwargs']))
+        scheduler = vars(torch.optim.lr_scheduler)[sch_cfg['method']](optimizer, **dict(sch_cfg['kwargs']))
+        return [optimizer], [scheduler]
+
+    # -- fused path -----------------------------------------------------------------------------------------------
+    def fused_trainer(self, process_group=None):
+        if self._trainer is None:
+            opt = dict(_get(self.cfg, 'model.optimizer.kwargs', {}))
+            sch = dict(_get(self.cfg, 'model.lr_scheduler.kwargs', {}))
+            self._trainer = FusedTrainer(
+                self.net, self.af_extractor, _LOSS_KIND[self.method], lr=opt.get('lr', 1e-4),
+                max_norm=_get(self.cfg, 'trainer.gradient_clip_val', 1.0), weight_decay=opt.get('weight_decay', 0.01),
+                betas=tuple(opt.get('betas', (0.9, 0.999))), eps=opt.get('eps', 1e-8),
+                step_size=sch.get('step_size', 20), gamma=sch.get('gamma', 0.1), process_group=process_group,
+                sync_bn=bool(_get(self.cfg, 'trainer.sync_batchnorm', False)),
+                loss_beta=getattr(self.loss, 'beta', 0.5))
+        return self._trainer
+
+    def fused_training_step(self, batch_sample, process_group=None):
+        batch_target = {k: v for k, v in batch_sample.items() if 'data' not in k}
+        return self.fused_trainer(process_group).training_step(batch_sample['data'], batch_target)

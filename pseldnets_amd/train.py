@@ -1,0 +1,132 @@
+"""`python -m pseldnets_amd.train experiment=synth_maccdoa [a.b=c ...]` — minimal mirror of the reference's
+`src/train.py:19-75` for the hot path: seed -> dataset descriptor -> model module -> fused MI355X train loop on
+SYNTHETIC in-memory batches (the data layer, Hydra composition, Lightning callbacks/loggers are out of scope; the
+config keys are the reference's, defaults from configs/{data/default,model/htsat,experiment/synth_maccdoa}.yaml)."""
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+DEFAULT_CFG = {
+    'seed': 2024, 'compile': False,
+    'data': {'sample_rate': 24000, 'nfft': 1024, 'hoplen': 240, 'window': 'hann', 'n_mels': 64,
+             'audio_feature': 'logmelIV', 'train_chunklen_sec': 10, 'num_classes': 170},
+    'model': {'method': 'multi_accdoa', 'backbone': 'HTSAT', 'batch_size': 32,
+              'kwargs': {'spec_size': 256, 'patch_size': 4, 'patch_stride': [4, 4], 'embed_dim': 96,
+                         'depths': [2, 2, 6, 2], 'num_heads': [4, 8, 16, 32], 'window_size': 8, 'mlp_ratio': 4,
+                         'qkv_bias': True, 'drop_rate': 0., 'attn_drop_rate': 0., 'drop_path_rate': 0.1, 'ape': False,
+                         'patch_norm': True, 'norm_before_mlp': 'ln', 'audioset_pretrain': True, 'pretrained_path': None},
+              'loss': {'_target_': 'loss.multi_accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'},
+              'optimizer': {'method': 'AdamW', 'kwargs': {'lr': 1e-4, 'amsgrad': False}},
+              'lr_scheduler': {'method': 'StepLR', 'kwargs': {'step_size': 20, 'gamma': 0.1}}},
+    'augment': {'type': [], 'AugMix': False},
+    'trainer': {'max_epochs': 1, 'gradient_clip_val': 1.0, 'precision': 'bf16-mixed', 'sync_batchnorm': False,
+                'limit_train_batches': 10},
+    'adapt': {},
+}
+EXPERIMENTS = {
+    'synth_maccdoa': {},
+    'synth_accdoa': {'model': {'method': 'accdoa', 'loss': {'_target_': 'loss.accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'}}},
+}
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+
+def _merge(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = v
+
+
+def compose(argv):
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    for arg in argv:
+        key, _, val = arg.partition('=')
+        if key == 'experiment':
+            _merge(cfg, copy.deepcopy(EXPERIMENTS[val]))
+            continue
+        try:
+            val = json.loads(val)
+        except json.JSONDecodeError:
+            pass
+        cur = cfg
+        parts = key.split('.')
+        for p in parts[:-1]:
+            cur = cur.setdefault(p, {})
+        cur[parts[-1]] = val
+    return AttrDict(cfg)
+
+
+class SyntheticDataset:
+    max_ov, label_resolution = 3, 0.1
+
+    def __init__(self, cfg):
+        self.num_classes = cfg.data.num_classes
+
+
+def synthetic_batch(cfg, method, device, gen):
+    B, C = cfg.model.batch_size, cfg.data.num_classes
+    L = int(cfg.data.train_chunklen_sec * cfg.data.sample_rate)
+    batch = {'data': 0.1 * torch.randn(B, 4, L, device=device, generator=gen)}
+    act = (torch.rand(B, 100, C, device=device, generator=gen) < 0.02).float()
+    doa = torch.randn(B, 100, 3, C, device=device, generator=gen)
+    doa = doa / doa.norm(dim=2, keepdim=True).clamp_min(1e-6) * act.unsqueeze(2)
+    if method == 'multi_accdoa':
+        lab = torch.zeros(B, 100, 6, 4, C, device=device)
+        lab[:, :, 0, 0], lab[:, :, 0, 1:] = act, doa
+        batch['adpit_label'] = lab
+    elif method == 'accdoa':
+        batch['accdoa_label'] = doa.reshape(B, 100, 3 * C)
+    else:
+        raise NotImplementedError(method)
+    return batch
+
+
+def main(argv=None):
+    from .models.model_module import SELDModelModule
+    cfg = compose(sys.argv[1:] if argv is None else argv)
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.manual_seed(cfg.seed)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+        group = dist.group.WORLD
+    module = SELDModelModule(cfg, SyntheticDataset(cfg)).setup('fit', device)
+    if world > 1:
+        import torch.distributed as dist
+        for p in module.net.parameters():
+            dist.broadcast(p.data, 0)
+    gen = torch.Generator(device=device).manual_seed(cfg.seed + rank)
+    trainer = module.fused_trainer(group)
+    for epoch in range(cfg.trainer.max_epochs):
+        t0 = time.perf_counter()
+        for it in range(cfg.trainer.limit_train_batches):
+            loss = module.fused_training_step(synthetic_batch(cfg, cfg.model.method, device, gen), group)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"epoch {epoch}: loss_all {loss['loss_all'].item():.5f}  lr {trainer.lr:.2e}  "
+                  f"{cfg.trainer.limit_train_batches * cfg.model.batch_size * world / (time.perf_counter() - t0):.1f} chunks/s")
+        trainer.end_epoch()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

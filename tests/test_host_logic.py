@@ -1,0 +1,115 @@
+"""CPU tests of the host-side logic around the HIP path: sampler mirror vs reference-generated goldens (single
+process and a real 2-process gloo group), arena layout / gradient buckets, config composition, pooled-head taps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_sampler_single_process_matches_golden():
+    from pseldnets_amd.data.components.sampler import UserDistributedBatchSampler
+    g = np.load(os.path.join(G, 'sampler.npz'))
+    want = g['n100_b8_w1_s2024_r0']
+    s = UserDistributedBatchSampler(100, 8, seed=2024)
+    it = iter(s)
+    got = np.stack([next(it).copy() for _ in range(want.shape[0])])
+    assert np.array_equal(got, want) and len(s) == want.shape[0] - 2
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pseldnets_amd.data.components.sampler import UserDistributedBatchSampler
+    from pseldnets_amd.models.components.arena import ParamArena
+    from pseldnets_amd.trainer import FusedTrainer
+    s = UserDistributedBatchSampler(100, 8, seed=2024)
+    it = iter(s)
+    batches = np.stack([next(it).copy() for _ in range(len(s) + 2)])
+    # gradient buckets: the trainer's range all-reduce over a flat arena, issued back to front
+    arena = ParamArena()
+    for i, n in enumerate((40, 24, 100, 8)):
+        arena.add(f'p{i}', (n,))
+    arena.flat = torch.zeros(arena.size)
+    arena.grad = torch.arange(arena.size, dtype=torch.float32) * (rank + 1)
+
+    class FakeNet:
+        pass
+    net = FakeNet(); net.arena = arena
+    tr = FusedTrainer.__new__(FusedTrainer)
+    tr.net, tr.group, tr._works = net, dist.group.WORLD, []
+    hi = arena.size
+    for name in ('p2', 'p1'):
+        lo = arena.offsets[name][0]
+        tr._reduce_range(lo, hi)
+        hi = lo
+    tr._reduce_range(0, hi)
+    for w in tr._works:
+        w.wait()
+    q.put((rank, batches, arena.grad.clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_process_gloo_sampler_and_gradient_buckets():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    g = np.load(os.path.join(G, 'sampler.npz'))
+    for rank, batches, grad in res:
+        assert np.array_equal(batches, g[f'n100_b8_w2_s2024_r{rank}'])
+        n = grad.shape[0]
+        assert np.array_equal(grad, np.arange(n, dtype=np.float32) * 3.0)   # (1 + 2) * arange: every element reduced once
+    a, b = sorted(res)[0][1], sorted(res)[1][1]
+    assert not set(a[0]).intersection(b[0])           # ranks draw disjoint halves of each global batch
+
+
+def test_arena_layout_is_forward_ordered_and_padded():
+    from pseldnets_amd.models import multi_accdoa
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    net = multi_accdoa.HTSAT(A(data=A(n_mels=64, sample_rate=24000, hoplen=240), adapt=A()), 170, 7, pretrained_path=None)
+    ar = net.arena
+    offs = [ar.offsets[n][0] for n in ar.entries]
+    assert offs == sorted(offs) and all(o % 8 == 0 for o in offs)
+    assert ar.offsets['tscam_conv.weight'][2] == 1536 and ar.offsets['tscam_conv.weight'][1][0] == 1530
+    l3, l2 = ar.offsets[net.enc.first_param_of_layer(3)][0], ar.offsets[net.enc.first_param_of_layer(2)][0]
+    assert 0 < l2 < l3 < ar.size
+    assert ar.entries.index('scalar.6.weight') < ar.entries.index('scalar.0.bias')   # BN weights contiguous
+    assert len(net.state_dict()) == 225
+
+
+def test_train_config_composition_and_module_wiring():
+    from pseldnets_amd.train import compose
+    cfg = compose(['experiment=synth_accdoa', 'model.batch_size=4', 'model.kwargs.drop_path_rate=0.0'])
+    assert cfg.model.method == 'accdoa' and cfg.model.batch_size == 4 and cfg.model.kwargs.drop_path_rate == 0.0
+    assert cfg.model.loss['_target_'] == 'loss.accdoa.Losses'
+    from pseldnets_amd.models.model_module import ModelMoodule, instantiate
+    assert hasattr(ModelMoodule['multi_accdoa'], 'HTSAT')
+    loss = instantiate({'_target_': 'loss.multi_accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'})
+    assert loss.loss_dict_keys == ['loss_all', 'loss_adpit', 'loss_other']
+    with pytest.raises(NotImplementedError):
+        ModelMoodule['accdoa'].CRNN(None, 3)
+
+
+def test_pool_taps_equal_the_oracle_interpolate_mean_map():
+    from oracle import htsat as oh
+    from pseldnets_amd import ops
+    t = ops.pool_taps()
+    assert torch.equal(t['dense'], oh.pool_matrix())
+    dense = torch.zeros(100, 32)
+    for f in range(100):
+        for j in range(3):
+            if t['i0'][f] + j < 32:
+                dense[f, t['i0'][f] + j] += t['w'][3 * f + j]
+    assert torch.allclose(dense, t['dense'])
