@@ -85,6 +85,17 @@ int pseld_bn_scalar_bwd(int dtype, const float* feat, const float* mean_rstd, co
                         long workspace_bytes, void* stream);
 /* DropPath backward factor per sample (model_utilities.py:216-232): y = x * scale[i / elems_per_scale] */
 int pseld_rowscale(int dtype, const void* x, const float* scale, void* y, long n, long elems_per_scale, void* stream);
+/* y = a + b: gradient fan-in where two heads consume the same tokens (einv2.py:420-421) */
+int pseld_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);
+
+/* ---- CrossStitch soft parameter sharing of EINV2 (model_utilities.py:35-54; einv2.py:303-305) -------------------
+ * x' = w00*x + w01*y ; y' = w10*x' + w11*y (y' uses the updated x'), w f32[C,2,2], tokens [M,C]. */
+int pseld_cross_stitch_fwd(int dtype, const void* x, const void* y, const float* w, void* x_out, void* y_out, long M,
+                           int C, void* stream);
+long pseld_cross_stitch_bwd_workspace(long M, int C);
+int pseld_cross_stitch_bwd(int dtype, const void* x, const void* y, const float* w, const void* dx_out,
+                           const void* dy_out, void* dx, void* dy, float* dw, long M, int C, int accumulate,
+                           float* workspace, long workspace_bytes, void* stream);
 
 /* ---- (shifted-)window attention ----------------------------------------------------------------------------------
  * htsat.py:23-50 (partition/reverse), :239-260 (roll), :118-138 (WindowAttention core), :203-222 (mask).

@@ -112,10 +112,23 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-// exact-erf GELU and its derivative (reference: nn.GELU default, model_utilities.py:145-166)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU and its derivative (reference: nn.GELU default, model_utilities.py:145-166).
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. below fp32 round-off of the product x*cdf for
+// the activations seen here): 1 rcp + 1 exp + 6 FMA instead of the ~35-instruction libm erff, which matters because
+// GELU is re-evaluated on the operand-load path of the fc2 / dW2 GEMMs.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
     const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }

@@ -22,6 +22,7 @@
 //
 // Roofline: MFMA-bound for C >= 384 layers; stage-0/1 layers (K = 96/192) are HBM-bound (72-150 flop/B).
 #include "common.h"
+#include <stdlib.h>
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
                         hipStream_t stream);
@@ -444,13 +445,24 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 // Weight gradient dW[N,K] (fp32) = dY[Mtok,N]^T @ X[Mtok,K], optionally with GELU applied to X on load
 // (dW2 = dY^T gelu(u)). Split over the token dimension into `splits` fp32 slabs in `workspace`
 // (needs splits*N*K floats), then reduced into dW (overwrite, or accumulate when `accumulate`).
-extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
-    // aim for >= ~1024 workgroups, at least 2048 tokens per split
-    const int tiles = pseld_cdiv(N, 96) * pseld_cdiv(K, 96);
-    int splits = pseld_cdiv(1024, tiles);
-    const int max_splits = pseld_cdiv(Mtok, 2048);
+// Split planning: enough workgroups to fill the chip twice over (2 resident per CU), counted with the tile the
+// dispatcher will actually use; at least 1024 tokens per split so the fp32 slab traffic stays small.
+static int wgrad_target_blocks() {
+    static int t = 0;
+    if (!t) { const char* e = getenv("PSELD_WGRAD_TARGET"); t = e ? atoi(e) : 384; if (t < 1) t = 384; }
+    return t;
+}
+static int wgrad_splits(int Mtok, int N, int K) {
+    const bool narrow = (K <= 96 || (K % 192 != 0 && K % 96 == 0 && K <= 288));   // mirrors dispatch_tile (g.N = K)
+    const int tiles = narrow ? pseld_cdiv(N, 256) * pseld_cdiv(K, 96) : pseld_cdiv(N, 128) * pseld_cdiv(K, 192);
+    int splits = pseld_cdiv(wgrad_target_blocks(), tiles);
+    const int max_splits = pseld_cdiv(Mtok, 1024);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    return splits;
+}
+extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
+    const int splits = wgrad_splits(Mtok, N, K) + 1;   // +1: rounding kchunk to the slice size can add one split
     if (splits_out) *splits_out = splits;
     return (long)splits * ((long)N * K + N) * (long)sizeof(float);   // dW slabs + bias-gradient slabs
 }
@@ -464,9 +476,9 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
                     "gemm_wgrad: K/ld must be multiples of 8 (%d,%d,%d)", K, lddy, ldx);
     PSELD_CHECK_ARG(N % 8 == 0 || lddy >= (N + 7) / 8 * 8, "gemm_wgrad: N=%d needs dY rows padded to 8", N);
     PSELD_CHECK_ARG(lddw == K, "gemm_wgrad: dW must be dense [N,K]");
-    int splits = 1;
-    const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, &splits);
+    const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr);
     PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
+    int splits = wgrad_splits(Mtok, N, K);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = X; g.C = workspace;

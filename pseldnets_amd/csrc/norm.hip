@@ -392,6 +392,18 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
 }
 
 template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float u[8], v[8];
+    load8<T>(a + i * 8, u);
+    load8<T>(b + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] += v[k];
+    store8<T>(y + i * 8, u);
+}
+
+template <typename T>
 __global__ void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y, long n8,
                                 long elems_per_scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -402,6 +414,78 @@ __global__ void rowscale_kernel(const T* __restrict__ x, const float* __restrict
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= s;
     store8<T>(y + i * 8, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CrossStitch (model_utilities.py:35-54): x' = w00*x + w01*y ; y' = w10*x' + w11*y  (y' uses the UPDATED x').
+// w f32[C,2,2]; tokens [M, C].
+template <typename T>
+__global__ void cross_stitch_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ w,
+                                        T* __restrict__ xo, T* __restrict__ yo, long n8, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const int c0 = (int)((i * 8) % C);
+    float a[8], b[8], oa[8], ob[8];
+    load8<T>(x + i * 8, a);
+    load8<T>(y + i * 8, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 ww = *(const f32x4*)(w + (c0 + k) * 4);
+        oa[k] = ww[0] * a[k] + ww[1] * b[k];
+        ob[k] = ww[2] * oa[k] + ww[3] * b[k];
+    }
+    store8<T>(xo + i * 8, oa);
+    store8<T>(yo + i * 8, ob);
+}
+// backward: dx, dy and per-block partial sums of dw [C][4] -> partial[block][C*4]
+template <typename T>
+__global__ __launch_bounds__(256) void cross_stitch_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                               const float* __restrict__ w, const T* __restrict__ dxo,
+                                                               const T* __restrict__ dyo, T* __restrict__ dx, T* __restrict__ dy,
+                                                               float* __restrict__ partial, long M, int C, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;                       // [RPI][C*4]
+    const int CG = C >> 3;                           // 8-channel groups per row
+    const int RPI = 256 / CG;                        // rows handled per iteration
+    const int cg = threadIdx.x % CG, r0 = threadIdx.x / CG;
+    float acc[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+    if (r0 < RPI) {
+        f32x4 ww[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ww[k] = *(const f32x4*)(w + (cg * 8 + k) * 4);
+        const long rbeg = (long)blockIdx.x * rows_per_block;
+        const long rend = min(M, rbeg + rows_per_block);
+        for (long row = rbeg + r0; row < rend; row += RPI) {
+            const long off = row * C + cg * 8;
+            float a[8], b[8], ga[8], gb[8], oa[8], ob[8];
+            load8<T>(x + off, a); load8<T>(y + off, b); load8<T>(dxo + off, ga); load8<T>(dyo + off, gb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xp = ww[k][0] * a[k] + ww[k][1] * b[k];     // x'
+                const float gxp = ga[k] + ww[k][2] * gb[k];             // total gradient reaching x'
+                oa[k] = ww[k][0] * gxp;
+                ob[k] = ww[k][1] * gxp + ww[k][3] * gb[k];
+                acc[k][0] += gxp * a[k]; acc[k][1] += gxp * b[k];
+                acc[k][2] += gb[k] * xp; acc[k][3] += gb[k] * b[k];
+            }
+            store8<T>(dx + off, oa);
+            store8<T>(dy + off, ob);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(r0 * C + cg * 8 + k) * 4 + j] = acc[k][j];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * 4; idx += 256) {
+        float s = 0.f;
+        for (int rr = 0; rr < RPI; ++rr) s += red[rr * C * 4 + idx];
+        partial[(long)blockIdx.x * C * 4 + idx] = s;
+    }
 }
 
 }  // namespace
@@ -564,5 +648,48 @@ extern "C" int pseld_rowscale(int dtype, const void* x, const float* scale, void
     if (dtype == PSELD_BF16) hipLaunchKernelGGL(rowscale_kernel<bf16_t>, dim3(pseld_cdiv(n8, 256)), dim3(256), 0, s, (const bf16_t*)x, scale, (bf16_t*)y, n8, elems_per_scale);
     else hipLaunchKernelGGL(rowscale_kernel<float>, dim3(pseld_cdiv(n8, 256)), dim3(256), 0, s, (const float*)x, scale, (float*)y, n8, elems_per_scale);
     PSELD_LAUNCH_CHECK("rowscale");
+    return PSELD_OK;
+}
+
+// ---- CrossStitch ---------------------------------------------------------------------------------------------------
+extern "C" int pseld_cross_stitch_fwd(int dtype, const void* x, const void* y, const float* w, void* x_out, void* y_out,
+                                      long M, int C, void* stream) {
+    PSELD_CHECK_ARG(x && y && w && x_out && y_out && M > 0 && C % 8 == 0, "cross_stitch_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long n8 = M * C / 8;
+    if (dtype == PSELD_BF16) hipLaunchKernelGGL(cross_stitch_fwd_kernel<bf16_t>, dim3(pseld_cdiv(n8, 256)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y, w, (bf16_t*)x_out, (bf16_t*)y_out, n8, C);
+    else if (dtype == PSELD_F32) hipLaunchKernelGGL(cross_stitch_fwd_kernel<float>, dim3(pseld_cdiv(n8, 256)), dim3(256), 0, s, (const float*)x, (const float*)y, w, (float*)x_out, (float*)y_out, n8, C);
+    else { pseld_set_error("cross_stitch_fwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    PSELD_LAUNCH_CHECK("cross_stitch_fwd");
+    return PSELD_OK;
+}
+static inline int cs_rows(long M) { long r = (M + 511) / 512; if (r < 64) r = 64; return (int)r; }
+extern "C" long pseld_cross_stitch_bwd_workspace(long M, int C) { return (long)pseld_cdiv(M, cs_rows(M)) * C * 4 * (long)sizeof(float); }
+// dx, dy from (dx', dy'); dw f32[C,2,2] overwritten or accumulated.
+extern "C" int pseld_cross_stitch_bwd(int dtype, const void* x, const void* y, const float* w, const void* dx_out,
+                                      const void* dy_out, void* dx, void* dy, float* dw, long M, int C, int accumulate,
+                                      float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(x && y && w && dx_out && dy_out && dx && dy && dw && workspace, "cross_stitch_bwd: null pointer");
+    PSELD_CHECK_ARG(M > 0 && C % 8 == 0 && C <= 2048, "cross_stitch_bwd: bad M/C");
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_cross_stitch_bwd_workspace(M, C), "cross_stitch_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = cs_rows(M), nb = pseld_cdiv(M, rows);
+    const size_t lds = (size_t)(256 / (C / 8)) * C * 4 * sizeof(float);
+    if (dtype == PSELD_BF16) hipLaunchKernelGGL(cross_stitch_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)y, w, (const bf16_t*)dx_out, (const bf16_t*)dy_out, (bf16_t*)dx, (bf16_t*)dy, workspace, M, C, rows);
+    else if (dtype == PSELD_F32) hipLaunchKernelGGL(cross_stitch_bwd_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)y, w, (const float*)dx_out, (const float*)dy_out, (float*)dx, (float*)dy, workspace, M, C, rows);
+    else { pseld_set_error("cross_stitch_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    PSELD_LAUNCH_CHECK("cross_stitch_bwd");
+    pseld_reduce_slabs(workspace, dw, (long)C * 4, nb, (long)C * 4, accumulate, s);
+    return PSELD_OK;
+}
+
+// y = a + b (gradient fan-in of the shared final tokens in HTSAT_SEDDOA, einv2.py:420-421)
+extern "C" int pseld_add(int dtype, const void* a, const void* b, void* y, long n, void* stream) {
+    PSELD_CHECK_ARG(a && b && y && n % 8 == 0, "add: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long n8 = n / 8;
+    if (dtype == PSELD_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(pseld_cdiv(n8, 256)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n8);
+    else hipLaunchKernelGGL(add_kernel<float>, dim3(pseld_cdiv(n8, 256)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, n8);
+    PSELD_LAUNCH_CHECK("add");
     return PSELD_OK;
 }

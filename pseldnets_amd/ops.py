@@ -357,3 +357,33 @@ def adamw_step(p, g, m, v, step, lr, grad_norm_t=None, max_norm=0.0, grad_scale=
 def cast_bf16(x, y):
     _chk(x, y)
     _lib.check(_lib.lib().pseld_cast_f32_to_bf16(_lib.ptr(x), _lib.ptr(y), x.numel(), _lib.stream_ptr()), "pseld_cast_f32_to_bf16")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CrossStitch (EINV2)
+def cross_stitch_fwd(x, y, w):
+    _chk(x, y, w)
+    xo, yo = torch.empty_like(x), torch.empty_like(y)
+    rc = _lib.lib().pseld_cross_stitch_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(y), _lib.ptr(w), _lib.ptr(xo), _lib.ptr(yo),
+                                           x.shape[0], x.shape[1], _lib.stream_ptr())
+    _lib.check(rc, "pseld_cross_stitch_fwd")
+    return xo, yo
+
+
+def cross_stitch_bwd(x, y, w, dxo, dyo, dw, accumulate=False):
+    _chk(x, y, w, dxo, dyo, dw)
+    M, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_cross_stitch_bwd_workspace(M, C), x.device)
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    rc = L.pseld_cross_stitch_bwd(dtype_code(x), _lib.ptr(x), _lib.ptr(y), _lib.ptr(w), _lib.ptr(dxo), _lib.ptr(dyo), _lib.ptr(dx),
+                                  _lib.ptr(dy), _lib.ptr(dw), M, C, int(accumulate), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_cross_stitch_bwd")
+    return dx, dy
+
+
+def add(a, b):
+    _chk(a, b)
+    y = torch.empty_like(a)
+    _lib.check(_lib.lib().pseld_add(dtype_code(a), _lib.ptr(a), _lib.ptr(b), _lib.ptr(y), a.numel(), _lib.stream_ptr()), "pseld_add")
+    return y

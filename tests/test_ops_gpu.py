@@ -225,3 +225,22 @@ def test_clip_adamw_matches_oracle(dev):
     check("adamw p", p, pr[0], 1e-6)
     check("adamw m", m, mr[0], 1e-5)
     check("adamw shadow", shadow, pr[0].to(torch.bfloat16), 1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(4096, 96), (1000, 768), (777, 48)])
+def test_cross_stitch(dev, dtype, M, C):
+    from pseldnets_amd import ops
+    x, y = rnd((M, C), 1, dtype), rnd((M, C), 2, dtype)
+    w = 0.5 + 0.4 * torch.sin(torch.arange(C * 4, dtype=torch.float32)).view(C, 2, 2)
+    gx, gy = rnd((M, C), 3, dtype), rnd((M, C), 4, dtype)
+    xo, yo = ops.cross_stitch_fwd(x.to(dev), y.to(dev), w.to(dev).view(-1, 4))
+    xr, yr, wr = x.double().requires_grad_(True), y.double().requires_grad_(True), w.double().requires_grad_(True)
+    xo_r, yo_r = oh.cross_stitch(xr, yr, wr)
+    check("stitch x'", xo, xo_r, tol(dtype)); check("stitch y'", yo, yo_r, tol(dtype))
+    (xo_r * gx.double()).sum().backward(retain_graph=True)
+    (yo_r * gy.double()).sum().backward()
+    dw = torch.empty(C, 2, 2, device=dev)
+    dx, dy = ops.cross_stitch_bwd(x.to(dev), y.to(dev), w.to(dev).view(-1, 4), gx.to(dev), gy.to(dev), dw.view(-1, 4))
+    check("stitch dx", dx, xr.grad, tol(dtype)); check("stitch dy", dy, yr.grad, tol(dtype))
+    check("stitch dw", dw, wr.grad, 1e-4 if dtype == torch.float32 else tol(dtype))
