@@ -36,12 +36,13 @@ int pseld_logmel_iv_fwd(const float* wave, float* feat, int B, int n_ch, long L,
  * nn.Linear forward and input gradient: htsat.py:123,141 (qkv, proj), model_utilities.py:166 (fc1, fc2),
  * htsat.py:309 (PatchMerging.reduction), model_utilities.py:209 (PatchEmbed.proj as GEMM), accdoa.py:230 (tscam_conv).
  * C[M,N] = A[M,K] * (trans_b ? B[K,N] : B[N,K]^T), then (in this order):
- *   + bias[N] (epi&1) ; * rowscale[m / rows_per_scale] (if rowscale) ; * gelu'(aux[m,n]) (epi&4) ;
- *   + resid[m,n] (epi&2) ; + C_old (epi&8).
- * pro&1 applies exact-erf GELU to A on load (fc2 consumes the stored pre-activation). */
+ *   + bias[N] (epi&1) ; * rowscale[m / rows_per_scale] (if rowscale) ; * gelu'(aux[m,n]) (epi&4) or * aux[m,n]
+ *   (epi&32) ; + resid[m,n] (epi&2) ; then either C = v (+ C_old if epi&8) or, with epi&16 (the Mlp fc1 of
+ *   model_utilities.py:166), C = gelu(v) and c2 = gelu'(v) so that neither fc2 nor the backward re-evaluates erf.
+ * pro&1 applies exact-erf GELU to A on load. */
 int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B, void* C, int M, int N, int K,
                int lda, int ldb, int ldc, const float* bias, const void* resid, int ldr, const float* rowscale,
-               int rows_per_scale, const void* aux, int ldaux, int epi, int pro, void* stream);
+               int rows_per_scale, const void* aux, int ldaux, int epi, int pro, void* c2, void* stream);
 
 /* Weight gradient of the same layers: dW f32[N,K] (+)= dY[Mtok,N]^T @ (gelu_on_x ? gelu(X) : X)[Mtok,K], and (when
  * dbias != NULL) the bias gradient dbias f32[N] (+)= sum_m dY[m,n] from the same pass. Split over tokens into fp32

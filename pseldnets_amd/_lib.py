@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpseld_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "pseld_hip.h")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_RESID, EPI_MULGELUGRAD, EPI_ACCUM = 0, 1, 2, 4, 8
+EPI_NONE, EPI_BIAS, EPI_RESID, EPI_MULGELUGRAD, EPI_ACCUM, EPI_GELU_DUAL, EPI_MULAUX = 0, 1, 2, 4, 8, 16, 32
 PRO_NONE, PRO_GELU_A, PRO_GELU_B = 0, 1, 2
 
 

@@ -19,10 +19,17 @@
 //
 // Roofline: HBM-bound (reads 3C, writes C per token; ~100 flop/B at head_dim 24).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-template <typename T> struct HeadsPerGroup { static constexpr int value = sizeof(T) == 2 ? 4 : 2; };  // = waves per workgroup
+// heads per workgroup (= waves per workgroup): 4 or 2 for bf16 (PSELD_ATTN_HG, default 4), 2 for f32 (LDS budget)
+static int attn_hg(int dtype) {
+    if (dtype != PSELD_BF16) return 2;
+    static int v = 0;
+    if (!v) { const char* e = getenv("PSELD_ATTN_HG"); v = (e && atoi(e) == 2) ? 2 : 4; }
+    return v;
+}
 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -266,9 +273,8 @@ __device__ __forceinline__ void store_tile(char* tile, int strideB, int col0, in
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    constexpr int HG = HeadsPerGroup<T>::value;
+template <typename T, int HG>
+__global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NTHR = HG * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
@@ -349,9 +355,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     window_copy<T, false>(tile, strideB, (T*)a.out, a.C, hg * GW, 0, heads_here * hd, toks);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
-    constexpr int HG = HeadsPerGroup<T>::value;
+template <typename T, int HG>
+__global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
     constexpr int NTHR = HG * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
@@ -545,8 +550,8 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
     dtable[i] = accumulate ? dtable[i] + s : s;
 }
 
-template <typename T> size_t fwd_lds(int hd) { constexpr int HG = HeadsPerGroup<T>::value; return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
-template <typename T> size_t bwd_lds(int hd) { constexpr int HG = HeadsPerGroup<T>::value; return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + HG * 64 * 3 * 4 + 64 * 8 + 64 * 4 + 64 * (HG * hd * sizeof(T) + 16) + 64 * (2 * HG * hd * sizeof(T) + 16); }
+template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
+template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + HG * 64 * 3 * 4 + 64 * 8 + 64 * 4 + 64 * (HG * hd * sizeof(T) + 16) + 64 * (2 * HG * hd * sizeof(T) + 16); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
     PSELD_CHECK_ARG(B > 0 && res >= 8 && res % 8 == 0, "%s: grid side must be a multiple of 8 (got %d)", who, res);
@@ -569,14 +574,15 @@ extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bi
     a.hd = C / heads; a.shift = shift; a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
-    const int hgv = dtype == PSELD_BF16 ? HeadsPerGroup<bf16_t>::value : HeadsPerGroup<float>::value;
+    const int hgv = attn_hg(dtype);
     dim3 grid(a.n_win_total, pseld_cdiv(heads, hgv));
     if (dtype == PSELD_BF16) {
-        hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(hgv * 64), fwd_lds<bf16_t>(a.hd), s, a);
+        if (hgv == 4) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(256), fwd_lds<bf16_t>(a.hd, 4), s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 2>), grid, dim3(128), fwd_lds<bf16_t>(a.hd, 2), s, a);
     } else if (dtype == PSELD_F32) {
         static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(hgv * 64), fwd_lds<float>(a.hd), s, a);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(128), fwd_lds<float>(a.hd, 2), s, a);
     } else { pseld_set_error("window_attn_fwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_fwd");
     return PSELD_OK;
@@ -603,18 +609,19 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     }
     // ~512-1024 workgroups in total, each walking several windows, so the d(bias) flush (one atomic tile per head
     // per workgroup) stays a small fraction of the traffic
-    const int hgv = dtype == PSELD_BF16 ? HeadsPerGroup<bf16_t>::value : HeadsPerGroup<float>::value;
+    const int hgv = attn_hg(dtype);
     const int nhg = pseld_cdiv(heads, hgv);
     int slots = 1024 / nhg;
     if (slots > a.n_win_total) slots = a.n_win_total;
     if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);
     if (dtype == PSELD_BF16) {
-        hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, dim3(hgv * 64), bwd_lds<bf16_t>(a.hd), s, a);
+        if (hgv == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(256), bwd_lds<bf16_t>(a.hd, 4), s, a);
+        else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), bwd_lds<bf16_t>(a.hd, 2), s, a);
     } else if (dtype == PSELD_F32) {
         static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, dim3(hgv * 64), bwd_lds<float>(a.hd), s, a);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), grid, dim3(128), bwd_lds<float>(a.hd, 2), s, a);
     } else { pseld_set_error("window_attn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_bwd");
     hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);

@@ -126,6 +126,20 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float y = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(y, x);
 }
+// gelu(x) and gelu'(x) together (they share the polynomial and exp(-x^2/2) = the A&S exponential)
+__device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-ax * ax);                 // = exp(-x^2 / 2)
+    const float erfv = copysignf(1.0f - p * t * e, x);
+    const float cdf = 0.5f * (1.0f + erfv);
+    y = x * cdf;
+    dy = cdf + x * 0.3989422804014327f * e;
+}
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));

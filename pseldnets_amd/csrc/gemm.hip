@@ -29,10 +29,9 @@ void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long
 
 namespace {
 
-constexpr int GEMM_THREADS = 256;
 constexpr int ROWB = 144;  // bytes per non-transposed LDS row: 128 B of K + 16 B pad
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_RESID = 2, EPI_MULGELUGRAD = 4, EPI_ACCUM = 8 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_RESID = 2, EPI_MULGELUGRAD = 4, EPI_ACCUM = 8, EPI_GELU_DUAL = 16, EPI_MULAUX = 32 };
 enum { PRO_NONE = 0, PRO_GELU_A = 1, PRO_GELU_B = 2 };
 
 struct GemmArgs {
@@ -42,7 +41,8 @@ struct GemmArgs {
     const float* bias;      // [N]
     const void* resid;      // [M, ldr] (T)
     const float* rowscale;  // [ceil(M / rows_per_scale)] or null
-    const void* aux;        // [M, ldaux] (T): pre-activation for EPI_MULGELUGRAD
+    const void* aux;        // [M, ldaux] (T): pre-activation for EPI_MULGELUGRAD / multiplier for EPI_MULAUX
+    void* C2;               // EPI_GELU_DUAL: C = gelu(v), C2 = gelu'(v), both [M, ldc]
     int M, N, K;
     int lda, ldb, ldc, ldr, ldaux;
     int rows_per_scale;
@@ -142,7 +142,8 @@ template <> __device__ __forceinline__ f32x4 gelu_chunk<float>(f32x4 v) { return
 
 // ---- the kernel ---------------------------------------------------------------------------------------
 template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+    constexpr int GEMM_THREADS = WM * WN * 64;
     constexpr int BM = WM * 64, BN = WN * 96;
     constexpr int BK = Mma<T>::BK, KSTEPS = Mma<T>::KSTEPS;
     constexpr int ES = (int)sizeof(T);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
     constexpr int B_STRIDE = TB ? TStride<T, BN>::value : ROWB;
     constexpr int A_BYTES = TA ? BK * A_STRIDE : BM * ROWB;
     constexpr int B_BYTES = TB ? BK * B_STRIDE : BN * ROWB;
-    constexpr int NCH_A = BM / 32, NCH_B = BN / 32;  // 16-byte chunks per thread per K slice
+    constexpr int NCH_A = BM * 8 / GEMM_THREADS, NCH_B = BN * 8 / GEMM_THREADS;  // 16-byte chunks per thread per K slice
     constexpr int A_CPR = TA ? BM / EPC : 8;         // chunks per image row
     constexpr int B_CPR = TB ? BN / EPC : 8;
     constexpr bool STAGED = (sizeof(OutT) == 2);      // bf16 output: LDS-staged, 16-byte coalesced epilogue
@@ -301,30 +302,61 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
             }
         __syncthreads();
         constexpr int CPR = BN / 8;
-        for (int c = tid; c < BM * CPR; c += GEMM_THREADS) {
-            const int row = c / CPR, cb = c - row * CPR;
-            const int m = m0 + row, n = n0 + cb * 8;
-            if (m >= g.M || n >= g.N) continue;
-            float v[8];
-            load8<bf16_t>((const bf16_t*)(Cs + row * CS_STRIDE + cb * 16), v);
-            if (g.rowscale) {
-                const float sc = g.rowscale[m / g.rows_per_scale];
+        constexpr int NCHUNK = BM * CPR / GEMM_THREADS;   // 16-byte chunks per thread (12 for every tile shape)
+        constexpr int UB = 4;                              // chunks in flight per thread: loads first, stores last
+        static_assert(NCHUNK % UB == 0, "epilogue batching");
+        const bool use_aux = (g.epi & (EPI_MULGELUGRAD | EPI_MULAUX)) != 0;
+        const bool use_res = (g.epi & EPI_RESID) != 0;
+#pragma unroll 1
+        for (int b0 = 0; b0 < NCHUNK; b0 += UB) {
+            float v[UB][8], u[UB][8], rr[UB][8];
+            int mrow[UB], ncol[UB];
+            bool ok[UB];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= sc;
+            for (int j = 0; j < UB; ++j) {
+                const int c = tid + (b0 + j) * GEMM_THREADS;
+                const int row = c / CPR, cb = c - row * CPR;
+                mrow[j] = m0 + row; ncol[j] = n0 + cb * 8;
+                ok[j] = mrow[j] < g.M && ncol[j] < g.N;
+                load8<bf16_t>((const bf16_t*)(Cs + row * CS_STRIDE + cb * 16), v[j]);
             }
-            if (g.epi & EPI_MULGELUGRAD) {
-                float u[8];
-                load8<bf16_t>((const bf16_t*)Ug + (long)m * g.ldaux + n, u);
+            if (use_aux) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(u[k]);
+                for (int j = 0; j < UB; ++j)
+                    if (ok[j]) load8<bf16_t>((const bf16_t*)Ug + (long)mrow[j] * g.ldaux + ncol[j], u[j]);
             }
-            if (g.epi & EPI_RESID) {
-                float rr[8];
-                load8<bf16_t>((const bf16_t*)Rg + (long)m * g.ldr + n, rr);
+            if (use_res) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                for (int j = 0; j < UB; ++j)
+                    if (ok[j]) load8<bf16_t>((const bf16_t*)Rg + (long)mrow[j] * g.ldr + ncol[j], rr[j]);
             }
-            store8<bf16_t>((bf16_t*)Cg + (long)m * g.ldc + n, v);
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                if (!ok[j]) continue;
+                if (g.rowscale) {
+                    const float sc = g.rowscale[mrow[j] / g.rows_per_scale];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[j][k] *= sc;
+                }
+                if (g.epi & EPI_MULAUX) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[j][k] *= u[j][k];
+                } else if (g.epi & EPI_MULGELUGRAD) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[j][k] *= gelu_grad_f(u[j][k]);
+                }
+                if (use_res) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[j][k] += rr[j][k];
+                }
+                if (g.epi & EPI_GELU_DUAL) {
+                    float dv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gelu_both(v[j][k], v[j][k], dv[k]);
+                    store8<bf16_t>((bf16_t*)g.C2 + (long)mrow[j] * g.ldc + ncol[j], dv);
+                }
+                store8<bf16_t>((bf16_t*)Cg + (long)mrow[j] * g.ldc + ncol[j], v[j]);
+            }
         }
     } else {
         // ---- f32 epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
@@ -332,20 +364,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
         for (int ni = 0; ni < 3; ++ni) {
             const int n = n0 + wn * 96 + ni * 32 + r;
             if (n >= g.N) continue;
-            const float bv = (g.epi & EPI_BIAS) ? g.bias[n] : 0.f;
+            if constexpr (TA) {
+                // weight-gradient slabs: plain fp32 stores, no fused options (keeps this variant at 2 waves/SIMD)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m >= g.M) continue;
-                    float v = acc[mi][ni][e] + bv;
-                    if (g.rowscale) v *= g.rowscale[m / g.rows_per_scale];
-                    if (g.epi & EPI_MULGELUGRAD) v *= gelu_grad_f(to_f32<T>(Ug[(long)m * g.ldaux + n]));
-                    if (g.epi & EPI_RESID) v += to_f32<T>(Rg[(long)m * g.ldr + n]);
-                    OutT* dst = Cg + (long)m * g.ldc + n;
-                    if (g.epi & EPI_ACCUM) v += to_f32<OutT>(*dst);
-                    *dst = from_f32<OutT>(v);
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (m < g.M) Cg[(long)m * g.ldc + n] = from_f32<OutT>(acc[mi][ni][e]);
+                    }
+            } else {
+                const float bv = (g.epi & EPI_BIAS) ? g.bias[n] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (m >= g.M) continue;
+                        float v = acc[mi][ni][e] + bv;
+                        if (g.rowscale) v *= g.rowscale[m / g.rows_per_scale];
+                        if (g.epi & EPI_MULGELUGRAD) v *= gelu_grad_f(to_f32<T>(Ug[(long)m * g.ldaux + n]));
+                        if (g.epi & EPI_MULAUX) v *= to_f32<T>(Ug[(long)m * g.ldaux + n]);
+                        if (g.epi & EPI_RESID) v += to_f32<T>(Rg[(long)m * g.ldr + n]);
+                        if (g.epi & EPI_GELU_DUAL) {
+                            float dv;
+                            gelu_both(v, v, dv);
+                            ((OutT*)g.C2)[(long)m * g.ldc + n] = from_f32<OutT>(dv);
+                        }
+                        OutT* dst = Cg + (long)m * g.ldc + n;
+                        if (g.epi & EPI_ACCUM) v += to_f32<OutT>(*dst);
+                        *dst = from_f32<OutT>(v);
+                    }
                 }
             }
         }
@@ -362,9 +411,19 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
     constexpr int CS_BYTES = (sizeof(OutT) == 2) ? BM * (BN * 2 + 16) : 0;
     constexpr int LDS = (A_BYTES + B_BYTES > CS_BYTES) ? (A_BYTES + B_BYTES) : CS_BYTES;
     dim3 grid(pseld_cdiv(g.N, BN), pseld_cdiv(g.M, BM), splits);
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(GEMM_THREADS), LDS, stream, g);
+    if (LDS > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, OutT, WM, WN, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(WM * WN * 64), LDS, stream, g);
     PSELD_LAUNCH_CHECK("gemm");
     return PSELD_OK;
+}
+
+static int gemm_big_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PSELD_GEMM_BIG"); v = e ? atoi(e) : 1; }
+    return v;
 }
 
 template <typename T, typename OutT, bool TA, bool TB>
@@ -372,6 +431,8 @@ int dispatch_tile(const GemmArgs& g, int splits, hipStream_t stream) {
     // 256x96 when one 96-column tile covers N (or N is not worth a 192 tile), else 128x192
     if (g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288))
         return launch_gemm<T, OutT, 4, 1, TA, TB>(g, splits, stream);
+    if (sizeof(T) == 2 && TA && gemm_big_tiles() && g.M >= 256)
+        return launch_gemm<T, OutT, 4, 2, TA, TB>(g, splits, stream);   // weight gradient: 256x192, 8 waves (measured +4 %)
     return launch_gemm<T, OutT, 2, 2, TA, TB>(g, splits, stream);
 }
 
@@ -411,7 +472,7 @@ static size_t g_ws_need = 0;
 extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B, void* C, int M, int N,
                           int K, int lda, int ldb, int ldc, const float* bias, const void* resid, int ldr,
                           const float* rowscale, int rows_per_scale, const void* aux, int ldaux, int epi, int pro,
-                          void* stream) {
+                          void* c2, void* stream) {
     PSELD_CHECK_ARG(A && B && C, "gemm: null operand");
     PSELD_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape %dx%dx%d", M, N, K);
     PSELD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 (%d,%d)", lda, ldb);
@@ -421,12 +482,13 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     PSELD_CHECK_ARG(!trans_a, "gemm: use pseld_gemm_wgrad for the split-K weight-gradient layout");
     PSELD_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm: EPI_BIAS without bias");
     PSELD_CHECK_ARG(!(epi & EPI_RESID) || resid, "gemm: EPI_RESID without resid");
-    PSELD_CHECK_ARG(!(epi & EPI_MULGELUGRAD) || aux, "gemm: EPI_MULGELUGRAD without aux");
+    PSELD_CHECK_ARG(!(epi & (EPI_MULGELUGRAD | EPI_MULAUX)) || aux, "gemm: aux-multiply epilogue without aux");
+    PSELD_CHECK_ARG(!(epi & EPI_GELU_DUAL) || c2, "gemm: EPI_GELU_DUAL without the second output");
     PSELD_CHECK_ARG(!trans_b || N % 8 == 0, "gemm: N must be a multiple of 8 when B is [K,N]");
     PSELD_CHECK_ARG(dtype != PSELD_BF16 || (N % 8 == 0 && ldc % 8 == 0 && (!resid || ldr % 8 == 0) && (!aux || ldaux % 8 == 0)),
                     "gemm(bf16): N and ldc/ldr/ldaux must be multiples of 8 (%d,%d)", N, ldc);
     GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid; g.rowscale = rowscale; g.aux = aux;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid; g.rowscale = rowscale; g.aux = aux; g.C2 = c2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux;
     g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     g.kchunk = K; g.slab_stride = 0; g.epi = epi; g.pro = pro; g.colsum = nullptr;
@@ -449,14 +511,14 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 // dispatcher will actually use; at least 1024 tokens per split so the fp32 slab traffic stays small.
 static int wgrad_target_blocks() {
     static int t = 0;
-    if (!t) { const char* e = getenv("PSELD_WGRAD_TARGET"); t = e ? atoi(e) : 384; if (t < 1) t = 384; }
+    if (!t) { const char* e = getenv("PSELD_WGRAD_TARGET"); t = e ? atoi(e) : 1024; if (t < 1) t = 1024; }
     return t;
 }
 static int wgrad_splits(int Mtok, int N, int K) {
-    const bool narrow = (K <= 96 || (K % 192 != 0 && K % 96 == 0 && K <= 288));   // mirrors dispatch_tile (g.N = K)
-    const int tiles = narrow ? pseld_cdiv(N, 256) * pseld_cdiv(K, 96) : pseld_cdiv(N, 128) * pseld_cdiv(K, 192);
+    // ~1024 workgroups counted in 96x96 units (measured best across the HTS-AT shapes), >= 2048 tokens per split
+    const int tiles = pseld_cdiv(N, 96) * pseld_cdiv(K, 96);
     int splits = pseld_cdiv(wgrad_target_blocks(), tiles);
-    const int max_splits = pseld_cdiv(Mtok, 1024);
+    const int max_splits = pseld_cdiv(Mtok, 2048);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     return splits;

@@ -7,15 +7,19 @@ and the head part of `models/accdoa.py:204-246`. No tensor arithmetic happens in
 into the C ABI (pseldnets_amd/ops.py). Differences from the reference that are deliberate and invisible in results:
   * tokens stay in natural [B*L, C] order for the whole network; roll / window partition / reverse / patch-merge
     gather / time-frequency fold / token->map reshapes are address maps inside the kernels, never copies;
-  * GELU is applied on the consumer side (fc2 reads the stored pre-activation), so one [M, 4C] tensor is saved
-    per block instead of two; attention probabilities are recomputed in backward instead of stored;
+  * fc1's GEMM epilogue emits gelu(u) AND gelu'(u) (the pre-activation itself is never stored), so erf is evaluated
+    once per element for forward + backward; attention probabilities are recomputed in backward instead of stored;
   * eval-mode attention-map averaging (htsat.py:371-377) is skipped — no SELD head consumes it.
 """
 import math
 
 import torch
 
+import os
+
 from ... import ops
+
+GELU_DUAL = os.environ.get('PSELD_GELU_DUAL', '1') != '0'
 
 DEFAULTS = dict(spec_size=256, patch_size=4, patch_stride=(4, 4), embed_dim=96, depths=(2, 2, 6, 2),
                 num_heads=(4, 8, 16, 32), window_size=8, mlp_ratio=4.0, qkv_bias=True, drop_rate=0.0,
@@ -138,10 +142,19 @@ class SwinEncoder:
             x_mid = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
                                    rowscale=s1, rows_per_scale=L)
             xh2 = ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
-            u = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'))
-            x_out = ops.linear_fwd(u, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
-                                   rowscale=s2, rows_per_scale=L, gelu_in=True)
-            saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, u=u, s1=s1, s2=s2, shift=shift))
+            if GELU_DUAL:
+                # fc1 epilogue emits h = gelu(u) and g = gelu'(u): erf is evaluated once per element, not in fc2/dW2/dU
+                hact, gact = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), gelu_dual=True)
+                x_out = ops.linear_fwd(hact, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
+                                       rowscale=s2, rows_per_scale=L)
+                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1,
+                                         s2=s2, shift=shift))
+            else:
+                u = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'))
+                x_out = ops.linear_fwd(u, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
+                                       rowscale=s2, rows_per_scale=L, gelu_in=True)
+                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, u=u, s1=s1, s2=s2,
+                                         shift=shift))
             x = x_out
         saved = dict(blocks=saved_blocks)
         if li < self.nl - 1:
@@ -166,8 +179,12 @@ class SwinEncoder:
             s = saved['blocks'][bi]
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
             dy2 = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
-            ops.linear_wgrad(dy2, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True)
-            du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'])
+            if 'h' in s:
+                ops.linear_wgrad(dy2, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'))
+                du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), mul=s['g'])
+            else:
+                ops.linear_wgrad(dy2, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True)
+                du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'])
             ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
             dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype))
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),

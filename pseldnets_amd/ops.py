@@ -6,8 +6,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (BF16, EPI_ACCUM, EPI_BIAS, EPI_MULGELUGRAD, EPI_NONE, EPI_RESID, F32, PRO_GELU_A,
-                   PRO_GELU_B, PRO_NONE)
+from ._lib import (BF16, EPI_ACCUM, EPI_BIAS, EPI_GELU_DUAL, EPI_MULAUX, EPI_MULGELUGRAD, EPI_NONE, EPI_RESID, F32,
+                   PRO_GELU_A, PRO_GELU_B, PRO_NONE)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -42,37 +42,42 @@ def workspace(nbytes, device):
     return buf
 
 
-def linear_fwd(x, w, bias=None, resid=None, rowscale=None, rows_per_scale=1, gelu_in=False, out=None):
-    """y[M,N] = (gelu(x) if gelu_in else x)[M,K] @ w[N,K]^T (+ bias) (* rowscale[m // rows_per_scale]) (+ resid)."""
+def linear_fwd(x, w, bias=None, resid=None, rowscale=None, rows_per_scale=1, gelu_in=False, out=None, gelu_dual=False):
+    """y[M,N] = (gelu(x) if gelu_in else x)[M,K] @ w[N,K]^T (+ bias) (* rowscale[m // rows_per_scale]) (+ resid).
+    gelu_dual: returns (gelu(y), gelu'(y)) instead of y."""
     _chk(x, w, bias, resid, rowscale)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and w.dtype == x.dtype
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESID if resid is not None else 0)
+    out2 = torch.empty_like(out) if gelu_dual else None
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESID if resid is not None else 0) | (EPI_GELU_DUAL if gelu_dual else 0)
     rc = _lib.lib().pseld_gemm(dtype_code(x), 0, 0, _lib.ptr(x), _lib.ptr(w), _lib.ptr(out), M, N, K,
                                x.stride(0), w.stride(0), out.stride(0), _lib.ptr(bias), _lib.ptr(resid),
                                resid.stride(0) if resid is not None else 0, _lib.ptr(rowscale), rows_per_scale,
-                               None, 0, epi, PRO_GELU_A if gelu_in else PRO_NONE, _lib.stream_ptr())
+                               None, 0, epi, PRO_GELU_A if gelu_in else PRO_NONE, _lib.ptr(out2), _lib.stream_ptr())
     _lib.check(rc, "pseld_gemm(fwd)")
-    return out
+    return (out, out2) if gelu_dual else out
 
 
-def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resid=None, out=None):
-    """dx[M,K] = dy[M,N] @ w[N,K] (* rowscale) (* gelu'(gelu_grad_of[m,k])) (+ resid)."""
-    _chk(dy, w, rowscale, gelu_grad_of, resid)
+def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resid=None, out=None, mul=None):
+    """dx[M,K] = dy[M,N] @ w[N,K] (* rowscale) (* gelu'(gelu_grad_of[m,k]) | * mul[m,k]) (+ resid)."""
+    _chk(dy, w, rowscale, gelu_grad_of, resid, mul)
+    assert gelu_grad_of is None or mul is None
     M, N = dy.shape
     K = w.shape[1]
     assert w.shape[0] == N and w.dtype == dy.dtype
     if out is None:
         out = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
-    epi = (EPI_MULGELUGRAD if gelu_grad_of is not None else 0) | (EPI_RESID if resid is not None else 0)
+    epi = (EPI_MULGELUGRAD if gelu_grad_of is not None else 0) | (EPI_RESID if resid is not None else 0) | \
+          (EPI_MULAUX if mul is not None else 0)
+    aux = gelu_grad_of if gelu_grad_of is not None else mul
     rc = _lib.lib().pseld_gemm(dtype_code(dy), 0, 1, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(out), M, K, N,
                                dy.stride(0), w.stride(0), out.stride(0), None, _lib.ptr(resid),
                                resid.stride(0) if resid is not None else 0, _lib.ptr(rowscale), rows_per_scale,
-                               _lib.ptr(gelu_grad_of), gelu_grad_of.stride(0) if gelu_grad_of is not None else 0,
-                               epi, PRO_NONE, _lib.stream_ptr())
+                               _lib.ptr(aux), aux.stride(0) if aux is not None else 0,
+                               epi, PRO_NONE, None, _lib.stream_ptr())
     _lib.check(rc, "pseld_gemm(dgrad)")
     return out
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 @pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason="libpseld_hip.so not built")
 def test_bad_argument_is_reported_not_crashed():
     lib = _lib.lib()
-    rc = lib.pseld_gemm(0, 0, 0, None, None, None, 1, 1, 8, 8, 8, 8, None, None, 0, None, 1, None, 0, 0, 0, None)
+    rc = lib.pseld_gemm(0, 0, 0, None, None, None, 1, 1, 8, 8, 8, 8, None, None, 0, None, 1, None, 0, 0, 0, None, None)
     assert rc == -1
     assert b"null" in lib.pseld_last_error()
 

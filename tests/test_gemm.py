@@ -103,3 +103,20 @@ def test_linear_wgrad_gelu_on_x_and_accumulate(dev, dtype):
         g = g.to(dtype).double()
     ref = 1.0 + dy.double().t() @ g
     _check("wgrad gelu_on_x + accumulate", dw, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fc1_dual_gelu_epilogue_and_mul_dgrad(dev, dtype):
+    """fc1 emits (gelu(u), gelu'(u)); the fc2 input-gradient multiplies by the stored gelu' (no erf in backward)."""
+    from pseldnets_amd import ops
+    M, N, K = 640, 384, 96
+    x, w, b = _mk((M, K), dtype, 1), _mk((N, K), dtype, 2, 0.2), _mk((N,), torch.float32, 3)
+    h, g = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), gelu_dual=True)
+    u = (x.double() @ w.double().t() + b.double()).requires_grad_(True)
+    hr = torch.nn.functional.gelu(u)
+    hr.sum().backward()
+    _check("gelu(u)", h, hr.detach(), dtype)
+    _check("gelu'(u)", g, u.grad, dtype)
+    dy, w2 = _mk((M, 96), dtype, 5), _mk((96, N), dtype, 6, 0.1)
+    du = ops.linear_dgrad(dy.to(dev), w2.to(dev), mul=g)
+    _check("dU = (dY W2) * g", du, (dy.double() @ w2.double()) * g.double().cpu(), dtype)
