@@ -65,7 +65,27 @@ template <> struct AMma<bf16_t> {
         s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
         return __builtin_bit_cast(bf16x8, s);
     }
+    // element j = M[row0 + 8*h2 + j][col0 + (lane&31)]  (the standard k-order of an operand fragment)
+    static __device__ __forceinline__ Frag ld_cols_std(const char* base, int strideB, int row0, int col0, int lane) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, gsel = (lane >> 4) & 1, h2 = lane >> 5;
+        const char* addr = base + (row0 + 8 * h2 + q) * strideB + (col0 + 16 * gsel + 4 * p) * 2;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 4 * strideB));
+        short8v s;
+        s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3];
+        s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, s);
+    }
 };
+template <typename T> __device__ __forceinline__ void store4(char* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<bf16_t>(char* p, float a, float b, float c, float d) {
+    bf16x4 v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+    *(bf16x4*)p = v;
+}
+template <> __device__ __forceinline__ void store4<float>(char* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    *(f32x4*)p = v;
+}
 struct AFragF32 { float v[8]; };
 template <> struct AMma<float> {
     using Frag = AFragF32;
@@ -97,6 +117,13 @@ template <> struct AMma<float> {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             f.v[j] = *(const float*)(base + (row0 + 8 * (j >> 2) + 4 * h2 + (j & 3)) * strideB + (col0 + r) * 4);
+        return f;
+    }
+    static __device__ __forceinline__ Frag ld_cols_std(const char* base, int strideB, int row0, int col0, int lane) {
+        const int r = lane & 31, h2 = lane >> 5;
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = *(const float*)(base + (row0 + 8 * h2 + j) * strideB + (col0 + r) * 4);
         return f;
     }
 };
@@ -355,22 +382,23 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     window_copy<T, false>(tile, strideB, (T*)a.out, a.C, hg * GW, 0, heads_here * hd, toks);
 }
 
+// row stride of the per-head [32 queries][64 keys] score images: 64 (mod 128) bytes for the transposed bf16 reads
+template <typename T> struct ImgStride { static constexpr int value = sizeof(T) == 2 ? 192 : 272; };
+
 template <typename T, int HG>
 __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
     constexpr int NTHR = HG * 64;
+    constexpr int IMG = ImgStride<T>::value;
+    using M = AMma<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
     const int GW = HG * hd;
     const int strideB = 4 * GW * (int)sizeof(T) + 16;    // q | k | v | dO
     char* tile = smem;
     float* btab = (float*)(smem + 64 * strideB);          // [HG][225]
-    float* stat = btab + HG * 225;                        // [HG][64][3]: m, 1/l, delta
-    long* toks = (long*)(stat + HG * 64 * 3);
+    long* toks = (long*)(btab + HG * 225);
     int* labels = (int*)(toks + 64);
-    const int dq_strideB = GW * (int)sizeof(T) + 16;
-    char* dqt = (char*)(labels + 64);                     // [64][GW] side tile for dQ
-    const int dkv_strideB = 2 * GW * (int)sizeof(T) + 16;
-    char* dkv = dqt + 64 * dq_strideB;                    // [64][dV | dK] side tile
+    char* imgs = smem + (((char*)(labels + 64) - smem + 15) & ~15);   // [HG][2][32][IMG]: P and dS of the current query tile
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hg = blockIdx.y;
@@ -395,7 +423,8 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
     const T* dout = (const T*)a.dout;
     const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd, cdo = 3 * GW + wave * hd;
     const float* bt = btab + wave * 225;
-    float* st_w = stat + wave * 64 * 3;
+    char* pimg = imgs + wave * 2 * 32 * IMG;
+    char* simg = pimg + 32 * IMG;
 
     for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x) {
         __syncthreads();  // previous iteration's stores out of the tile are done
@@ -411,8 +440,15 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
         __syncthreads();
 
         if (active) {
-            // ---- transposed orientation (rows = keys, lane = query), one 32-query tile at a time so that only
-            // 2+2 score tiles are live next to the persistent d(bias) accumulators --------------------------------
+            // Scores are formed once, transposed (rows = keys, lane = query), one 32-query tile at a time. Each
+            // tile's P and dS are also dropped into LDS as natural [query][key] images so that the products that
+            // contract over QUERIES (dV = P^T dO, dK = dS^T Q) read them back as k-major MFMA operands
+            // (ds_read_b64_tr_b16) — no second softmax, no accumulator transposes.
+            f32x16 dv[2], dk[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { dv[kt][e] = 0.f; dk[kt][e] = 0.f; }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 f32x16 pt[2], dpt[2];
@@ -453,7 +489,6 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
                         delta += pt[kt][e] * dpt[kt][e];
                     }
                 delta += __shfl_xor(delta, 32, 64);
-                if (h2 == 0) { st_w[qi * 3 + 0] = m; st_w[qi * 3 + 1] = il; st_w[qi * 3 + 2] = delta; }
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -462,7 +497,16 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
                         dpt[kt][e] = ds;               // dS^T
                         dsum[kt][qt][e] += ds;
                     }
-                // dQ[query tile qt][d] = sum_key dS^T[key][query] K[key][d]
+                // images: row = query r of this tile, 4 consecutive keys per register group
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int key0 = kt * 32 + 8 * g4 + 4 * h2;
+                        store4<T>(pimg + r * IMG + key0 * (int)sizeof(T), pt[kt][4 * g4], pt[kt][4 * g4 + 1], pt[kt][4 * g4 + 2], pt[kt][4 * g4 + 3]);
+                        store4<T>(simg + r * IMG + key0 * (int)sizeof(T), dpt[kt][4 * g4], dpt[kt][4 * g4 + 1], dpt[kt][4 * g4 + 2], dpt[kt][4 * g4 + 3]);
+                    }
+                // dQ[query tile qt][d] = sum_key dS^T[key][query] K[key][d]  (accumulators re-used as A operands)
                 f32x16 dq;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) dq[e] = 0.f;
@@ -470,53 +514,31 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int sx = 0; sx < 2; ++sx)
-                        AMma<T>::mma(AMma<T>::from_acc(dpt[kt], sx), AMma<T>::ld_cols(tile, strideB, kt * 32 + 16 * sx, ck, lane), dq);
-                store_tile<T>(dqt, dq_strideB, cq, qt, dq, a.scale, hd, lane);   // side tile: q is still needed below
+                        M::mma(M::from_acc(dpt[kt], sx), M::ld_cols(tile, strideB, kt * 32 + 16 * sx, ck, lane), dq);
+                // dV[key][d] += sum_{query in tile} P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Q[query][d]
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const typename M::Frag fdo = M::ld_cols_std(tile, strideB, qt * 32 + 16 * sx, cdo, lane);
+                    const typename M::Frag fq = M::ld_cols_std(tile, strideB, qt * 32 + 16 * sx, cq, lane);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        M::mma(M::ld_cols_std(pimg, IMG, 16 * sx, kt * 32, lane), fdo, dv[kt]);
+                        M::mma(M::ld_cols_std(simg, IMG, 16 * sx, kt * 32, lane), fq, dk[kt]);
+                    }
+                }
+                // every read of this head's q rows of tile qt is complete: overwrite them with dQ
+                store_tile<T>(tile, strideB, cq, qt, dq, a.scale, hd, lane);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- natural orientation (rows = queries, lane = key), one 32-key tile at a time -----------------------
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x16 p[2], dp[2];
-                qk_half_b<T>(p, tile, strideB, cq, ck, kt, hd, lane);      // S[:, kt] = Q K_kt^T
-                qk_half_b<T>(dp, tile, strideB, cdo, cv, kt, hd, lane);    // dP[:, kt] = dO V_kt^T
-                const int ki = kt * 32 + r;
-                const int kl = labels[ki];
-                const float* btk = bt + 112 + 4 * h2 - (ki >> 3) * 15 - (ki & 7);
-                const int* labh = labels + 4 * h2;
-                const float* sth = st_w + 12 * h2;
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int qc = qt * 32 + (e & 3) + 8 * (e >> 2);
-                        float sv = p[qt][e] * a.scale + btk[(qt * 4 + (e >> 2)) * 15 + (e & 3)];
-                        sv -= (labh[qc] != kl) ? 100.f : 0.f;
-                        const float pv = __expf(sv - sth[qc * 3 + 0]) * sth[qc * 3 + 1];
-                        p[qt][e] = pv;
-                        dp[qt][e] = pv * (dp[qt][e] - sth[qc * 3 + 2]);   // dS
-                    }
-                f32x16 gv, gk;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { gv[e] = 0.f; gk[e] = 0.f; }
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                    for (int sx = 0; sx < 2; ++sx) {
-                        // dV[key tile][d] += P[query][key]^T dO[query][d];  dK += dS^T Q
-                        AMma<T>::mma(AMma<T>::from_acc(p[qt], sx), AMma<T>::ld_cols(tile, strideB, qt * 32 + 16 * sx, cdo, lane), gv);
-                        AMma<T>::mma(AMma<T>::from_acc(dp[qt], sx), AMma<T>::ld_cols(tile, strideB, qt * 32 + 16 * sx, cq, lane), gk);
-                    }
-                // dV / dK of this key tile go to a second side tile: v and k rows of OTHER key tiles are still needed
-                store_tile<T>(dkv, dkv_strideB, cq, kt, gv, 1.f, hd, lane);
-                store_tile<T>(dkv, dkv_strideB, GW + cq, kt, gk, a.scale, hd, lane);
-                __builtin_amdgcn_sched_barrier(0);
+                store_tile<T>(tile, strideB, cv, kt, dv[kt], 1.f, hd, lane);
+                store_tile<T>(tile, strideB, ck, kt, dk[kt], a.scale, hd, lane);
             }
         }
         __syncthreads();
-        window_copy<T, false>(dqt, dq_strideB, (T*)a.dqkv, 3 * a.C, hg * GW, 0, heads_here * hd, toks);
-        window_copy<T, false>(dkv, dkv_strideB, (T*)a.dqkv, 3 * a.C, 1 * a.C + hg * GW, GW, heads_here * hd, toks);   // dK
-        window_copy<T, false>(dkv, dkv_strideB, (T*)a.dqkv, 3 * a.C, 2 * a.C + hg * GW, 0, heads_here * hd, toks);    // dV
+        for (int sel = 0; sel < 3; ++sel)
+            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
     }
     // flush d(bias) partial sums: dbias_acc[head][key][query] += dsum (lane = query: 128-byte contiguous atomics)
     if (active) {
@@ -551,7 +573,7 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
 }
 
 template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
-template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + HG * 64 * 3 * 4 + 64 * 8 + 64 * 4 + 64 * (HG * hd * sizeof(T) + 16) + 64 * (2 * HG * hd * sizeof(T) + 16); }
+template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4 + 16 + (size_t)HG * 2 * 32 * (sizeof(T) == 2 ? 192 : 272); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
     PSELD_CHECK_ARG(B > 0 && res >= 8 && res % 8 == 0, "%s: grid side must be a multiple of 8 (got %d)", who, res);

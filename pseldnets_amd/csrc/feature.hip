@@ -90,50 +90,48 @@ __global__ __launch_bounds__(NT) void logmel_iv_kernel(FeatArgs a) {
     for (int n = tid; n < a.nnz; n += NT) melw[n] = a.mel_w[n];
     for (int n = tid; n < a.n_mels; n += NT) { mlo[n] = a.mel_lo[n]; mcnt[n] = a.mel_cnt[n]; moff[n] = a.mel_off[n]; }
 
-    float win[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) win[t] = a.window[tid + t * NT];
+    // thread i owns the 4 CONSECUTIVE samples 4i..4i+3 of a frame: one 16-byte load per channel (frame starts are
+    // multiples of 16 samples when hop % 16 == 0), instead of 16 scalar loads of a 4.27x-overlapped stream
+    const f32x4 win4 = *(const f32x4*)(a.window + 4 * tid);
     __syncthreads();
 
     const float* wv = a.wave + (long)b * a.n_ch * a.L;
     const int n_pairs = (a.n_ch + 1) >> 1;
+    const bool vec_ok = (a.hop % 4 == 0) && (a.L % 4 == 0) && (((unsigned long)a.wave & 15) == 0);
 
     for (int f = 0; f < FPB; ++f) {
         const int frame = frame0 + f;
         if (frame >= a.T) break;  // uniform across the workgroup
 
-        // ---- pass 1 (P = 1): windowed, reflect-padded frame straight from HBM/L2 -------------------
-        long sidx[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            long s = (long)frame * a.hop - NFFT / 2 + tid + t * NT;
-            if (s < 0) s = -s;
-            if (s >= a.L) s = 2 * (a.L - 1) - s;
-            sidx[t] = s;
-        }
+        // ---- windowed, reflect-padded frame from HBM/L2 into LDS in natural order (buf1) ------------------
+        const long s0 = (long)frame * a.hop - NFFT / 2;
+        const bool interior = vec_ok && s0 >= 0 && s0 + NFFT <= a.L;   // uniform: no reflection in this frame
         for (int pr = 0; pr < n_pairs; ++pr) {
             const int c0 = 2 * pr, c1 = 2 * pr + 1;
             const float* w0 = wv + (long)c0 * a.L;
             const float* w1 = wv + (long)c1 * a.L;
             const bool has1 = c1 < a.n_ch;
-            float2 u[4];
+            f32x4 x0, x1 = {0.f, 0.f, 0.f, 0.f};
+            if (interior) {
+                x0 = *(const f32x4*)(w0 + s0 + 4 * tid);
+                if (has1) x1 = *(const f32x4*)(w1 + s0 + 4 * tid);
+            } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float xr = w0[sidx[t]] * win[t];
-                const float xi = has1 ? w1[sidx[t]] * win[t] : 0.f;
-                u[t] = make_float2(xr, xi);
+                for (int t = 0; t < 4; ++t) {
+                    long sx = s0 + 4 * tid + t;
+                    if (sx < 0) sx = -sx;
+                    if (sx >= a.L) sx = 2 * (a.L - 1) - sx;
+                    x0[t] = w0[sx];
+                    if (has1) x1[t] = w1[sx];
+                }
             }
-            const float2 v0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
-            const float2 v1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
-            const float2 v2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
-            const float2 d = make_float2(u[1].x - u[3].x, u[1].y - u[3].y);
-            const float2 v3 = make_float2(d.y, -d.x);
-            float2* dst = buf0 + pr * NFFT + 4 * tid;
-            dst[0] = make_float2(v0.x + v2.x, v0.y + v2.y);
-            dst[1] = make_float2(v1.x + v3.x, v1.y + v3.y);
-            dst[2] = make_float2(v0.x - v2.x, v0.y - v2.y);
-            dst[3] = make_float2(v1.x - v3.x, v1.y - v3.y);
+            float2* dst = buf1 + pr * NFFT + 4 * tid;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t] = make_float2(x0[t] * win4[t], x1[t] * win4[t]);
         }
+        __syncthreads();
+        // ---- pass 1 (P = 1, no twiddles) ------------------------------------------------------------------
+        for (int pr = 0; pr < n_pairs; ++pr) radix4_pass<1>(buf1 + pr * NFFT, buf0 + pr * NFFT, tw, tid);
         __syncthreads();
         // ---- passes 2..5 in LDS ------------------------------------------------------------------------
         for (int pr = 0; pr < n_pairs; ++pr) radix4_pass<4>(buf0 + pr * NFFT, buf1 + pr * NFFT, tw, tid);
@@ -178,18 +176,44 @@ __global__ __launch_bounds__(NT) void logmel_iv_kernel(FeatArgs a) {
         __syncthreads();
 
         // ---- mel projection over each filter's compact support, dB for the power channels -----------
-        const int n_tasks = a.n_out * a.n_mels;
-        for (int task = tid; task < n_tasks; task += NT) {
-            const int oc = task / a.n_mels;
-            const int m = task - oc * a.n_mels;
-            const int vc = (oc < a.n_ch) ? oc : (4 + oc - a.n_ch);  // IV rows live at 4..6
-            const float* vr = val + vc * VAL_LD + mlo[m];
-            const float* wr = melw + moff[m];
-            const int cnt = mcnt[m];
-            float acc = 0.f;
-            for (int q = 0; q < cnt; ++q) acc = fmaf(vr[q], wr[q], acc);
-            if (oc < a.n_ch) acc = 10.0f * log10f(fmaxf(acc, a.amin));
-            a.feat[(((long)b * a.n_out + oc) * a.T + frame) * a.n_mels + m] = acc;
+        // thread = (mel m, quarter q): the 4 lanes of a mel interleave its bins and carry all output channels at
+        // once (7 independent FMA chains per LDS weight read), then combine with two shuffles.
+        for (int mb = 0; mb < a.n_mels; mb += NT / 4) {
+            const int m = mb + (tid >> 2), q = tid & 3;
+            float acc[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) acc[c] = 0.f;
+            if (m < a.n_mels) {
+                const int lo = mlo[m], cnt = mcnt[m];
+                const float* wr = melw + moff[m];
+                for (int i = q; i < cnt; i += 4) {
+                    const float w = wr[i];
+                    const float* vr = val + lo + i;
+#pragma unroll
+                    for (int c = 0; c < 7; ++c)
+                        if (c < a.n_ch || (a.with_iv && c >= 4)) acc[c] = fmaf(vr[c * VAL_LD], w, acc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                acc[c] += __shfl_xor(acc[c], 1, 64);
+                acc[c] += __shfl_xor(acc[c], 2, 64);
+            }
+            if (m < a.n_mels) {
+                // lane q writes output channels q and q + 4 (value rows: power 0..n_ch-1, IV 4..6)
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int oc = q + 4 * rep;
+                    if (oc < a.n_out) {
+                        const int vc = (oc < a.n_ch) ? oc : (4 + oc - a.n_ch);
+                        float v = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) v = (c == vc) ? acc[c] : v;
+                        if (oc < a.n_ch) v = 10.0f * log10f(fmaxf(v, a.amin));
+                        a.feat[(((long)b * a.n_out + oc) * a.T + frame) * a.n_mels + m] = v;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
