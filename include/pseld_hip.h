@@ -52,6 +52,10 @@ int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float*
                      int lddy, int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
                      long workspace_bytes, void* stream);
 
+/* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
+ * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */
+void pseld_gemm_set_debug_buffer(void* device_buffer);
+
 /* Bias gradient: out f32[N] (+)= sum_m X[m,n]. */
 long pseld_colsum_workspace(int M, int N);
 int pseld_colsum(int dtype, const void* X, float* out, int M, int N, int ld, int accumulate, float* workspace,
