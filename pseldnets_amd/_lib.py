@@ -23,7 +23,7 @@ class PseldError(RuntimeError):
 _lib = None
 
 
-_CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
+_CTYPES = {"void": None, "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 def _ctype_of(decl):
