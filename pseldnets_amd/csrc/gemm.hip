@@ -48,7 +48,8 @@ struct GemmArgs {
     int rows_per_scale;
     int kchunk;             // contraction elements per split (multiple of BK); == K when no split
     long slab_stride;       // elements between split-K output slabs
-    float* colsum;          // TA only: per-split column sums of A (= bias gradient), [splits][M]
+    float* colsum;          // TA only: per-split column sums of A (= bias gradient), split z at colsum + z*colsum_stride
+    long colsum_stride;
     int epi, pro;
     unsigned long long* dbg;  // diagnostic build only: per-workgroup s_memtime stamps
 };
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 
     if (g.dbg) t2 = __builtin_amdgcn_s_memtime();
     if (TA && g.colsum && blockIdx.x == 0 && tid < BM && m0 + tid < g.M)
-        g.colsum[(long)blockIdx.z * g.M + m0 + tid] = colacc;
+        g.colsum[(long)blockIdx.z * g.colsum_stride + m0 + tid] = colacc;
     OutT* Cg = (OutT*)g.C + (long)blockIdx.z * g.slab_stride;
     const T* Rg = (const T*)g.resid;
     const T* Ug = (const T*)g.aux;
@@ -569,7 +570,11 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     kchunk = pseld_cdiv(kchunk, bk) * bk;
     splits = pseld_cdiv(Mtok, kchunk);
     g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = gelu_on_x ? PRO_GELU_B : PRO_NONE;
-    g.colsum = dbias ? workspace + (long)splits * N * K : nullptr;
+    // when the bias gradient sits right behind the weight gradient (as in the parameter arena) the bias slabs are
+    // interleaved with the dW slabs and ONE reduction covers both
+    const bool fused_bias = dbias && dbias == dW + (long)N * K;
+    if (fused_bias) { g.slab_stride = (long)N * K + N; g.colsum = workspace + (long)N * K; g.colsum_stride = g.slab_stride; }
+    else { g.colsum = dbias ? workspace + (long)splits * N * K : nullptr; g.colsum_stride = N; }
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true>(g, splits, s);
@@ -577,8 +582,12 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     else { pseld_set_error("gemm_wgrad: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
     if (rc != PSELD_OK) return rc;
     const long n = (long)N * K;
-    pseld_reduce_slabs(workspace, dW, n, splits, g.slab_stride, accumulate, s);
-    if (dbias) pseld_reduce_slabs(g.colsum, dbias, (long)N, splits, (long)N, accumulate, s);
+    if (fused_bias) {
+        pseld_reduce_slabs(workspace, dW, n + N, splits, g.slab_stride, accumulate, s);
+    } else {
+        pseld_reduce_slabs(workspace, dW, n, splits, g.slab_stride, accumulate, s);
+        if (dbias) pseld_reduce_slabs(g.colsum, dbias, (long)N, splits, (long)N, accumulate, s);
+    }
     PSELD_LAUNCH_CHECK("splitk_reduce");
     return PSELD_OK;
 }

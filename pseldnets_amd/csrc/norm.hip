@@ -538,8 +538,12 @@ extern "C" int pseld_layernorm_bwd(int dtype, const void* dy, const void* x, con
     else { pseld_set_error("layernorm_bwd: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
     if (rc != PSELD_OK) return rc;
     // partial layout [nb][2][C]: reduce the two halves separately
-    pseld_reduce_slabs(workspace, dgamma, (long)C, nb, (long)2 * C, accumulate, s);
-    pseld_reduce_slabs(workspace + C, dbeta, (long)C, nb, (long)2 * C, accumulate, s);
+    if (dbeta == dgamma + C) {   // adjacent in the parameter arena: one reduction for both
+        pseld_reduce_slabs(workspace, dgamma, (long)2 * C, nb, (long)2 * C, accumulate, s);
+    } else {
+        pseld_reduce_slabs(workspace, dgamma, (long)C, nb, (long)2 * C, accumulate, s);
+        pseld_reduce_slabs(workspace + C, dbeta, (long)C, nb, (long)2 * C, accumulate, s);
+    }
     PSELD_LAUNCH_CHECK("layernorm_bwd reduce");
     return PSELD_OK;
 }
