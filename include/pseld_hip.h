@@ -113,6 +113,39 @@ int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, c
                           float* dbias_table, int B, int res, int C, int heads, int shift, int accumulate,
                           float* workspace, long workspace_bytes, void* stream);
 
+/* ---- global multi-head self-attention of the PaSST blocks -----------------------------------------------------------
+ * passt.py:62-82 (Attention.forward: qkv split, q k^T * head_dim^-0.5, softmax, @ v, head merge), head_dim 64.
+ * qkv [B, N, 3E] -> out [B, N, E]; lse f32[B, heads, N] (log-sum-exp of the scaled scores) is what backward needs
+ * besides qkv and out; the score matrix is never materialised. Backward is deterministic (no atomics). */
+int pseld_mhsa_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int E, int heads, void* stream);
+long pseld_mhsa_bwd_workspace(int B, int N, int heads);
+int pseld_mhsa_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                   int N, int E, int heads, float* workspace, long workspace_bytes, void* stream);
+
+/* ---- PaSST front / back end ------------------------------------------------------------------------------------------
+ * accdoa.py:320-327 scalar BN + im2col of model_utilities.py:174-213 PatchEmbed (Conv2d k16 s10 pad 3 on the
+ * [C, mel, T] image): feat f32[B,Cin,T,64] -> A [B*6*Tg, Cin*256] (k = c*256 + kf*16 + kt = the conv weight's
+ * flattening), Tg = pseld_passt_grid_t(T); bn_bwd folds dA back through the overlapping patches into the BN
+ * weight/bias gradients. assemble: passt.py:219-247, X[b] = [cls+npos0, dist+npos1, P[b] + tpos[:,tg] + fpos[:,fg]]
+ * ([B, 6*Tg+2, E]); its backward emits dP and the five positional/token gradients (summed over the batch).
+ * pool: passt.py:296-300 mean over the 6 frequency rows, [B, 6*Tg+2, E] -> [B, Tg, E]. tanh: accdoa.py:328. */
+int pseld_passt_grid_t(int T);
+int pseld_passt_patchify(int dtype, const float* feat, const float* scale_shift, void* A, int B, int Cin, int T,
+                         void* stream);
+long pseld_passt_bn_bwd_workspace(int B, int Cin, int T);
+int pseld_passt_bn_bwd(int dtype, const float* feat, const float* mean_rstd, const void* dA, float* dweight,
+                       float* dbias, int B, int Cin, int T, float* workspace, long workspace_bytes, void* stream);
+int pseld_passt_assemble_fwd(int dtype, const void* P, const float* tpos, const float* fpos, const float* cls,
+                             const float* dist, const float* npos, void* X, int B, int E, int Tg, void* stream);
+long pseld_passt_assemble_bwd_workspace(int E, int Tg);
+int pseld_passt_assemble_bwd(int dtype, const void* dX, void* dP, float* dtpos, float* dfpos, float* dcls,
+                             float* ddist, float* dnpos, int B, int E, int Tg, float* workspace, long workspace_bytes,
+                             void* stream);
+int pseld_passt_pool_fwd(int dtype, const void* X, void* Y, int B, int E, int Tg, void* stream);
+int pseld_passt_pool_bwd(int dtype, const void* dY, void* dX, int B, int E, int Tg, void* stream);
+int pseld_tanh_fwd(int dtype, const void* z, int ldz, float* y, long rows, int D, void* stream);
+int pseld_tanh_bwd(int dtype, const float* dy, const float* y, void* dz, int ldz, long rows, int D, void* stream);
+
 /* ---- output head ---------------------------------------------------------------------------------------------------
  * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):
  * tok [B,64,C] -> A [B*32, C*6] (k = c*6 + cf*3 + dt, matching the conv weight's [D, C, 2, 3] flattening).

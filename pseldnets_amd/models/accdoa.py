@@ -1,10 +1,11 @@
 """ACCDOA networks on MI355X — mirror of the reference's `models/accdoa.py` registry module (HTSAT :107-246).
 Constructor signature, forward contract ({'accdoa': f32[B, 100, 3*C]}) and state-dict keys are the reference's;
-the arithmetic is the HIP path (components/htsat.py). CRNN / ConvConformer / PASST backbones of the reference
-registry are not built on this path yet and raise NotImplementedError."""
+the arithmetic is the HIP path (components/htsat.py). PASST (:249-329) runs on the same kernels plus the global-attention ones; the CRNN / ConvConformer backbones of the
+reference registry are not built on this path yet and raise NotImplementedError."""
 import torch
 
 from .components.htsat import SwinEncoder, TscamHead
+from .components.passt import FcTanhHead, PasstEncoder
 from .components.seld_net import HTSATNetBase
 
 
@@ -91,10 +92,96 @@ class HTSAT(HTSATNetBase):
         return {self.out_key: self._run(x)}
 
 
+class PASST(HTSATNetBase):
+    """models/accdoa.py:249-329: scalar BatchNorms -> PaSST -> Linear(E, 3*C) -> tanh."""
+    out_key = 'accdoa'
+    tracks_axes = 3
+
+    def __init__(self, cfg, num_classes, in_channels=7, pretrained_path='ckpts/passt-s-f128-p16-s10-ap.476-swa.pt', **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self._init_common(cfg, in_channels)
+        self.enc = PasstEncoder(self.arena, 'encoder.', in_channels, mel_bins=self.mel_bins, **kwargs)
+        self.head = FcTanhHead(self.arena, 'fc.', self.enc.num_features, num_classes * self.tracks_axes)
+        self._finish_init()
+        if pretrained_path:
+            self.load_ckpts(pretrained_path)
+
+    def load_ckpts(self, pretrained_path, audioset_pretrain=True):
+        """accdoa.py:270-309: AudioSet PaSST checkpoints (1-channel patch-embed replicated / in_channels, the time /
+        frequency positional embeddings centre-cropped — or bilinearly stretched — to the grid in use, only head.0 of
+        the classifier kept) or PSELDNets checkpoints (fc skipped)."""
+        own = self.state_dict()
+        if audioset_pretrain:
+            ck = torch.load(pretrained_path, map_location='cpu')
+            for key in own:
+                if not key.startswith('encoder.'):
+                    continue
+                src = key[len('encoder.'):]
+                if src == 'patch_embed.proj.weight':
+                    own[key].copy_(ck[src].repeat(1, self.in_channels, 1, 1) / self.in_channels)
+                elif src in ('time_new_pos_embed', 'freq_new_pos_embed'):
+                    axis = -1 if src.startswith('time') else -2
+                    have, want = ck[src].shape[axis], own[key].shape[axis]
+                    if have >= want:
+                        own[key].copy_(ck[src].narrow(axis, int((have - want) / 2), want))
+                    else:
+                        own[key].copy_(torch.nn.functional.interpolate(ck[src], size=(1, want), mode='bilinear'))
+                elif 'head' in src:
+                    if src in ('head.0.weight', 'head.0.bias'):
+                        own[key].copy_(ck[src])
+                else:
+                    own[key].copy_(ck[src])
+        else:
+            ck = torch.load(pretrained_path, map_location='cpu')['state_dict']
+            ck = {k.replace('net.', '').replace('_orig_mod.', ''): v for k, v in ck.items()}
+            for key in own:
+                if not key.startswith('fc.'):
+                    own[key].copy_(ck[key])
+        self.shadow_trusted = False
+
+    def _forward_impl(self, x, training):
+        B, dt = x.shape[0], self.compute_dtype
+        mean_rstd, scale_shift = self._bn_front(x, training)
+        drop = self._drop_scales(B, self.enc, x.device, training)
+        tok, s_front = self.enc.forward_front(x, scale_shift, dt)
+        s_blocks = []
+        for i in range(self.enc.depth):
+            tok, s = self.enc.forward_block(i, tok, B, drop)
+            s_blocks.append(s)
+        fmap, s_back = self.enc.forward_back(tok, B)
+        y, s_head = self.head.forward(fmap, B)
+        return y, dict(feat=x, mean_rstd=mean_rstd, front=s_front, blocks=s_blocks, back=s_back, head=s_head, B=B)
+
+    def _backward_impl(self, saved, douts, on_range_done=None):
+        dy = douts[0] if isinstance(douts, (tuple, list)) else douts
+        B, dt, a = saved['B'], self.compute_dtype, self.arena
+        dfmap = self.head.backward(dy, saved['head'], dt)
+        dx = self.enc.backward_back(dfmap, saved['back'], B)
+        hi = a.size
+        cuts = {self.enc.depth - 2, self.enc.depth - 4}          # all-reduce buckets: last 2 blocks + tail, 2 more, rest
+        for i in reversed(range(self.enc.depth)):
+            dx = self.enc.backward_block(i, dx, saved['blocks'][i], B)
+            if on_range_done is not None and i in cuts and i > 0:
+                lo = a.offsets[self.enc.first_param_of_block(i)][0]
+                on_range_done(lo, hi)
+                hi = lo
+        dw, db = self._bn_grads()
+        self.enc.backward_front(dx, saved['front'], saved['feat'], saved['mean_rstd'], dw, db, B)
+        if on_range_done is not None:
+            on_range_done(0, hi)
+
+    def forward(self, x):
+        """
+        x: (batch_size, num_channels, time_frames, mel_bins) features of 10-second chunks
+        """
+        return {self.out_key: self._run(x)}
+
+
 class _NotBuilt:
     def __init__(self, *a, **k):
         raise NotImplementedError("this backbone of the reference registry is not built on the MI355X path yet "
                                   "(SURVEY.md §8 rows a16/a17); use backbone=HTSAT")
 
 
-CRNN = ConvConformer = PASST = _NotBuilt
+CRNN = ConvConformer = _NotBuilt

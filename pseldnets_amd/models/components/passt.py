@@ -1,0 +1,174 @@
+"""PaSST encoder driven on MI355X kernels — forward AND hand-written backward.
+
+Host-side mirror of the reference's `models/components/passt.py` (PaSST :106-312, Block :85-101, Attention :50-82)
+with `models/components/model_utilities.py` PatchEmbed :174-213 and Mlp :129-171, as instantiated by
+configs/model/passt.yaml (64x1001 image, patch 16 / stride 10 -> 6 x 100 grid, distilled: cls + dist tokens,
+no patch-out). No tensor arithmetic happens in this file: every step is one call into the C ABI (ops.py).
+  * tokens stay [B*602, E] row-major through all blocks; q/k/v head split, softmax and head merge live inside the
+    streaming attention kernels (mhsa.hip), whose backward recomputes probabilities from the saved log-sum-exp;
+  * fc1's GEMM epilogue emits gelu(u) and gelu'(u) like the Swin path; DropPath factors ride in the GEMM epilogues;
+  * the training-time random time offset of the positional embedding (passt.py:223-227) is randint(1) == 0 for the
+    100-column grid, so the embedding is added whole;
+  * structured / unstructured patch-out (passt.py:250-269) are 0 in every shipped config; non-zero values raise.
+"""
+import torch
+
+from ... import ops
+
+
+DEFAULTS = dict(u_patchout=0, s_patchout_t=0, s_patchout_f=0, img_size=(64, 1001), patch_size=16, stride=10, embed_dim=768,
+                depth=7, num_heads=12, mlp_ratio=4.0, qkv_bias=True, representation_size=None, distilled=True, drop_rate=0.0,
+                drop_path_rate=0.0, norm_layer=None, act_layer=None)
+
+
+class PasstEncoder:
+    """One PaSST whose parameters live in `arena` under `prefix` (reference key names)."""
+
+    def __init__(self, arena, prefix, in_chans, mel_bins=64, **kw):
+        cfg = dict(DEFAULTS)
+        cfg.update({k: v for k, v in kw.items() if k in DEFAULTS})
+        cfg['img_size'] = tuple(cfg['img_size'])
+        if cfg['patch_size'] != 16 or cfg['stride'] != 10 or cfg['img_size'][0] != 64 or mel_bins != 64 \
+                or not cfg['distilled'] or cfg['drop_rate'] or not cfg['qkv_bias'] or cfg['representation_size'] \
+                or cfg['norm_layer'] is not None or cfg['act_layer'] is not None:
+            raise NotImplementedError("the MI355X path is built for the reference's PaSST geometry: 64 mel bins, patch 16 / "
+                                      "stride 10, distilled, LayerNorm(1e-6) + GELU blocks, no dropout")
+        if cfg['u_patchout'] or cfg['s_patchout_t'] or cfg['s_patchout_f']:
+            raise NotImplementedError("patch-out (passt.py:250-269) is 0 in the shipped configs and is not built")
+        self.cfg, self.arena, self.prefix, self.in_chans = cfg, arena, prefix, in_chans
+        self.E, self.depth, self.heads = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
+        if self.E != 64 * self.heads:
+            raise NotImplementedError("global attention kernels are built for head_dim 64")
+        self.Fg = 6
+        self.Tg = (cfg['img_size'][1] + 6 - 16) // 10 + 1
+        self.num_features = self.E
+        self.rates = [v.item() for v in torch.linspace(0, cfg['drop_path_rate'], self.depth)]
+        a, p, E = arena, prefix, self.E
+        hid = int(E * cfg['mlp_ratio'])
+        a.add(p + 'patch_embed.proj.weight', (E, in_chans, 16, 16))
+        a.add(p + 'patch_embed.proj.bias', (E,))
+        a.add(p + 'time_new_pos_embed', (1, E, 1, self.Tg))
+        a.add(p + 'freq_new_pos_embed', (1, E, self.Fg, 1))
+        a.add(p + 'cls_token', (1, 1, E))
+        a.add(p + 'dist_token', (1, 1, E))
+        a.add(p + 'new_pos_embed', (1, 2, E))
+        for i in range(self.depth):
+            b = f'{p}blocks.{i}.'
+            a.add(b + 'norm1.weight', (E,)); a.add(b + 'norm1.bias', (E,))
+            a.add(b + 'attn.qkv.weight', (3 * E, E)); a.add(b + 'attn.qkv.bias', (3 * E,))
+            a.add(b + 'attn.proj.weight', (E, E)); a.add(b + 'attn.proj.bias', (E,))
+            a.add(b + 'norm2.weight', (E,)); a.add(b + 'norm2.bias', (E,))
+            a.add(b + 'mlp.fc1.weight', (hid, E)); a.add(b + 'mlp.fc1.bias', (hid,))
+            a.add(b + 'mlp.fc2.weight', (E, hid)); a.add(b + 'mlp.fc2.bias', (E,))
+        a.add(p + 'norm.weight', (E,)); a.add(p + 'norm.bias', (E,))
+        a.add(p + 'head.0.weight', (E,)); a.add(p + 'head.0.bias', (E,))
+
+    def static_buffers(self):
+        return {}
+
+    def first_param_of_block(self, i):
+        return f'{self.prefix}blocks.{i}.norm1.weight'
+
+    @property
+    def seq(self):
+        return self.Fg * self.Tg + 2
+
+    # -- forward -------------------------------------------------------------------------------------------
+    def forward_front(self, feat, scale_shift, dtype):
+        """passt.py:214-247: BN'd image -> patches -> + positional embeddings -> [cls, dist, patches]."""
+        a, p = self.arena, self.prefix
+        B, _, T, _ = feat.shape
+        if ops.passt_grid_t(T) != self.Tg:
+            raise ValueError(f"PaSST positional grid is built for {self.cfg['img_size'][1]} frames, got {T}")
+        A0 = ops.passt_patchify(feat, scale_shift, dtype)
+        W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 256)
+        P0 = ops.linear_fwd(A0, W, a.p(p + 'patch_embed.proj.bias'))
+        x = ops.passt_assemble_fwd(P0, a.p(p + 'time_new_pos_embed'), a.p(p + 'freq_new_pos_embed'), a.p(p + 'cls_token'),
+                                   a.p(p + 'dist_token'), a.p(p + 'new_pos_embed'), B, self.Tg)
+        return x, dict(A0=A0)
+
+    def backward_front(self, dx, saved, feat, mean_rstd, bn_dw, bn_db, B):
+        a, p = self.arena, self.prefix
+        dtype = dx.dtype
+        dP0 = ops.passt_assemble_bwd(dx, a.g(p + 'time_new_pos_embed'), a.g(p + 'freq_new_pos_embed'), a.g(p + 'cls_token'),
+                                     a.g(p + 'dist_token'), a.g(p + 'new_pos_embed'), B, self.Tg)
+        ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 256),
+                         dbias=a.g(p + 'patch_embed.proj.bias'))
+        W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 256)
+        dA0 = ops.linear_dgrad(dP0, W)
+        ops.passt_bn_bwd(feat, mean_rstd, dA0, bn_dw, bn_db)
+
+    def forward_block(self, i, x, B, drop_scale=None):
+        """Block i (passt.py:97-101)."""
+        a, dtype, N = self.arena, x.dtype, self.seq
+        b = f'{self.prefix}blocks.{i}.'
+        s1 = s2 = None
+        if drop_scale is not None and self.rates[i] > 0:
+            s1, s2 = drop_scale[i, 0], drop_scale[i, 1]
+        xh1 = ops.layernorm_fwd(x, a.p(b + 'norm1.weight'), a.p(b + 'norm1.bias'), eps=1e-6)
+        qkv = ops.linear_fwd(xh1, a.w(b + 'attn.qkv.weight', dtype), a.p(b + 'attn.qkv.bias'))
+        ao, lse = ops.mhsa_fwd(qkv, B, N, self.heads)
+        x_mid = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x, rowscale=s1,
+                               rows_per_scale=N)
+        xh2 = ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'), eps=1e-6)
+        hact, gact = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), gelu_dual=True)
+        x_out = ops.linear_fwd(hact, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid, rowscale=s2,
+                               rows_per_scale=N)
+        return x_out, dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1, s2=s2)
+
+    def backward_block(self, i, dx, s, B):
+        a, dtype, N, E = self.arena, dx.dtype, self.seq, self.E
+        b = f'{self.prefix}blocks.{i}.'
+        dy2 = ops.rowscale(dx, s['s2'], N * E) if s['s2'] is not None else dx
+        ops.linear_wgrad(dy2, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'))
+        du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), mul=s['g'])
+        ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
+        dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype))
+        dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'), a.g(b + 'norm2.bias'),
+                                   dres=dx, eps=1e-6)
+        dyp = ops.rowscale(dx_mid, s['s1'], N * E) if s['s1'] is not None else dx_mid
+        ops.linear_wgrad(dyp, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'))
+        dao = ops.linear_dgrad(dyp, a.w(b + 'attn.proj.weight', dtype))
+        dqkv = ops.mhsa_bwd(s['qkv'], s['ao'], dao, s['lse'], B, N, self.heads)
+        ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
+        dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype))
+        return ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'), a.g(b + 'norm1.bias'),
+                                 dres=dx_mid, eps=1e-6)
+
+    def forward_back(self, x, B):
+        """passt.py:292-311: final LayerNorm(1e-6), drop cls/dist, mean over frequency rows, head LayerNorm(1e-5)."""
+        a, p = self.arena, self.prefix
+        xn = ops.layernorm_fwd(x, a.p(p + 'norm.weight'), a.p(p + 'norm.bias'), eps=1e-6)
+        pooled = ops.passt_pool_fwd(xn, B, self.Tg)
+        fmap = ops.layernorm_fwd(pooled, a.p(p + 'head.0.weight'), a.p(p + 'head.0.bias'), eps=1e-5)
+        return fmap, dict(x_last=x, pooled=pooled)
+
+    def backward_back(self, dfmap, saved, B):
+        a, p = self.arena, self.prefix
+        dpooled = ops.layernorm_bwd(dfmap, saved['pooled'], a.p(p + 'head.0.weight'), a.g(p + 'head.0.weight'),
+                                    a.g(p + 'head.0.bias'), eps=1e-5)
+        dxn = ops.passt_pool_bwd(dpooled, B, self.Tg)
+        return ops.layernorm_bwd(dxn, saved['x_last'], a.p(p + 'norm.weight'), a.g(p + 'norm.weight'), a.g(p + 'norm.bias'),
+                                 eps=1e-6)
+
+
+class FcTanhHead:
+    """accdoa.py:311,328: Linear(E, D) + tanh on the [B*100, E] feature map (D padded to a multiple of 8 rows)."""
+
+    def __init__(self, arena, prefix, in_features, out_dim):
+        self.arena, self.prefix, self.C, self.D = arena, prefix, in_features, out_dim
+        self.Dp = (out_dim + 7) // 8 * 8
+        arena.add(prefix + 'weight', (out_dim, in_features), pad_rows=self.Dp)
+        arena.add(prefix + 'bias', (out_dim,), pad_rows=self.Dp)
+
+    def forward(self, fmap, B):
+        a, p, dtype = self.arena, self.prefix, fmap.dtype
+        z = ops.linear_fwd(fmap, a.w(p + 'weight', dtype, padded=True), a.p(p + 'bias', padded=True))
+        y = ops.tanh_fwd(z, self.D)
+        return y.view(B, -1, self.D), dict(fmap=fmap, y=y)
+
+    def backward(self, dy, saved, dtype):
+        a, p = self.arena, self.prefix
+        dz = ops.tanh_bwd(dy.contiguous().view(-1, self.D).float(), saved['y'], self.Dp, dtype)
+        ops.linear_wgrad(dz, saved['fmap'], a.g(p + 'weight', padded=True), dbias=a.g(p + 'bias', padded=True))
+        return ops.linear_dgrad(dz, a.w(p + 'weight', dtype, padded=True))

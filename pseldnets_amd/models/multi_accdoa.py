@@ -1,4 +1,4 @@
-"""Multi-ACCDOA networks on MI355X — mirror of the reference's `models/multi_accdoa.py` (HTSAT :29-44):
+"""Multi-ACCDOA networks on MI355X — mirror of the reference's `models/multi_accdoa.py` (HTSAT :29-44, PASST :46-54):
 the ACCDOA net with a 3 tracks x 3 axes x C head and output key 'multi_accdoa'."""
 from . import accdoa
 
@@ -8,4 +8,9 @@ class HTSAT(accdoa.HTSAT):
     tracks_axes = 9
 
 
-CRNN = ConvConformer = PASST = accdoa._NotBuilt
+class PASST(accdoa.PASST):
+    out_key = 'multi_accdoa'
+    tracks_axes = 9
+
+
+CRNN = ConvConformer = accdoa._NotBuilt

@@ -392,3 +392,108 @@ def add(a, b):
     y = torch.empty_like(a)
     _lib.check(_lib.lib().pseld_add(dtype_code(a), _lib.ptr(a), _lib.ptr(b), _lib.ptr(y), a.numel(), _lib.stream_ptr()), "pseld_add")
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PaSST: global attention, patch front end, positional assembly, frequency pooling, tanh head
+def mhsa_fwd(qkv, B, N, heads):
+    _chk(qkv)
+    E = qkv.shape[1] // 3
+    out = torch.empty((qkv.shape[0], E), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    rc = _lib.lib().pseld_mhsa_fwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), B, N, E, heads, _lib.stream_ptr())
+    _lib.check(rc, "pseld_mhsa_fwd")
+    return out, lse
+
+
+def mhsa_bwd(qkv, out, dout, lse, B, N, heads):
+    _chk(qkv, out, dout, lse)
+    E = qkv.shape[1] // 3
+    L = _lib.lib()
+    ws = workspace(L.pseld_mhsa_bwd_workspace(B, N, heads), qkv.device)
+    dqkv = torch.empty_like(qkv)
+    rc = L.pseld_mhsa_bwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(out), _lib.ptr(dout), _lib.ptr(lse), _lib.ptr(dqkv), B, N, E,
+                          heads, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_mhsa_bwd")
+    return dqkv
+
+
+def passt_grid_t(T):
+    return _lib.lib().pseld_passt_grid_t(T)
+
+
+def passt_patchify(feat, scale_shift, dtype):
+    _chk(feat, scale_shift)
+    B, C, T, F = feat.shape
+    if F != 64:
+        raise ValueError("passt_patchify is built for 64 mel bins")
+    Tg = passt_grid_t(T)
+    A = torch.empty((B * 6 * Tg, C * 256), dtype=dtype, device=feat.device)
+    rc = _lib.lib().pseld_passt_patchify(dtype_code(A), _lib.ptr(feat), _lib.ptr(scale_shift), _lib.ptr(A), B, C, T, _lib.stream_ptr())
+    _lib.check(rc, "pseld_passt_patchify")
+    return A
+
+
+def passt_bn_bwd(feat, mean_rstd, dA, dweight, dbias):
+    _chk(feat, mean_rstd, dA, dweight, dbias)
+    B, C, T, _ = feat.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_passt_bn_bwd_workspace(B, C, T), feat.device)
+    rc = L.pseld_passt_bn_bwd(dtype_code(dA), _lib.ptr(feat), _lib.ptr(mean_rstd), _lib.ptr(dA), _lib.ptr(dweight), _lib.ptr(dbias),
+                              B, C, T, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_passt_bn_bwd")
+
+
+def passt_assemble_fwd(P, tpos, fpos, cls, dist, npos, B, Tg):
+    _chk(P, tpos, fpos, cls, dist, npos)
+    E = P.shape[1]
+    X = torch.empty((B * (6 * Tg + 2), E), dtype=P.dtype, device=P.device)
+    rc = _lib.lib().pseld_passt_assemble_fwd(dtype_code(P), _lib.ptr(P), _lib.ptr(tpos), _lib.ptr(fpos), _lib.ptr(cls), _lib.ptr(dist),
+                                             _lib.ptr(npos), _lib.ptr(X), B, E, Tg, _lib.stream_ptr())
+    _lib.check(rc, "pseld_passt_assemble_fwd")
+    return X
+
+
+def passt_assemble_bwd(dX, dtpos, dfpos, dcls, ddist, dnpos, B, Tg):
+    _chk(dX, dtpos, dfpos, dcls, ddist, dnpos)
+    E = dX.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.pseld_passt_assemble_bwd_workspace(E, Tg), dX.device)
+    dP = torch.empty((B * 6 * Tg, E), dtype=dX.dtype, device=dX.device)
+    rc = L.pseld_passt_assemble_bwd(dtype_code(dX), _lib.ptr(dX), _lib.ptr(dP), _lib.ptr(dtpos), _lib.ptr(dfpos), _lib.ptr(dcls),
+                                    _lib.ptr(ddist), _lib.ptr(dnpos), B, E, Tg, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_passt_assemble_bwd")
+    return dP
+
+
+def passt_pool_fwd(X, B, Tg):
+    _chk(X)
+    Y = torch.empty((B * Tg, X.shape[1]), dtype=X.dtype, device=X.device)
+    _lib.check(_lib.lib().pseld_passt_pool_fwd(dtype_code(X), _lib.ptr(X), _lib.ptr(Y), B, X.shape[1], Tg, _lib.stream_ptr()),
+               "pseld_passt_pool_fwd")
+    return Y
+
+
+def passt_pool_bwd(dY, B, Tg):
+    _chk(dY)
+    dX = torch.empty((B * (6 * Tg + 2), dY.shape[1]), dtype=dY.dtype, device=dY.device)
+    _lib.check(_lib.lib().pseld_passt_pool_bwd(dtype_code(dY), _lib.ptr(dY), _lib.ptr(dX), B, dY.shape[1], Tg, _lib.stream_ptr()),
+               "pseld_passt_pool_bwd")
+    return dX
+
+
+def tanh_fwd(z, D):
+    _chk(z)
+    y = torch.empty((z.shape[0], D), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.lib().pseld_tanh_fwd(dtype_code(z), _lib.ptr(z), z.shape[1], _lib.ptr(y), z.shape[0], D, _lib.stream_ptr()),
+               "pseld_tanh_fwd")
+    return y
+
+
+def tanh_bwd(dy, y, ldz, dtype):
+    _chk(dy, y)
+    rows, D = y.shape
+    dz = torch.empty((rows, ldz), dtype=dtype, device=y.device)
+    _lib.check(_lib.lib().pseld_tanh_bwd(dtype_code(dz), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dz), ldz, rows, D, _lib.stream_ptr()),
+               "pseld_tanh_bwd")
+    return dz

@@ -29,6 +29,7 @@ from models import accdoa, einv2, multi_accdoa  # noqa: E402
 import utils.feature as ref_feature  # noqa: E402
 
 from oracle import htsat as oh  # noqa: E402
+from oracle import passt as op  # noqa: E402
 from oracle import synth  # noqa: E402
 
 torch.set_num_threads(8)
@@ -251,11 +252,82 @@ def gen_sampler():
     save('sampler.npz', **out)
 
 
+PASST_TINY = dict(embed_dim=128, depth=2, num_heads=2)
+PASST_FULL = dict(embed_dim=768, depth=7, num_heads=12)
+
+
+def passt_kwargs(c):
+    """configs/model/passt.yaml with the size overrides of the test configuration"""
+    return dict(u_patchout=0, s_patchout_t=0, s_patchout_f=0, img_size=[64, 1001], patch_size=16, stride=10, mlp_ratio=4,
+                qkv_bias=True, representation_size=None, distilled=True, drop_rate=0., drop_path_rate=0., norm_layer=None,
+                act_layer=None, **c)
+
+
+def gen_passt():
+    C = 3
+    out = {}
+    x = oh.formula_features(2)
+    net = multi_accdoa.PASST(CFG, C, 7, pretrained_path=None, **passt_kwargs(PASST_TINY))
+    missing, unexpected = net.load_state_dict(op.formula_state('multi_accdoa', C, 7, PASST_TINY), strict=False)
+    assert not missing and not unexpected
+    net.eval()
+    with torch.no_grad():
+        out['maccdoa_eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net.train()
+    pred = net(x.clone())
+    lab = synth.formula_adpit_label(2, 100, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab})
+    ld['loss_all'].backward()
+    out['maccdoa_train'] = pred['multi_accdoa'].detach().numpy()
+    out['maccdoa_loss'] = ld['loss_all'].item()
+    names, norms, heads = [], [], []
+    for n, p in net.named_parameters():
+        if n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    sd = net.state_dict()
+    out['running_mean'] = torch.stack([sd[f'scalar.{c}.running_mean'] for c in range(7)]).numpy()
+    out['running_var'] = torch.stack([sd[f'scalar.{c}.running_var'] for c in range(7)]).numpy()
+    net64 = multi_accdoa.PASST(CFG, C, 7, pretrained_path=None, **passt_kwargs(PASST_TINY)).double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in op.formula_state('multi_accdoa', C, 7, PASST_TINY).items()})
+    net64.train()
+    lossf = loss.multi_accdoa.Losses('mse', 'loss_all')
+
+    def L():
+        return lossf(net64(x.double().clone()), {'adpit_label': lab.double()})['loss_all'].item()
+    fd, h = [], 1e-5
+    with torch.no_grad():
+        for (c, kind, j) in [(0, 'bias', 3), (5, 'bias', 61), (2, 'weight', 0), (6, 'weight', 40)]:
+            prm = getattr(net64.scalar[c], kind)
+            prm[j] += h; lp = L(); prm[j] -= 2 * h; lm = L(); prm[j] += h
+            fd.append((c, 0 if kind == 'bias' else 1, j, (lp - lm) / (2 * h)))
+    out['bn_fd_check'] = np.array(fd)
+    # ACCDOA head
+    net = accdoa.PASST(CFG, C, 7, pretrained_path=None, **passt_kwargs(PASST_TINY))
+    net.load_state_dict(op.formula_state('accdoa', C, 7, PASST_TINY))
+    net.eval()
+    with torch.no_grad():
+        out['accdoa_eval'] = net(x.clone())['accdoa'].numpy()
+    # full-size (configs/model/passt.yaml) multi-ACCDOA, 13 classes, one chunk, eval
+    net = multi_accdoa.PASST(CFG, 13, 7, pretrained_path=None, **passt_kwargs(PASST_FULL))
+    net.load_state_dict(op.formula_state('multi_accdoa', 13, 7, PASST_FULL))
+    net.eval()
+    with torch.no_grad():
+        y = net(oh.formula_features(1))['multi_accdoa']
+    out['full_eval'] = y.numpy()
+    out['full_n_params'] = sum(p.numel() for p in net.parameters())
+    save('passt.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
     if 'losses' in which: gen_losses()
     if 'optim' in which: gen_optim()
     if 'sampler' in which: gen_sampler()
+    if 'passt' in which: gen_passt()

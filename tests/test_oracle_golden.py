@@ -176,3 +176,49 @@ def test_sampler_golden():
         want = g[key]
         got = oo.distributed_batches(n, b, w, r, seed=s, n_batches=want.shape[0])
         assert np.array_equal(np.stack(got), want), key
+
+
+PASST_TINY = dict(embed_dim=128, depth=2, num_heads=2)
+PASST_FULL = dict(embed_dim=768, depth=7, num_heads=12)
+
+
+def test_passt_tiny_golden():
+    """oracle/passt.py against the reference's PASST networks (models/accdoa.py:249-329, multi_accdoa.py:46-54)."""
+    from oracle import passt as op
+    g = gold('passt.npz')
+    x = oh.formula_features(2)
+    with torch.no_grad():
+        close(op.accdoa_passt_forward(x.clone(), op.formula_state('multi_accdoa', 3, 7, PASST_TINY), PASST_TINY,
+                                      key='multi_accdoa')['multi_accdoa'], g['maccdoa_eval'])
+        close(op.accdoa_passt_forward(x.clone(), op.formula_state('accdoa', 3, 7, PASST_TINY), PASST_TINY)['accdoa'],
+              g['accdoa_eval'])
+    sd = op.formula_state('multi_accdoa', 3, 7, PASST_TINY)
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    upd = {}
+    pred = op.accdoa_passt_forward(x.clone(), p, PASST_TINY, training=True, bn_update=upd, key='multi_accdoa')
+    close(pred['multi_accdoa'], g['maccdoa_train'])
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3)})
+    assert abs(ld['loss_all'].item() - float(g['maccdoa_loss'])) < 1e-6
+    ld['loss_all'].backward()
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= 2e-4 * max(norm, 1e-3), n
+        k = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:k].numpy() - head[:k]).max() <= 2e-4 * max(np.abs(head).max(), 1e-4) + 1e-7, n
+    close(torch.stack([upd[f'scalar.{c}.running_mean'] for c in range(7)]), g['running_mean'], 1e-4)
+    close(torch.stack([upd[f'scalar.{c}.running_var'] for c in range(7)]), g['running_var'], 1e-3)
+    for c, is_w, j, fd in g['bn_fd_check']:
+        name = f"scalar.{int(c)}.{'weight' if is_w else 'bias'}"
+        got = p[name].grad[int(j)].item()
+        assert abs(got - fd) <= 2e-3 * max(abs(fd), 1e-3), (name, got, fd)
+
+
+def test_passt_full_size_golden():
+    from oracle import passt as op
+    g = gold('passt.npz')
+    sd = op.formula_state('multi_accdoa', 13, 7, PASST_FULL)
+    n_params = sum(int(np.prod(shp)) for k, shp in op.net_shapes('multi_accdoa', 13, 7, PASST_FULL).items() if 'running_' not in k)
+    assert n_params == int(g['full_n_params'])
+    with torch.no_grad():
+        y = op.accdoa_passt_forward(oh.formula_features(1), sd, PASST_FULL, key='multi_accdoa')['multi_accdoa']
+    close(y, g['full_eval'], 5e-5)

@@ -1,0 +1,217 @@
+"""Parity of the PaSST path on the MI355X: global attention and front/back-end kernels against plain fp32 torch, and
+the whole network (forward, loss, backward, BN running stats) against the reference-generated golden vectors and the
+CPU oracle (oracle/passt.py). f32 (parity) mode gates at 1e-3 rel; bf16 is reported and gated loosely."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import htsat as oh
+from oracle import passt as op
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+TINY = dict(embed_dim=128, depth=2, num_heads=2)
+FULL = dict(embed_dim=768, depth=7, num_heads=12)
+
+
+class A(dict):
+    __getattr__ = dict.__getitem__
+
+
+CFG = A(data=A(n_mels=64, sample_rate=24000, hoplen=240), adapt=A())
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def torch_mhsa(qkv, B, N, heads):
+    E = qkv.shape[1] // 3
+    q, k, v = qkv.view(B, N, 3, heads, E // heads).permute(2, 0, 3, 1, 4)
+    attn = ((q @ k.transpose(-2, -1)) * (E // heads) ** -0.5).softmax(-1)
+    return (attn @ v).transpose(1, 2).reshape(B * N, E)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,N,heads", [(2, 602, 2), (1, 70, 1), (3, 129, 3), (1, 64, 12)])
+def test_mhsa_matches_torch(dev, dtype, tol, B, N, heads):
+    from pseldnets_amd import ops
+    torch.manual_seed(N)
+    E = 64 * heads
+    qkv32 = torch.randn(B * N, 3 * E, device=dev) * 1.5
+    dout32 = torch.randn(B * N, E, device=dev)
+    qkv = qkv32.to(dtype); dout = dout32.to(dtype)
+    ref_in = qkv.float().requires_grad_(True)
+    ref = torch_mhsa(ref_in, B, N, heads)
+    ref.backward(dout.float())
+    out, lse = ops.mhsa_fwd(qkv, B, N, heads)
+    assert rel(out, ref) < tol
+    dqkv = ops.mhsa_bwd(qkv, out, dout, lse, B, N, heads)
+    for name, sl in (('dq', slice(0, E)), ('dk', slice(E, 2 * E)), ('dv', slice(2 * E, 3 * E))):
+        r = rel(dqkv[:, sl], ref_in.grad[:, sl])
+        assert r < tol, (name, r)
+
+
+def test_mhsa_rejects_other_head_dims(dev):
+    from pseldnets_amd import _lib, ops
+    with pytest.raises(_lib.PseldError):
+        ops.mhsa_fwd(torch.zeros(10, 3 * 96, device=dev), 1, 10, 2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_front_and_back_end_kernels(dev, dtype, tol):
+    from pseldnets_amd import ops
+    torch.manual_seed(3)
+    B, C, T, E = 2, 3, 1001, 64
+    feat = torch.randn(B, C, T, 64, device=dev)
+    ss = torch.randn(C * 64, 2, device=dev)
+    mr = torch.stack([torch.randn(C * 64, device=dev), torch.rand(C * 64, device=dev) + 0.5], -1).contiguous()
+    # patchify == unfold of the BN'd, transposed image
+    img = (feat * ss[:, 0].view(1, C, 1, 64) + ss[:, 1].view(1, C, 1, 64)).transpose(-1, -2)
+    want = F.unfold(img, 16, padding=3, stride=10).transpose(1, 2).reshape(B * 600, C * 256)
+    A0 = ops.passt_patchify(feat, ss.contiguous(), dtype)
+    assert ops.passt_grid_t(T) == 100 and rel(A0, want) < tol
+    # BN gradients through the overlapping patches == autograd of the same map
+    w = torch.ones(C * 64, device=dev, requires_grad=True); b = torch.zeros(C * 64, device=dev, requires_grad=True)
+    xh = (feat - mr[:, 0].view(1, C, 1, 64)) * mr[:, 1].view(1, C, 1, 64)
+    img = (xh * w.view(1, C, 1, 64) + b.view(1, C, 1, 64)).transpose(-1, -2)
+    dA = torch.randn(B * 600, C * 256, device=dev).to(dtype)
+    (F.unfold(img, 16, padding=3, stride=10).transpose(1, 2).reshape(B * 600, C * 256) * dA.float()).sum().backward()
+    dw, db = torch.empty(C * 64, device=dev), torch.empty(C * 64, device=dev)
+    ops.passt_bn_bwd(feat, mr, dA, dw, db)
+    assert rel(dw, w.grad) < 1e-4 and rel(db, b.grad) < 1e-4
+    # assemble + its backward
+    P = torch.randn(B * 600, E, device=dev).to(dtype)
+    prm = [torch.randn(s, device=dev, requires_grad=True) for s in ((1, E, 1, 100), (1, E, 6, 1), (1, 1, E), (1, 1, E), (1, 2, E))]
+    tpos, fpos, cls, dist, npos = prm
+    Pr = P.float().requires_grad_(True)
+    body = (Pr.view(B, 6, 100, E).permute(0, 3, 1, 2) + tpos + fpos).flatten(2).transpose(1, 2)
+    Xr = torch.cat((cls.expand(B, -1, -1) + npos[:, :1], dist.expand(B, -1, -1) + npos[:, 1:], body), 1).reshape(B * 602, E)
+    X = ops.passt_assemble_fwd(P, *[t.detach().contiguous() for t in prm], B, 100)
+    assert rel(X, Xr) < tol
+    dX = torch.randn(B * 602, E, device=dev).to(dtype)
+    Xr.backward(dX.float())
+    grads = [torch.empty_like(t) for t in prm]
+    dP = ops.passt_assemble_bwd(dX, *grads, B, 100)
+    assert rel(dP, Pr.grad) < tol
+    for got, t in zip(grads, prm):
+        assert rel(got, t.grad) < 1e-5
+    # pool + backward
+    Xn = torch.randn(B * 602, E, device=dev).to(dtype)
+    Xf = Xn.float().requires_grad_(True)
+    Yr = Xf.view(B, 602, E)[:, 2:].reshape(B, 6, 100, E).mean(1).reshape(B * 100, E)
+    assert rel(ops.passt_pool_fwd(Xn, B, 100), Yr) < tol
+    dY = torch.randn(B * 100, E, device=dev).to(dtype)
+    Yr.backward(dY.float())
+    assert rel(ops.passt_pool_bwd(dY, B, 100), Xf.grad) < tol
+    # tanh head activation on a padded-row GEMM output
+    z = torch.randn(50, 32, device=dev).to(dtype)
+    zf = z.float().requires_grad_(True)
+    yr = torch.tanh(zf[:, :27])
+    y = ops.tanh_fwd(z, 27)
+    assert rel(y, yr) < 1e-5
+    dy = torch.randn(50, 27, device=dev)
+    yr.backward(dy)
+    dz = ops.tanh_bwd(dy, y, 32, dtype)
+    assert rel(dz, zf.grad) < tol and dz[:, 27:].abs().max().item() == 0
+
+
+def build(mod, kind, C, cfg, dev, dtype=torch.float32):
+    net = mod.PASST(CFG, C, 7, pretrained_path=None, **cfg)
+    missing, unexpected = net.load_state_dict(op.formula_state(kind, C, 7, cfg), strict=True)
+    net.compute_dtype = dtype
+    return net.to(dev)
+
+
+def test_tiny_eval_forward_vs_golden(dev):
+    from pseldnets_amd.models import accdoa, multi_accdoa
+    g = np.load(os.path.join(G, 'passt.npz'))
+    x = oh.formula_features(2).to(dev)
+    net = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev).eval()
+    with torch.no_grad():
+        y = net(x.clone())['multi_accdoa']
+    r = rel(y, g['maccdoa_eval'])
+    print('PaSST tiny mACCDOA eval rel', r)
+    assert y.shape == (2, 100, 27) and r < 1e-3
+    net = build(accdoa, 'accdoa', 3, TINY, dev).eval()
+    with torch.no_grad():
+        assert rel(net(x.clone())['accdoa'], g['accdoa_eval']) < 1e-3
+
+
+def test_tiny_train_step_vs_golden(dev):
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'passt.npz'))
+    x = oh.formula_features(2).to(dev)
+    net = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev).train()
+    pred = net(x.clone())
+    assert rel(pred['multi_accdoa'], g['maccdoa_train']) < 1e-3
+    lab = synth.formula_adpit_label(2, 100, 3).to(dev)
+    ld = Losses('mse', 'loss_all')(pred, {'adpit_label': lab})
+    assert abs(ld['loss_all'].item() - float(g['maccdoa_loss'])) < 1e-3 * abs(float(g['maccdoa_loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        gr = params[str(n)].grad
+        assert gr is not None, n
+        e = abs(gr.norm().item() - norm) / max(norm, 1e-6)
+        worst = max(worst, e)
+        assert e < 2e-3, (n, gr.norm().item(), norm)
+        k = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:k].cpu().numpy() - head[:k]).max() <= 2e-3 * max(np.abs(head).max(), norm / np.sqrt(gr.numel())) + 1e-7, n
+    print('PaSST worst grad-norm rel err', worst)
+    for c, is_w, j, fd in g['bn_fd_check']:
+        got = params[f"scalar.{int(c)}.{'weight' if is_w else 'bias'}"].grad[int(j)].item()
+        assert abs(got - fd) <= 3e-3 * max(abs(fd), 1e-3), (c, is_w, j, got, fd)
+    sdn = net.state_dict()
+    assert rel(torch.stack([sdn[f'scalar.{c}.running_mean'] for c in range(7)]), g['running_mean']) < 1e-4
+    assert rel(torch.stack([sdn[f'scalar.{c}.running_var'] for c in range(7)]), g['running_var']) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,gate", [(torch.float32, 1e-3), (torch.bfloat16, 2.5e-1)])
+def test_full_size_forward_vs_golden(dev, dtype, gate):
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'passt.npz'))
+    net = build(multi_accdoa, 'multi_accdoa', 13, FULL, dev, dtype).eval()
+    assert sum(p.numel() for p in net.parameters()) == int(g['full_n_params'])
+    with torch.no_grad():
+        y = net(oh.formula_features(1).to(dev))['multi_accdoa']
+    r = rel(y, g['full_eval'])
+    print(f'PaSST full-size mACCDOA eval ({dtype}) rel err {r:.3e}')
+    assert y.shape == (1, 100, 117) and r < gate
+
+
+@pytest.mark.parametrize("dtype,gate", [(torch.float32, 2e-3), (torch.bfloat16, 1.5e-1)])
+def test_all_gradients_vs_oracle(dev, dtype, gate):
+    """Every parameter gradient against the oracle's autograd on the tiny config, B=3."""
+    from pseldnets_amd import ops
+    from pseldnets_amd.models import multi_accdoa
+    net = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev, dtype).train()
+    x = oh.formula_features(3)
+    lab = synth.formula_adpit_label(3, 100, 3)
+    net._materialize(dev)
+    y, saved = net._forward_impl(x.to(dev), True)
+    loss, dpred = ops.adpit_loss(y, lab.to(dev))
+    net.zero_grad_arena()
+    net._backward_impl(saved, (dpred,))
+    from oracle import losses as ol
+    sd = op.formula_state('multi_accdoa', 3, 7, TINY)
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    pred = op.accdoa_passt_forward(x.clone(), p, TINY, training=True, key='multi_accdoa')
+    lo = ol.adpit(pred, {'adpit_label': lab})['loss_all']
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < gate * abs(lo.item())
+    worst = ('', 0.0)
+    for n in net.arena.entries:
+        got, want = net.arena.g(n), p[n].grad
+        e = (got.cpu() - want).norm().item() / max(want.norm().item(), 1e-8)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f'PaSST worst parameter-gradient rel-L2 ({dtype}):', worst)
+    assert worst[1] < gate, worst
