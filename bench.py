@@ -20,6 +20,7 @@ import torch  # noqa: E402
 
 CLIP_SECONDS, CHUNKS_PER_CLIP, FS, CLASSES = 60, 6, 24000, 170
 GFLOP_PER_CHUNK_TRAIN = 37.61       # 37.026 (net fwd+bwd) + 0.583 (features)
+GFLOP_PER_CHUNK_TRAIN_PASST = 207.9  # 3 x (patch 1.65 + 7 blocks x (12 E^2 N + 4 N^2 E) = 67.8) + features; N=602, E=768
 PEAK_BF16_TFLOPS = 2516.6           # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -128,6 +129,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--clips', type=int, default=32, help='60 s clips per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt'],
+                    help='htsat = the headline workload (BASELINE.json configs[1]); passt = the PaSST backbone, same data')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -153,7 +156,10 @@ def main():
 
     cfg = make_cfg()
     torch.manual_seed(2024)
-    net = multi_accdoa.HTSAT(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/htsat.yaml geometry
+    if args.backbone == 'htsat':
+        net = multi_accdoa.HTSAT(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/htsat.yaml geometry
+    else:
+        net = multi_accdoa.PASST(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/passt.yaml geometry
     net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     net.to(device)
     if world > 1:
@@ -193,17 +199,19 @@ def main():
     clips_per_s = args.clips * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
+    name = 'HTS-AT' if args.backbone == 'htsat' else 'PaSST'
+    gflop_chunk = GFLOP_PER_CHUNK_TRAIN if args.backbone == 'htsat' else GFLOP_PER_CHUNK_TRAIN_PASST
     out = {
-        "metric": "train clips/sec (60 s 4-ch FOA) HTS-AT mACCDOA", "value": round(clips_per_s, 2), "unit": "clips/s",
+        "metric": f"train clips/sec (60 s 4-ch FOA) {name} mACCDOA", "value": round(clips_per_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"HTS-AT mACCDOA {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
+        "config": {"workload": f"{name} mACCDOA {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
                                f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, ADPIT, clip 1.0, AdamW, "
-                               "drop_path 0.1, BN train mode, no augmentation",
+                               f"drop_path {0.1 if args.backbone == 'htsat' else 0.0}, BN train mode, no augmentation",
                    "global_clips": args.clips * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
     }
-    step_tflops = clips_per_s * CHUNKS_PER_CLIP * GFLOP_PER_CHUNK_TRAIN / 1e3
+    step_tflops = clips_per_s * CHUNKS_PER_CLIP * gflop_chunk / 1e3
     out["roofline_step"] = {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4)}
     if rank == 0 and timer is not None:
