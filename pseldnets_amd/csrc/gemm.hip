@@ -126,6 +126,20 @@ template <typename T, int X> struct TStride {
     static constexpr int value = (raw % 128 == 64) ? raw : raw + 64;
 };
 
+template <typename T> __device__ __forceinline__ float frag_sum(const typename Mma<T>::Frag& f);
+template <> __device__ __forceinline__ float frag_sum<bf16_t>(const bf16x8& f) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)f[j];
+    return s;
+}
+template <> __device__ __forceinline__ float frag_sum<float>(const FragF32& f) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f.v[j];
+    return s;
+}
+
 __device__ __forceinline__ f32x4 gelu4_bf16(f32x4 v) {
     // v carries 8 packed bf16; apply exact GELU elementwise
     bf16x8 x = __builtin_bit_cast(bf16x8, v);
@@ -241,7 +255,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    float colacc = 0.f;
+    // bias gradient for free (TA): column sums of dY taken from the A fragments already in registers — lane (row, h)
+    // holds 8 tokens of its column per k-step; halves and k-steps are summed at the end (no extra LDS traffic)
+    float colacc[2] = {0.f, 0.f};
+    const bool do_colsum = TA && g.colsum && blockIdx.x == 0 && wn == 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     if (g.dbg) t0 = __builtin_amdgcn_s_memtime();
     if (kbeg < kend) load_regs(kbeg);
@@ -251,11 +268,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
         if (g.dbg && k0 == kbeg) t1 = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (k0 + BK < kend) load_regs(k0 + BK);
-        if (TA && g.colsum && blockIdx.x == 0 && tid < BM) {
-            // bias gradient for free: column sums of the dY image this workgroup has in LDS anyway
-#pragma unroll 8
-            for (int kr = 0; kr < BK; ++kr) colacc += to_f32<T>(*(const T*)(As + kr * A_STRIDE + tid * ES));
-        }
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             if (k0 + kk * 16 < kend) {  // uniform: skip MFMA steps that are pure K padding
@@ -264,6 +276,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
                 for (int mi = 0; mi < 2; ++mi) {
                     const int base = wm * 64 + mi * 32;
                     fa[mi] = TA ? ld_frag_t<T>(As, A_STRIDE, base, kk, lane) : ld_frag_n<T>(As, base + r, kk, h);
+                    if (TA && do_colsum) colacc[mi] += frag_sum<T>(fa[mi]);
                 }
 #pragma unroll
                 for (int ni = 0; ni < 3; ++ni) {
@@ -284,8 +297,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     }
 
     if (g.dbg) t2 = __builtin_amdgcn_s_memtime();
-    if (TA && g.colsum && blockIdx.x == 0 && tid < BM && m0 + tid < g.M)
-        g.colsum[(long)blockIdx.z * g.colsum_stride + m0 + tid] = colacc;
+    if (TA && do_colsum) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float cs = colacc[mi] + __shfl_xor(colacc[mi], 32, 64);
+            const int m = m0 + wm * 64 + mi * 32 + r;
+            if (h == 0 && m < g.M) g.colsum[(long)blockIdx.z * g.colsum_stride + m] = cs;
+        }
+    }
     OutT* Cg = (OutT*)g.C + (long)blockIdx.z * g.slab_stride;
     const T* Rg = (const T*)g.resid;
     const T* Ug = (const T*)g.aux;
@@ -449,8 +468,12 @@ int dispatch_tile(const GemmArgs& g, int splits, hipStream_t stream) {
     // 256x96 when one 96-column tile covers N (or N is not worth a 192 tile), else 128x192
     if (g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288))
         return launch_gemm<T, OutT, 4, 1, TA, TB>(g, splits, stream);
-    if (sizeof(T) == 2 && TA && gemm_big_tiles() && g.M >= 256)
-        return launch_gemm<T, OutT, 4, 2, TA, TB>(g, splits, stream);   // weight gradient: 256x192, 8 waves (measured +4 %)
+    if (sizeof(T) == 2 && TA && g.M >= 256) {
+        const char* e = getenv("PSELD_WGRAD_TILE");          // experiment knob: 22 / 42
+        const int force = e ? atoi(e) : 0;
+        if (force == 42 || (force == 0 && gemm_big_tiles()))
+            return launch_gemm<T, OutT, 4, 2, TA, TB>(g, splits, stream);   // weight gradient: 256x192, 8 waves (measured +4 %)
+    }
     return launch_gemm<T, OutT, 2, 2, TA, TB>(g, splits, stream);
 }
 
@@ -529,15 +552,20 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 // Split planning: enough workgroups to fill the chip twice over (2 resident per CU), counted with the tile the
 // dispatcher will actually use; at least 1024 tokens per split so the fp32 slab traffic stays small.
 static int wgrad_target_blocks() {
-    static int t = 0;
-    if (!t) { const char* e = getenv("PSELD_WGRAD_TARGET"); t = e ? atoi(e) : 1024; if (t < 1) t = 1024; }
-    return t;
+    const char* e = getenv("PSELD_WGRAD_TARGET");
+    const int t = e ? atoi(e) : 1024;
+    return t < 1 ? 1024 : t;
+}
+static int wgrad_min_tokens() {
+    const char* e = getenv("PSELD_WGRAD_MINTOK");
+    const int t = e ? atoi(e) : 512;
+    return t < 64 ? 512 : t;
 }
 static int wgrad_splits(int Mtok, int N, int K) {
-    // ~1024 workgroups counted in 96x96 units (measured best across the HTS-AT shapes), >= 2048 tokens per split
+    // ~1024 workgroups counted in 96x96 units, >= 512 tokens per split (tools/wgrad_sweep.py on the HTS-AT shapes)
     const int tiles = pseld_cdiv(N, 96) * pseld_cdiv(K, 96);
     int splits = pseld_cdiv(wgrad_target_blocks(), tiles);
-    const int max_splits = pseld_cdiv(Mtok, 2048);
+    const int max_splits = pseld_cdiv(Mtok, wgrad_min_tokens());
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     return splits;
