@@ -156,6 +156,110 @@ template <typename T> __device__ __forceinline__ f32x4 gelu_chunk(f32x4 v);
 template <> __device__ __forceinline__ f32x4 gelu_chunk<bf16_t>(f32x4 v) { return gelu4_bf16(v); }
 template <> __device__ __forceinline__ f32x4 gelu_chunk<float>(f32x4 v) { return gelu4_f32(v); }
 
+// ---- bf16 epilogue, second half: C tile in LDS -> fused options -> 16-byte coalesced global stores -----------------
+enum { EM_PLAIN, EM_RESID, EM_RESID_SCALE, EM_GELU_DUAL, EM_MULAUX, EM_GENERIC };
+
+__device__ __forceinline__ void unpack8(const f32x4& p, float (&v)[8]) {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
+}
+__device__ __forceinline__ f32x4 pack8(const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (bf16_t)v[k];
+    return __builtin_bit_cast(f32x4, x);
+}
+
+template <int MODE, int BM, int BN, int THREADS>
+__device__ __forceinline__ void store_rows(const GemmArgs& g, const char* Cs, int m0, int n0, int tid, bf16_t* Cg) {
+    constexpr int CS_STRIDE = BN * 2 + 16;
+    constexpr int CPR = BN / 8;
+    constexpr int NCHUNK = BM * CPR / THREADS;        // 16-byte chunks per thread (12 for every tile shape)
+    constexpr int UB = (MODE == EM_GENERIC) ? 4 : 6;  // chunks in flight per thread: loads first, stores last
+    static_assert(NCHUNK % UB == 0, "epilogue batching");
+    const bf16_t* Rg = (const bf16_t*)g.resid;
+    const bf16_t* Ug = (const bf16_t*)g.aux;
+    const int mlast = g.M - 1, nlast = max(g.N - 8, 0);
+#pragma unroll
+    for (int b0 = 0; b0 < NCHUNK; b0 += UB) {
+        f32x4 cv[UB], xv[UB];
+        float sc[UB];
+        long orow[UB], rrow[UB];
+        bool ok[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int c = tid + (b0 + j) * THREADS;
+            const int row = c / CPR, cb = c - row * CPR;
+            const int mrow = m0 + row, ncol = n0 + cb * 8;
+            ok[j] = mrow < g.M && ncol < g.N;
+            cv[j] = *(const f32x4*)(Cs + row * CS_STRIDE + cb * 16);
+            const int mr = min(mrow, mlast), nc = min(ncol, nlast);   // clamped: loads never branch
+            orow[j] = (long)mr * g.ldc + nc;
+            rrow[j] = (long)mr * g.ldr + nc;
+            if constexpr (MODE == EM_RESID || MODE == EM_RESID_SCALE) xv[j] = *(const f32x4*)(Rg + rrow[j]);
+            if constexpr (MODE == EM_MULAUX) xv[j] = *(const f32x4*)(Ug + (long)mr * g.ldaux + nc);
+            if constexpr (MODE == EM_RESID_SCALE) sc[j] = g.rowscale[mr / g.rows_per_scale];
+            if constexpr (MODE == EM_GENERIC) {
+                const bool use_aux = (g.epi & (EPI_MULGELUGRAD | EPI_MULAUX)) != 0;
+                xv[j] = use_aux ? *(const f32x4*)(Ug + (long)mr * g.ldaux + nc) : cv[j];
+                sc[j] = g.rowscale ? g.rowscale[mr / g.rows_per_scale] : 1.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            float v[8];
+            unpack8(cv[j], v);
+            if constexpr (MODE == EM_RESID) {
+                float x[8];
+                unpack8(xv[j], x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += x[k];
+            } else if constexpr (MODE == EM_RESID_SCALE) {
+                float x[8];
+                unpack8(xv[j], x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], sc[j], x[k]);
+            } else if constexpr (MODE == EM_MULAUX) {
+                float x[8];
+                unpack8(xv[j], x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= x[k];
+            } else if constexpr (MODE == EM_GELU_DUAL) {
+                float dv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gelu_both(v[k], v[k], dv[k]);
+                if (ok[j]) *(f32x4*)((bf16_t*)g.C2 + orow[j]) = pack8(dv);
+            } else if constexpr (MODE == EM_GENERIC) {
+                float x[8];
+                unpack8(xv[j], x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= sc[j];
+                if (g.epi & EPI_MULAUX) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] *= x[k];
+                } else if (g.epi & EPI_MULGELUGRAD) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(x[k]);
+                }
+                if (g.epi & EPI_RESID) {
+                    float rr[8];
+                    unpack8(*(const f32x4*)(Rg + rrow[j]), rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                }
+                if (g.epi & EPI_GELU_DUAL) {
+                    float dv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gelu_both(v[k], v[k], dv[k]);
+                    if (ok[j]) *(f32x4*)((bf16_t*)g.C2 + orow[j]) = pack8(dv);
+                }
+            }
+            if (ok[j]) *(f32x4*)(Cg + orow[j]) = pack8(v);
+        }
+    }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------
 template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
@@ -310,6 +414,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     const T* Ug = (const T*)g.aux;
     if constexpr (STAGED) {
         // ---- bf16 epilogue: tile^T -> LDS (8-byte row segments) -> 16-byte coalesced rows with the fused ops ----
+        // The lane's 12 bias groups are fetched BEFORE the C tile is written: bias_s and Cs live in the same LDS
+        // array, so a read placed between the writes is ordered after each of them (24 serial LDS round trips, 4k
+        // cycles per tile measured with s_memtime).
+        f32x4 bvv[3][4];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bvv[ni][q] = *(const f32x4*)(bias_s + wn * 96 + ni * 32 + 8 * q + 4 * h);
         __syncthreads();  // every wave is done with the operand images
         char* Cs = smem;
 #pragma unroll
@@ -320,72 +432,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int nl = wn * 96 + ni * 32 + 8 * q + 4 * h;
-                    const f32x4 bv = *(const f32x4*)(bias_s + nl);   // zero when there is no bias / past N
                     bf16x4 pk;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)(acc[mi][ni][4 * q + j] + bv[j]);
+                    for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)(acc[mi][ni][4 * q + j] + bvv[ni][q][j]);
                     *(bf16x4*)(Cs + ml * CS_STRIDE + nl * 2) = pk;
                 }
             }
         __syncthreads();
         if (g.dbg) t4 = __builtin_amdgcn_s_memtime();
-        constexpr int CPR = BN / 8;
-        constexpr int NCHUNK = BM * CPR / GEMM_THREADS;   // 16-byte chunks per thread (12 for every tile shape)
-        constexpr int UB = 4;                              // chunks in flight per thread: loads first, stores last
-        static_assert(NCHUNK % UB == 0, "epilogue batching");
-        const bool use_aux = (g.epi & (EPI_MULGELUGRAD | EPI_MULAUX)) != 0;
-        const bool use_res = (g.epi & EPI_RESID) != 0;
-#pragma unroll 1
-        for (int b0 = 0; b0 < NCHUNK; b0 += UB) {
-            float v[UB][8], u[UB][8], rr[UB][8];
-            int mrow[UB], ncol[UB];
-            bool ok[UB];
-#pragma unroll
-            for (int j = 0; j < UB; ++j) {
-                const int c = tid + (b0 + j) * GEMM_THREADS;
-                const int row = c / CPR, cb = c - row * CPR;
-                mrow[j] = m0 + row; ncol[j] = n0 + cb * 8;
-                ok[j] = mrow[j] < g.M && ncol[j] < g.N;
-                load8<bf16_t>((const bf16_t*)(Cs + row * CS_STRIDE + cb * 16), v[j]);
-            }
-            if (use_aux) {
-#pragma unroll
-                for (int j = 0; j < UB; ++j)
-                    if (ok[j]) load8<bf16_t>((const bf16_t*)Ug + (long)mrow[j] * g.ldaux + ncol[j], u[j]);
-            }
-            if (use_res) {
-#pragma unroll
-                for (int j = 0; j < UB; ++j)
-                    if (ok[j]) load8<bf16_t>((const bf16_t*)Rg + (long)mrow[j] * g.ldr + ncol[j], rr[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < UB; ++j) {
-                if (!ok[j]) continue;
-                if (g.rowscale) {
-                    const float sc = g.rowscale[mrow[j] / g.rows_per_scale];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[j][k] *= sc;
-                }
-                if (g.epi & EPI_MULAUX) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[j][k] *= u[j][k];
-                } else if (g.epi & EPI_MULGELUGRAD) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[j][k] *= gelu_grad_f(u[j][k]);
-                }
-                if (use_res) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[j][k] += rr[j][k];
-                }
-                if (g.epi & EPI_GELU_DUAL) {
-                    float dv[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) gelu_both(v[j][k], v[j][k], dv[k]);
-                    store8<bf16_t>((bf16_t*)g.C2 + (long)mrow[j] * g.ldc + ncol[j], dv);
-                }
-                store8<bf16_t>((bf16_t*)Cg + (long)mrow[j] * g.ldc + ncol[j], v[j]);
-            }
-        }
+        // the fused-option combinations the networks use get straight-line code (no per-lane branches, every load
+        // unconditional at a clamped address); anything else takes the generic loop
+        const int e = g.epi & ~EPI_BIAS;
+        if (e == 0 && !g.rowscale) store_rows<EM_PLAIN, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
+        else if (e == EPI_RESID && !g.rowscale) store_rows<EM_RESID, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
+        else if (e == EPI_RESID) store_rows<EM_RESID_SCALE, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
+        else if (e == EPI_GELU_DUAL && !g.rowscale) store_rows<EM_GELU_DUAL, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
+        else if (e == EPI_MULAUX && !g.rowscale) store_rows<EM_MULAUX, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
+        else store_rows<EM_GENERIC, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
     } else {
         // ---- f32 epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
 #pragma unroll

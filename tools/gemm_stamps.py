@@ -4,10 +4,10 @@ from pseldnets_amd import ops, _lib
 L = _lib.lib()
 raw = L
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-for (name, M, N, K, kind) in [('s0 qkv fwd', 786432, 288, 96, 'fwd'), ('s0 qkv dgrad', 786432, 288, 96, 'dgrad'), ('s0 fc1 fwd', 786432, 384, 96, 'fwd'), ('s2 fc1 fwd', 49152, 1536, 384, 'fwd')]:
+for (name, M, N, K, kind) in [('s0 fc1 fwd (out-heavy)', 786432, 384, 96, 'fwd'), ('s0 fc2 fwd (in-heavy)', 786432, 96, 384, 'fwd'), ('s0 fc2 dgrad (out-heavy)', 786432, 96, 384, 'dgrad'), ('s0 fc1 dgrad (in-heavy)', 786432, 384, 96, 'dgrad'), ('s2 fc1 fwd', 49152, 1536, 384, 'fwd'), ('s3 fc1 fwd', 12288, 3072, 768, 'fwd')]:
     x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt); b = torch.randn(N, device=dev)
     dy = torch.randn(M, N, device=dev).to(dt)
-    dbg = torch.zeros(40000 * 6, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(60000 * 6, dtype=torch.int64, device=dev)
     fn = (lambda: ops.linear_fwd(x, w, b)) if kind == 'fwd' else (lambda: ops.linear_dgrad(dy, w))
     fn(); fn(); torch.cuda.synchronize()
     raw.pseld_gemm_set_debug_buffer(dbg.data_ptr())
