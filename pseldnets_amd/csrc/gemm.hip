@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
         }
     }
 
-    if (g.dbg) t2 = __builtin_amdgcn_s_memtime();
+    if (g.dbg) t2 = t4 = __builtin_amdgcn_s_memtime();
     if (TA && do_colsum) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -612,29 +612,35 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 // Weight gradient dW[N,K] (fp32) = dY[Mtok,N]^T @ X[Mtok,K], optionally with GELU applied to X on load
 // (dW2 = dY^T gelu(u)). Split over the token dimension into `splits` fp32 slabs in `workspace`
 // (needs splits*N*K floats), then reduced into dW (overwrite, or accumulate when `accumulate`).
-// Split planning: enough workgroups to fill the chip twice over (2 resident per CU), counted with the tile the
-// dispatcher will actually use; at least 1024 tokens per split so the fp32 slab traffic stays small.
-static int wgrad_target_blocks() {
-    const char* e = getenv("PSELD_WGRAD_TARGET");
-    const int t = e ? atoi(e) : 1024;
-    return t < 1 ? 1024 : t;
+// Split planning (tools/wgrad_sweep.py, s_memtime stamps): ONE resident round of workgroups — the number of splits is
+// the number of workgroup slots of the chip (256 CUs x workgroups resident per CU for the tile the dispatcher will use)
+// divided by the number of output tiles, so no CU idles and there is no tail round; at least 512 tokens per split
+// keeps the fp32 slab traffic small.
+static int wgrad_fill_percent() {
+    const char* e = getenv("PSELD_WGRAD_FILL");
+    const int t = e ? atoi(e) : 100;
+    return t < 10 ? 100 : t;
 }
 static int wgrad_min_tokens() {
     const char* e = getenv("PSELD_WGRAD_MINTOK");
     const int t = e ? atoi(e) : 512;
     return t < 64 ? 512 : t;
 }
-static int wgrad_splits(int Mtok, int N, int K) {
-    // ~1024 workgroups counted in 96x96 units, >= 512 tokens per split (tools/wgrad_sweep.py on the HTS-AT shapes)
-    const int tiles = pseld_cdiv(N, 96) * pseld_cdiv(K, 96);
-    int splits = pseld_cdiv(wgrad_target_blocks(), tiles);
+static int wgrad_splits_for(int dtype, int Mtok, int N, int K) {
+    int bm, bn, slots;
+    if (K <= 96 || (K % 192 != 0 && K % 96 == 0 && K <= 288)) { bm = 256; bn = 96; slots = 512; }
+    else if (dtype == PSELD_BF16 && N >= 256 && gemm_big_tiles()) { bm = 256; bn = 192; slots = 256; }
+    else { bm = 128; bn = 192; slots = dtype == PSELD_BF16 ? 512 : 256; }
+    const int tiles = pseld_cdiv(N, bm) * pseld_cdiv(K, bn);
+    int splits = (int)((long)slots * wgrad_fill_percent() / 100 / tiles);
     const int max_splits = pseld_cdiv(Mtok, wgrad_min_tokens());
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     return splits;
 }
 extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
-    const int splits = wgrad_splits(Mtok, N, K) + 1;   // +1: rounding kchunk to the slice size can add one split
+    const int sa = wgrad_splits_for(PSELD_BF16, Mtok, N, K), sb = wgrad_splits_for(PSELD_F32, Mtok, N, K);
+    const int splits = (sa > sb ? sa : sb) + 1;        // +1: rounding kchunk to the slice size can add one split
     if (splits_out) *splits_out = splits;
     return (long)splits * ((long)N * K + N) * (long)sizeof(float);   // dW slabs + bias-gradient slabs
 }
@@ -650,7 +656,7 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     PSELD_CHECK_ARG(lddw == K, "gemm_wgrad: dW must be dense [N,K]");
     const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr);
     PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
-    int splits = wgrad_splits(Mtok, N, K);
+    int splits = wgrad_splits_for(dtype, Mtok, N, K);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = X; g.C = workspace;
@@ -660,6 +666,7 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     int kchunk = pseld_cdiv(Mtok, splits);
     kchunk = pseld_cdiv(kchunk, bk) * bk;
     splits = pseld_cdiv(Mtok, kchunk);
+    g.dbg = g_gemm_dbg;
     g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = gelu_on_x ? PRO_GELU_B : PRO_NONE;
     // when the bias gradient sits right behind the weight gradient (as in the parameter arena) the bias slabs are
     // interleaved with the dW slabs and ONE reduction covers both

@@ -4,11 +4,12 @@ from pseldnets_amd import ops, _lib
 L = _lib.lib()
 raw = L
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-for (name, M, N, K, kind) in [('s0 fc1 fwd (out-heavy)', 786432, 384, 96, 'fwd'), ('s0 fc2 fwd (in-heavy)', 786432, 96, 384, 'fwd'), ('s0 fc2 dgrad (out-heavy)', 786432, 96, 384, 'dgrad'), ('s0 fc1 dgrad (in-heavy)', 786432, 384, 96, 'dgrad'), ('s2 fc1 fwd', 49152, 1536, 384, 'fwd'), ('s3 fc1 fwd', 12288, 3072, 768, 'fwd')]:
+for (name, M, N, K, kind) in [('s0 fc1 fwd (out-heavy)', 786432, 384, 96, 'fwd'), ('s0 fc2 fwd (in-heavy)', 786432, 96, 384, 'fwd'), ('s0 fc2 dgrad (out-heavy)', 786432, 96, 384, 'dgrad'), ('s0 fc1 dgrad (in-heavy)', 786432, 384, 96, 'dgrad'), ('s2 fc1 fwd', 49152, 1536, 384, 'fwd'), ('s3 fc1 fwd', 12288, 3072, 768, 'fwd'), ('s0 qkv wgrad', 786432, 288, 96, 'wgrad'), ('s1 fc1 wgrad', 196608, 768, 192, 'wgrad'), ('s2 fc1 wgrad', 49152, 1536, 384, 'wgrad'), ('s2 proj wgrad', 49152, 384, 384, 'wgrad')]:
     x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt); b = torch.randn(N, device=dev)
     dy = torch.randn(M, N, device=dev).to(dt)
     dbg = torch.zeros(60000 * 6, dtype=torch.int64, device=dev)
-    fn = (lambda: ops.linear_fwd(x, w, b)) if kind == 'fwd' else (lambda: ops.linear_dgrad(dy, w))
+    dwb = torch.empty(N * K + N, device=dev); dw = dwb[:N * K].view(N, K); db = dwb[N * K:]
+    fn = (lambda: ops.linear_fwd(x, w, b)) if kind == 'fwd' else ((lambda: ops.linear_dgrad(dy, w)) if kind == 'dgrad' else (lambda: ops.linear_wgrad(dy, x, dw, dbias=db)))
     fn(); fn(); torch.cuda.synchronize()
     raw.pseld_gemm_set_debug_buffer(dbg.data_ptr())
     fn(); torch.cuda.synchronize()

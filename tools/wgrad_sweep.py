@@ -1,5 +1,5 @@
-"""Sweep the split-K planning knobs of the weight-gradient GEMM over the HTS-AT shapes (one subprocess per setting,
-because the knobs are read from the environment).  python tools/wgrad_sweep.py"""
+"""Sweep the split-K planning knob of the weight-gradient GEMM over the HTS-AT shapes (one subprocess per setting,
+because the knob is read from the environment).  python tools/wgrad_sweep.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INNER = r'''
@@ -22,12 +22,11 @@ for li, C in enumerate((96, 192, 384, 768)):
         dwb = torch.empty(N * K + N, device=dev); dw = dwb[:N * K].view(N, K); db = dwb[N * K:]
         out.append(timeit(lambda: ops.linear_wgrad(dy, x, dw, dbias=db)))
         del x, dy, dwb
-print(' '.join('%%5.0f' %% t for t in out))
+print(' '.join('%%5.0f' %% t for t in out), ' | weighted ms %%.2f' %% (sum(t * w for t, w in zip(out, [2]*8 + [6]*4 + [2]*4)) / 1e3))
 ''' % ROOT
-print('setting (tile,target,mintok) | s0 qkv proj fc1 fc2 | s1 ... | s2 ... | s3 ...  (us)')
-for tile in ('22', '42'):
-    for target in ('512', '1024', '2048'):
-        for mintok in ('512', '1024', '2048'):
-            env = dict(os.environ, PSELD_WGRAD_TILE=tile, PSELD_WGRAD_TARGET=target, PSELD_WGRAD_MINTOK=mintok)
-            r = subprocess.run([sys.executable, '-c', INNER], env=env, capture_output=True, text=True)
-            print(tile, target.rjust(4), mintok.rjust(4), '|', r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
+print('setting (fill%,mintok) | s0 qkv proj fc1 fc2 | s1 ... | s2 ... | s3 ...  (us)')
+for fill in ('50', '100', '200', '300'):
+    for mintok in ('256', '512', '1024'):
+        env = dict(os.environ, PSELD_WGRAD_FILL=fill, PSELD_WGRAD_MINTOK=mintok)
+        r = subprocess.run([sys.executable, '-c', INNER], env=env, capture_output=True, text=True)
+        print(fill.rjust(4), mintok.rjust(4), '|', r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
