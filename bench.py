@@ -74,6 +74,23 @@ class KernelTimer:
                 return rc
             setattr(self.lib, n, wrapped)
 
+    def detail(self):
+        rows = {}
+        for n, a, s, e in self.records:
+            if n == 'pseld_gemm':
+                key = ('gemm', a[1], a[2], a[6], a[7], a[8], a[19], a[20])      # ta, tb, M, N, K, epi, pro
+            elif n == 'pseld_gemm_wgrad':
+                key = ('wgrad', 1, 1, a[5], a[6], a[7], 0, a[11])
+            else:
+                continue
+            d = rows.setdefault(key, [0.0, 0])
+            d[0] += s.elapsed_time(e); d[1] += 1
+        for key, (t, c) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+            kind, ta, tb, M, N, K, epi, pro = key
+            fl = 2.0 * M * N * K
+            print(f"{kind:5s} ta{ta} tb{tb} M={M:7d} N={N:5d} K={K:5d} epi={epi:2d} pro={pro}: {c // 2:3d} launches/step, "
+                  f"{t / c * 1e3:7.1f} us each, {fl / (t / c * 1e-3) / 1e12:6.0f} TF/s, {t / 2:7.3f} ms/step", file=sys.stderr)
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
@@ -142,6 +159,7 @@ def main():
                     help='htsat = the headline workload (BASELINE.json configs[1]); passt = the PaSST backbone, same data')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -232,6 +250,8 @@ def main():
         for _ in range(2):
             trainer.training_step(wave, target)
         agg = timer.summary()
+        if args.gemm_detail:
+            timer.detail()
         timer.on = False
         total = sum(v[0] for v in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1][0])

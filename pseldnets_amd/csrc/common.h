@@ -114,11 +114,12 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 
 // exact-erf GELU and its derivative (reference: nn.GELU default, model_utilities.py:145-166).
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. below fp32 round-off of the product x*cdf for
-// the activations seen here): 1 rcp + 1 exp + 6 FMA instead of the ~35-instruction libm erff, which matters because
-// GELU is re-evaluated on the operand-load path of the fc2 / dW2 GEMMs.
+// the activations seen here): 1 v_rcp_f32 (the raw 1-ulp instruction: __frcp_rn expands to the correctly rounded
+// division sequence, 8 more instructions) + 1 v_exp_f32 + 6 FMA instead of the ~35-instruction libm erff, which
+// matters because GELU runs in the epilogue of every fc1 GEMM.
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -129,7 +130,7 @@ __device__ __forceinline__ float erf_fast(float x) {
 // gelu(x) and gelu'(x) together (they share the polynomial and exp(-x^2/2) = the A&S exponential)
 __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
     const float ax = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -139,6 +140,27 @@ __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
     const float cdf = 0.5f * (1.0f + erfv);
     y = x * cdf;
     dy = cdf + x * 0.3989422804014327f * e;
+}
+// the same for two values at once: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per instruction)
+__device__ __forceinline__ void gelu_both2(f32x2 x, f32x2& y, f32x2& dy) {
+    f32x2 ax;
+    ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+    ax = ax * 0.70710678118654752f;
+    const f32x2 den = ax * 0.3275911f + 1.0f;
+    f32x2 t;
+    t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+    f32x2 p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f32x2 a2 = ax * ax * (-1.4426950408889634f);           // exp(-ax^2) = exp2(-ax^2 * log2 e)
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(a2[0]); e[1] = __builtin_amdgcn_exp2f(a2[1]);
+    f32x2 er = 1.0f - p * t * e;
+    er[0] = copysignf(er[0], x[0]); er[1] = copysignf(er[1], x[1]);
+    const f32x2 cdf = er * 0.5f + 0.5f;
+    y = x * cdf;
+    dy = x * 0.3989422804014327f * e + cdf;
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

@@ -171,98 +171,144 @@ __device__ __forceinline__ f32x4 pack8(const float (&v)[8]) {
     return __builtin_bit_cast(f32x4, x);
 }
 
-template <int MODE, int BM, int BN, int THREADS>
-__device__ __forceinline__ void store_rows(const GemmArgs& g, const char* Cs, int m0, int n0, int tid, bf16_t* Cg) {
+// The whole bf16 epilogue for one fused-option combination (straight-line code: no per-lane branches, every load
+// unconditional at a clamped address). Order matters for latency: the residual / aux rows and the DropPath factors
+// this thread will need are requested from HBM FIRST, so their latency hides behind the barrier and the
+// accumulator -> LDS staging. bias_s must be a shared object of its own: when it shared the array with Cs every
+// bias read between the C-tile writes was ordered after the previous write (24 serial LDS round trips, 4k cycles per
+// tile measured with s_memtime).
+template <int MODE, int WM, int WN>
+__device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, const float* bias_s, const f32x16 (&acc)[2][3],
+                                                int m0, int n0, bf16_t* Cg, unsigned long long& t4) {
+    constexpr int THREADS = WM * WN * 64, BM = WM * 64, BN = WN * 96;
     constexpr int CS_STRIDE = BN * 2 + 16;
     constexpr int CPR = BN / 8;
     constexpr int NCHUNK = BM * CPR / THREADS;        // 16-byte chunks per thread (12 for every tile shape)
-    constexpr int UB = (MODE == EM_GENERIC) ? 4 : 6;  // chunks in flight per thread: loads first, stores last
-    static_assert(NCHUNK % UB == 0, "epilogue batching");
+    constexpr bool HAS_X = MODE == EM_RESID || MODE == EM_RESID_SCALE || MODE == EM_MULAUX;
+    constexpr int NCAND = BM / 64 + 2;   // DropPath factors a BM-row tile can meet when a sample has >= 64 rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
     const bf16_t* Rg = (const bf16_t*)g.resid;
     const bf16_t* Ug = (const bf16_t*)g.aux;
     const int mlast = g.M - 1, nlast = max(g.N - 8, 0);
+
+    f32x4 xv[HAS_X ? NCHUNK : 1];
+    if constexpr (HAS_X) {
 #pragma unroll
-    for (int b0 = 0; b0 < NCHUNK; b0 += UB) {
-        f32x4 cv[UB], xv[UB];
-        float sc[UB];
-        long orow[UB], rrow[UB];
-        bool ok[UB];
-#pragma unroll
-        for (int j = 0; j < UB; ++j) {
-            const int c = tid + (b0 + j) * THREADS;
+        for (int j = 0; j < NCHUNK; ++j) {
+            const int c = tid + j * THREADS;
             const int row = c / CPR, cb = c - row * CPR;
-            const int mrow = m0 + row, ncol = n0 + cb * 8;
-            ok[j] = mrow < g.M && ncol < g.N;
-            cv[j] = *(const f32x4*)(Cs + row * CS_STRIDE + cb * 16);
-            const int mr = min(mrow, mlast), nc = min(ncol, nlast);   // clamped: loads never branch
-            orow[j] = (long)mr * g.ldc + nc;
-            rrow[j] = (long)mr * g.ldr + nc;
-            if constexpr (MODE == EM_RESID || MODE == EM_RESID_SCALE) xv[j] = *(const f32x4*)(Rg + rrow[j]);
+            const int mr = min(m0 + row, mlast), nc = min(n0 + cb * 8, nlast);   // clamped: loads never branch
             if constexpr (MODE == EM_MULAUX) xv[j] = *(const f32x4*)(Ug + (long)mr * g.ldaux + nc);
-            if constexpr (MODE == EM_RESID_SCALE) sc[j] = g.rowscale[mr / g.rows_per_scale];
-            if constexpr (MODE == EM_GENERIC) {
-                const bool use_aux = (g.epi & (EPI_MULGELUGRAD | EPI_MULAUX)) != 0;
-                xv[j] = use_aux ? *(const f32x4*)(Ug + (long)mr * g.ldaux + nc) : cv[j];
-                sc[j] = g.rowscale ? g.rowscale[mr / g.rows_per_scale] : 1.f;
+            else xv[j] = *(const f32x4*)(Rg + (long)mr * g.ldr + nc);
+        }
+    }
+    // DropPath: the (at most NCAND) per-sample factors this tile's rows can meet, fetched through uniform addresses
+    float cand[MODE == EM_RESID_SCALE ? NCAND : 1];
+    const int s_first = (MODE == EM_RESID_SCALE) ? m0 / g.rows_per_scale : 0;
+    if constexpr (MODE == EM_RESID_SCALE) {
+        const int s_last = mlast / g.rows_per_scale;
+#pragma unroll
+        for (int i = 0; i < NCAND; ++i) cand[i] = g.rowscale[min(s_first + i, s_last)];
+    }
+    __syncthreads();  // every wave is done with the operand images
+    char* Cs = smem;
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            __builtin_amdgcn_sched_barrier(0);   // one 32x32 tile at a time: 16 accumulators leave the AGPRs, not 96
+            const int ml = wm * 64 + mi * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 96 + ni * 32 + 8 * q + 4 * h;
+                bf16x4 pk;
+                const f32x4 bv = *(const f32x4*)(bias_s + nl);   // zero when there is no bias / past N
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)(acc[mi][ni][4 * q + j] + bv[j]);
+                *(bf16x4*)(Cs + ml * CS_STRIDE + nl * 2) = pk;
             }
         }
+    __syncthreads();
+    if (g.dbg) t4 = __builtin_amdgcn_s_memtime();
+    // the chunk coordinates are RE-derived from a laundered thread id: otherwise the compiler keeps all 12 chunks'
+    // rows / columns / addresses from the prefetch above alive across the staging (+100 VGPRs, one wave per SIMD less)
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
 #pragma unroll
-        for (int j = 0; j < UB; ++j) {
-            float v[8];
-            unpack8(cv[j], v);
-            if constexpr (MODE == EM_RESID) {
-                float x[8];
-                unpack8(xv[j], x);
+    for (int j = 0; j < NCHUNK; ++j) {
+        if (j % 2 == 0) __builtin_amdgcn_sched_barrier(0);   // two chunks in flight: bounds the live registers
+        const int c = tid2 + j * THREADS;
+        const int row = c / CPR, cb = c - row * CPR;
+        const int mrow = m0 + row, ncol = n0 + cb * 8;
+        const bool okj = mrow < g.M && ncol < g.N;
+        const long orowj = (long)min(mrow, mlast) * g.ldc + min(ncol, nlast);
+        float v[8];
+        unpack8(*(const f32x4*)(Cs + row * CS_STRIDE + cb * 16), v);
+        if constexpr (MODE == EM_RESID) {
+            float x[8];
+            unpack8(xv[j], x);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += x[k];
-            } else if constexpr (MODE == EM_RESID_SCALE) {
-                float x[8];
-                unpack8(xv[j], x);
+            for (int k = 0; k < 8; ++k) v[k] += x[k];
+        } else if constexpr (MODE == EM_RESID_SCALE) {
+            float x[8];
+            unpack8(xv[j], x);
+            const int si = min(mrow, mlast) / g.rows_per_scale - s_first;
+            float scj = cand[0];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], sc[j], x[k]);
-            } else if constexpr (MODE == EM_MULAUX) {
-                float x[8];
-                unpack8(xv[j], x);
+            for (int i = 1; i < NCAND; ++i) scj = (si == i) ? cand[i] : scj;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], scj, x[k]);
+        } else if constexpr (MODE == EM_MULAUX) {
+            float x[8];
+            unpack8(xv[j], x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= x[k];
+        } else if constexpr (MODE == EM_GELU_DUAL) {
+            float dv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                f32x2 xx = {v[k], v[k + 1]}, yy, dd;
+                gelu_both2(xx, yy, dd);
+                v[k] = yy[0]; v[k + 1] = yy[1]; dv[k] = dd[0]; dv[k + 1] = dd[1];
+            }
+            if (okj) *(f32x4*)((bf16_t*)g.C2 + orowj) = pack8(dv);
+        } else if constexpr (MODE == EM_GENERIC) {
+            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (g.epi & (EPI_MULGELUGRAD | EPI_MULAUX))
+                unpack8(*(const f32x4*)(Ug + (long)min(mrow, mlast) * g.ldaux + min(ncol, nlast)), x);
+            if (g.rowscale) {
+                const float scj = g.rowscale[min(mrow, mlast) / g.rows_per_scale];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= scj;
+            }
+            if (g.epi & EPI_MULAUX) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] *= x[k];
-            } else if constexpr (MODE == EM_GELU_DUAL) {
+            } else if (g.epi & EPI_MULGELUGRAD) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(x[k]);
+            }
+            if (g.epi & EPI_RESID) {
+                float rr[8];
+                unpack8(*(const f32x4*)(Rg + (long)min(mrow, mlast) * g.ldr + min(ncol, nlast)), rr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+            }
+            if (g.epi & EPI_GELU_DUAL) {
                 float dv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) gelu_both(v[k], v[k], dv[k]);
-                if (ok[j]) *(f32x4*)((bf16_t*)g.C2 + orow[j]) = pack8(dv);
-            } else if constexpr (MODE == EM_GENERIC) {
-                float x[8];
-                unpack8(xv[j], x);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= sc[j];
-                if (g.epi & EPI_MULAUX) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] *= x[k];
-                } else if (g.epi & EPI_MULGELUGRAD) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(x[k]);
-                }
-                if (g.epi & EPI_RESID) {
-                    float rr[8];
-                    unpack8(*(const f32x4*)(Rg + rrow[j]), rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                if (g.epi & EPI_GELU_DUAL) {
-                    float dv[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) gelu_both(v[k], v[k], dv[k]);
-                    if (ok[j]) *(f32x4*)((bf16_t*)g.C2 + orow[j]) = pack8(dv);
-                }
+                if (okj) *(f32x4*)((bf16_t*)g.C2 + orowj) = pack8(dv);
             }
-            if (ok[j]) *(f32x4*)(Cg + orow[j]) = pack8(v);
         }
+        if (okj) *(f32x4*)(Cg + orowj) = pack8(v);
     }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------
 template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void gemm_kernel(GemmArgs g) {
     constexpr int GEMM_THREADS = WM * WN * 64;
     constexpr int BM = WM * 64, BN = WN * 96;
     constexpr int BK = Mma<T>::BK, KSTEPS = Mma<T>::KSTEPS;
@@ -281,10 +327,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + A_BYTES;
-    // the tile's BN bias values sit in LDS behind the operand / C-tile region: read once per workgroup instead of
-    // 24 dependent global loads per lane in the epilogue (measured: 20k of a 42k-cycle workgroup lifetime)
-    constexpr int MAIN_BYTES = (A_BYTES + B_BYTES > (STAGED ? BM * CS_STRIDE : 0)) ? (A_BYTES + B_BYTES) : BM * CS_STRIDE;
-    float* bias_s = (float*)(smem + MAIN_BYTES);
+    // the tile's BN bias values sit in LDS: read once per workgroup instead of 24 dependent global loads per lane in
+    // the epilogue (measured: 20k of a 42k-cycle workgroup lifetime). A SEPARATE shared object, so that the compiler can
+    // prove the epilogue's C-tile writes do not alias it and batch the bias reads.
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -414,41 +460,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     const T* Ug = (const T*)g.aux;
     if constexpr (STAGED) {
         // ---- bf16 epilogue: tile^T -> LDS (8-byte row segments) -> 16-byte coalesced rows with the fused ops ----
-        // The lane's 12 bias groups are fetched BEFORE the C tile is written: bias_s and Cs live in the same LDS
-        // array, so a read placed between the writes is ordered after each of them (24 serial LDS round trips, 4k
-        // cycles per tile measured with s_memtime).
-        f32x4 bvv[3][4];
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bvv[ni][q] = *(const f32x4*)(bias_s + wn * 96 + ni * 32 + 8 * q + 4 * h);
-        __syncthreads();  // every wave is done with the operand images
-        char* Cs = smem;
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int ml = wm * 64 + mi * 32 + r;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nl = wn * 96 + ni * 32 + 8 * q + 4 * h;
-                    bf16x4 pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)(acc[mi][ni][4 * q + j] + bvv[ni][q][j]);
-                    *(bf16x4*)(Cs + ml * CS_STRIDE + nl * 2) = pk;
-                }
-            }
-        __syncthreads();
-        if (g.dbg) t4 = __builtin_amdgcn_s_memtime();
-        // the fused-option combinations the networks use get straight-line code (no per-lane branches, every load
-        // unconditional at a clamped address); anything else takes the generic loop
+        // the fused-option combinations the networks use get their own straight-line instance; the rest is generic
         const int e = g.epi & ~EPI_BIAS;
-        if (e == 0 && !g.rowscale) store_rows<EM_PLAIN, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
-        else if (e == EPI_RESID && !g.rowscale) store_rows<EM_RESID, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
-        else if (e == EPI_RESID) store_rows<EM_RESID_SCALE, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
-        else if (e == EPI_GELU_DUAL && !g.rowscale) store_rows<EM_GELU_DUAL, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
-        else if (e == EPI_MULAUX && !g.rowscale) store_rows<EM_MULAUX, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
-        else store_rows<EM_GENERIC, BM, BN, GEMM_THREADS>(g, Cs, m0, n0, tid, (bf16_t*)Cg);
+        bf16_t* Cb = (bf16_t*)Cg;
+        if (e == 0 && !g.rowscale) staged_epilogue<EM_PLAIN, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else if (e == EPI_RESID && !g.rowscale) staged_epilogue<EM_RESID, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else if (e == EPI_RESID && g.rows_per_scale >= 64) staged_epilogue<EM_RESID_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else if (e == EPI_GELU_DUAL && !g.rowscale) staged_epilogue<EM_GELU_DUAL, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else if (e == EPI_MULAUX && !g.rowscale) staged_epilogue<EM_MULAUX, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else staged_epilogue<EM_GENERIC, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
     } else {
         // ---- f32 epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
 #pragma unroll
@@ -509,7 +529,7 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
     constexpr int A_BYTES = TA ? BK * A_STRIDE : BM * ROWB;
     constexpr int B_BYTES = TB ? BK * B_STRIDE : BN * ROWB;
     constexpr int CS_BYTES = (sizeof(OutT) == 2) ? BM * (BN * 2 + 16) : 0;
-    constexpr int LDS = ((A_BYTES + B_BYTES > CS_BYTES) ? (A_BYTES + B_BYTES) : CS_BYTES) + BN * 4;
+    constexpr int LDS = (A_BYTES + B_BYTES > CS_BYTES) ? (A_BYTES + B_BYTES) : CS_BYTES;
     dim3 grid(pseld_cdiv(g.N, BN), pseld_cdiv(g.M, BM), splits);
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
