@@ -212,32 +212,62 @@ int launch_ln(const LnArgs& a, bool bwd, int rows_per_block, int nblocks, hipStr
     return PSELD_OK;
 }
 
+// rows per workgroup of the backward: each row group walks its rows serially (load -> two reductions -> store is one
+// dependent chain per row), so small inputs need MANY short workgroups to keep loads in flight; the cap bounds the
+// dgamma/dbeta partial slabs the reduction has to read
 constexpr int LN_BWD_MAX_BLOCKS = 1024;
-static inline int ln_bwd_rows(long M) { long r = (M + LN_BWD_MAX_BLOCKS - 1) / LN_BWD_MAX_BLOCKS; if (r < 64) r = 64; return (int)r; }
+static inline int ln_bwd_rows(long M) { long r = (M + LN_BWD_MAX_BLOCKS - 1) / LN_BWD_MAX_BLOCKS; if (r < 16) r = 16; return (int)r; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Scalar BatchNorm statistics: sums[c][f][0..1] = (sum x, sum x^2) over (b, t) of feat[B, Cin, T, F]
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ feat, float* __restrict__ part,
-                                                       int B, int Cin, int T, int F, int rows_per_block) {
-    // grid: (blocks over b*t rows, Cin); lane = f (F <= 64), 4 waves stride the rows
-    __shared__ float red[4][64][2];
-    const int f = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.y;
+// 16 lanes cover one 64-bin row with 16-byte loads, so a workgroup iteration moves 16 rows (4 KiB); 4 iterations are
+// kept in flight. MODE 0: (sum x, sum x^2); MODE 1: centred second pass, sum (x - mean)^2.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_rows_kernel(const float* __restrict__ feat, const float* __restrict__ sums, float count,
+                                                      float* __restrict__ part, int B, int Cin, int T, int rows_per_block) {
+    __shared__ float red[16][64][2];
+    const int fq = threadIdx.x & 15, rr = threadIdx.x >> 4, c = blockIdx.y;
     const long rows = (long)B * T;
     const long rbeg = (long)blockIdx.x * rows_per_block;
     const long rend = min(rows, rbeg + rows_per_block);
-    float s = 0.f, q = 0.f;
-    if (f < F)
-        for (long r = rbeg + w; r < rend; r += 4) {
-            const long b = r / T, t = r - b * T;
-            const float v = feat[((b * Cin + c) * T + t) * F + f];
-            s += v; q += v * v;
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mean[k] = sums[2 * (c * 64 + 4 * fq + k)] / count;
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    for (long r0 = rbeg + rr; r0 < rend; r0 += 64) {
+        f32x4 v[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + 16 * u;
+            live[u] = r < rend;
+            const long rc = live[u] ? r : rbeg;
+            const long b = rc / T, t = rc - b * T;
+            v[u] = *(const f32x4*)(feat + ((b * Cin + c) * T + t) * 64 + 4 * fq);
         }
-    red[w][f][0] = s; red[w][f][1] = q;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!live[u]) continue;
+            if (MODE == 0) { s += v[u]; q += v[u] * v[u]; }
+            else { const f32x4 d = v[u] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[rr][4 * fq + k][0] = s[k]; red[rr][4 * fq + k][1] = q[k]; }
     __syncthreads();
-    if (w == 0 && f < F) {
-        float* o = part + (((long)blockIdx.x * Cin + c) * F + f) * 2;
-        o[0] = red[0][f][0] + red[1][f][0] + red[2][f][0] + red[3][f][0];
-        o[1] = red[0][f][1] + red[1][f][1] + red[2][f][1] + red[3][f][1];
+    if (threadIdx.x < 64) {
+        const int f = threadIdx.x;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a0 += red[i][f][0]; a1 += red[i][f][1]; }
+        if (MODE == 0) {
+            float* o = part + (((long)blockIdx.x * Cin + c) * 64 + f) * 2;
+            o[0] = a0; o[1] = a1;
+        } else {
+            part[((long)blockIdx.x * Cin + c) * 64 + f] = a1;
+        }
     }
 }
 
@@ -263,29 +293,6 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
     mean_rstd[2 * i] = mean; mean_rstd[2 * i + 1] = rstd;
     scale_shift[2 * i] = weight[i] * rstd;
     scale_shift[2 * i + 1] = bias[i] - mean * rstd * weight[i];
-}
-
-// Centred second pass for the variance (matches torch's two-pass numerics): sums[..][1] = sum (x-mean)^2
-__global__ __launch_bounds__(256) void bn_var_kernel(const float* __restrict__ feat, const float* __restrict__ sums,
-                                                     float count, float* __restrict__ part, int B, int Cin, int T,
-                                                     int F, int rows_per_block) {
-    __shared__ float red[4][64];
-    const int f = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.y;
-    const long rows = (long)B * T;
-    const long rbeg = (long)blockIdx.x * rows_per_block;
-    const long rend = min(rows, rbeg + rows_per_block);
-    float q = 0.f;
-    if (f < F) {
-        const float mean = sums[2 * (c * F + f)] / count;
-        for (long r = rbeg + w; r < rend; r += 4) {
-            const long b = r / T, t = r - b * T;
-            const float d = feat[((b * Cin + c) * T + t) * F + f] - mean;
-            q += d * d;
-        }
-    }
-    red[w][f] = q;
-    __syncthreads();
-    if (w == 0 && f < F) part[((long)blockIdx.x * Cin + c) * F + f] = red[0][f] + red[1][f] + red[2][f] + red[3][f];
 }
 
 // BN apply + zero-pad + fold + 4x4 patch extraction: A[(b, ph, pw)][c*16 + i*4 + j] = bn(feat[b,c,t,f]) with
@@ -317,41 +324,44 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 }
 
 // BN parameter gradients from dA (gradient of the patch matrix): dweight[c,f] = sum dy*xhat, dbias = sum dy.
-// Accumulates (+=) so that the SED and DOA encoders of EINV2 can both contribute to the shared scalars.
+// A thread owns one 16-byte chunk position of the dA rows (k -> channel c = k/2 and the patch-row pair i0 = 2*(k&1))
+// for one frequency group fh = ph % 16, i.e. the two mel bins f = 4*fh + i0 + {0,1} of channel c: every (c, f) has
+// exactly one owner, so the sums stay in registers and no cross-thread reduction is needed. Lanes with equal fh read
+// one whole contiguous dA row; lanes with equal c read whole 256-byte feature rows.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ mean_rstd,
                                                      const T* __restrict__ dA, float* __restrict__ part, int B, int Cin,
                                                      int c_first, int Cuse, int Tn, int cols_per_block) {
-    // grid (blocks over (b, r, pw) triples, Cuse); lane = f; waves stride the triples
-    __shared__ float red[4][64][2];
-    const int f = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.y, cs = c_first + c;
-    const long total = (long)B * 4 * 64;
-    const long beg = (long)blockIdx.x * cols_per_block;
-    const long end = min(total, beg + cols_per_block);
-    const float mean = mean_rstd[2 * (cs * 64 + f)], rstd = mean_rstd[2 * (cs * 64 + f) + 1];
-    float dw = 0.f, db = 0.f;
-    for (long q = beg + w; q < end; q += 4) {
-        const int pw = (int)(q % 64);
-        const int r = (int)((q / 64) % 4);
-        const long b = q / 256;
-        const int ph = 16 * r + (f >> 2), i = f & 3;
-        const T* src = dA + ((b * 64 + ph) * 64 + pw) * (long)(Cuse * 16) + c * 16 + i * 4;
+    const int cpr = Cuse * 2;                                  // 8-element chunks per dA row
+    const int fh = threadIdx.x & 15, k = threadIdx.x >> 4;     // 16 chunk slots per workgroup pass
+    const long total = (long)B * 4 * 64;                      // (b, r, pw) triples
+    const long beg = (long)blockIdx.x * cols_per_block, end = min(total, beg + cols_per_block);
+    for (int kk = k; kk < cpr; kk += 16) {
+        const int c = kk >> 1, i0 = (kk & 1) * 2, cs = c_first + c, f0 = 4 * fh + i0;
+        const float m0 = mean_rstd[2 * (cs * 64 + f0)], r0 = mean_rstd[2 * (cs * 64 + f0) + 1];
+        const float m1 = mean_rstd[2 * (cs * 64 + f0 + 1)], r1 = mean_rstd[2 * (cs * 64 + f0 + 1) + 1];
+        float dw0 = 0.f, dw1 = 0.f, db0 = 0.f, db1 = 0.f;
+#pragma unroll 4
+        for (long q = beg; q < end; ++q) {
+            const int pw = (int)(q & 63), r = (int)((q >> 6) & 3);
+            const long b = q >> 8;
+            float g[8];
+            load8<T>(dA + ((b * 64 + 16 * r + fh) * 64 + pw) * (long)(Cuse * 16) + kk * 8, g);
+            const int t0 = 256 * r + 4 * pw;
+            const float* src = feat + ((b * Cin + cs) * Tn) * 64 + f0;
+            f32x2 x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = 256 * r + 4 * pw + j;
-            if (t < Tn) {
-                const float g = to_f32<T>(src[j]);
-                const float xh = (feat[((b * Cin + cs) * Tn + t) * 64 + f] - mean) * rstd;
-                dw += g * xh; db += g;
+            for (int j = 0; j < 4; ++j) x[j] = *(const f32x2*)(src + (long)min(t0 + j, Tn - 1) * 64);   // unconditional
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float live = (t0 + j < Tn) ? 1.f : 0.f;      // rows past T are the zero padding of the fold
+                const float ga = g[j] * live, gb = g[4 + j] * live;
+                dw0 += ga * (x[j][0] - m0); db0 += ga;
+                dw1 += gb * (x[j][1] - m1); db1 += gb;
             }
         }
-    }
-    red[w][f][0] = dw; red[w][f][1] = db;
-    __syncthreads();
-    if (w == 0) {
-        float* o = part + (((long)blockIdx.x * Cuse + c) * 64 + f) * 2;
-        o[0] = red[0][f][0] + red[1][f][0] + red[2][f][0] + red[3][f][0];
-        o[1] = red[0][f][1] + red[1][f][1] + red[2][f][1] + red[3][f][1];
+        float* o = part + (((long)blockIdx.x * Cuse + c) * 64 + f0) * 2;
+        o[0] = dw0 * r0; o[1] = db0; o[2] = dw1 * r1; o[3] = db1;
     }
 }
 
@@ -549,7 +559,7 @@ extern "C" int pseld_layernorm_bwd(int dtype, const void* dy, const void* x, con
 }
 
 // ---- scalar BatchNorm --------------------------------------------------------------------------------------
-static const int BN_ROWS = 2048;
+static const int BN_ROWS = 512;
 
 extern "C" long pseld_bn_scalar_workspace(int B, int Cin, int T) {
     return (long)pseld_cdiv((long)B * T, BN_ROWS) * Cin * 64 * 2 * (long)sizeof(float);
@@ -567,11 +577,11 @@ extern "C" int pseld_bn_scalar_stats(const float* feat, float* sums, int B, int 
     hipStream_t s = (hipStream_t)stream;
     const int nb = pseld_cdiv((long)B * T, BN_ROWS);
     const int n = Cin * F;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, Cin), dim3(256), 0, s, feat, workspace, B, Cin, T, F, BN_ROWS);
+    hipLaunchKernelGGL(bn_rows_kernel<0>, dim3(nb, Cin), dim3(256), 0, s, feat, (const float*)nullptr, 0.f, workspace, B, Cin, T, BN_ROWS);
     pseld_reduce_slabs(workspace, sums, (long)2 * n, nb, (long)2 * n, 0, s);
     if (centered) {
         const float count = (float)((long)B * T);
-        hipLaunchKernelGGL(bn_var_kernel, dim3(nb, Cin), dim3(256), 0, s, feat, sums, count, workspace, B, Cin, T, F, BN_ROWS);
+        hipLaunchKernelGGL(bn_rows_kernel<1>, dim3(nb, Cin), dim3(256), 0, s, feat, (const float*)sums, count, workspace, B, Cin, T, BN_ROWS);
         // overwrite sums[i][1] with count*var_centered + count*mean^2 so finalize's E[x^2]-mean^2 recovers it
         // exactly: done in finalize via the `centered` flag instead (keeps this buffer all-reducible).
         pseld_reduce_slabs(workspace, sums + 2 * n, (long)n, nb, (long)n, 0, s);
@@ -621,9 +631,9 @@ extern "C" int pseld_bn_fold_patchify(int dtype, const float* feat, const float*
     return PSELD_OK;
 }
 
-static const int BN_BWD_COLS = 1024;
+static const int BN_BWD_COLS = 64;
 extern "C" long pseld_bn_scalar_bwd_workspace(int B, int Cuse) {
-    return (long)pseld_cdiv((long)B * 256, BN_BWD_COLS) * Cuse * 64 * 2 * (long)sizeof(float);
+    return ((long)pseld_cdiv((long)B * 256, BN_BWD_COLS) + 1) * Cuse * 64 * 2 * (long)sizeof(float);   // slabs + their sum
 }
 // Step 4 (backward): dweight/dbias [Cin*64] rows c_first.. (+)= from dA [B*4096, Cuse*16]
 extern "C" int pseld_bn_scalar_bwd(int dtype, const float* feat, const float* mean_rstd, const void* dA, float* dweight,
@@ -634,12 +644,14 @@ extern "C" int pseld_bn_scalar_bwd(int dtype, const float* feat, const float* me
     hipStream_t s = (hipStream_t)stream;
     const int nb = pseld_cdiv((long)B * 256, BN_BWD_COLS);
     if (dtype == PSELD_BF16)
-        hipLaunchKernelGGL(bn_bwd_kernel<bf16_t>, dim3(nb, Cuse), dim3(256), 0, s, feat, mean_rstd, (const bf16_t*)dA, workspace, B, Cin, c_first, Cuse, T, BN_BWD_COLS);
+        hipLaunchKernelGGL(bn_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, feat, mean_rstd, (const bf16_t*)dA, workspace, B, Cin, c_first, Cuse, T, BN_BWD_COLS);
     else if (dtype == PSELD_F32)
-        hipLaunchKernelGGL(bn_bwd_kernel<float>, dim3(nb, Cuse), dim3(256), 0, s, feat, mean_rstd, (const float*)dA, workspace, B, Cin, c_first, Cuse, T, BN_BWD_COLS);
+        hipLaunchKernelGGL(bn_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, feat, mean_rstd, (const float*)dA, workspace, B, Cin, c_first, Cuse, T, BN_BWD_COLS);
     else { pseld_set_error("bn_scalar_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     const int n = Cuse * 64;
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, workspace, nb, n, dweight + c_first * 64, dbias + c_first * 64, accumulate);
+    float* total = workspace + (long)nb * n * 2;
+    pseld_reduce_slabs(workspace, total, (long)n * 2, nb, (long)n * 2, 0, s);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, total, 1, n, dweight + c_first * 64, dbias + c_first * 64, accumulate);
     PSELD_LAUNCH_CHECK("bn_scalar_bwd");
     return PSELD_OK;
 }
