@@ -275,7 +275,7 @@ def main():
                                "frac_shape_aware": round(roof_ms / tms, 4),
                                "time_share_mfma_bound_shapes": round(mfma_bound_ms / tms, 4)}
         out["kernel_time_share"] = {k: {"ms_per_step": round(v[0] / 2, 3), "launches": v[1] // 2,
-                                        "share": round(v[0] / total, 4)} for k, v in top[:10]}
+                                        "share": round(v[0] / total, 4)} for k, v in top[:(40 if args.gemm_detail else 10)]}
         for k, v in agg.items():
             if k.startswith('gemm_kernel(wgrad') and k in out["kernel_time_share"]:
                 out["kernel_time_share"][k]["frac_shape_aware"] = round(v[4] / v[0], 4)

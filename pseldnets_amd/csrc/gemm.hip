@@ -52,6 +52,8 @@ struct GemmArgs {
     long colsum_stride;
     int epi, pro;
     unsigned long long* dbg;  // diagnostic build only: per-workgroup s_memtime stamps
+    int nx, ny, nz;           // tile grid (N tiles, M tiles, K splits); the launch is 1-D and XCD-swizzled
+    int xcd_swizzle;          // 0: plain x-fastest order (experiment knob PSELD_GEMM_XCD=0)
 };
 
 template <typename T> struct Mma;
@@ -335,8 +337,28 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    // XCD-aware tile order. Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2:
+    // tiles that read the same operand slice are therefore given ids that are congruent mod 8. Forward / input
+    // gradient (nz == 1): the nx column tiles of one row block share the A rows. Weight gradient: the nx*ny tiles of
+    // one K split share the same token range of dY and X (otherwise every slice is fetched by up to 8 L2s).
+    int bx, by, bz;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        if (!g.xcd_swizzle) {
+            const int nxy = g.nx * g.ny, t = L % nxy;
+            bz = L / nxy; bx = t % g.nx; by = t / g.nx;
+            if (bz >= g.nz) return;
+        } else if (g.nz == 1) {
+            by = (j / g.nx) * 8 + xcd; bx = j % g.nx; bz = 0;
+            if (by >= g.ny) return;
+        } else {
+            const int nxy = g.nx * g.ny, t = j % nxy;
+            bz = (j / nxy) * 8 + xcd; bx = t % g.nx; by = t / g.nx;
+            if (bz >= g.nz) return;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
     const char* Ag = (const char*)g.A;
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     // bias gradient for free (TA): column sums of dY taken from the A fragments already in registers — lane (row, h)
     // holds 8 tokens of its column per k-step; halves and k-steps are summed at the end (no extra LDS traffic)
     float colacc[2] = {0.f, 0.f};
-    const bool do_colsum = TA && g.colsum && blockIdx.x == 0 && wn == 0;
+    const bool do_colsum = TA && g.colsum && bx == 0 && wn == 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     if (g.dbg) t0 = __builtin_amdgcn_s_memtime();
     if (kbeg < kend) load_regs(kbeg);
@@ -452,10 +474,10 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         for (int mi = 0; mi < 2; ++mi) {
             const float cs = colacc[mi] + __shfl_xor(colacc[mi], 32, 64);
             const int m = m0 + wm * 64 + mi * 32 + r;
-            if (h == 0 && m < g.M) g.colsum[(long)blockIdx.z * g.colsum_stride + m] = cs;
+            if (h == 0 && m < g.M) g.colsum[(long)bz * g.colsum_stride + m] = cs;
         }
     }
-    OutT* Cg = (OutT*)g.C + (long)blockIdx.z * g.slab_stride;
+    OutT* Cg = (OutT*)g.C + (long)bz * g.slab_stride;
     const T* Rg = (const T*)g.resid;
     const T* Ug = (const T*)g.aux;
     if constexpr (STAGED) {
@@ -515,10 +537,17 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         t3 = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
-            const long b = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const long b = ((long)bz * g.ny + by) * g.nx + bx;
             g.dbg[b * 6 + 0] = t0; g.dbg[b * 6 + 1] = t1; g.dbg[b * 6 + 2] = t2; g.dbg[b * 6 + 3] = t3; g.dbg[b * 6 + 4] = t4; g.dbg[b * 6 + 5] = t5;
         }
     }
+}
+
+// PSELD_GEMM_XCD: bit 0 = swizzle forward / input-gradient launches, bit 1 = swizzle weight-gradient launches
+static int gemm_xcd_mode(bool wgrad) {
+    const char* e = getenv("PSELD_GEMM_XCD");
+    const int v = e ? atoi(e) : 3;
+    return wgrad ? (v >> 1) & 1 : v & 1;
 }
 
 template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
@@ -530,12 +559,18 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
     constexpr int B_BYTES = TB ? BK * B_STRIDE : BN * ROWB;
     constexpr int CS_BYTES = (sizeof(OutT) == 2) ? BM * (BN * 2 + 16) : 0;
     constexpr int LDS = (A_BYTES + B_BYTES > CS_BYTES) ? (A_BYTES + B_BYTES) : CS_BYTES;
-    dim3 grid(pseld_cdiv(g.N, BN), pseld_cdiv(g.M, BM), splits);
+    GemmArgs ga = g;
+    ga.nx = pseld_cdiv(g.N, BN); ga.ny = pseld_cdiv(g.M, BM); ga.nz = splits;
+    // split launches are swizzled only when every XCD gets the same number of whole splits
+    ga.xcd_swizzle = gemm_xcd_mode(TA) && (splits == 1 || splits % 8 == 0);
+    const long nblocks = !ga.xcd_swizzle ? (long)ga.nx * ga.ny * splits
+                         : splits == 1 ? (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx : (long)8 * pseld_cdiv(splits, 8) * ga.nx * ga.ny;
+    dim3 grid((unsigned)nblocks);
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, OutT, WM, WN, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     }
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(WM * WN * 64), LDS, stream, g);
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(WM * WN * 64), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm");
     return PSELD_OK;
 }
@@ -653,6 +688,8 @@ static int wgrad_splits_for(int dtype, int Mtok, int N, int K) {
     else { bm = 128; bn = 192; slots = dtype == PSELD_BF16 ? 512 : 256; }
     const int tiles = pseld_cdiv(N, bm) * pseld_cdiv(K, bn);
     int splits = (int)((long)slots * wgrad_fill_percent() / 100 / tiles);
+    // XCD-swizzled launches give whole splits to one XCD: keep the 8 XCDs evenly loaded
+    if (gemm_xcd_mode(true) && splits >= 8) splits = splits / 8 * 8;
     const int max_splits = pseld_cdiv(Mtok, wgrad_min_tokens());
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

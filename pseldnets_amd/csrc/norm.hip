@@ -108,22 +108,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a, int rows_per_bloc
     }
     const long rbeg = (long)blockIdx.x * rows_per_block;
     const long rend = min(a.M, rbeg + rows_per_block);
-    for (long row = rbeg + grp; row < rend; row += GROUPS) {
-        float v[NV][8], d[NV][8];
-        float s = 0.f;
+    // The rows a group owns form one dependent chain each (load -> mean -> variance -> two projections -> store), so
+    // the NEXT row's x / dy / dres vectors are requested (still packed) before the current row is reduced.
+    Vec8<T> nx[NV] = {}, nd[NV] = {}, nr[NV] = {};
+    auto fetch = [&](long row) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = (i * G + g) * 8;
             if (e < a.C) {
-                load8<T>(x + row_elem_offset<MERGE>(a, row, e), v[i]);
-                load8<T>(dy + row * a.C + e, d[i]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s += v[i][k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { v[i][k] = 0.f; d[i][k] = 0.f; }
+                const long off = row_elem_offset<MERGE>(a, row, e);
+                nx[i] = *(const Vec8<T>*)(x + off);
+                nd[i] = *(const Vec8<T>*)(dy + row * a.C + e);
+                if (dres) nr[i] = *(const Vec8<T>*)(dres + off);
             }
         }
+    };
+    if (rbeg + grp < rend) fetch(rbeg + grp);
+    for (long row = rbeg + grp; row < rend; row += GROUPS) {
+        float v[NV][8], d[NV][8], rs[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (i * G + g) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in = e < a.C;
+                v[i][k] = in ? nx[i].get(k) : 0.f;
+                d[i][k] = in ? nd[i].get(k) : 0.f;
+                rs[i][k] = (in && dres) ? nr[i].get(k) : 0.f;
+                s += v[i][k];
+            }
+        }
+        if (row + GROUPS < rend) fetch(row + GROUPS);
         const float mean = group_sum<G>(s) / a.C;
         float q = 0.f;
 #pragma unroll
@@ -161,12 +177,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a, int rows_per_bloc
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = rstd * (d[i][k] - c1 - v[i][k] * c2);
                 const long off = row_elem_offset<MERGE>(a, row, e);
-                if (dres) {
-                    float r8[8];
-                    load8<T>(dres + off, r8);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) o[k] += r8[k];
-                }
+                for (int k = 0; k < 8; ++k) o[k] += rs[i][k];
                 store8<T>(dx + off, o);
             }
         }
