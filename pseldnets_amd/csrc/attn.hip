@@ -328,18 +328,80 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
     char* pimg = imgs + wave * 2 * 32 * IMG;
     char* simg = pimg + 32 * IMG;
 
-    for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x) {
-        __syncthreads();  // previous iteration's stores out of the tile are done
+    // bf16: the NEXT window's q|k|v|dO rows are requested from HBM (16-byte chunks held in registers) while the
+    // current window is being computed — with one workgroup per CU nothing else would hide that latency (measured:
+    // 400 of 905 us at stage 0 were exposed loads). Token lists are double-buffered in LDS for that.
+    constexpr bool PREFETCH_T = sizeof(T) == 2;
+    constexpr int MAXCH = PREFETCH_T ? 12 : 1;             // 12 chunks per thread cover head_dim <= 24 (every HTS-AT stage)
+    f32x4 pre[MAXCH];
+    const int cps = (heads_here * hd) >> 3;                 // 16-byte chunks per token per segment
+    const int nchunks = 4 * 64 * cps;
+    const bool PREFETCH = PREFETCH_T && nchunks <= MAXCH * NTHR;
+    auto issue_loads = [&](const long* tk) {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int c = threadIdx.x + j * NTHR;
+            if (c < nchunks) {
+                const int seg = c / (64 * cps), rem = c - seg * 64 * cps, t = rem / cps, k = rem - t * cps;
+                const T* src = seg < 3 ? qkv + tk[t] * (3 * a.C) + seg * a.C + hg * GW + k * 8
+                                       : dout + tk[t] * a.C + hg * GW + k * 8;
+                pre[j] = *(const f32x4*)src;
+            }
+        }
+    };
+    auto stage_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int c = threadIdx.x + j * NTHR;
+            if (c < nchunks) {
+                const int seg = c / (64 * cps), rem = c - seg * 64 * cps, t = rem / cps, k = rem - t * cps;
+                *(f32x4*)(tile + t * strideB + (seg * GW + k * 8) * (int)sizeof(T)) = pre[j];
+            }
+        }
+    };
+    long* toks2 = (long*)(imgs + HG * 2 * 32 * IMG);          // second token / label list (PREFETCH)
+    int* labels2 = (int*)(toks2 + 64);
+    int par = 0;
+    if (PREFETCH && blockIdx.x < a.n_win_total) {
         if (threadIdx.x < 64) {
             long tk; int lb;
-            window_token(a, wi, threadIdx.x, tk, lb);
+            window_token(a, blockIdx.x, threadIdx.x, tk, lb);
             toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
         }
         __syncthreads();
-        for (int sel = 0; sel < 3; ++sel)
-            window_copy<const T, true>(tile, strideB, qkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
-        window_copy<const T, true>(tile, strideB, dout, a.C, hg * GW, 3 * GW, heads_here * hd, toks);
-        __syncthreads();
+        issue_loads(toks);
+    }
+    for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x) {
+        long* tcur = par ? toks2 : toks;
+        int* lcur = par ? labels2 : labels;
+        long* tnext = par ? toks : toks2;
+        int* lnext = par ? labels : labels2;
+        __syncthreads();  // previous iteration's stores out of the tile are done
+        if (PREFETCH) {
+            stage_loads();
+            const int wn = wi + gridDim.x;
+            if (wn < a.n_win_total && threadIdx.x < 64) {
+                long tk; int lb;
+                window_token(a, wn, threadIdx.x, tk, lb);
+                tnext[threadIdx.x] = tk; lnext[threadIdx.x] = lb;
+            }
+            __syncthreads();
+            if (wn < a.n_win_total) issue_loads(tnext);
+        } else {
+            if (threadIdx.x < 64) {
+                long tk; int lb;
+                window_token(a, wi, threadIdx.x, tk, lb);
+                tcur[threadIdx.x] = tk; lcur[threadIdx.x] = lb;
+            }
+            __syncthreads();
+            for (int sel = 0; sel < 3; ++sel)
+                window_copy<const T, true>(tile, strideB, qkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, tcur);
+            window_copy<const T, true>(tile, strideB, dout, a.C, hg * GW, 3 * GW, heads_here * hd, tcur);
+            __syncthreads();
+        }
+        par ^= PREFETCH ? 1 : 0;
+        const int* labels_w = lcur;
+        const long* toks_w = tcur;
 
         if (active) {
             // Scores are formed once, transposed (rows = keys, lane = query), one 32-query tile at a time. Each
@@ -357,9 +419,9 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
                 qk_half<T>(pt, tile, strideB, ck, cq, qt, hd, lane);      // S^T[:, qt] = K Q_qt^T
                 qk_half<T>(dpt, tile, strideB, cv, cdo, qt, hd, lane);    // dP^T[:, qt] = V dO_qt^T
                 const int qi = qt * 32 + r;
-                const int ql = labels[qi];
+                const int ql = labels_w[qi];
                 const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
-                const int* labh = labels + 4 * h2;
+                const int* labh = labels_w + 4 * h2;
                 float m = -1e30f;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -440,7 +502,7 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
         }
         __syncthreads();
         for (int sel = 0; sel < 3; ++sel)
-            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
+            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks_w);
     }
     // flush d(bias) partial sums: dbias_acc[head][key][query] += dsum (lane = query: 128-byte contiguous atomics)
     if (active) {
@@ -475,7 +537,7 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
 }
 
 template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
-template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4 + 16 + (size_t)HG * 2 * 32 * (sizeof(T) == 2 ? 192 : 272); }
+template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 2 * (64 * 8 + 64 * 4) + 16 + (size_t)HG * 2 * 32 * (sizeof(T) == 2 ? 192 : 272); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
     PSELD_CHECK_ARG(B > 0 && res >= 8 && res % 8 == 0, "%s: grid side must be a multiple of 8 (got %d)", who, res);
