@@ -413,6 +413,31 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
     }
 }
 
+// many slabs, many columns (split-K weight gradients): 64 float4 columns x 4 slab groups per workgroup, so every
+// wave-load is 1 KiB contiguous; the 4 partial sums are combined in fixed order (deterministic)
+__global__ __launch_bounds__(256) void reduce_slabs_vec4_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                long n4, int splits, long slab_stride, int accumulate) {
+    __shared__ f32x4 red[4][64];
+    const int c = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + c;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        const f32x4* p = (const f32x4*)slabs + i;
+        const long st4 = slab_stride >> 2;
+#pragma unroll 4
+        for (int z = sg; z < splits; z += 4) s += p[z * st4];
+    }
+    red[sg][c] = s;
+    __syncthreads();
+    if (sg == 0 && i < n4) {
+        f32x4 t = red[0][c];
+        t += red[1][c]; t += red[2][c]; t += red[3][c];
+        f32x4* o = (f32x4*)out + i;
+        if (accumulate) t += *o;
+        *o = t;
+    }
+}
+
 template <typename T>
 __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,7 +539,10 @@ __global__ __launch_bounds__(256) void cross_stitch_bwd_kernel(const T* __restri
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
                         hipStream_t stream) {
-    if (splits > 32)
+    if (splits >= 4 && n >= 4096 && n % 4 == 0 && slab_stride % 4 == 0 && ((unsigned long)slabs & 15) == 0 && ((unsigned long)out & 15) == 0)
+        hipLaunchKernelGGL(reduce_slabs_vec4_kernel, dim3(pseld_cdiv(n / 4, 64)), dim3(256), 0, stream, slabs, out, n / 4, splits,
+                           slab_stride, accumulate);
+    else if (splits > 32)
         hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3(pseld_cdiv(n, 16)), dim3(256), 0, stream, slabs, out, n, splits,
                            slab_stride, accumulate);
     else
