@@ -595,7 +595,8 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     }
     // ~512-1024 workgroups in total, each walking several windows, so the d(bias) flush (one atomic tile per head
     // per workgroup) stays a small fraction of the traffic
-    const int hgv = attn_hg(dtype);
+    // backward: 2 heads per workgroup (50 KB LDS, 3 workgroups per CU) wins from 8 heads up, 4 at stage 0 (tools/attn_bench.py)
+    const int hgv = (dtype == PSELD_BF16 && !getenv("PSELD_ATTN_HG")) ? (heads >= 8 ? 2 : 4) : attn_hg(dtype);
     const int nhg = pseld_cdiv(heads, hgv);
     int slots = 1024 / nhg;
     if (slots > a.n_win_total) slots = a.n_win_total;
