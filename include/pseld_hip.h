@@ -46,11 +46,13 @@ int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B
 
 /* Weight gradient of the same layers: dW f32[N,K] (+)= dY[Mtok,N]^T @ (gelu_on_x ? gelu(X) : X)[Mtok,K], and (when
  * dbias != NULL) the bias gradient dbias f32[N] (+)= sum_m dY[m,n] from the same pass. Split over tokens into fp32
- * slabs in `workspace`, reduced in a fixed order (bitwise reproducible). */
+ * slabs in `workspace`, reduced in a fixed order (bitwise reproducible). rowscale (optional, f32[Mtok / rows_per_scale]):
+ * dY row m is multiplied by rowscale[m / rows_per_scale] on load — the DropPath factor of its sample
+ * (model_utilities.py:216-232), so the branch gradient s*dy never has to be materialised. */
 long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out);
 int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, int Mtok, int N, int K,
                      int lddy, int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
-                     long workspace_bytes, void* stream);
+                     long workspace_bytes, const float* rowscale, int rows_per_scale, void* stream);
 
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */

@@ -32,7 +32,7 @@ namespace {
 constexpr int ROWB = 144;  // bytes per non-transposed LDS row: 128 B of K + 16 B pad
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_RESID = 2, EPI_MULGELUGRAD = 4, EPI_ACCUM = 8, EPI_GELU_DUAL = 16, EPI_MULAUX = 32 };
-enum { PRO_NONE = 0, PRO_GELU_A = 1, PRO_GELU_B = 2 };
+enum { PRO_NONE = 0, PRO_GELU_A = 1, PRO_GELU_B = 2, PRO_ROWSCALE_A = 4 };   // ROWSCALE_A: weight gradient only
 
 struct GemmArgs {
     const void* A;
@@ -154,12 +154,20 @@ __device__ __forceinline__ f32x4 gelu4_f32(f32x4 v) {
     for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
     return v;
 }
+template <typename T> __device__ __forceinline__ f32x4 scale_chunk(f32x4 v, float s);
+template <> __device__ __forceinline__ f32x4 scale_chunk<bf16_t>(f32x4 v, float s) {
+    bf16x8 x = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (bf16_t)((float)x[i] * s);
+    return __builtin_bit_cast(f32x4, x);
+}
+template <> __device__ __forceinline__ f32x4 scale_chunk<float>(f32x4 v, float s) { return v * s; }
 template <typename T> __device__ __forceinline__ f32x4 gelu_chunk(f32x4 v);
 template <> __device__ __forceinline__ f32x4 gelu_chunk<bf16_t>(f32x4 v) { return gelu4_bf16(v); }
 template <> __device__ __forceinline__ f32x4 gelu_chunk<float>(f32x4 v) { return gelu4_f32(v); }
 
 // ---- bf16 epilogue, second half: C tile in LDS -> fused options -> 16-byte coalesced global stores -----------------
-enum { EM_PLAIN, EM_RESID, EM_RESID_SCALE, EM_GELU_DUAL, EM_MULAUX, EM_GENERIC };
+enum { EM_PLAIN, EM_RESID, EM_RESID_SCALE, EM_GELU_DUAL, EM_MULAUX, EM_MULAUX_SCALE, EM_SCALE, EM_GENERIC };
 
 __device__ __forceinline__ void unpack8(const f32x4& p, float (&v)[8]) {
     const bf16x8 x = __builtin_bit_cast(bf16x8, p);
@@ -186,7 +194,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, c
     constexpr int CS_STRIDE = BN * 2 + 16;
     constexpr int CPR = BN / 8;
     constexpr int NCHUNK = BM * CPR / THREADS;        // 16-byte chunks per thread (12 for every tile shape)
-    constexpr bool HAS_X = MODE == EM_RESID || MODE == EM_RESID_SCALE || MODE == EM_MULAUX;
+    constexpr bool HAS_X = MODE == EM_RESID || MODE == EM_RESID_SCALE || MODE == EM_MULAUX || MODE == EM_MULAUX_SCALE;
+    constexpr bool SCALED = MODE == EM_RESID_SCALE || MODE == EM_MULAUX_SCALE || MODE == EM_SCALE;
     constexpr int NCAND = BM / 64 + 2;   // DropPath factors a BM-row tile can meet when a sample has >= 64 rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
@@ -201,14 +210,14 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, c
             const int c = tid + j * THREADS;
             const int row = c / CPR, cb = c - row * CPR;
             const int mr = min(m0 + row, mlast), nc = min(n0 + cb * 8, nlast);   // clamped: loads never branch
-            if constexpr (MODE == EM_MULAUX) xv[j] = *(const f32x4*)(Ug + (long)mr * g.ldaux + nc);
+            if constexpr (MODE == EM_MULAUX || MODE == EM_MULAUX_SCALE) xv[j] = *(const f32x4*)(Ug + (long)mr * g.ldaux + nc);
             else xv[j] = *(const f32x4*)(Rg + (long)mr * g.ldr + nc);
         }
     }
     // DropPath: the (at most NCAND) per-sample factors this tile's rows can meet, fetched through uniform addresses
-    float cand[MODE == EM_RESID_SCALE ? NCAND : 1];
-    const int s_first = (MODE == EM_RESID_SCALE) ? m0 / g.rows_per_scale : 0;
-    if constexpr (MODE == EM_RESID_SCALE) {
+    float cand[SCALED ? NCAND : 1];
+    const int s_first = SCALED ? m0 / g.rows_per_scale : 0;
+    if constexpr (SCALED) {
         const int s_last = mlast / g.rows_per_scale;
 #pragma unroll
         for (int i = 0; i < NCAND; ++i) cand[i] = g.rowscale[min(s_first + i, s_last)];
@@ -247,6 +256,14 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, c
         const long orowj = (long)min(mrow, mlast) * g.ldc + min(ncol, nlast);
         float v[8];
         unpack8(*(const f32x4*)(Cs + row * CS_STRIDE + cb * 16), v);
+        float scj = 1.f;
+        if constexpr (SCALED) {
+            // sample index relative to the tile's first sample = number of sample boundaries at or below this row
+            const int rel = mrow - s_first * g.rows_per_scale;
+            scj = cand[0];
+#pragma unroll
+            for (int i = 1; i < NCAND; ++i) scj = (rel >= i * g.rows_per_scale) ? cand[i] : scj;
+        }
         if constexpr (MODE == EM_RESID) {
             float x[8];
             unpack8(xv[j], x);
@@ -255,17 +272,16 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, c
         } else if constexpr (MODE == EM_RESID_SCALE) {
             float x[8];
             unpack8(xv[j], x);
-            const int si = min(mrow, mlast) / g.rows_per_scale - s_first;
-            float scj = cand[0];
-#pragma unroll
-            for (int i = 1; i < NCAND; ++i) scj = (si == i) ? cand[i] : scj;
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], scj, x[k]);
-        } else if constexpr (MODE == EM_MULAUX) {
+        } else if constexpr (MODE == EM_SCALE) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= scj;
+        } else if constexpr (MODE == EM_MULAUX || MODE == EM_MULAUX_SCALE) {
             float x[8];
             unpack8(xv[j], x);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= x[k];
+            for (int k = 0; k < 8; ++k) v[k] *= x[k] * scj;
         } else if constexpr (MODE == EM_GELU_DUAL) {
             float dv[8];
 #pragma unroll
@@ -365,9 +381,12 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     const char* Bg = (const char*)g.B;
 
     f32x4 ra[NCH_A], rb[NCH_B];
+    float rsa[TA ? NCH_A : 1];       // TA + PRO_ROWSCALE_A: DropPath factor of the token each A chunk belongs to
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (STAGED && tid < BN) bias_s[tid] = ((g.epi & EPI_BIAS) && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
 
+    // a K slice (BK tokens) lies inside one sample when samples are whole multiples of BK tokens: one uniform factor
+    const bool slice_uniform = TA && (g.rows_per_scale % BK == 0) && (g.kchunk % BK == 0);
     auto load_regs = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NCH_A; ++i) {
@@ -378,6 +397,8 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
             if (TA) {  // image row = contraction index, chunk runs along M
                 ok = (k0 + row < kend) && (m0 + cb * EPC < g.M);
                 off = ((long)(k0 + row) * g.lda + m0 + cb * EPC) * ES;
+                if (g.pro & PRO_ROWSCALE_A)
+                    rsa[i] = g.rowscale[slice_uniform ? k0 / g.rows_per_scale : min(k0 + row, g.K - 1) / g.rows_per_scale];
             } else {
                 ok = (m0 + row < g.M) && (k0 + cb * EPC < kend);
                 off = ((long)(m0 + row) * g.lda + k0 + cb * EPC) * ES;
@@ -407,6 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
             const int row = c / A_CPR, cb = c % A_CPR;
             f32x4 v = ra[i];
             if (g.pro & PRO_GELU_A) v = gelu_chunk<T>(v);
+            if (TA && (g.pro & PRO_ROWSCALE_A)) v = scale_chunk<T>(v, rsa[i]);
             *(f32x4*)(As + row * A_STRIDE + cb * 16) = v;
         }
 #pragma unroll
@@ -490,6 +512,8 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         else if (e == EPI_RESID && g.rows_per_scale >= 64) staged_epilogue<EM_RESID_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
         else if (e == EPI_GELU_DUAL && !g.rowscale) staged_epilogue<EM_GELU_DUAL, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
         else if (e == EPI_MULAUX && !g.rowscale) staged_epilogue<EM_MULAUX, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else if (e == EPI_MULAUX && g.rows_per_scale >= 64) staged_epilogue<EM_MULAUX_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+        else if (e == 0 && g.rows_per_scale >= 64) staged_epilogue<EM_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
         else staged_epilogue<EM_GENERIC, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
     } else {
         // ---- f32 epilogue: C layout of the 32x32 tile is col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
@@ -704,7 +728,7 @@ extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_o
 
 extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, int Mtok, int N, int K,
                                 int lddy, int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
-                                long workspace_bytes, void* stream) {
+                                long workspace_bytes, const float* rowscale, int rows_per_scale, void* stream) {
     PSELD_CHECK_ARG(dY && X && dW && workspace, "gemm_wgrad: null pointer");
     PSELD_CHECK_ARG(Mtok > 0 && N > 0 && K > 0, "gemm_wgrad: bad shape");
     PSELD_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && K % 8 == 0,
@@ -718,13 +742,14 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = X; g.C = workspace;
     g.M = N; g.N = K; g.K = Mtok; g.lda = lddy; g.ldb = ldx; g.ldc = K;
-    g.rows_per_scale = 1;
+    g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    g.rowscale = rowscale;
     const int bk = (dtype == PSELD_BF16) ? 64 : 32;
     int kchunk = pseld_cdiv(Mtok, splits);
     kchunk = pseld_cdiv(kchunk, bk) * bk;
     splits = pseld_cdiv(Mtok, kchunk);
     g.dbg = g_gemm_dbg;
-    g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = gelu_on_x ? PRO_GELU_B : PRO_NONE;
+    g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = (gelu_on_x ? PRO_GELU_B : PRO_NONE) | (rowscale ? PRO_ROWSCALE_A : PRO_NONE);
     // when the bias gradient sits right behind the weight gradient (as in the parameter arena) the bias slabs are
     // interleaved with the dW slabs and ONE reduction covers both
     const bool fused_bias = dbias && dbias == dW + (long)N * K;

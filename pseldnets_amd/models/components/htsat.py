@@ -178,21 +178,19 @@ class SwinEncoder:
             b = f'{p}layers.{li}.blocks.{bi}.'
             s = saved['blocks'][bi]
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
-            dy2 = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
             if 'h' in s:
-                ops.linear_wgrad(dy2, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'))
-                du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), mul=s['g'])
+                ops.linear_wgrad(dx, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), rowscale=s['s2'], rows_per_scale=L)
+                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
             else:
-                ops.linear_wgrad(dy2, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True)
-                du = ops.linear_dgrad(dy2, a.w(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'])
+                ops.linear_wgrad(dx, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L)
+                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
             ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
             dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype))
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
                                        a.g(b + 'norm2.bias'), dres=dx)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
-            dyp = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
-            ops.linear_wgrad(dyp, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'))
-            dao = ops.linear_dgrad(dyp, a.w(b + 'attn.proj.weight', dtype))
+            ops.linear_wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=L)
+            dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
             ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))

@@ -82,9 +82,10 @@ def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resi
     return out
 
 
-def linear_wgrad(dy, x, dw, dbias=None, gelu_on_x=False, accumulate=False):
-    """dw f32[N,K] (+)= dy[M,N]^T @ (gelu(x) if gelu_on_x else x)[M,K]; dbias f32[N] (+)= column sums of dy."""
-    _chk(dy, x, dw, dbias)
+def linear_wgrad(dy, x, dw, dbias=None, gelu_on_x=False, accumulate=False, rowscale=None, rows_per_scale=1):
+    """dw f32[N,K] (+)= (s*dy)[M,N]^T @ (gelu(x) if gelu_on_x else x)[M,K]; dbias f32[N] (+)= column sums of s*dy,
+    s = rowscale[m // rows_per_scale] (DropPath factor per sample) or 1."""
+    _chk(dy, x, dw, dbias, rowscale)
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dw.shape == (N, K) and dw.dtype == torch.float32 and dy.dtype == x.dtype
@@ -93,7 +94,7 @@ def linear_wgrad(dy, x, dw, dbias=None, gelu_on_x=False, accumulate=False):
     ws = workspace(need, dy.device)
     rc = L.pseld_gemm_wgrad(dtype_code(dy), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(dbias), M, N, K, dy.stride(0),
                             x.stride(0), dw.stride(0), int(gelu_on_x), int(accumulate), _lib.ptr(ws),
-                            ws.numel() * 4, _lib.stream_ptr())
+                            ws.numel() * 4, _lib.ptr(rowscale), rows_per_scale, _lib.stream_ptr())
     _lib.check(rc, "pseld_gemm_wgrad")
     return dw
 

@@ -120,3 +120,28 @@ def test_fc1_dual_gelu_epilogue_and_mul_dgrad(dev, dtype):
     dy, w2 = _mk((M, 96), dtype, 5), _mk((96, N), dtype, 6, 0.1)
     du = ops.linear_dgrad(dy.to(dev), w2.to(dev), mul=g)
     _check("dU = (dY W2) * g", du, (dy.double() @ w2.double()) * g.double().cpu(), dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows_per_scale", [64, 256, 602])
+def test_droppath_factor_folded_into_backward_gemms(dev, dtype, rows_per_scale):
+    """DropPath backward: s*dy is never materialised — the per-sample factor rides in the weight-gradient operand load
+    (and its fused bias gradient) and in the input-gradient epilogues (plain and x aux)."""
+    from pseldnets_amd import ops
+    nsamp = 5
+    M, N, K = nsamp * rows_per_scale, 96, 384
+    dy, h, w = _mk((M, N), dtype, 1), _mk((M, K), dtype, 2), _mk((N, K), dtype, 3, 0.1)
+    g = _mk((M, K), dtype, 4)
+    s = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25])
+    srow = s.repeat_interleave(rows_per_scale).double()[:, None]
+    dwb = torch.empty(N * K + N, device=dev)
+    dw, db = dwb[:N * K].view(N, K), dwb[N * K:]
+    ops.linear_wgrad(dy.to(dev), h.to(dev), dw, dbias=db, rowscale=s.to(dev), rows_per_scale=rows_per_scale)
+    sdy = dy.double() * srow
+    denom = (dy.double().abs().t() @ h.double().abs()).max().item()
+    _check("dW = (s dY)^T H", dw, sdy.t() @ h.double(), dtype, denom)
+    _check("db = sum s dY", db, sdy.sum(0), dtype, dy.double().abs().sum(0).max().item())
+    du = ops.linear_dgrad(dy.to(dev), w.to(dev), mul=g.to(dev), rowscale=s.to(dev), rows_per_scale=rows_per_scale)
+    _check("dU = s (dY W) * g", du, (sdy @ w.double()) * g.double(), dtype)
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev), rowscale=s.to(dev), rows_per_scale=rows_per_scale)
+    _check("dX = s dY W", dx, sdy @ w.double(), dtype)
