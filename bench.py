@@ -117,6 +117,18 @@ class KernelTimer:
         return agg
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel family from the PMC counters. Counters cannot be read from inside
+    this process: the figure is the one measured with rocprofv3 on this same command (two separate --pmc passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/."""
+    path = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic_pmc.json')
+    if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return round(d['traffic_bytes_per_launch'], 1), 'profiles/r01_gemm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+
+
 def cpu_baseline(chunks=4, steps=2):
     """The CPU oracle (a port: the reference's Python cannot travel) timed on this host: features + HTS-AT mACCDOA
     fwd + ADPIT + backward + clip + AdamW on `chunks` 10 s chunks, fp32, all host threads."""
@@ -264,11 +276,13 @@ def main():
             # that binds most of its measured time; frac/achieved/peak are quoted against that ceiling, and
             # frac_shape_aware = sum(per-launch roofline time) / sum(measured time) uses each launch's own ceiling.
             hbm = mfma_bound_ms < 0.5 * tms
+            traffic, traffic_src = pmc_traffic(args)
             out["roofline"] = {"bound": "hbm" if hbm else "mfma",
                                "achieved": round(gbs if hbm else ach, 2), "peak": PEAK_HBM_GBS if hbm else PEAK_FLOPS,
                                "unit": "GB/s" if hbm else "TFLOP/s",
                                "frac": round((gbs / PEAK_HBM_GBS) if hbm else (ach / PEAK_FLOPS), 4),
-                               "traffic": None, "kernel": "gemm_kernel<T,WM,WN,TA=0,TB> (forward + input-gradient launches)",
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "kernel": "gemm_kernel<T,WM,WN,TA=0,TB> (forward + input-gradient launches)",
                                "launches": n // 2, "avg_launch_ms": round(tms / n, 4),
                                "flops_per_launch_avg": round(fl / n, 1), "bytes_per_launch_avg": round(nb / n, 1),
                                "achieved_tflops": round(ach, 2), "achieved_gbs": round(gbs, 1),
