@@ -20,6 +20,7 @@ import torch  # noqa: E402
 
 CLIP_SECONDS, CHUNKS_PER_CLIP, FS, CLASSES = 60, 6, 24000, 170
 GFLOP_PER_CHUNK_TRAIN = 37.61       # 37.026 (net fwd+bwd) + 0.583 (features)
+GFLOP_PER_CHUNK_TRAIN_EINV2 = 72.28  # 3 x 23.90 (SURVEY §6 probe, EINV2-HTSAT forward) + features
 GFLOP_PER_CHUNK_TRAIN_PASST = 207.9  # 3 x (patch 1.65 + 7 blocks x (12 E^2 N + 4 N^2 E) = 67.8) + features; N=602, E=768
 PEAK_BF16_TFLOPS = 2516.6           # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -167,8 +168,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--clips', type=int, default=32, help='60 s clips per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt'],
-                    help='htsat = the headline workload (BASELINE.json configs[1]); passt = the PaSST backbone, same data')
+    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2'],
+                    help='htsat = the headline workload (BASELINE.json configs[1]); htsat_einv2 = configs[2] (dual-branch, tPIT); '
+                         'passt = the PaSST backbone, same data')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
@@ -197,6 +199,9 @@ def main():
     torch.manual_seed(2024)
     if args.backbone == 'htsat':
         net = multi_accdoa.HTSAT(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/htsat.yaml geometry
+    elif args.backbone == 'htsat_einv2':
+        from pseldnets_amd.models import einv2
+        net = einv2.HTSAT(cfg, CLASSES, 7, pretrained_path=None)             # einv2.py:189-327: SED + DOA encoders
     else:
         net = multi_accdoa.PASST(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/passt.yaml geometry
     net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -205,9 +210,19 @@ def main():
         import torch.distributed as dist
         for p in net.parameters():            # identical initial weights on every rank
             dist.broadcast(p.data, 0)
-    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'adpit', lr=1e-4, max_norm=1.0, process_group=group,
-                           sync_bn=False)
+    einv2_mode = args.backbone == 'htsat_einv2'
+    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
+                           process_group=group, sync_bn=False)
     wave, target = synthetic_batch(args.clips, device, 2024 + rank)
+    if einv2_mode:     # track-wise labels: track 0 carries the ADPIT A0 events, tracks 1-2 silent
+        lab = target['adpit_label']
+        act = lab[:, :, 0, 0]                                        # [chunks, 100, C]
+        sed = torch.zeros(act.shape[0], 100, 3, CLASSES, device=device)
+        first = (act.cumsum(-1) == 1) & (act > 0)                    # one class per track: the first active one
+        sed[:, :, 0] = first.float()
+        doa = torch.zeros(act.shape[0], 100, 3, 3, device=device)
+        doa[:, :, 0] = (lab[:, :, 0, 1:] * first.unsqueeze(2)).sum(-1)
+        target = {'sed_label': sed, 'doa_label': doa}
 
     lib = _lib.lib()
     global PEAK_FLOPS, ESIZE
@@ -241,15 +256,15 @@ def main():
     clips_per_s = args.clips * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
-    name = 'HTS-AT' if args.backbone == 'htsat' else 'PaSST'
-    gflop_chunk = GFLOP_PER_CHUNK_TRAIN if args.backbone == 'htsat' else GFLOP_PER_CHUNK_TRAIN_PASST
+    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2'}[args.backbone]
+    gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2}[args.backbone]
     out = {
-        "metric": f"train clips/sec (60 s 4-ch FOA) {name} mACCDOA", "value": round(clips_per_s, 2), "unit": "clips/s",
+        "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA"), "value": round(clips_per_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{name} mACCDOA {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
-                               f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, ADPIT, clip 1.0, AdamW, "
-                               f"drop_path {0.1 if args.backbone == 'htsat' else 0.0}, BN train mode, no augmentation",
+        "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
+                               f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
+                               f"drop_path {0.0 if args.backbone == 'passt' else 0.1}, BN train mode, no augmentation",
                    "global_clips": args.clips * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
     }
