@@ -165,7 +165,9 @@ class HTSATNetBase(nn.Module):
         """Per-sample DropPath factors (model_utilities.py:216-232): 0 or 1/keep for every (block, branch)."""
         if not training or enc.cfg['drop_path_rate'] <= 0:
             return None
-        keep = 1.0 - torch.tensor(enc.rates, device=device, dtype=torch.float32).view(-1, 1, 1)
+        keep = getattr(enc, '_keep', None)
+        if keep is None or keep.device != device:      # built once: a per-step torch.tensor(...) is a blocking H2D copy
+            keep = enc._keep = 1.0 - torch.tensor(enc.rates, device=device, dtype=torch.float32).view(-1, 1, 1)
         u = torch.rand(len(enc.rates), 2, B, device=device)
         return (torch.floor(keep + u) / keep).contiguous()
 
