@@ -324,6 +324,23 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, c
     }
 }
 
+// linear workgroup id -> (N tile, M tile, K split); false = padding workgroup of the swizzled launch
+__device__ __forceinline__ bool tile_coords(const GemmArgs& g, int& bx, int& by, int& bz) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    if (!g.xcd_swizzle) {
+        const int nxy = g.nx * g.ny, t = L % nxy;
+        bz = L / nxy; bx = t % g.nx; by = t / g.nx;
+        return bz < g.nz;
+    }
+    if (g.nz == 1) {
+        by = (j / g.nx) * 8 + xcd; bx = j % g.nx; bz = 0;
+        return by < g.ny;
+    }
+    const int nxy = g.nx * g.ny, t = j % nxy;
+    bz = (j / nxy) * 8 + xcd; bx = t % g.nx; by = t / g.nx;
+    return bz < g.nz;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------
 template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void gemm_kernel(GemmArgs g) {
@@ -358,21 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     // gradient (nz == 1): the nx column tiles of one row block share the A rows. Weight gradient: the nx*ny tiles of
     // one K split share the same token range of dY and X (otherwise every slice is fetched by up to 8 L2s).
     int bx, by, bz;
-    {
-        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-        if (!g.xcd_swizzle) {
-            const int nxy = g.nx * g.ny, t = L % nxy;
-            bz = L / nxy; bx = t % g.nx; by = t / g.nx;
-            if (bz >= g.nz) return;
-        } else if (g.nz == 1) {
-            by = (j / g.nx) * 8 + xcd; bx = j % g.nx; bz = 0;
-            if (by >= g.ny) return;
-        } else {
-            const int nxy = g.nx * g.ny, t = j % nxy;
-            bz = (j / nxy) * 8 + xcd; bx = t % g.nx; by = t / g.nx;
-            if (bz >= g.nz) return;
-        }
-    }
+    if (!tile_coords(g, bx, by, bz)) return;
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
