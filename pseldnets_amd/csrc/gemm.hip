@@ -570,6 +570,115 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     }
 }
 
+// ---- forward GEMM (both operands k-contiguous, bf16) fed by LDS-DMA --------------------------------------------------
+// Same tiles, fragment maps and epilogue as gemm_kernel; operands reach LDS by global_load_lds_dwordx4: no VGPR
+// staging (165 registers instead of 200) and no ds_write, two 32-element K slices in LDS (20 KB each; the C-tile
+// staging of the epilogue is the larger user), so THREE workgroups fit per CU instead of two — that occupancy, not
+// the DMA itself, is what pays (a 3-slice / 2-workgroup version measured equal to the register-staged kernel;
+// this one is 7 % faster over the HTS-AT forward shapes: tools/gemm_shapes.py, one session, 4.06 -> 3.77 ms).
+// One raw s_barrier per slice; the next slice's DMA is issued right after it. Images are lane-linear 64-byte rows; the
+// 16-byte chunk each lane FETCHES is XOR-ed with (row>>2)&3 so every ds_read_b128 lane group is bank-conflict free.
+// PSELD_GEMM_DMA=0 falls back to gemm_kernel (A/B knob).
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+template <int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 3) void gemm_dma_kernel(GemmArgs g) {
+    constexpr int THREADS = WM * WN * 64, WAVES = WM * WN, BM = WM * 64, BN = WN * 96;
+    constexpr int BKD = 32, STAGES = 2;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024, TOTAL = STAGE / 1024;
+    constexpr int LPW = (TOTAL + WAVES - 1) / WAVES;          // DMA instructions per wave per slice (padded with dummies)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
+    char* dummy = smem + STAGES * STAGE;                     // 1 KiB sink for the padding instructions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    int bx, by, bz;
+    if (!tile_coords(g, bx, by, bz)) return;
+    const int m0 = by * BM, n0 = bx * BN;
+    if (tid < BN) bias_s[tid] = ((g.epi & EPI_BIAS) && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+    const bf16_t* Ag = (const bf16_t*)g.A;
+    const bf16_t* Bg = (const bf16_t*)g.B;
+    const int nslices = g.K / BKD;
+
+    auto issue = [&](int s) {
+        char* st = smem + (s % STAGES) * STAGE;
+        const int k0 = s * BKD;
+#pragma unroll
+        for (int j = 0; j < LPW; ++j) {
+            const int i = wave + WAVES * j;                  // wave-uniform instruction index inside the slice
+            if (i < TOTAL) {
+                const bool isA = i < A_INSTR;
+                const int ii = isA ? i : i - A_INSTR;
+                const int row = ii * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
+                const bf16_t* src = isA ? Ag + (long)min(m0 + row, g.M - 1) * g.lda + k0 + chunk * 8
+                                        : Bg + (long)min(n0 + row, g.N - 1) * g.ldb + k0 + chunk * 8;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(st + i * 1024), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(Ag + lane * 8), (lds_void_ptr)dummy, 16, 0, 0);
+            }
+        }
+    };
+    auto frag = [&](const char* img, int row, int kk) -> bf16x8 {
+        return *(const bf16x8*)(img + row * 64 + (((2 * kk + h) ^ ((row >> 2) & 3)) << 4));
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    if (nslices > 0) issue(0);
+    for (int s = 0; s < nslices; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nslices) issue(s + 1);
+        const char* As = smem + (s % STAGES) * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[3];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[mi] = frag(As, wm * 64 + mi * 32 + r, kk);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) fb[ni] = frag(Bs, wn * 96 + ni * 32 + r, kk);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    unsigned long long t4 = 0;
+    bf16_t* Cb = (bf16_t*)g.C;
+    const int e = g.epi & ~EPI_BIAS;
+    if (e == 0 && !g.rowscale) staged_epilogue<EM_PLAIN, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_RESID && !g.rowscale) staged_epilogue<EM_RESID, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_RESID && g.rows_per_scale >= 64) staged_epilogue<EM_RESID_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_GELU_DUAL && !g.rowscale) staged_epilogue<EM_GELU_DUAL, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else staged_epilogue<EM_GENERIC, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+}
+
+template <int WM, int WN>
+int launch_gemm_dma(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 96;
+    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int CS_BYTES = BM * (BN * 2 + 16);
+    constexpr int LDS = (2 * STAGE + 1024 > CS_BYTES) ? 2 * STAGE + 1024 : CS_BYTES;
+    GemmArgs ga = g;
+    ga.nx = pseld_cdiv(g.N, BN); ga.ny = pseld_cdiv(g.M, BM); ga.nz = 1;
+    ga.xcd_swizzle = 1;
+    const long nblocks = (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL((gemm_dma_kernel<WM, WN>), dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, stream, ga);
+    PSELD_LAUNCH_CHECK("gemm_dma");
+    return PSELD_OK;
+}
+
 // PSELD_GEMM_XCD: bit 0 = swizzle forward / input-gradient launches, bit 1 = swizzle weight-gradient launches
 static int gemm_xcd_mode(bool wgrad) {
     const char* e = getenv("PSELD_GEMM_XCD");
@@ -680,6 +789,14 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     g.kchunk = K; g.slab_stride = 0; g.epi = epi; g.pro = pro; g.colsum = nullptr; g.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0 && M >= 128) {
+        const char* e = getenv("PSELD_GEMM_DMA");
+        if (!(e && e[0] == '0')) {
+            const bool narrow = g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288);
+            if (narrow && K < 384) return launch_gemm_dma<4, 1>(g, s);     // 256x96 with a long K loop: gemm_kernel is faster
+            if (!narrow) return launch_gemm_dma<2, 2>(g, s);
+        }
+    }
     if (dtype == PSELD_BF16) {
         return trans_b ? dispatch_tile<bf16_t, bf16_t, false, true>(g, 1, s)
                        : dispatch_tile<bf16_t, bf16_t, false, false>(g, 1, s);
