@@ -659,6 +659,9 @@ __global__ __launch_bounds__(WM * WN * 64, 3) void gemm_dma_kernel(GemmArgs g) {
     else if (e == EPI_RESID && !g.rowscale) staged_epilogue<EM_RESID, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
     else if (e == EPI_RESID && g.rows_per_scale >= 64) staged_epilogue<EM_RESID_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
     else if (e == EPI_GELU_DUAL && !g.rowscale) staged_epilogue<EM_GELU_DUAL, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_MULAUX && !g.rowscale) staged_epilogue<EM_MULAUX, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_MULAUX && g.rows_per_scale >= 64) staged_epilogue<EM_MULAUX_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == 0 && g.rows_per_scale >= 64) staged_epilogue<EM_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
     else staged_epilogue<EM_GENERIC, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
 }
 

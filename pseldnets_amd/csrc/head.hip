@@ -412,6 +412,44 @@ extern "C" int pseld_adamw_step(float* p, const float* g, float* m, float* v, vo
     PSELD_LAUNCH_CHECK("adamw_step");
     return PSELD_OK;
 }
+// Batched transpose of the 2-D bf16 weights of a parameter arena: tensor t = [rows, cols] at element offset off (same
+// offset in src and dst) becomes [cols, rows]. desc = {off, rows, cols, first_tile} per tensor (longs), 32x32 tiles.
+// The input-gradient GEMMs read these copies so that dX = dY W is a k-contiguous product like the forward.
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const long* __restrict__ desc, int n_desc) {
+    __shared__ bf16_t tile[32][34];
+    int lo = 0, hi = n_desc - 1;                         // last tensor whose first_tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[4 * mid + 3] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long off = desc[4 * lo], rows = desc[4 * lo + 1], cols = desc[4 * lo + 2];
+    const long t = (long)blockIdx.x - desc[4 * lo + 3];
+    const long tiles_c = (cols + 31) / 32;
+    const long r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[off + r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) dst[off + c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int pseld_transpose_batch_bf16(const void* src, void* dst, const long* desc, int n_desc, long total_tiles,
+                                          void* stream) {
+    PSELD_CHECK_ARG(src && dst && desc && n_desc > 0 && total_tiles > 0, "transpose_batch_bf16: bad arguments");
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (bf16_t*)dst, desc, n_desc);
+    PSELD_LAUNCH_CHECK("transpose_batch_bf16");
+    return PSELD_OK;
+}
+
 extern "C" int pseld_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
     PSELD_CHECK_ARG(x && y && n > 0, "cast: bad arguments");
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);

@@ -27,6 +27,9 @@ class ParamArena:
         self.m = self.v = None
         self.step = 0
         self.shadow_valid = False
+        self.shadow_t = None   # transposed bf16 copies of the 2-D weights (input-gradient GEMMs)
+        self.shadow_t_valid = False
+        self._t_desc = None
 
     def add(self, name, shape, pad_rows=None):
         """Reserve space; `pad_rows` pads dim 0 (zero rows the kernels may read, e.g. the 1530 -> 1536 head)."""
@@ -69,7 +72,42 @@ class ParamArena:
         if not self.shadow_valid:
             ops.cast_bf16(self.flat, self.shadow)
             self.shadow_valid = True
+            self.shadow_t_valid = False
         return self.view(self.shadow, name, padded)
+
+    def wt(self, name, dtype, padded=False):
+        """Transposed bf16 copy [cols, rows] of a weight viewed as [rows, prod(rest)] (None in fp32 mode: the fp32 path
+        reads the master weights through the transposing loader). All weights are refreshed by ONE batched kernel the
+        first time one is asked for after an optimiser step."""
+        if dtype != torch.bfloat16:
+            return None
+        self.w(name, dtype, padded)                       # makes sure the bf16 shadow itself is current
+        if self._t_desc is None:
+            rows_cols, first = [], 0
+            for n in self.entries:
+                off, shape, rows = self.offsets[n]
+                if len(shape) < 2:
+                    continue
+                cols = 1
+                for d in shape[1:]:
+                    cols *= d
+                rows_cols += [off, rows, cols, first]
+                first += ((rows + 31) // 32) * ((cols + 31) // 32)
+            self._t_desc = (torch.tensor(rows_cols, dtype=torch.long, device=self.flat.device), len(rows_cols) // 4, first)
+            self.shadow_t = torch.zeros(self.size, dtype=torch.bfloat16, device=self.flat.device)
+            self.shadow_t_valid = False
+        if not self.shadow_t_valid:
+            desc, n_desc, tiles = self._t_desc
+            ops.transpose_batch_bf16(self.shadow, self.shadow_t, desc, n_desc, tiles)
+            self.shadow_t_valid = True
+        off, shape, rows = self.offsets[name]
+        lead = rows if padded else shape[0]
+        cols = 1
+        for d in shape[1:]:
+            cols *= d
+        # the copy was made with the PADDED row count as the transposed row stride
+        return self.shadow_t[off:off + rows * cols].view(cols, rows)[:, :lead] if lead != rows else \
+            self.shadow_t[off:off + rows * cols].view(cols, rows)
 
     def range_of(self, first_name, last_name=None):
         a = self.offsets[first_name][0]

@@ -171,7 +171,7 @@ class SwinEncoder:
         if li < self.nl - 1:
             d = f'{p}layers.{li}.downsample.'
             ops.linear_wgrad(dx, saved['xm'], a.g(d + 'reduction.weight'))
-            dxm = ops.linear_dgrad(dx, a.w(d + 'reduction.weight', dtype))
+            dxm = ops.linear_dgrad(dx, a.w(d + 'reduction.weight', dtype), wt=a.wt(d + 'reduction.weight', dtype))
             dx = ops.layernorm_bwd(dxm, saved['x_pre'], a.p(d + 'norm.weight'), a.g(d + 'norm.weight'),
                                    a.g(d + 'norm.bias'), merge_res=res)
         for bi in reversed(range(self.depths[li])):
@@ -180,21 +180,21 @@ class SwinEncoder:
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
             if 'h' in s:
                 ops.linear_wgrad(dx, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), rowscale=s['s2'], rows_per_scale=L)
-                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
+                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
             else:
                 ops.linear_wgrad(dx, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L)
-                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
+                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
             ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
-            dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype))
+            dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype), wt=a.wt(b + 'mlp.fc1.weight', dtype))
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
                                        a.g(b + 'norm2.bias'), dres=dx)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
             ops.linear_wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=L)
-            dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
+            dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
             ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
-            dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype))
+            dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype), wt=a.wt(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
                                    a.g(b + 'norm1.bias'), dres=dx_mid)
         return dx
@@ -239,7 +239,7 @@ class TscamHead:
         ops.linear_wgrad(dz, saved['A'], a.g(p + 'weight', padded=True).view(self.Dp, self.C * 6),
                          dbias=a.g(p + 'bias', padded=True))
         W = a.w(p + 'weight', dtype, padded=True).view(self.Dp, self.C * 6)
-        dA = ops.linear_dgrad(dz, W)
+        dA = ops.linear_dgrad(dz, W, wt=a.wt(p + 'weight', dtype, padded=True))
         return ops.head_col2im(dA, B)
 
 

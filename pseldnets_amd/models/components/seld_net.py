@@ -204,5 +204,6 @@ class HTSATNetBase(nn.Module):
                        grad_scale=grad_scale, betas=betas, eps=eps, weight_decay=weight_decay, shadow=shadow)
         if shadow is not None:
             a.shadow_valid = True
+            a.shadow_t_valid = False       # the transposed copies follow lazily (arena.wt)
             self.shadow_trusted = True
         return grad_norm

@@ -61,9 +61,11 @@ def linear_fwd(x, w, bias=None, resid=None, rowscale=None, rows_per_scale=1, gel
     return (out, out2) if gelu_dual else out
 
 
-def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resid=None, out=None, mul=None):
-    """dx[M,K] = dy[M,N] @ w[N,K] (* rowscale) (* gelu'(gelu_grad_of[m,k]) | * mul[m,k]) (+ resid)."""
-    _chk(dy, w, rowscale, gelu_grad_of, resid, mul)
+def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resid=None, out=None, mul=None, wt=None):
+    """dx[M,K] = dy[M,N] @ w[N,K] (* rowscale) (* gelu'(gelu_grad_of[m,k]) | * mul[m,k]) (+ resid).
+    wt: optional pre-transposed copy of w ([K,N], same values): the product is then k-contiguous on both operands and
+    runs on the forward kernel."""
+    _chk(dy, w, rowscale, gelu_grad_of, resid, mul, wt)
     assert gelu_grad_of is None or mul is None
     M, N = dy.shape
     K = w.shape[1]
@@ -73,8 +75,13 @@ def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resi
     epi = (EPI_MULGELUGRAD if gelu_grad_of is not None else 0) | (EPI_RESID if resid is not None else 0) | \
           (EPI_MULAUX if mul is not None else 0)
     aux = gelu_grad_of if gelu_grad_of is not None else mul
-    rc = _lib.lib().pseld_gemm(dtype_code(dy), 0, 1, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(out), M, K, N,
-                               dy.stride(0), w.stride(0), out.stride(0), None, _lib.ptr(resid),
+    if wt is not None:
+        assert wt.shape == (K, N) and wt.dtype == dy.dtype
+        bmat, tb, ldb = wt, 0, wt.stride(0)
+    else:
+        bmat, tb, ldb = w, 1, w.stride(0)
+    rc = _lib.lib().pseld_gemm(dtype_code(dy), 0, tb, _lib.ptr(dy), _lib.ptr(bmat), _lib.ptr(out), M, K, N,
+                               dy.stride(0), ldb, out.stride(0), None, _lib.ptr(resid),
                                resid.stride(0) if resid is not None else 0, _lib.ptr(rowscale), rows_per_scale,
                                _lib.ptr(aux), aux.stride(0) if aux is not None else 0,
                                epi, PRO_NONE, None, _lib.stream_ptr())
@@ -358,6 +365,12 @@ def adamw_step(p, g, m, v, step, lr, grad_norm_t=None, max_norm=0.0, grad_scale=
                                      _lib.ptr(grad_norm_t), max_norm, grad_scale, lr, betas[0], betas[1], eps, weight_decay,
                                      step, _lib.stream_ptr())
     _lib.check(rc, "pseld_adamw_step")
+
+
+def transpose_batch_bf16(src, dst, desc, n_desc, total_tiles):
+    _chk(src, dst, desc)
+    _lib.check(_lib.lib().pseld_transpose_batch_bf16(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(desc), n_desc, total_tiles,
+                                                     _lib.stream_ptr()), "pseld_transpose_batch_bf16")
 
 
 def cast_bf16(x, y):

@@ -145,3 +145,31 @@ def test_droppath_factor_folded_into_backward_gemms(dev, dtype, rows_per_scale):
     _check("dU = s (dY W) * g", du, (sdy @ w.double()) * g.double(), dtype)
     dx = ops.linear_dgrad(dy.to(dev), w.to(dev), rowscale=s.to(dev), rows_per_scale=rows_per_scale)
     _check("dX = s dY W", dx, sdy @ w.double(), dtype)
+
+
+def test_input_gradient_through_transposed_weight_copies(dev):
+    """bf16 input gradients read pre-transposed weight copies (one batched transpose per optimiser step) so that
+    dX = dY W runs on the k-contiguous forward kernel: same result as the transposing-loader path."""
+    from pseldnets_amd import ops
+    dtype = torch.bfloat16
+    shapes = [(384, 96), (96, 384), (1536, 4608), (200, 72)]
+    total = sum(r * c for r, c in shapes)
+    flat = (torch.randn(total) * 0.1).to(dtype).to(dev)
+    flat_t = torch.zeros_like(flat)
+    desc, off, tiles = [], 0, 0
+    for r, c in shapes:
+        desc += [off, r, c, tiles]
+        off += r * c
+        tiles += ((r + 31) // 32) * ((c + 31) // 32)
+    ops.transpose_batch_bf16(flat, flat_t, torch.tensor(desc, dtype=torch.long, device=dev), len(shapes), tiles)
+    off = 0
+    for r, c in shapes:
+        w = flat[off:off + r * c].view(r, c)
+        wt = flat_t[off:off + r * c].view(c, r)
+        assert torch.equal(wt, w.t().contiguous())
+        if c % 32 == 0 or True:
+            dy = _mk((512, r), dtype, 7).to(dev)
+            a = ops.linear_dgrad(dy, w)
+            b = ops.linear_dgrad(dy, w, wt=wt)
+            _check(f"dX via W^T copy {r}x{c}", b, a.double().cpu(), dtype)
+        off += r * c
