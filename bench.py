@@ -181,13 +181,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # PSELD_BENCH_BACKEND=gloo: control-flow check of the multi-rank path on a box with fewer GPUs than ranks (ranks
+    # then share devices; RCCL refuses that). The measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get('PSELD_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from pseldnets_amd import _lib
@@ -271,11 +279,15 @@ def main():
     step_tflops = clips_per_s * CHUNKS_PER_CLIP * gflop_chunk / 1e3
     out["roofline_step"] = {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4)}
-    if rank == 0 and timer is not None:
-        # separate instrumented steps: HIP events around every launch on the launch stream
-        timer.on = True
+    if not args.no_kernel_timing:
+        # separate instrumented steps (HIP events around every launch on the launch stream, recorded on rank 0). EVERY
+        # rank runs them: a training step contains the gradient all-reduce, so rank 0 cannot step alone.
+        if timer is not None:
+            timer.on = True
         for _ in range(2):
             trainer.training_step(wave, target)
+        barrier()
+    if rank == 0 and timer is not None:
         agg = timer.summary()
         if args.gemm_detail:
             timer.detail()

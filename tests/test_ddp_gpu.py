@@ -72,3 +72,23 @@ def test_two_ranks_equal_one_process_with_double_batch(dev):
     print('2-rank vs 1-process parameter rel L2 diff', rel)
     assert rel < 2e-5
     assert (torch.from_numpy(res[0][3]) - rm1).abs().max().item() < 1e-4   # synchronised running statistics
+
+
+def test_bench_two_ranks_terminates_and_reports(dev):
+    """The driver's multi-GPU launch of bench.py (torch.distributed.run, one rank per GPU) as a control-flow check with
+    two ranks sharing cuda:0 over gloo: every rank must take part in every step that contains a gradient all-reduce
+    (including the instrumented steps after the timed region), and rank 0 prints exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSELD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29517', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--clips', '1']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and 'roofline' in out
+    assert out['config']['global_clips'] == 2 and 'cpu_baseline' not in out
