@@ -13,14 +13,22 @@
 // used as the parity mode); both share one fragment layout: lane (r = l&31, h = l>>5) holds the 8
 // contraction elements k = 16*kk + 8*h + j of row/column r, so every loader is dtype-agnostic.
 //
-// Workgroup = 4 waves, each owning a 64x96 output tile (2x3 MFMA tiles, 96 accumulator VGPRs):
-//   WM=4,WN=1 -> 256x96 block tile (N == 96-ish layers), WM=2,WN=2 -> 128x192.
-// K is consumed in 128-byte slices (64 bf16 / 32 f32) staged HBM -> registers -> LDS with the next slice's
-// loads in flight during the MFMAs. Non-transposed LDS rows are 128 B + 16 B pad (conflict-free
-// ds_read_b128 over a 16-lane group); transposed operands keep their [k][m] image and are read with
-// ds_read_b64_tr_b16 (bf16) so no transpose pass ever runs.
+// Workgroup = 4 waves (8 for the 256x192 weight-gradient tile), each owning a 64x96 output tile (2x3 MFMA tiles, 96
+// accumulators): WM=4,WN=1 -> 256x96 block tile (N == 96-ish layers), WM=2,WN=2 -> 128x192, WM=4,WN=2 -> 256x192.
+// Two feeders share the tiles, fragment maps and epilogues:
+//   * gemm_kernel: K in 128-byte slices (64 bf16 / 32 f32) staged HBM -> registers -> LDS with the next slice's loads in
+//     flight during the MFMAs. Non-transposed LDS rows are 128 B + 16 B pad (conflict-free ds_read_b128 over a
+//     16-lane group); transposed operands keep their [k][m] image and are read with ds_read_b64_tr_b16 (bf16), so no
+//     transpose pass ever runs. Every f32 product, every weight gradient, shapes the DMA feeder does not take.
+//   * gemm_dma_kernel: bf16 products with both operands k-contiguous (forward; input gradient through the arena's
+//     pre-transposed weight copies) fed by LDS-DMA, no staging registers -> three workgroups per CU.
+// bf16 epilogue: the tile is computed transposed, staged through LDS and written as 16-byte coalesced rows by one
+// straight-line instance per fused-option set (bias / residual / DropPath factor / GELU pair / x aux).
+// Launches are 1-D with an XCD-aware tile order (tile_coords). The weight gradient is split-K over the tokens with
+// one resident round of workgroups (wgrad_splits_for), fp32 slabs and a deterministic reduce.
 //
-// Roofline: MFMA-bound for C >= 384 layers; stage-0/1 layers (K = 96/192) are HBM-bound (72-150 flop/B).
+// Roofline: HBM-bound for stages 0-2 of HTS-AT (arithmetic intensity <= 307 flop/B, ridge 314), MFMA-bound for stage 3
+// and PaSST. Measured per shape: tools/gemm_shapes.py; phase stamps: tools/gemm_stamps.py.
 #include "common.h"
 #include <stdlib.h>
 
