@@ -6,6 +6,8 @@ import torch
 
 from .components.htsat import SwinEncoder, TscamHead
 from .components.passt import FcTanhHead, PasstEncoder
+from .components.crnn import ConvEncoder
+from .. import ops
 from .components.seld_net import HTSATNetBase
 
 
@@ -178,10 +180,120 @@ class PASST(HTSATNetBase):
         return {self.out_key: self._run(x)}
 
 
+class CRNN(HTSATNetBase):
+    """models/accdoa.py:12-95: scalar BatchNorms -> CNN8 / CNN12 (the PANNs CNN14 conv stack) -> frequency mean ->
+    decoder -> 'repeat' x8 interpolation + 10-frame mean -> Linear -> tanh. Built on the MI355X path with
+    `cfg.model.decoder = None` (nn.Identity in the reference, model_utilities.py:260-261); the GRU / Conformer /
+    Transformer decoders are not built yet and raise."""
+    out_key = 'accdoa'
+    tracks_axes = 3
+
+    def __init__(self, cfg, num_classes, in_channels=7, encoder='CNN8', pretrained_path=None, audioset_pretrain=True,
+                 num_features=[32, 64, 128, 256]):
+        super().__init__()
+        model = cfg.model if hasattr(cfg, 'model') else cfg.get('model', {})
+        decoder = (model.decoder if hasattr(model, 'decoder') else model.get('decoder')) if model is not None else None
+        if decoder is not None:
+            raise NotImplementedError(f"decoder '{decoder}' (model_utilities.py:245-269) is not built on the MI355X path yet; "
+                                      "set model.decoder: null")
+        self.num_classes = num_classes
+        self.interpolate_time_ratio = 2 ** 3
+        self._init_common(cfg, in_channels)
+        self.conv_enc = ConvEncoder(self.arena, 'convs.', in_channels, encoder, list(num_features))
+        self.num_features = list(num_features)
+        self.head = FcTanhHead(self.arena, 'fc.', self.num_features[-1], num_classes * self.tracks_axes)
+        self._finish_init()
+        self._taps = None
+        self._bn_bufs = None
+        if pretrained_path:
+            self.load_ckpts(pretrained_path, audioset_pretrain)
+
+    def load_ckpts(self, pretrained_path, audioset_pretrain=True):
+        """accdoa.py:44-63: PANNs CNN14 checkpoints (first conv replicated / in_channels, bn0 copied into every scalar)
+        or PSELDNets checkpoints (fc skipped)."""
+        own = self.state_dict()
+        if audioset_pretrain:
+            ck = torch.load(pretrained_path, map_location='cpu')['model']
+            for key in own:
+                if not key.startswith('convs.'):
+                    continue
+                src = key[len('convs.'):]
+                if src == 'conv_block1.conv1.weight':
+                    own[key].copy_(ck[src].repeat(1, self.in_channels, 1, 1) / self.in_channels)
+                else:
+                    own[key].copy_(ck[src])
+            for c in range(self.in_channels):
+                for leaf in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                    own[f'scalar.{c}.{leaf}'].copy_(ck[f'bn0.{leaf}'])
+        else:
+            ck = torch.load(pretrained_path, map_location='cpu')['state_dict']
+            ck = {k.replace('net.', '').replace('_orig_mod.', ''): v for k, v in ck.items()}
+            for key in own:
+                if not key.startswith('fc.'):
+                    own[key].copy_(ck[key])
+        self.shadow_trusted = False
+
+    def _encoders(self):
+        return [self.conv_enc]
+
+    def _materialize(self, device):
+        fresh = self._materialized_on != device
+        super()._materialize(device)
+        if fresh:
+            from .components.seld_net import _get
+            self._bn_bufs = {}
+            for name in self.conv_enc.static_buffers():
+                node = _get(self, name.rsplit('.', 1)[0])
+                leaf = name.rsplit('.', 1)[1]
+                t = node._buffers[leaf].detach().to(device)
+                t = (t.float() if t.is_floating_point() else t.long()).contiguous()
+                node._buffers[leaf] = t
+                self._bn_bufs[name] = t
+
+    def _pool(self, device, n_in):
+        if self._taps is None or self._taps['i0'].device != device or self._taps['n_in'] != n_in:
+            taps = ops.pool_taps(n_in=n_in, ratio=self.interpolate_time_ratio, n_keep=self.tgt_output_frames * self.pred_res,
+                                 group=self.pred_res, method='repeat')
+            self._taps = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in taps.items()}
+        return self._taps
+
+    def _forward_impl(self, x, training):
+        B, _, T, F = x.shape
+        dt = self.compute_dtype
+        mean_rstd, scale_shift = self._bn_front(x, training)
+        x0 = ops.cnn_input(x, scale_shift, dt, self.conv_enc.cin_p)
+        enc, s_enc = self.conv_enc.forward(x0, B, T, F, dt, training, self._bn_bufs)
+        n_in = s_enc['T_out']
+        if n_in * self.interpolate_time_ratio != self.tgt_output_frames * self.pred_res:
+            raise NotImplementedError(f"{n_in} encoder frames x {self.interpolate_time_ratio} do not cover "
+                                      f"{self.tgt_output_frames} x {self.pred_res} output frames")
+        taps = self._pool(x.device, n_in)
+        pooled = ops.rows_pool_fwd(enc, taps, B)
+        y, s_head = self.head.forward(pooled, B)
+        return y, dict(feat=x, mean_rstd=mean_rstd, enc=s_enc, head=s_head, taps=taps, B=B)
+
+    def _backward_impl(self, saved, douts, on_range_done=None):
+        dy = douts[0] if isinstance(douts, (tuple, list)) else douts
+        B, dt = saved['B'], self.compute_dtype
+        dpooled = self.head.backward(dy, saved['head'], dt)
+        denc = ops.rows_pool_bwd(dpooled, saved['taps'], B)
+        dx0 = self.conv_enc.backward(denc, saved['enc'], B, dt)
+        dw, db = self._bn_grads()
+        ops.cnn_input_bwd(saved['feat'], saved['mean_rstd'], dx0, dw, db)
+        if on_range_done is not None:
+            on_range_done(0, self.arena.size)
+
+    def forward(self, x):
+        """
+        x: waveform features, (batch_size, num_channels, time_frames, mel_bins)
+        """
+        return {self.out_key: self._run(x)}
+
+
 class _NotBuilt:
     def __init__(self, *a, **k):
         raise NotImplementedError("this backbone of the reference registry is not built on the MI355X path yet "
                                   "(SURVEY.md §8 rows a16/a17); use backbone=HTSAT")
 
 
-CRNN = ConvConformer = _NotBuilt
+ConvConformer = _NotBuilt

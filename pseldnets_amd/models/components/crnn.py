@@ -1,0 +1,139 @@
+"""Convolutional encoder of the CRNN networks driven on MI355X kernels — forward AND hand-written backward.
+
+Host-side mirror of the reference's `models/components/backbone.py` (CNN8 :6-31, CNN12 :33-60 = the conv stack of PANNs
+CNN14) and `models/components/model_utilities.py` ConvBlock :92-126. Activations are NHWC rows [B*T*F, C]; every 3x3
+convolution is im2col -> MFMA GEMM (weights used in the reference's [Cout, Cin, 3, 3] layout, k = c*9 + tap), its input
+gradient GEMM -> col2im, its weight gradient the split-K GEMM over the recomputed im2col matrix. The im2col matrix is
+built per slice of the batch so that it stays bounded. BatchNorm2d (train-mode batch statistics) + ReLU and the
+average pools are per-column / per-pixel kernels (csrc/cnn.hip). No tensor arithmetic happens in this file.
+"""
+import torch
+
+from ... import ops
+
+CONV_SLICE_ELEMS = 1 << 28      # im2col elements per batch slice (512 MB in bf16)
+
+
+class ConvEncoder:
+    """CNN8 / CNN12 whose parameters live in `arena` under `prefix` (reference key names)."""
+
+    def __init__(self, arena, prefix, in_chans, kind, num_features):
+        if kind == 'CNN8':
+            pools = [(2, 2), (2, 2), (2, 2), (1, 2)]
+        elif kind == 'CNN12':
+            pools = [(2, 2), (2, 2), (2, 2), (1, 2), (1, 2), (1, 2)]
+        else:
+            raise NotImplementedError(f'encoder {kind} is not implemented')
+        if len(num_features) != len(pools):
+            raise ValueError(f'{kind} needs {len(pools)} feature widths')
+        self.arena, self.prefix, self.in_chans, self.pools = arena, prefix, in_chans, pools
+        self.cin_p = (in_chans + 7) // 8 * 8                   # input channels padded so that 9*Cin is a multiple of 8
+        self.widths = list(num_features)
+        self.num_features = self.widths[-1]
+        self.bn_buffers = {}
+        cin = in_chans
+        for i, cout in enumerate(self.widths):
+            b = f'{prefix}conv_block{i + 1}.'
+            arena.add(b + 'conv1.weight', (cout, cin, 3, 3))
+            arena.add(b + 'bn1.weight', (cout,)); arena.add(b + 'bn1.bias', (cout,))
+            arena.add(b + 'conv2.weight', (cout, cout, 3, 3))
+            arena.add(b + 'bn2.weight', (cout,)); arena.add(b + 'bn2.bias', (cout,))
+            cin = cout
+
+    def static_buffers(self):
+        out = {}
+        for i, cout in enumerate(self.widths):
+            for j in (1, 2):
+                b = f'{self.prefix}conv_block{i + 1}.bn{j}.'
+                out[b + 'running_mean'] = torch.zeros(cout)
+                out[b + 'running_var'] = torch.ones(cout)
+                out[b + 'num_batches_tracked'] = torch.zeros((), dtype=torch.long)
+        return out
+
+    # -- one convolution: y[B*T*F, Cout] = im2col(x) @ W^T, in batch slices ---------------------------------------
+    def _weight(self, name, dtype, cin, cin_p, cout):
+        """[Cout, 9*Cin] view of the conv weight in the compute dtype; the first layer's 63-column rows are copied into a
+        72-column zero-padded matrix (GEMM rows must be multiples of 8 elements)."""
+        w = self.arena.w(name, dtype).view(cout, cin * 9)
+        if cin_p == cin:
+            return w
+        wp = torch.empty((cout, cin_p * 9), dtype=dtype, device=w.device)
+        return ops.copy2d(w, wp, cin * 9)
+
+    @staticmethod
+    def _slices(B, rows_per_sample, K):
+        per = max(1, CONV_SLICE_ELEMS // max(1, rows_per_sample * K))
+        return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+
+    def _conv_fwd(self, x, W, B, T, F):
+        rows, K = T * F, W.shape[1]
+        y = torch.empty((B * rows, W.shape[0]), dtype=x.dtype, device=x.device)
+        for b0, b1 in self._slices(B, rows, K):
+            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F, lda=K)
+            ops.linear_fwd(A, W, out=y[b0 * rows:b1 * rows])
+        return y
+
+    def _conv_bwd(self, dy, x, W, dW, B, T, F, need_dx, cin_p):
+        """dW (+)= over the batch slices, dx = col2im(dy @ W)."""
+        rows, K = T * F, W.shape[1]
+        dx = torch.empty((B * rows, cin_p), dtype=x.dtype, device=x.device) if need_dx else None
+        for n, (b0, b1) in enumerate(self._slices(B, rows, K)):
+            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F, lda=K)
+            ops.linear_wgrad(dy[b0 * rows:b1 * rows], A, dW, accumulate=n > 0)
+            if need_dx:
+                dA = ops.linear_dgrad(dy[b0 * rows:b1 * rows], W)
+                ops.col2im3x3(dA, b1 - b0, T, F, cin_p, out=dx[b0 * rows:b1 * rows])
+        return dx
+
+    def _bn(self, b, j, y, training, buffers):
+        a = self.arena
+        rm, rv, nbt = buffers[b + f'bn{j}.running_mean'], buffers[b + f'bn{j}.running_var'], buffers[b + f'bn{j}.num_batches_tracked']
+        sums = ops.bn2d_stats(y) if training else None
+        mean_rstd, scale_shift = ops.bn2d_finalize(sums, y.shape[0], a.p(b + f'bn{j}.weight'), a.p(b + f'bn{j}.bias'), rm, rv, nbt,
+                                                   training)
+        return ops.bn_relu_fwd(y, scale_shift), mean_rstd
+
+    # -- forward / backward over the whole stack ----------------------------------------------------------------
+    def forward(self, x, B, T, F, dtype, training, buffers):
+        """x: NHWC rows [B*T*F, cin_p] (already normalised). Returns ([B*T', C_last] after the frequency mean, saved)."""
+        saved = []
+        cin, cin_p = self.in_chans, self.cin_p
+        for i, cout in enumerate(self.widths):
+            b = f'{self.prefix}conv_block{i + 1}.'
+            W1 = self._weight(b + 'conv1.weight', dtype, cin, cin_p, cout)
+            y1 = self._conv_fwd(x, W1, B, T, F)
+            z1, mr1 = self._bn(b, 1, y1, training, buffers)
+            W2 = self._weight(b + 'conv2.weight', dtype, cout, cout, cout)
+            y2 = self._conv_fwd(z1, W2, B, T, F)
+            z2, mr2 = self._bn(b, 2, y2, training, buffers)
+            pt, pf = self.pools[i]
+            saved.append(dict(x=x, y1=y1, z1=z1, mr1=mr1, y2=y2, z2=z2, mr2=mr2, T=T, F=F, cin=cin, cin_p=cin_p))
+            x = ops.avgpool_fwd(z2, B, T, F, pt, pf)
+            T, F, cin, cin_p = T // pt, F // pf, cout, cout
+        if F > 1:
+            x = ops.avgpool_fwd(x, B, T, F, 1, F)              # x.mean(dim=3), accdoa.py:81
+        return x, dict(blocks=saved, T_out=T, F_last=F)
+
+    def backward(self, dx, saved, B, dtype):
+        a = self.arena
+        T, F = saved['T_out'], saved['F_last']
+        if F > 1:
+            dx = ops.avgpool_bwd(dx, B, T, F, 1, F)
+        for i in reversed(range(len(self.widths))):
+            s, cout = saved['blocks'][i], self.widths[i]
+            b = f'{self.prefix}conv_block{i + 1}.'
+            pt, pf = self.pools[i]
+            dz2 = ops.avgpool_bwd(dx, B, s['T'], s['F'], pt, pf)
+            dy2 = ops.bn_relu_bwd(s['y2'], s['z2'], dz2, s['mr2'], a.p(b + 'bn2.weight'), a.g(b + 'bn2.weight'), a.g(b + 'bn2.bias'))
+            W2 = self._weight(b + 'conv2.weight', dtype, cout, cout, cout)
+            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight').view(cout, cout * 9), B, s['T'], s['F'], True, cout)
+            dy1 = ops.bn_relu_bwd(s['y1'], s['z1'], dz1, s['mr1'], a.p(b + 'bn1.weight'), a.g(b + 'bn1.weight'), a.g(b + 'bn1.bias'))
+            W1 = self._weight(b + 'conv1.weight', dtype, s['cin'], s['cin_p'], cout)
+            if s['cin_p'] == s['cin']:
+                dW1 = a.g(b + 'conv1.weight').view(cout, s['cin'] * 9)
+                dx = self._conv_bwd(dy1, s['x'], W1, dW1, B, s['T'], s['F'], True, s['cin_p'])
+            else:                                               # first layer: gradient through the zero-padded weight matrix
+                dWp = torch.empty((cout, s['cin_p'] * 9), dtype=torch.float32, device=dy1.device)
+                dx = self._conv_bwd(dy1, s['x'], W1, dWp, B, s['T'], s['F'], True, s['cin_p'])
+                ops.copy2d(dWp, a.g(b + 'conv1.weight').view(cout, s['cin'] * 9), s['cin'] * 9)
+        return dx

@@ -254,7 +254,7 @@ def default_init(name, shape):
         t.uniform_(0.1, 0.9)
     elif 'token' in name or 'pos_embed' in name:                       # passt.py:139-149,201-207
         torch.nn.init.trunc_normal_(t, std=.02)
-    elif 'norm' in name or name.startswith('scalar') or '.head.0.' in name:
+    elif 'norm' in name or name.startswith('scalar') or '.head.0.' in name or '.bn1.' in name or '.bn2.' in name:
         t.fill_(1.0 if leaf == 'weight' else 0.0)
     elif leaf == 'weight':
         torch.nn.init.kaiming_uniform_(t.view(shape[0], -1), a=math.sqrt(5))

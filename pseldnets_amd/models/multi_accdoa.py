@@ -13,4 +13,9 @@ class PASST(accdoa.PASST):
     tracks_axes = 9
 
 
-CRNN = ConvConformer = accdoa._NotBuilt
+class CRNN(accdoa.CRNN):
+    out_key = 'multi_accdoa'
+    tracks_axes = 9
+
+
+ConvConformer = accdoa._NotBuilt

@@ -239,12 +239,16 @@ def window_attn_bwd(qkv, bias_table, dout, dbias_table, B, res, heads, shift, ac
 
 # ---------------------------------------------------------------------------------------------------------
 # head
-def pool_taps(n_in=32, ratio=32, n_keep=1000, group=10):
+def pool_taps(n_in=32, ratio=32, n_keep=1000, group=10, method='bilinear'):
     """The interpolate(x`ratio`, bilinear, align_corners=False) -> crop -> mean(group) chain of
-    models/accdoa.py:236-240 as a sparse [n_keep/group, n_in] map in both compact forms the kernels take."""
+    models/accdoa.py:236-240 (or, method='repeat', the repeat-interpolation + mean of the CRNN nets, accdoa.py:86-87)
+    as a sparse [n_keep/group, n_in] map in both compact forms the kernels take."""
     n_out = n_keep // group
     P = [[0.0] * n_in for _ in range(n_out)]
     for o in range(n_keep):
+        if method == 'repeat':
+            P[o // group][min(o // ratio, n_in - 1)] += 1.0 / group
+            continue
         src = (o + 0.5) / ratio - 0.5
         src = max(src, 0.0)
         i0 = min(int(src), n_in - 1)
@@ -511,3 +515,132 @@ def tanh_bwd(dy, y, ldz, dtype):
     _lib.check(_lib.lib().pseld_tanh_bwd(dtype_code(dz), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dz), ldz, rows, D, _lib.stream_ptr()),
                "pseld_tanh_bwd")
     return dz
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CRNN: convolutional encoder around the GEMMs (csrc/cnn.hip)
+def cnn_input(feat, scale_shift, dtype, Cp):
+    _chk(feat, scale_shift)
+    B, C, T, F = feat.shape
+    X = torch.empty((B * T * F, Cp), dtype=dtype, device=feat.device)
+    _lib.check(_lib.lib().pseld_cnn_input(dtype_code(X), _lib.ptr(feat), _lib.ptr(scale_shift), _lib.ptr(X), B, C, T, Cp,
+                                          _lib.stream_ptr()), "pseld_cnn_input")
+    return X
+
+
+def cnn_input_bwd(feat, mean_rstd, dX, dweight, dbias):
+    _chk(feat, mean_rstd, dX, dweight, dbias)
+    B, C, T, _ = feat.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_cnn_input_bwd_workspace(B, C, T), feat.device)
+    _lib.check(L.pseld_cnn_input_bwd(dtype_code(dX), _lib.ptr(feat), _lib.ptr(mean_rstd), _lib.ptr(dX), _lib.ptr(dweight),
+                                     _lib.ptr(dbias), B, C, T, dX.shape[1], _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+               "pseld_cnn_input_bwd")
+
+
+def im2col3x3(X, B, T, F, lda=None, out=None):
+    _chk(X, out)
+    C = X.shape[1]
+    lda = lda or 9 * C
+    A = out if out is not None else torch.empty((B * T * F, lda), dtype=X.dtype, device=X.device)
+    _lib.check(_lib.lib().pseld_im2col3x3(dtype_code(X), _lib.ptr(X), _lib.ptr(A), B, T, F, C, lda, _lib.stream_ptr()),
+               "pseld_im2col3x3")
+    return A
+
+
+def col2im3x3(dA, B, T, F, C, out=None):
+    _chk(dA, out)
+    dX = out if out is not None else torch.empty((B * T * F, C), dtype=dA.dtype, device=dA.device)
+    _lib.check(_lib.lib().pseld_col2im3x3(dtype_code(dA), _lib.ptr(dA), _lib.ptr(dX), B, T, F, C, dA.shape[1], _lib.stream_ptr()),
+               "pseld_col2im3x3")
+    return dX
+
+
+def bn2d_stats(X):
+    _chk(X)
+    rows, C = X.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_bn2d_workspace(rows, C), X.device)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=X.device)
+    _lib.check(L.pseld_bn2d_stats(dtype_code(X), _lib.ptr(X), _lib.ptr(sums), rows, C, _lib.ptr(ws), ws.numel() * 4,
+                                  _lib.stream_ptr()), "pseld_bn2d_stats")
+    return sums
+
+
+def bn_relu_fwd(X, scale_shift):
+    _chk(X, scale_shift)
+    Y = torch.empty_like(X)
+    _lib.check(_lib.lib().pseld_bn_relu_fwd(dtype_code(X), _lib.ptr(X), _lib.ptr(scale_shift), _lib.ptr(Y), X.shape[0], X.shape[1],
+                                            _lib.stream_ptr()), "pseld_bn_relu_fwd")
+    return Y
+
+
+def bn_relu_bwd(X, Y, dY, mean_rstd, gamma, dgamma, dbeta):
+    _chk(X, Y, dY, mean_rstd, gamma, dgamma, dbeta)
+    rows, C = X.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_bn2d_workspace(rows, C), X.device)
+    dX = torch.empty_like(X)
+    _lib.check(L.pseld_bn_relu_bwd(dtype_code(X), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(dY), _lib.ptr(mean_rstd), _lib.ptr(gamma),
+                                   _lib.ptr(dX), _lib.ptr(dgamma), _lib.ptr(dbeta), rows, C, _lib.ptr(ws), ws.numel() * 4,
+                                   _lib.stream_ptr()), "pseld_bn_relu_bwd")
+    return dX
+
+
+def avgpool_fwd(X, B, T, F, pt, pf):
+    _chk(X)
+    C = X.shape[1]
+    Y = torch.empty((B * (T // pt) * (F // pf), C), dtype=X.dtype, device=X.device)
+    _lib.check(_lib.lib().pseld_avgpool_fwd(dtype_code(X), _lib.ptr(X), _lib.ptr(Y), B, T, F, C, pt, pf, _lib.stream_ptr()),
+               "pseld_avgpool_fwd")
+    return Y
+
+
+def avgpool_bwd(dY, B, T, F, pt, pf):
+    _chk(dY)
+    C = dY.shape[1]
+    dX = torch.empty((B * T * F, C), dtype=dY.dtype, device=dY.device)
+    _lib.check(_lib.lib().pseld_avgpool_bwd(dtype_code(dY), _lib.ptr(dY), _lib.ptr(dX), B, T, F, C, pt, pf, _lib.stream_ptr()),
+               "pseld_avgpool_bwd")
+    return dX
+
+
+def rows_pool_fwd(X, taps, B):
+    _chk(X, taps['i0'], taps['w'])
+    C = X.shape[1]
+    Y = torch.empty((B * taps['n_out'], C), dtype=X.dtype, device=X.device)
+    _lib.check(_lib.lib().pseld_rows_pool_fwd(dtype_code(X), _lib.ptr(X), _lib.ptr(taps['i0']), _lib.ptr(taps['w']), _lib.ptr(Y), B,
+                                              taps['n_in'], taps['n_out'], C, _lib.stream_ptr()), "pseld_rows_pool_fwd")
+    return Y
+
+
+def rows_pool_bwd(dY, taps, B):
+    _chk(dY, taps['i0'], taps['w'])
+    C = dY.shape[1]
+    dX = torch.empty((B * taps['n_in'], C), dtype=dY.dtype, device=dY.device)
+    _lib.check(_lib.lib().pseld_rows_pool_bwd(dtype_code(dY), _lib.ptr(dY), _lib.ptr(taps['i0']), _lib.ptr(taps['w']), _lib.ptr(dX), B,
+                                              taps['n_in'], taps['n_out'], C, _lib.stream_ptr()), "pseld_rows_pool_bwd")
+    return dX
+
+
+def copy2d(src, dst, cols):
+    """dst[r, :cols] = src[r, :cols]; dst[r, cols:] = 0 (both row-major, any leading dimensions >= cols)."""
+    _chk(src, dst)
+    assert src.dtype == dst.dtype and src.shape[0] == dst.shape[0]
+    _lib.check(_lib.lib().pseld_copy2d(dtype_code(src), _lib.ptr(src), src.stride(0), _lib.ptr(dst), dst.stride(0), src.shape[0], cols,
+                                       _lib.stream_ptr()), "pseld_copy2d")
+    return dst
+
+
+def bn2d_finalize(sums, count, weight, bias, running_mean, running_var, num_batches, training, momentum=0.1, eps=1e-5):
+    """BatchNorm2d over NHWC rows: sums f32[C][2] -> (mean_rstd, scale_shift) f32[C][2]; running statistics updated in place
+    (one num_batches_tracked counter per layer)."""
+    C = weight.numel()
+    mean_rstd = torch.empty(C * 2, dtype=torch.float32, device=weight.device)
+    scale_shift = torch.empty(C * 2, dtype=torch.float32, device=weight.device)
+    rc = _lib.lib().pseld_bn_scalar_finalize(_lib.ptr(sums), float(count), 0, _lib.ptr(weight), _lib.ptr(bias),
+                                             _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches),
+                                             _lib.ptr(mean_rstd), _lib.ptr(scale_shift), 1, C, momentum, eps,
+                                             int(training), _lib.stream_ptr())
+    _lib.check(rc, "pseld_bn_scalar_finalize")
+    return mean_rstd, scale_shift

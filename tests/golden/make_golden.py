@@ -30,6 +30,7 @@ import utils.feature as ref_feature  # noqa: E402
 
 from oracle import htsat as oh  # noqa: E402
 from oracle import passt as op  # noqa: E402
+from oracle import crnn as oc  # noqa: E402
 from oracle import synth  # noqa: E402
 
 torch.set_num_threads(8)
@@ -322,8 +323,72 @@ def gen_passt():
     save('passt.npz', **out)
 
 
+CRNN_TINY = [8, 16, 16, 32, 32, 64]
+CRNN_FULL = [64, 128, 256, 512, 1024, 2048]
+
+
+def gen_crnn():
+    """CRNN(encoder='CNN12') with cfg.model.decoder = None (Identity decoder). Gradients are taken from a FLOAT64 run of
+    the reference on a seeded well-conditioned state (oracle/crnn.py:random_state): with the closed-form state its own fp32
+    gradients differ from float64 by up to 4e-2 (BatchNorm-parameter gradients are residuals of cancelling sums);
+    scalar.* gradients are left out (torch CPU BN-backward bug)."""
+    C = 3
+    cfgc = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'),
+                      model=R.AttrDict(decoder=None, num_decoder_layers=1), adapt=dict())
+    out = {}
+    x = oh.formula_features(2)
+    sd = oc.formula_state('multi_accdoa', C, 7, 'CNN12', CRNN_TINY)
+    net = multi_accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    net.eval()
+    with torch.no_grad():
+        out['maccdoa_eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net.train()
+    with torch.no_grad():
+        out['maccdoa_train'] = net(x.clone())['multi_accdoa'].numpy()
+    sdn = net.state_dict()
+    bn_names = [k for k in sdn if k.startswith('convs.') and k.endswith('running_var')]
+    out['bn_names'] = np.array(bn_names)
+    out['running_var'] = np.stack([np.pad(sdn[k].numpy(), (0, 64 - sdn[k].numel())) for k in bn_names])
+    out['running_mean'] = np.stack([np.pad(sdn[k.replace('running_var', 'running_mean')].numpy(), (0, 64 - sdn[k].numel())) for k in bn_names])
+    sdr = oc.random_state('multi_accdoa', C, 7, 'CNN12', CRNN_TINY, seed=0)
+    xr = oc.random_features(3, seed=1)
+    net64 = multi_accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY).double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sdr.items()})
+    net64.train()
+    pred = net64(xr.double().clone())
+    lab = synth.formula_adpit_label(3, 100, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab.double()})
+    ld['loss_all'].backward()
+    out['maccdoa_loss'] = ld['loss_all'].item()
+    names, norms, heads = [], [], []
+    for n, p in net64.named_parameters():
+        if n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    # ACCDOA head, CNN8 encoder (frequency mean over 4 bins)
+    sd8 = oc.formula_state('accdoa', C, 7, 'CNN8', [8, 16, 32, 64])
+    net = accdoa.CRNN(cfgc, C, 7, encoder='CNN8', pretrained_path=None, num_features=[8, 16, 32, 64])
+    net.load_state_dict(sd8)
+    net.eval()
+    with torch.no_grad():
+        out['accdoa_cnn8_eval'] = net(x.clone())['accdoa'].numpy()
+    # full size (configs/model/crnn.yaml kwargs), 13 classes, one chunk, eval
+    net = accdoa.CRNN(cfgc, 13, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_FULL)
+    net.load_state_dict(oc.formula_state('accdoa', 13, 7, 'CNN12', CRNN_FULL))
+    net.eval()
+    with torch.no_grad():
+        out['full_eval'] = net(oh.formula_features(1))['accdoa'].numpy()
+    out['full_n_params'] = sum(p.numel() for p in net.parameters())
+    save('crnn.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -331,3 +396,4 @@ if __name__ == '__main__':
     if 'optim' in which: gen_optim()
     if 'sampler' in which: gen_sampler()
     if 'passt' in which: gen_passt()
+    if 'crnn' in which: gen_crnn()

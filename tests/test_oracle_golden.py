@@ -222,3 +222,50 @@ def test_passt_full_size_golden():
     with torch.no_grad():
         y = op.accdoa_passt_forward(oh.formula_features(1), sd, PASST_FULL, key='multi_accdoa')['multi_accdoa']
     close(y, g['full_eval'], 5e-5)
+
+
+CRNN_TINY = [8, 16, 16, 32, 32, 64]
+CRNN_FULL = [64, 128, 256, 512, 1024, 2048]
+
+
+def test_crnn_golden():
+    """oracle/crnn.py against the reference's CRNN (models/accdoa.py:12-95, decoder = None). Gradients: the golden is
+    the reference in float64 (its fp32 autograd is off by up to 4e-2 in this configuration), so the oracle is run in
+    float64 too."""
+    from oracle import crnn as oc
+    g = gold('crnn.npz')
+    x = oh.formula_features(2)
+    sd = oc.formula_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY)
+    with torch.no_grad():
+        close(oc.accdoa_crnn_forward(x.clone(), sd, 'CNN12', key='multi_accdoa')['multi_accdoa'], g['maccdoa_eval'], 5e-5)
+        upd = {}
+        close(oc.accdoa_crnn_forward(x.clone(), sd, 'CNN12', training=True, bn_update=upd, key='multi_accdoa')['multi_accdoa'],
+              g['maccdoa_train'], 5e-5)
+        for name, rv, rm in zip(g['bn_names'], g['running_var'], g['running_mean']):
+            name = str(name)
+            n = upd[name].numel()
+            close(upd[name], rv[:n], 1e-5)
+            close(upd[name.replace('running_var', 'running_mean')], rm[:n], 1e-5)
+        sd8 = oc.formula_state('accdoa', 3, 7, 'CNN8', [8, 16, 32, 64])
+        close(oc.accdoa_crnn_forward(x.clone(), sd8, 'CNN8')['accdoa'], g['accdoa_cnn8_eval'], 5e-5)
+    sdr = oc.random_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY, seed=0)
+    p = {k: (v.double().clone().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sdr.items()}
+    pred = oc.accdoa_crnn_forward(oc.random_features(3, seed=1).double(), p, 'CNN12', training=True, key='multi_accdoa')
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(3, 100, 3).double()})
+    assert abs(ld['loss_all'].item() - float(g['maccdoa_loss'])) < 1e-9
+    ld['loss_all'].backward()
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= 1e-8 * max(norm, 1e-6), n
+        k = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:k].numpy() - head[:k]).max() <= 1e-8 * max(np.abs(head).max(), 1e-6) + 1e-15, n
+
+
+def test_crnn_full_size_golden():
+    from oracle import crnn as oc
+    g = gold('crnn.npz')
+    shapes = oc.net_shapes('accdoa', 13, 7, 'CNN12', CRNN_FULL)
+    assert sum(int(np.prod(s)) for k, s in shapes.items() if 'running_' not in k) == int(g['full_n_params'])
+    with torch.no_grad():
+        y = oc.accdoa_crnn_forward(oh.formula_features(1), oc.formula_state('accdoa', 13, 7, 'CNN12', CRNN_FULL), 'CNN12')['accdoa']
+    close(y, g['full_eval'], 5e-5)
