@@ -20,6 +20,7 @@ import torch  # noqa: E402
 
 CLIP_SECONDS, CHUNKS_PER_CLIP, FS, CLASSES = 60, 6, 24000, 170
 GFLOP_PER_CHUNK_TRAIN = 37.61       # 37.026 (net fwd+bwd) + 0.583 (features)
+GFLOP_PER_CHUNK_TRAIN_CRNN = 282.0   # 3 x 93.8 (conv stack + fc of the CNN14-Conformer probe's 94.94 without the Conformer) + features
 GFLOP_PER_CHUNK_TRAIN_EINV2 = 72.28  # 3 x 23.90 (SURVEY §6 probe, EINV2-HTSAT forward) + features
 GFLOP_PER_CHUNK_TRAIN_PASST = 207.9  # 3 x (patch 1.65 + 7 blocks x (12 E^2 N + 4 N^2 E) = 67.8) + features; N=602, E=768
 PEAK_BF16_TFLOPS = 2516.6           # dense MFMA bf16 peak, MI355X_MICROARCH.md
@@ -168,7 +169,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--clips', type=int, default=32, help='60 s clips per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2'],
+    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2', 'crnn'],
                     help='htsat = the headline workload (BASELINE.json configs[1]); htsat_einv2 = configs[2] (dual-branch, tPIT); '
                          'passt = the PaSST backbone, same data')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -210,6 +211,10 @@ def main():
     elif args.backbone == 'htsat_einv2':
         from pseldnets_amd.models import einv2
         net = einv2.HTSAT(cfg, CLASSES, 7, pretrained_path=None)             # einv2.py:189-327: SED + DOA encoders
+    elif args.backbone == 'crnn':
+        cfg['model'] = AttrDict(decoder=None, num_decoder_layers=1)          # Identity decoder (Conformer not built yet)
+        net = multi_accdoa.CRNN(cfg, CLASSES, 7, encoder='CNN12', pretrained_path=None,
+                                num_features=[64, 128, 256, 512, 1024, 2048])   # configs/model/crnn.yaml kwargs
     else:
         net = multi_accdoa.PASST(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/passt.yaml geometry
     net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -264,15 +269,16 @@ def main():
     clips_per_s = args.clips * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
-    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2'}[args.backbone]
-    gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2}[args.backbone]
+    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'crnn': 'CNN14 (CRNN/CNN12, Identity decoder)'}[args.backbone]
+    gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2,
+                   'crnn': GFLOP_PER_CHUNK_TRAIN_CRNN}[args.backbone]
     out = {
         "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA"), "value": round(clips_per_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
                                f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
-                               f"drop_path {0.0 if args.backbone == 'passt' else 0.1}, BN train mode, no augmentation",
+                               f"drop_path {0.0 if args.backbone in ('passt', 'crnn') else 0.1}, BN train mode, no augmentation",
                    "global_clips": args.clips * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
     }
