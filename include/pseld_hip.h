@@ -151,18 +151,21 @@ int pseld_tanh_bwd(int dtype, const float* dy, const float* y, void* dz, int ldz
 /* ---- convolutional encoder of the CRNN networks (CNN8 / CNN12 = the PANNs CNN14 conv stack) ------------------------------
  * accdoa.py:72-90, backbone.py:6-60, model_utilities.py:92-126 (ConvBlock), utils.py:25-52 (interpolate 'repeat').
  * Activations are NHWC rows [B*T*F, C]. cnn_input: scalar BN + NCHW->NHWC (Cp >= Cin padded channels, zeros);
- * im2col3x3 / col2im3x3: A[(b,t,f)][c*9 + (dt+1)*3 + (df+1)] = X[b,t+dt,f+df,c] (k order = the [Cout,Cin,3,3] weight's
- * flattening; columns 9C..lda are zero) and its adjoint; bn2d_stats: sums f32[C][2] = (sum x, sum x^2) over the rows
+ * im2col3x3 / col2im3x3: A[(b,t,f)][tap*C + c] = X[b,t+dt,f+df,c], tap = (dt+1)*3 + (df+1) (tap-major: 16-byte
+ * copies, C % 8 == 0) and its adjoint; conv_weight_to_tap / conv_wgrad_from_tap: the [Cout,Cin,3,3] weight <-> the
+ * tap-major [Cout,9,Cp] matrix the GEMMs use (Cp >= Cin zero-padded channels), and the fp32 gradient back; bn2d_stats: sums f32[C][2] = (sum x, sum x^2) over the rows
  * (finalise with pseld_bn_scalar_finalize(Cin = 1, F = C)); bn_relu: y = relu(x*scale + shift) and its train-mode
  * backward (dgamma, dbeta overwritten); avgpool: AvgPool2d((pt,pf)), floor; rows_pool: y[b,j] = sum_k w[j][k] *
- * x[b, i0[j]+k], k < 3 (the 'repeat' x 8 + 10-frame mean map); copy2d: row-padded copy of a weight matrix. */
+ * x[b, i0[j]+k], k < 3 (the 'repeat' x 8 + 10-frame mean map). */
 int pseld_cnn_input(int dtype, const float* feat, const float* scale_shift, void* X, int B, int Cin, int T, int Cp,
                     void* stream);
 long pseld_cnn_input_bwd_workspace(int B, int Cin, int T);
 int pseld_cnn_input_bwd(int dtype, const float* feat, const float* mean_rstd, const void* dX, float* dweight, float* dbias,
                         int B, int Cin, int T, int Cp, float* workspace, long workspace_bytes, void* stream);
-int pseld_im2col3x3(int dtype, const void* X, void* A, int B, int T, int F, int C, int lda, void* stream);
-int pseld_col2im3x3(int dtype, const void* dA, void* dX, int B, int T, int F, int C, int lda, void* stream);
+int pseld_im2col3x3(int dtype, const void* X, void* A, int B, int T, int F, int C, void* stream);
+int pseld_col2im3x3(int dtype, const void* dA, void* dX, int B, int T, int F, int C, void* stream);
+int pseld_conv_weight_to_tap(int dtype, const void* W, void* Wp, int Cout, int Cin, int Cp, void* stream);
+int pseld_conv_wgrad_from_tap(const float* dWp, float* dW, int Cout, int Cin, int Cp, void* stream);
 long pseld_bn2d_workspace(long rows, int C);
 int pseld_bn2d_stats(int dtype, const void* X, float* sums, long rows, int C, float* workspace, long workspace_bytes,
                      void* stream);
@@ -176,7 +179,6 @@ int pseld_rows_pool_fwd(int dtype, const void* X, const int* i0, const float* w,
                         void* stream);
 int pseld_rows_pool_bwd(int dtype, const void* dY, const int* i0, const float* w, void* dX, int B, int n_in, int n_out, int C,
                         void* stream);
-int pseld_copy2d(int dtype, const void* src, int ld_src, void* dst, int ld_dst, long rows, int cols, void* stream);
 
 /* ---- output head ---------------------------------------------------------------------------------------------------
  * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):

@@ -6,8 +6,8 @@
 // interpolation + 10-frame mean), models/components/backbone.py:6-60 (CNN8, CNN12), models/components/
 // model_utilities.py:92-126 (ConvBlock: conv3x3 -> BatchNorm2d -> ReLU, twice, AvgPool2d), models/components/
 // utils.py:25-52 (interpolate, method 'repeat') — and the autograd of each. All HBM-bound address maps / reductions;
-// first version: correctness and parity first (the im2col matrix is materialised, k = c*9 + tap so that the
-// reference's [Cout, Cin, 3, 3] weights are used as they are).
+// the im2col matrix is materialised per batch slice in tap-major column order (k = tap*C + c: 16-byte copies); the
+// reference's [Cout, Cin, 3, 3] weights are permuted to that order once per step and their gradient permuted back.
 #include "common.h"
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
@@ -62,96 +62,154 @@ __global__ void deinterleave2_kernel(const float* __restrict__ tot, int n, float
     if (i < n) { a[i] = tot[2 * i]; b[i] = tot[2 * i + 1]; }
 }
 
-// A[(b,t,f)][c*9 + (dt+1)*3 + (df+1)] = X[b, t+dt, f+df, c] (0 outside the map); columns >= 9C (padding up to lda) = 0.
-// one thread = one (row, c): 9 taps
+// A[(b,t,f)][tap*C + c] = X[b, t+dt, f+df, c] (0 outside the map), tap = (dt+1)*3 + (df+1): TAP-MAJOR columns, so
+// that every tap is one contiguous C-vector of the neighbouring pixel and the copy runs in 16-byte chunks (C % 8 == 0).
+// The weights are permuted to the same order once per step (conv_weight_kernel). One thread = one 8-channel chunk.
 template <typename T>
-__global__ void im2col3x3_kernel(const T* __restrict__ X, T* __restrict__ A, int Tn, int Fn, int C, int lda, long total) {
+__global__ void im2col3x3_kernel(const T* __restrict__ X, T* __restrict__ A, int Tn, int Fn, int C, long total) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
-    const int cp = lda / 9 + 1;                               // channel slots per row incl. one slot for the pad columns
-    const int c = (int)(id % cp);
-    const long row = id / cp;
-    T* dst = A + row * lda;
-    if (c * 9 >= lda) return;
-    if (c >= C) {                                             // pad columns
-        for (int k = C * 9 + (c - C) * 9; k < min(lda, C * 9 + (c - C + 1) * 9); ++k) dst[k] = from_f32<T>(0.f);
-        return;
-    }
+    const int c8 = C >> 3;
+    const int ch = (int)(id % c8);
+    long rest = id / c8;
+    const int tap = (int)(rest % 9);
+    const long row = rest / 9;
+    const int dt = tap / 3 - 1, df = tap % 3 - 1;
     const int f = (int)(row % Fn);
-    const long bt = row / Fn;
-    const int t = (int)(bt % Tn);
-#pragma unroll
-    for (int dt = -1; dt <= 1; ++dt)
-#pragma unroll
-        for (int df = -1; df <= 1; ++df) {
-            const bool in = t + dt >= 0 && t + dt < Tn && f + df >= 0 && f + df < Fn;
-            dst[c * 9 + (dt + 1) * 3 + (df + 1)] = in ? X[(row + (long)dt * Fn + df) * C + c] : from_f32<T>(0.f);
-        }
+    const int t = (int)((row / Fn) % Tn);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t + dt >= 0 && t + dt < Tn && f + df >= 0 && f + df < Fn) load8<T>(X + (row + (long)dt * Fn + df) * C + ch * 8, v);
+    store8<T>(A + row * (9L * C) + (long)tap * C + ch * 8, v);
 }
-// dX[b,t,f,c] = sum over taps of dA[(b, t-dt, f-df)][c*9 + tap]
+// dX[b,t,f,c] = sum over taps of dA[(b, t-dt, f-df)][tap*C + c]; one thread = one 8-channel chunk
 template <typename T>
-__global__ void col2im3x3_kernel(const T* __restrict__ dA, T* __restrict__ dX, int Tn, int Fn, int C, int lda, long total) {
+__global__ void col2im3x3_kernel(const T* __restrict__ dA, T* __restrict__ dX, int Tn, int Fn, int C, long total) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
-    const int c = (int)(id % C);
-    const long row = id / C;
+    const int c8 = C >> 3;
+    const int ch = (int)(id % c8);
+    const long row = id / c8;
     const int f = (int)(row % Fn);
-    const long bt = row / Fn;
-    const int t = (int)(bt % Tn);
-    float s = 0.f;
+    const int t = (int)((row / Fn) % Tn);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int dt = -1; dt <= 1; ++dt)
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dt = tap / 3 - 1, df = tap % 3 - 1;
+        const int ts = t - dt, fs = f - df;
+        if (ts >= 0 && ts < Tn && fs >= 0 && fs < Fn) {
+            float v[8];
+            load8<T>(dA + (row - (long)dt * Fn - df) * (9L * C) + (long)tap * C + ch * 8, v);
 #pragma unroll
-        for (int df = -1; df <= 1; ++df) {
-            const int ts = t - dt, fs = f - df;
-            if (ts >= 0 && ts < Tn && fs >= 0 && fs < Fn)
-                s += to_f32<T>(dA[(row - (long)dt * Fn - df) * lda + c * 9 + (dt + 1) * 3 + (df + 1)]);
+            for (int k = 0; k < 8; ++k) s[k] += v[k];
         }
-    dX[id] = from_f32<T>(s);
+    }
+    store8<T>(dX + row * C + ch * 8, s);
+}
+// conv weight [Cout][Cin][9] (the reference's [Cout, Cin, 3, 3]) -> tap-major [Cout][9][Cp] with zero channels
+// Cin..Cp-1 (TO_TAP), or the gradient back: dW[co][ci][tap] = dWp[co][tap][ci] (!TO_TAP)
+template <typename TS, typename TD, bool TO_TAP>
+__global__ void conv_weight_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int Cin, int Cp, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    if (TO_TAP) {
+        const int ci = (int)(id % Cp);
+        const int tap = (int)((id / Cp) % 9);
+        const long co = id / (9L * Cp);
+        dst[id] = ci < Cin ? (TD)src[(co * Cin + ci) * 9 + tap] : (TD)0.f;
+    } else {
+        const int tap = (int)(id % 9);
+        const int ci = (int)((id / 9) % Cin);
+        const long co = id / (9L * Cin);
+        dst[id] = (TD)src[(co * 9 + tap) * Cp + ci];
+    }
 }
 
 // per-column sums over a block of rows: MODE 0: (sum x, sum x^2); MODE 1: with g = dy * (y > 0): (sum g*xhat, sum g).
-// part[block][C][2]; thread = column (C <= blockDim.x * gridDim.y)
+// part[block][C][2]. A workgroup covers CW = min(C, 256) columns with 256 / CW row lanes striding its rows (coalesced
+// row segments, every thread busy also for narrow maps); the row lanes are combined through LDS.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn2d_sums_kernel(const T* __restrict__ X, const T* __restrict__ Y, const T* __restrict__ dY,
                                                         const float* __restrict__ mean_rstd, float* __restrict__ part, long rows,
                                                         int C, int rows_per_block) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
+    // a thread owns 8 consecutive columns (16-byte loads); a workgroup covers CW8 = min(C/8, 256) column octets with
+    // 256 / CW8 row lanes striding its rows; the row lanes are combined through LDS
+    __shared__ float red[256][16];
+    const int c8 = C >> 3;
+    const int cw = c8 < 256 ? c8 : 256;
+    const int lanes = 256 / cw;
+    const int cl = threadIdx.x % cw, rl = threadIdx.x / cw;
+    const int co = blockIdx.y * cw + cl;                   // column octet
     const long beg = (long)blockIdx.x * rows_per_block, end = min(rows, beg + rows_per_block);
-    float a = 0.f, b = 0.f;
-    float mean = 0.f, rstd = 1.f;
-    if (MODE == 1) { mean = mean_rstd[2 * c]; rstd = mean_rstd[2 * c + 1]; }
-    for (long r = beg; r < end; ++r) {
-        const float x = to_f32<T>(X[r * C + c]);
-        if (MODE == 0) { a += x; b += x * x; }
-        else {
-            const float g = to_f32<T>(Y[r * C + c]) > 0.f ? to_f32<T>(dY[r * C + c]) : 0.f;
-            a += g * (x - mean) * rstd; b += g;
+    float a[8], b[8], mean[8], rstd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = 0.f; b[k] = 0.f; mean[k] = 0.f; rstd[k] = 1.f; }
+    if (co < c8 && rl < lanes) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { mean[k] = mean_rstd[2 * (co * 8 + k)]; rstd[k] = mean_rstd[2 * (co * 8 + k) + 1]; }
+        }
+        for (long r = beg + rl; r < end; r += lanes) {
+            float x[8];
+            load8<T>(X + r * C + co * 8, x);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a[k] += x[k]; b[k] += x[k] * x[k]; }
+            } else {
+                float y[8], dy[8];
+                load8<T>(Y + r * C + co * 8, y);
+                load8<T>(dY + r * C + co * 8, dy);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float g = y[k] > 0.f ? dy[k] : 0.f;
+                    a[k] += g * (x[k] - mean[k]) * rstd[k]; b[k] += g;
+                }
+            }
         }
     }
-    float* o = part + ((long)blockIdx.x * C + c) * 2;
-    o[0] = a; o[1] = b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = a[k]; red[threadIdx.x][8 + k] = b[k]; }
+    __syncthreads();
+    if (rl == 0 && co < c8) {
+        for (int i = 1; i < lanes; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k] += red[i * cw + cl][k]; b[k] += red[i * cw + cl][8 + k]; }
+        float* o = part + ((long)blockIdx.x * C + co * 8) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = b[k]; }
+    }
 }
 template <typename T>
-__global__ void bn_relu_fwd_kernel(const T* __restrict__ X, const float* __restrict__ ss, T* __restrict__ Y, int C, long total) {
+__global__ void bn_relu_fwd_kernel(const T* __restrict__ X, const float* __restrict__ ss, T* __restrict__ Y, int C, long total8) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int c = (int)(id % C);
-    Y[id] = from_f32<T>(fmaxf(to_f32<T>(X[id]) * ss[2 * c] + ss[2 * c + 1], 0.f));
+    if (id >= total8) return;
+    const int c0 = (int)((id * 8) % C);
+    float x[8];
+    load8<T>(X + id * 8, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k] * ss[2 * (c0 + k)] + ss[2 * (c0 + k) + 1], 0.f);
+    store8<T>(Y + id * 8, x);
 }
 // dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * (y > 0); sums = [C][2] = (sum g*xhat, sum g)
 template <typename T>
 __global__ void bn_relu_bwd_kernel(const T* __restrict__ X, const T* __restrict__ Y, const T* __restrict__ dY,
                                    const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-                                   const float* __restrict__ sums, float inv_n, T* __restrict__ dX, int C, long total) {
+                                   const float* __restrict__ sums, float inv_n, T* __restrict__ dX, int C, long total8) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int c = (int)(id % C);
-    const float mean = mean_rstd[2 * c], rstd = mean_rstd[2 * c + 1];
-    const float g = to_f32<T>(Y[id]) > 0.f ? to_f32<T>(dY[id]) : 0.f;
-    const float xh = (to_f32<T>(X[id]) - mean) * rstd;
-    dX[id] = from_f32<T>(gamma[c] * rstd * (g - sums[2 * c + 1] * inv_n - xh * sums[2 * c] * inv_n));
+    if (id >= total8) return;
+    const int c0 = (int)((id * 8) % C);
+    float x[8], y[8], dy[8], o[8];
+    load8<T>(X + id * 8, x);
+    load8<T>(Y + id * 8, y);
+    load8<T>(dY + id * 8, dy);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        const float mean = mean_rstd[2 * c], rstd = mean_rstd[2 * c + 1];
+        const float g = y[k] > 0.f ? dy[k] : 0.f;
+        const float xh = (x[k] - mean) * rstd;
+        o[k] = gamma[c] * rstd * (g - sums[2 * c + 1] * inv_n - xh * sums[2 * c] * inv_n);
+    }
+    store8<T>(dX + id * 8, o);
 }
 
 // AvgPool2d((pt, pf)) on [B, T, F, C] rows (floor mode, stride = kernel)
@@ -221,16 +279,6 @@ __global__ void rows_pool_bwd_kernel(const T* __restrict__ dY, const int* __rest
     dX[id] = from_f32<T>(s);
 }
 
-// dst[r, 0:cols] = src[r, 0:cols], dst[r, cols:ldd] = 0 (weight matrices whose row length is not a multiple of 8)
-template <typename T>
-__global__ void copy2d_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int cols, long total) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int c = (int)(id % ldd);
-    const long r = id / ldd;
-    dst[id] = c < cols ? src[r * lds_ + c] : from_f32<T>(0.f);
-}
-
 constexpr int CNN_ROWS_PER_BLOCK = 1024;
 
 }  // namespace
@@ -272,19 +320,37 @@ extern "C" int pseld_cnn_input_bwd(int dtype, const float* feat, const float* me
     return PSELD_OK;
 }
 
-extern "C" int pseld_im2col3x3(int dtype, const void* X, void* A, int B, int Tn, int Fn, int C, int lda, void* stream) {
-    PSELD_CHECK_ARG(X && A && B > 0 && Tn > 0 && Fn > 0 && C > 0 && lda >= 9 * C, "im2col3x3: bad argument");
+extern "C" int pseld_im2col3x3(int dtype, const void* X, void* A, int B, int Tn, int Fn, int C, void* stream) {
+    PSELD_CHECK_ARG(X && A && B > 0 && Tn > 0 && Fn > 0 && C > 0 && C % 8 == 0, "im2col3x3: bad argument (C must be a multiple of 8)");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * Tn * Fn * (lda / 9 + 1);
+    const long total = (long)B * Tn * Fn * 9 * (C / 8);
     CNN_DISPATCH("im2col3x3", hipLaunchKernelGGL(im2col3x3_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)X, (T*)A,
-                                                 Tn, Fn, C, lda, total));
+                                                 Tn, Fn, C, total));
 }
-extern "C" int pseld_col2im3x3(int dtype, const void* dA, void* dX, int B, int Tn, int Fn, int C, int lda, void* stream) {
-    PSELD_CHECK_ARG(dA && dX && B > 0 && Tn > 0 && Fn > 0 && C > 0 && lda >= 9 * C, "col2im3x3: bad argument");
+extern "C" int pseld_col2im3x3(int dtype, const void* dA, void* dX, int B, int Tn, int Fn, int C, void* stream) {
+    PSELD_CHECK_ARG(dA && dX && B > 0 && Tn > 0 && Fn > 0 && C > 0 && C % 8 == 0, "col2im3x3: bad argument (C must be a multiple of 8)");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * Tn * Fn * C;
+    const long total = (long)B * Tn * Fn * (C / 8);
     CNN_DISPATCH("col2im3x3", hipLaunchKernelGGL(col2im3x3_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)dA, (T*)dX,
-                                                 Tn, Fn, C, lda, total));
+                                                 Tn, Fn, C, total));
+}
+/* weights in the compute dtype, reference layout [Cout, Cin, 3, 3] -> tap-major [Cout, 9, Cp]; fp32 gradient back */
+extern "C" int pseld_conv_weight_to_tap(int dtype, const void* W, void* Wp, int Cout, int Cin, int Cp, void* stream) {
+    PSELD_CHECK_ARG(W && Wp && Cout > 0 && Cin > 0 && Cp >= Cin && Cp % 8 == 0, "conv_weight_to_tap: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)Cout * 9 * Cp;
+    if (dtype == PSELD_BF16) hipLaunchKernelGGL((conv_weight_kernel<bf16_t, bf16_t, true>), dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)W, (bf16_t*)Wp, Cin, Cp, total);
+    else if (dtype == PSELD_F32) hipLaunchKernelGGL((conv_weight_kernel<float, float, true>), dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const float*)W, (float*)Wp, Cin, Cp, total);
+    else { pseld_set_error("conv_weight_to_tap: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    PSELD_LAUNCH_CHECK("conv_weight_to_tap");
+    return PSELD_OK;
+}
+extern "C" int pseld_conv_wgrad_from_tap(const float* dWp, float* dW, int Cout, int Cin, int Cp, void* stream) {
+    PSELD_CHECK_ARG(dWp && dW && Cout > 0 && Cin > 0 && Cp >= Cin, "conv_wgrad_from_tap: bad argument");
+    const long total = (long)Cout * Cin * 9;
+    hipLaunchKernelGGL((conv_weight_kernel<float, float, false>), dim3(pseld_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dWp, dW, Cin, Cp, total);
+    PSELD_LAUNCH_CHECK("conv_wgrad_from_tap");
+    return PSELD_OK;
 }
 
 /* BatchNorm2d statistics over the rows of an NHWC map: sums f32[C][2] = (sum x, sum x^2) */
@@ -297,7 +363,8 @@ extern "C" int pseld_bn2d_stats(int dtype, const void* X, float* sums, long rows
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn2d_stats: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int nb = pseld_cdiv(rows, CNN_ROWS_PER_BLOCK);
-    const dim3 grid(nb, pseld_cdiv(C, 256));
+    PSELD_CHECK_ARG(C % 8 == 0, "bn2d_stats: C must be a multiple of 8");
+    const dim3 grid(nb, pseld_cdiv(C / 8, C / 8 < 256 ? C / 8 : 256));
     if (dtype == PSELD_BF16)
         hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, workspace, rows, C, CNN_ROWS_PER_BLOCK);
     else if (dtype == PSELD_F32)
@@ -310,7 +377,8 @@ extern "C" int pseld_bn2d_stats(int dtype, const void* X, float* sums, long rows
 extern "C" int pseld_bn_relu_fwd(int dtype, const void* X, const float* scale_shift, void* Y, long rows, int C, void* stream) {
     PSELD_CHECK_ARG(X && scale_shift && Y && rows > 0 && C > 0, "bn_relu_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const long total = rows * C;
+    PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_fwd: C must be a multiple of 8");
+    const long total = rows * C / 8;
     CNN_DISPATCH("bn_relu_fwd", hipLaunchKernelGGL(bn_relu_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)X,
                                                    scale_shift, (T*)Y, C, total));
 }
@@ -322,9 +390,10 @@ extern "C" int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const 
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn_relu_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int nb = pseld_cdiv(rows, CNN_ROWS_PER_BLOCK);
-    const dim3 grid(nb, pseld_cdiv(C, 256));
+    PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_bwd: C must be a multiple of 8");
+    const dim3 grid(nb, pseld_cdiv(C / 8, C / 8 < 256 ? C / 8 : 256));
     float* total = workspace + (long)nb * C * 2;
-    const long n = rows * C;
+    const long n = rows * C / 8;
     if (dtype == PSELD_BF16) {
         hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, workspace, rows, C, CNN_ROWS_PER_BLOCK);
         pseld_reduce_slabs(workspace, total, (long)C * 2, nb, (long)C * 2, 0, s);
@@ -368,11 +437,4 @@ extern "C" int pseld_rows_pool_bwd(int dtype, const void* dY, const int* i0, con
     const long total = (long)B * n_in * C;
     CNN_DISPATCH("rows_pool_bwd", hipLaunchKernelGGL(rows_pool_bwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)dY, i0,
                                                      w, (T*)dX, n_in, n_out, C, total));
-}
-extern "C" int pseld_copy2d(int dtype, const void* src, int ld_src, void* dst, int ld_dst, long rows, int cols, void* stream) {
-    PSELD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "copy2d: bad argument");
-    hipStream_t s = (hipStream_t)stream;
-    const long total = rows * ld_dst;
-    CNN_DISPATCH("copy2d", hipLaunchKernelGGL(copy2d_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)src, ld_src, (T*)dst,
-                                              ld_dst, cols, total));
 }

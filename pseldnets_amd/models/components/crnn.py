@@ -2,8 +2,9 @@
 
 Host-side mirror of the reference's `models/components/backbone.py` (CNN8 :6-31, CNN12 :33-60 = the conv stack of PANNs
 CNN14) and `models/components/model_utilities.py` ConvBlock :92-126. Activations are NHWC rows [B*T*F, C]; every 3x3
-convolution is im2col -> MFMA GEMM (weights used in the reference's [Cout, Cin, 3, 3] layout, k = c*9 + tap), its input
-gradient GEMM -> col2im, its weight gradient the split-K GEMM over the recomputed im2col matrix. The im2col matrix is
+convolution is im2col (tap-major columns, 16-byte copies) -> MFMA GEMM against a tap-major copy of the reference's
+[Cout, Cin, 3, 3] weight, its input gradient GEMM -> col2im, its weight gradient the split-K GEMM over the recomputed
+im2col matrix, permuted back into the reference layout. The im2col matrix is
 built per slice of the batch so that it stays bounded. BatchNorm2d (train-mode batch statistics) + ReLU and the
 average pools are per-column / per-pixel kernels (csrc/cnn.hip). No tensor arithmetic happens in this file.
 """
@@ -50,15 +51,10 @@ class ConvEncoder:
                 out[b + 'num_batches_tracked'] = torch.zeros((), dtype=torch.long)
         return out
 
-    # -- one convolution: y[B*T*F, Cout] = im2col(x) @ W^T, in batch slices ---------------------------------------
-    def _weight(self, name, dtype, cin, cin_p, cout):
-        """[Cout, 9*Cin] view of the conv weight in the compute dtype; the first layer's 63-column rows are copied into a
-        72-column zero-padded matrix (GEMM rows must be multiples of 8 elements)."""
-        w = self.arena.w(name, dtype).view(cout, cin * 9)
-        if cin_p == cin:
-            return w
-        wp = torch.empty((cout, cin_p * 9), dtype=dtype, device=w.device)
-        return ops.copy2d(w, wp, cin * 9)
+    # -- one convolution: y[B*T*F, Cout] = im2col(x) @ Wp^T, in batch slices ---------------------------------------
+    def _weight(self, name, dtype, cin_p):
+        """Tap-major [Cout, 9*cin_p] copy of the conv weight in the compute dtype (zero rows for the padded channels)."""
+        return ops.conv_weight_to_tap(self.arena.w(name, dtype), cin_p)
 
     @staticmethod
     def _slices(B, rows_per_sample, K):
@@ -69,20 +65,21 @@ class ConvEncoder:
         rows, K = T * F, W.shape[1]
         y = torch.empty((B * rows, W.shape[0]), dtype=x.dtype, device=x.device)
         for b0, b1 in self._slices(B, rows, K):
-            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F, lda=K)
+            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
             ops.linear_fwd(A, W, out=y[b0 * rows:b1 * rows])
         return y
 
-    def _conv_bwd(self, dy, x, W, dW, B, T, F, need_dx, cin_p):
-        """dW (+)= over the batch slices, dx = col2im(dy @ W)."""
+    def _conv_bwd(self, dy, x, W, dW, B, T, F, cin_p):
+        """dW (reference layout, overwritten) and dx = col2im(dy @ Wp)."""
         rows, K = T * F, W.shape[1]
-        dx = torch.empty((B * rows, cin_p), dtype=x.dtype, device=x.device) if need_dx else None
+        dx = torch.empty((B * rows, cin_p), dtype=x.dtype, device=x.device)
+        dWp = torch.empty((W.shape[0], K), dtype=torch.float32, device=x.device)
         for n, (b0, b1) in enumerate(self._slices(B, rows, K)):
-            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F, lda=K)
-            ops.linear_wgrad(dy[b0 * rows:b1 * rows], A, dW, accumulate=n > 0)
-            if need_dx:
-                dA = ops.linear_dgrad(dy[b0 * rows:b1 * rows], W)
-                ops.col2im3x3(dA, b1 - b0, T, F, cin_p, out=dx[b0 * rows:b1 * rows])
+            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
+            ops.linear_wgrad(dy[b0 * rows:b1 * rows], A, dWp, accumulate=n > 0)
+            dA = ops.linear_dgrad(dy[b0 * rows:b1 * rows], W)
+            ops.col2im3x3(dA, b1 - b0, T, F, cin_p, out=dx[b0 * rows:b1 * rows])
+        ops.conv_wgrad_from_tap(dWp, dW, cin_p)
         return dx
 
     def _bn(self, b, j, y, training, buffers):
@@ -100,10 +97,10 @@ class ConvEncoder:
         cin, cin_p = self.in_chans, self.cin_p
         for i, cout in enumerate(self.widths):
             b = f'{self.prefix}conv_block{i + 1}.'
-            W1 = self._weight(b + 'conv1.weight', dtype, cin, cin_p, cout)
+            W1 = self._weight(b + 'conv1.weight', dtype, cin_p)
             y1 = self._conv_fwd(x, W1, B, T, F)
             z1, mr1 = self._bn(b, 1, y1, training, buffers)
-            W2 = self._weight(b + 'conv2.weight', dtype, cout, cout, cout)
+            W2 = self._weight(b + 'conv2.weight', dtype, cout)
             y2 = self._conv_fwd(z1, W2, B, T, F)
             z2, mr2 = self._bn(b, 2, y2, training, buffers)
             pt, pf = self.pools[i]
@@ -125,15 +122,9 @@ class ConvEncoder:
             pt, pf = self.pools[i]
             dz2 = ops.avgpool_bwd(dx, B, s['T'], s['F'], pt, pf)
             dy2 = ops.bn_relu_bwd(s['y2'], s['z2'], dz2, s['mr2'], a.p(b + 'bn2.weight'), a.g(b + 'bn2.weight'), a.g(b + 'bn2.bias'))
-            W2 = self._weight(b + 'conv2.weight', dtype, cout, cout, cout)
-            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight').view(cout, cout * 9), B, s['T'], s['F'], True, cout)
+            W2 = self._weight(b + 'conv2.weight', dtype, cout)
+            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout)
             dy1 = ops.bn_relu_bwd(s['y1'], s['z1'], dz1, s['mr1'], a.p(b + 'bn1.weight'), a.g(b + 'bn1.weight'), a.g(b + 'bn1.bias'))
-            W1 = self._weight(b + 'conv1.weight', dtype, s['cin'], s['cin_p'], cout)
-            if s['cin_p'] == s['cin']:
-                dW1 = a.g(b + 'conv1.weight').view(cout, s['cin'] * 9)
-                dx = self._conv_bwd(dy1, s['x'], W1, dW1, B, s['T'], s['F'], True, s['cin_p'])
-            else:                                               # first layer: gradient through the zero-padded weight matrix
-                dWp = torch.empty((cout, s['cin_p'] * 9), dtype=torch.float32, device=dy1.device)
-                dx = self._conv_bwd(dy1, s['x'], W1, dWp, B, s['T'], s['F'], True, s['cin_p'])
-                ops.copy2d(dWp, a.g(b + 'conv1.weight').view(cout, s['cin'] * 9), s['cin'] * 9)
+            W1 = self._weight(b + 'conv1.weight', dtype, s['cin_p'])
+            dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'])
         return dx

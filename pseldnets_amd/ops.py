@@ -538,12 +538,12 @@ def cnn_input_bwd(feat, mean_rstd, dX, dweight, dbias):
                "pseld_cnn_input_bwd")
 
 
-def im2col3x3(X, B, T, F, lda=None, out=None):
-    _chk(X, out)
+def im2col3x3(X, B, T, F):
+    """NHWC rows [B*T*F, C] -> [B*T*F, 9*C], columns tap-major (k = tap*C + c)."""
+    _chk(X)
     C = X.shape[1]
-    lda = lda or 9 * C
-    A = out if out is not None else torch.empty((B * T * F, lda), dtype=X.dtype, device=X.device)
-    _lib.check(_lib.lib().pseld_im2col3x3(dtype_code(X), _lib.ptr(X), _lib.ptr(A), B, T, F, C, lda, _lib.stream_ptr()),
+    A = torch.empty((B * T * F, 9 * C), dtype=X.dtype, device=X.device)
+    _lib.check(_lib.lib().pseld_im2col3x3(dtype_code(X), _lib.ptr(X), _lib.ptr(A), B, T, F, C, _lib.stream_ptr()),
                "pseld_im2col3x3")
     return A
 
@@ -551,9 +551,26 @@ def im2col3x3(X, B, T, F, lda=None, out=None):
 def col2im3x3(dA, B, T, F, C, out=None):
     _chk(dA, out)
     dX = out if out is not None else torch.empty((B * T * F, C), dtype=dA.dtype, device=dA.device)
-    _lib.check(_lib.lib().pseld_col2im3x3(dtype_code(dA), _lib.ptr(dA), _lib.ptr(dX), B, T, F, C, dA.shape[1], _lib.stream_ptr()),
+    _lib.check(_lib.lib().pseld_col2im3x3(dtype_code(dA), _lib.ptr(dA), _lib.ptr(dX), B, T, F, C, _lib.stream_ptr()),
                "pseld_col2im3x3")
     return dX
+
+
+def conv_weight_to_tap(w, cp):
+    """[Cout, Cin, 3, 3] -> tap-major [Cout, 9*cp] (channels Cin..cp-1 zero) in the same dtype."""
+    _chk(w)
+    cout, cin = w.shape[0], w.shape[1]
+    wp = torch.empty((cout, 9 * cp), dtype=w.dtype, device=w.device)
+    _lib.check(_lib.lib().pseld_conv_weight_to_tap(dtype_code(w), _lib.ptr(w), _lib.ptr(wp), cout, cin, cp, _lib.stream_ptr()),
+               "pseld_conv_weight_to_tap")
+    return wp
+
+
+def conv_wgrad_from_tap(dwp, dw, cp):
+    """fp32 gradient of the tap-major matrix [Cout, 9*cp] -> the reference layout dw [Cout, Cin, 3, 3] (overwritten)."""
+    _chk(dwp, dw)
+    _lib.check(_lib.lib().pseld_conv_wgrad_from_tap(_lib.ptr(dwp), _lib.ptr(dw), dw.shape[0], dw.shape[1], cp, _lib.stream_ptr()),
+               "pseld_conv_wgrad_from_tap")
 
 
 def bn2d_stats(X):
@@ -621,15 +638,6 @@ def rows_pool_bwd(dY, taps, B):
     _lib.check(_lib.lib().pseld_rows_pool_bwd(dtype_code(dY), _lib.ptr(dY), _lib.ptr(taps['i0']), _lib.ptr(taps['w']), _lib.ptr(dX), B,
                                               taps['n_in'], taps['n_out'], C, _lib.stream_ptr()), "pseld_rows_pool_bwd")
     return dX
-
-
-def copy2d(src, dst, cols):
-    """dst[r, :cols] = src[r, :cols]; dst[r, cols:] = 0 (both row-major, any leading dimensions >= cols)."""
-    _chk(src, dst)
-    assert src.dtype == dst.dtype and src.shape[0] == dst.shape[0]
-    _lib.check(_lib.lib().pseld_copy2d(dtype_code(src), _lib.ptr(src), src.stride(0), _lib.ptr(dst), dst.stride(0), src.shape[0], cols,
-                                       _lib.stream_ptr()), "pseld_copy2d")
-    return dst
 
 
 def bn2d_finalize(sums, count, weight, bias, running_mean, running_var, num_batches, training, momentum=0.1, eps=1e-5):

@@ -44,18 +44,27 @@ def test_conv_encoder_kernels(dev, dtype, tol):
     x = torch.randn(B, C, T, Fq, device=dev)
     xr = nhwc(x).to(dtype)
     x4 = xr.float().view(B, T, Fq, C).permute(0, 3, 1, 2)
-    # im2col in the [Cout, Cin, 3, 3] weight's k order, and col2im = its adjoint
+    # im2col with tap-major columns (k = tap*C + c) and col2im = its adjoint
     A_ = ops.im2col3x3(xr, B, T, Fq)
-    want = F.unfold(x4, 3, padding=1).transpose(1, 2).reshape(B * T * Fq, C * 9)
+    want = F.unfold(x4, 3, padding=1).transpose(1, 2).reshape(B * T * Fq, C, 9).transpose(1, 2).reshape(B * T * Fq, 9 * C)
     assert rel(A_, want) < tol
-    dA = torch.randn(B * T * Fq, C * 9, device=dev).to(dtype)
+    dA = torch.randn(B * T * Fq, 9 * C, device=dev).to(dtype)
     dx = ops.col2im3x3(dA, B, T, Fq, C)
-    want_dx = F.fold(dA.float().view(B, T * Fq, C * 9).transpose(1, 2), (T, Fq), 3, padding=1)
+    dA_c = dA.float().view(B, T * Fq, 9, C).transpose(2, 3).reshape(B, T * Fq, C * 9)
+    want_dx = F.fold(dA_c.transpose(1, 2), (T, Fq), 3, padding=1)
     assert rel(dx, nhwc(want_dx)) < tol
-    # conv as im2col + GEMM == F.conv2d
-    w = (torch.randn(Co, C, 3, 3, device=dev) * 0.1).to(dtype)
-    y = ops.linear_fwd(A_, w.view(Co, C * 9))
-    assert rel(y, nhwc(F.conv2d(x4, w.float(), padding=1))) < 3 * tol
+    # conv as im2col + GEMM against the tap-major weight copy == F.conv2d; the gradient comes back in the reference layout
+    w = (torch.randn(Co, C - 3, 3, 3, device=dev) * 0.1).to(dtype)
+    wp = ops.conv_weight_to_tap(w, C)
+    w_full = torch.zeros(Co, C, 3, 3, device=dev)
+    w_full[:, :C - 3] = w.float()
+    assert torch.equal(wp.view(Co, 9, C).float(), w_full.view(Co, C, 9).transpose(1, 2))
+    y = ops.linear_fwd(A_, wp)
+    assert rel(y, nhwc(F.conv2d(x4, w_full, padding=1))) < 3 * tol
+    dwp = torch.randn(Co, 9 * C, device=dev)
+    dw = torch.empty(Co, C - 3, 3, 3, device=dev)
+    ops.conv_wgrad_from_tap(dwp, dw, C)
+    assert torch.equal(dw.view(Co, C - 3, 9), dwp.view(Co, 9, C).transpose(1, 2)[:, :C - 3])
     # BatchNorm2d (train) + ReLU forward / backward
     yr = torch.randn(B * T * Fq, Co, device=dev).to(dtype)
     gam, bet = torch.rand(Co, device=dev) + 0.5, torch.randn(Co, device=dev)
