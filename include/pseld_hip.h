@@ -173,12 +173,45 @@ int pseld_bn_relu_fwd(int dtype, const void* X, const float* scale_shift, void* 
 int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd, const float* gamma,
                       void* dX, float* dgamma, float* dbeta, long rows, int C, float* workspace, long workspace_bytes,
                       void* stream);
+/* the BatchNorm1d of the Conformer conv module (conformer/convolution.py:129): same statistics kernels, no ReLU; its
+ * backward is pseld_bn_relu_bwd with Y = NULL */
+int pseld_bn_affine_fwd(int dtype, const void* X, const float* scale_shift, void* Y, long rows, int C, void* stream);
 int pseld_avgpool_fwd(int dtype, const void* X, void* Y, int B, int T, int F, int C, int pt, int pf, void* stream);
 int pseld_avgpool_bwd(int dtype, const void* dY, void* dX, int B, int T, int F, int C, int pt, int pf, void* stream);
 int pseld_rows_pool_fwd(int dtype, const void* X, const int* i0, const float* w, void* Y, int B, int n_in, int n_out, int C,
                         void* stream);
 int pseld_rows_pool_bwd(int dtype, const void* dY, const int* i0, const float* w, void* dX, int B, int n_in, int n_out, int C,
                         void* stream);
+
+/* ---- Conformer decoder glue (CRNN decoder='conformer') ---------------------------------------------------------------
+ * components/conformer/modules.py:23-35 (module(x)*factor + x -> axpby), activation.py (Swish, GLU), feed_forward.py,
+ * convolution.py:94-151 (pointwise -> GLU -> depthwise Conv1d(k=31,'same') -> BatchNorm1d -> Swish -> pointwise),
+ * attention.py:28-147 (RelativeMultiHeadAttention with the Transformer-XL relative shift). Rows are [B*T, D]
+ * channel-last; n, D multiples of 8. axpby: out = a*x + b*y. mul: y = x*m*scale (dropout: m the 0/1 keep mask, scale 1/(1-p)).
+ * swish: y = u*sigmoid(u). glu: x [M, 2D] -> y [M, D] = x[:, :D] * sigmoid(x[:, D:]). dwconv: w f32 [D, K]
+ * (Conv1d(groups=D).weight[D,1,K]); flip != 0 gives the input gradient; wgrad overwrites dw f32 [D, K].
+ * relattn: q,k,v [B*T, D] (head h in columns h*D/heads..), pos f32 [T, D] = pos_proj(PE[:T]) (batch independent),
+ * u_bias/v_bias f32 [heads*hd]; score = ((q+u) k^T + shift((q+v) pos^T)) / sqrt(D); attn f32 [B,heads,T,T] is the
+ * softmax output kept for the backward; mask (same dtype as q, [B,heads,T,T], 0/1 keep, times mask_scale = 1/(1-p)) or NULL; T <= 128.
+ * relattn_bwd overwrites dq, dk, dv and dpos f32 [T, D], du_bias, dv_bias f32 [D] (summed over the batch). */
+int pseld_axpby(int dtype, const void* x, const void* y, void* out, float a, float b, long n, void* stream);
+int pseld_mul(int dtype, const void* x, const void* m, void* y, float scale, long n, void* stream);
+int pseld_swish_fwd(int dtype, const void* u, void* y, long n, void* stream);
+int pseld_swish_bwd(int dtype, const void* u, const void* dy, void* du, long n, void* stream);
+int pseld_glu_fwd(int dtype, const void* x, void* y, long M, int D, void* stream);
+int pseld_glu_bwd(int dtype, const void* x, const void* dy, void* dx, long M, int D, void* stream);
+int pseld_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int D, int K, int flip, void* stream);
+long pseld_dwconv_wgrad_workspace(int B, int T, int D, int K);
+int pseld_dwconv_wgrad(int dtype, const void* x, const void* dy, float* dw, int B, int T, int D, int K, float* workspace,
+                       long workspace_bytes, void* stream);
+int pseld_relattn_fwd(int dtype, const void* q, const void* k, const void* v, const float* pos, const float* u_bias,
+                      const float* v_bias, const void* mask, float mask_scale, void* out, float* attn, int B, int T, int D,
+                      int heads, void* stream);
+long pseld_relattn_bwd_workspace(int B, int T, int D);
+int pseld_relattn_bwd(int dtype, const void* q, const void* k, const void* v, const float* pos, const float* u_bias,
+                      const float* v_bias, const void* mask, float mask_scale, const float* attn, const void* dout, void* dq,
+                      void* dk, void* dv, float* dpos, float* du_bias, float* dv_bias, int B, int T, int D, int heads,
+                      float* workspace, long workspace_bytes, void* stream);
 
 /* ---- output head ---------------------------------------------------------------------------------------------------
  * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):

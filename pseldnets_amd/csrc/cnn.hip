@@ -156,11 +156,11 @@ __global__ __launch_bounds__(256) void bn2d_sums_kernel(const T* __restrict__ X,
                 for (int k = 0; k < 8; ++k) { a[k] += x[k]; b[k] += x[k] * x[k]; }
             } else {
                 float y[8], dy[8];
-                load8<T>(Y + r * C + co * 8, y);
+                if (Y) load8<T>(Y + r * C + co * 8, y);
                 load8<T>(dY + r * C + co * 8, dy);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float g = y[k] > 0.f ? dy[k] : 0.f;
+                    const float g = (!Y || y[k] > 0.f) ? dy[k] : 0.f;
                     a[k] += g * (x[k] - mean[k]) * rstd[k]; b[k] += g;
                 }
             }
@@ -179,14 +179,15 @@ __global__ __launch_bounds__(256) void bn2d_sums_kernel(const T* __restrict__ X,
     }
 }
 template <typename T>
-__global__ void bn_relu_fwd_kernel(const T* __restrict__ X, const float* __restrict__ ss, T* __restrict__ Y, int C, long total8) {
+__global__ void bn_relu_fwd_kernel(const T* __restrict__ X, const float* __restrict__ ss, T* __restrict__ Y, int C, long total8,
+                                   float floor_) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total8) return;
     const int c0 = (int)((id * 8) % C);
     float x[8];
     load8<T>(X + id * 8, x);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k] * ss[2 * (c0 + k)] + ss[2 * (c0 + k) + 1], 0.f);
+    for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k] * ss[2 * (c0 + k)] + ss[2 * (c0 + k) + 1], floor_);   // floor -inf: plain affine
     store8<T>(Y + id * 8, x);
 }
 // dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * (y > 0); sums = [C][2] = (sum g*xhat, sum g)
@@ -199,13 +200,13 @@ __global__ void bn_relu_bwd_kernel(const T* __restrict__ X, const T* __restrict_
     const int c0 = (int)((id * 8) % C);
     float x[8], y[8], dy[8], o[8];
     load8<T>(X + id * 8, x);
-    load8<T>(Y + id * 8, y);
+    if (Y) load8<T>(Y + id * 8, y);
     load8<T>(dY + id * 8, dy);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = c0 + k;
         const float mean = mean_rstd[2 * c], rstd = mean_rstd[2 * c + 1];
-        const float g = y[k] > 0.f ? dy[k] : 0.f;
+        const float g = (!Y || y[k] > 0.f) ? dy[k] : 0.f;
         const float xh = (x[k] - mean) * rstd;
         o[k] = gamma[c] * rstd * (g - sums[2 * c + 1] * inv_n - xh * sums[2 * c] * inv_n);
     }
@@ -380,13 +381,23 @@ extern "C" int pseld_bn_relu_fwd(int dtype, const void* X, const float* scale_sh
     PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_fwd: C must be a multiple of 8");
     const long total = rows * C / 8;
     CNN_DISPATCH("bn_relu_fwd", hipLaunchKernelGGL(bn_relu_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)X,
-                                                   scale_shift, (T*)Y, C, total));
+                                                   scale_shift, (T*)Y, C, total, 0.f));
+}
+/* y = x*scale + shift without the ReLU (the Conformer's BatchNorm1d, convolution.py:129); its backward is
+ * pseld_bn_relu_bwd with Y = NULL */
+extern "C" int pseld_bn_affine_fwd(int dtype, const void* X, const float* scale_shift, void* Y, long rows, int C, void* stream) {
+    PSELD_CHECK_ARG(X && scale_shift && Y && rows > 0 && C > 0, "bn_affine_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    PSELD_CHECK_ARG(C % 8 == 0, "bn_affine_fwd: C must be a multiple of 8");
+    const long total = rows * C / 8;
+    CNN_DISPATCH("bn_affine_fwd", hipLaunchKernelGGL(bn_relu_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)X,
+                                                     scale_shift, (T*)Y, C, total, -INFINITY));
 }
 /* backward of y = relu(bn(x)): dX, dgamma (+)=, dbeta (+)= (train-mode batch statistics) */
 extern "C" int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd,
                                  const float* gamma, void* dX, float* dgamma, float* dbeta, long rows, int C, float* workspace,
                                  long workspace_bytes, void* stream) {
-    PSELD_CHECK_ARG(X && Y && dY && mean_rstd && gamma && dX && dgamma && dbeta && workspace, "bn_relu_bwd: null pointer");
+    PSELD_CHECK_ARG(X && dY && mean_rstd && gamma && dX && dgamma && dbeta && workspace, "bn_relu_bwd: null pointer");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn_relu_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int nb = pseld_cdiv(rows, CNN_ROWS_PER_BLOCK);

@@ -7,6 +7,7 @@ import torch
 from .components.htsat import SwinEncoder, TscamHead
 from .components.passt import FcTanhHead, PasstEncoder
 from .components.crnn import ConvEncoder
+from .components.conformer import ConformerDecoder
 from .. import ops
 from .components.seld_net import HTSATNetBase
 
@@ -183,24 +184,33 @@ class PASST(HTSATNetBase):
 class CRNN(HTSATNetBase):
     """models/accdoa.py:12-95: scalar BatchNorms -> CNN8 / CNN12 (the PANNs CNN14 conv stack) -> frequency mean ->
     decoder -> 'repeat' x8 interpolation + 10-frame mean -> Linear -> tanh. Built on the MI355X path with
-    `cfg.model.decoder = None` (nn.Identity in the reference, model_utilities.py:260-261); the GRU / Conformer /
-    Transformer decoders are not built yet and raise."""
+    `cfg.model.decoder` = 'conformer' (configs/model/crnn.yaml:5; ConformerBlocks, model_utilities.py:254-255) or None
+    (nn.Identity, :260-261); the GRU / Transformer decoders are not built yet and raise."""
     out_key = 'accdoa'
     tracks_axes = 3
+    decoder_prefix = 'decoder.decoder.'          # Decoder(...).decoder = ConformerBlocks
+    forced_decoder_layers = None
 
     def __init__(self, cfg, num_classes, in_channels=7, encoder='CNN8', pretrained_path=None, audioset_pretrain=True,
                  num_features=[32, 64, 128, 256]):
         super().__init__()
         model = cfg.model if hasattr(cfg, 'model') else cfg.get('model', {})
         decoder = (model.decoder if hasattr(model, 'decoder') else model.get('decoder')) if model is not None else None
-        if decoder is not None:
+        if self.forced_decoder_layers is not None:
+            decoder, n_layers = 'conformer', self.forced_decoder_layers
+        else:
+            n_layers = (model.num_decoder_layers if hasattr(model, 'num_decoder_layers') else model.get('num_decoder_layers', 2)) \
+                if model is not None else 2
+        if decoder not in (None, 'conformer'):
             raise NotImplementedError(f"decoder '{decoder}' (model_utilities.py:245-269) is not built on the MI355X path yet; "
-                                      "set model.decoder: null")
+                                      "set model.decoder: conformer or null")
         self.num_classes = num_classes
         self.interpolate_time_ratio = 2 ** 3
         self._init_common(cfg, in_channels)
         self.conv_enc = ConvEncoder(self.arena, 'convs.', in_channels, encoder, list(num_features))
         self.num_features = list(num_features)
+        self.dec_blocks = ConformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers) \
+            if decoder == 'conformer' else None
         self.head = FcTanhHead(self.arena, 'fc.', self.num_features[-1], num_classes * self.tracks_axes)
         self._finish_init()
         self._taps = None
@@ -234,7 +244,7 @@ class CRNN(HTSATNetBase):
         self.shadow_trusted = False
 
     def _encoders(self):
-        return [self.conv_enc]
+        return [self.conv_enc] + ([self.dec_blocks] if self.dec_blocks is not None else [])
 
     def _materialize(self, device):
         fresh = self._materialized_on != device
@@ -242,7 +252,8 @@ class CRNN(HTSATNetBase):
         if fresh:
             from .components.seld_net import _get
             self._bn_bufs = {}
-            for name in self.conv_enc.static_buffers():
+            names = [n for e in self._encoders() for n in e.static_buffers()]
+            for name in names:
                 node = _get(self, name.rsplit('.', 1)[0])
                 leaf = name.rsplit('.', 1)[1]
                 t = node._buffers[leaf].detach().to(device)
@@ -264,19 +275,24 @@ class CRNN(HTSATNetBase):
         x0 = ops.cnn_input(x, scale_shift, dt, self.conv_enc.cin_p)
         enc, s_enc = self.conv_enc.forward(x0, B, T, F, dt, training, self._bn_bufs)
         n_in = s_enc['T_out']
+        s_dec = None
+        if self.dec_blocks is not None:
+            enc, s_dec = self.dec_blocks.forward(enc, B, n_in, training, self._bn_bufs)
         if n_in * self.interpolate_time_ratio != self.tgt_output_frames * self.pred_res:
             raise NotImplementedError(f"{n_in} encoder frames x {self.interpolate_time_ratio} do not cover "
                                       f"{self.tgt_output_frames} x {self.pred_res} output frames")
         taps = self._pool(x.device, n_in)
         pooled = ops.rows_pool_fwd(enc, taps, B)
         y, s_head = self.head.forward(pooled, B)
-        return y, dict(feat=x, mean_rstd=mean_rstd, enc=s_enc, head=s_head, taps=taps, B=B)
+        return y, dict(feat=x, mean_rstd=mean_rstd, enc=s_enc, dec=s_dec, head=s_head, taps=taps, B=B)
 
     def _backward_impl(self, saved, douts, on_range_done=None):
         dy = douts[0] if isinstance(douts, (tuple, list)) else douts
         B, dt = saved['B'], self.compute_dtype
         dpooled = self.head.backward(dy, saved['head'], dt)
         denc = ops.rows_pool_bwd(dpooled, saved['taps'], B)
+        if saved['dec'] is not None:
+            denc = self.dec_blocks.backward(denc, saved['dec'], B)
         dx0 = self.conv_enc.backward(denc, saved['enc'], B, dt)
         dw, db = self._bn_grads()
         ops.cnn_input_bwd(saved['feat'], saved['mean_rstd'], dx0, dw, db)
@@ -296,4 +312,7 @@ class _NotBuilt:
                                   "(SURVEY.md §8 rows a16/a17); use backbone=HTSAT")
 
 
-ConvConformer = _NotBuilt
+class ConvConformer(CRNN):
+    """models/accdoa.py:98-104: CRNN whose decoder is replaced by ConformerBlocks(num_layers=2) (keys `decoder.layers.*`)."""
+    decoder_prefix = 'decoder.'
+    forced_decoder_layers = 2

@@ -252,6 +252,16 @@ def default_init(name, shape):
         torch.nn.init.trunc_normal_(t, std=.02)
     elif name.startswith('stitch'):
         t.uniform_(0.1, 0.9)
+    elif '.sequential.' in name and 'layers.' in name:                 # Conformer decoder (conformer/modules.py:41-47, attention.py:69-70)
+        if len(shape) == 1 and '.conv.bias' in name:
+            fan_in = shape[0] // 2 if '.2.conv.' in name else shape[0]
+            t.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+        elif len(shape) == 1:
+            t.fill_(1.0 if leaf == 'weight' else 0.0)
+        elif '.conv.weight' in name:
+            torch.nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+        else:
+            torch.nn.init.xavier_uniform_(t)
     elif 'token' in name or 'pos_embed' in name:                       # passt.py:139-149,201-207
         torch.nn.init.trunc_normal_(t, std=.02)
     elif 'norm' in name or name.startswith('scalar') or '.head.0.' in name or '.bn1.' in name or '.bn2.' in name:

@@ -1,4 +1,4 @@
-"""Multi-ACCDOA networks on MI355X — mirror of the reference's `models/multi_accdoa.py` (HTSAT :29-44, PASST :46-54):
+"""Multi-ACCDOA networks on MI355X — mirror of the reference's `models/multi_accdoa.py` (CRNN :5-16, ConvConformer :18-27, HTSAT :29-44, PASST :46-54):
 the ACCDOA net with a 3 tracks x 3 axes x C head and output key 'multi_accdoa'."""
 from . import accdoa
 
@@ -18,4 +18,6 @@ class CRNN(accdoa.CRNN):
     tracks_axes = 9
 
 
-ConvConformer = accdoa._NotBuilt
+class ConvConformer(accdoa.ConvConformer):
+    out_key = 'multi_accdoa'
+    tracks_axes = 9

@@ -652,3 +652,118 @@ def bn2d_finalize(sums, count, weight, bias, running_mean, running_var, num_batc
                                              int(training), _lib.stream_ptr())
     _lib.check(rc, "pseld_bn_scalar_finalize")
     return mean_rstd, scale_shift
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Conformer decoder glue (csrc/conformer.hip)
+def bn_affine_fwd(X, scale_shift):
+    _chk(X, scale_shift)
+    Y = torch.empty_like(X)
+    _lib.check(_lib.lib().pseld_bn_affine_fwd(dtype_code(X), _lib.ptr(X), _lib.ptr(scale_shift), _lib.ptr(Y), X.shape[0], X.shape[1],
+                                              _lib.stream_ptr()), "pseld_bn_affine_fwd")
+    return Y
+
+
+def bn_affine_bwd(X, dY, mean_rstd, gamma, dgamma, dbeta):
+    _chk(X, dY, mean_rstd, gamma, dgamma, dbeta)
+    rows, C = X.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_bn2d_workspace(rows, C), X.device)
+    dX = torch.empty_like(X)
+    _lib.check(L.pseld_bn_relu_bwd(dtype_code(X), _lib.ptr(X), None, _lib.ptr(dY), _lib.ptr(mean_rstd), _lib.ptr(gamma),
+                                   _lib.ptr(dX), _lib.ptr(dgamma), _lib.ptr(dbeta), rows, C, _lib.ptr(ws), ws.numel() * 4,
+                                   _lib.stream_ptr()), "pseld_bn_relu_bwd")
+    return dX
+
+
+def axpby(x, y, a, b, out=None):
+    """out = a*x + b*y"""
+    _chk(x, y, out)
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().pseld_axpby(dtype_code(x), _lib.ptr(x), _lib.ptr(y), _lib.ptr(out), float(a), float(b), x.numel(),
+                                      _lib.stream_ptr()), "pseld_axpby")
+    return out
+
+
+def mul(x, m, scale=1.0):
+    """y = x * m * scale (dropout with a 0/1 keep mask)"""
+    _chk(x, m)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pseld_mul(dtype_code(x), _lib.ptr(x), _lib.ptr(m), _lib.ptr(y), float(scale), x.numel(), _lib.stream_ptr()),
+               "pseld_mul")
+    return y
+
+
+def swish_fwd(u):
+    _chk(u)
+    y = torch.empty_like(u)
+    _lib.check(_lib.lib().pseld_swish_fwd(dtype_code(u), _lib.ptr(u), _lib.ptr(y), u.numel(), _lib.stream_ptr()), "pseld_swish_fwd")
+    return y
+
+
+def swish_bwd(u, dy):
+    _chk(u, dy)
+    du = torch.empty_like(u)
+    _lib.check(_lib.lib().pseld_swish_bwd(dtype_code(u), _lib.ptr(u), _lib.ptr(dy), _lib.ptr(du), u.numel(), _lib.stream_ptr()),
+               "pseld_swish_bwd")
+    return du
+
+
+def glu_fwd(x):
+    _chk(x)
+    M, D2 = x.shape
+    y = torch.empty((M, D2 // 2), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().pseld_glu_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(y), M, D2 // 2, _lib.stream_ptr()), "pseld_glu_fwd")
+    return y
+
+
+def glu_bwd(x, dy):
+    _chk(x, dy)
+    M, D2 = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().pseld_glu_bwd(dtype_code(x), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), M, D2 // 2, _lib.stream_ptr()),
+               "pseld_glu_bwd")
+    return dx
+
+
+def dwconv_fwd(x, w, B, T, flip=False):
+    """depthwise Conv1d over time on [B*T, D] rows, w f32 [D, K]; flip: the input gradient."""
+    _chk(x, w)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pseld_dwconv_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B, T, x.shape[1], w.shape[1], int(flip),
+                                           _lib.stream_ptr()), "pseld_dwconv_fwd")
+    return y
+
+
+def dwconv_wgrad(x, dy, dw, B, T):
+    _chk(x, dy, dw)
+    D, K = dw.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_dwconv_wgrad_workspace(B, T, D, K), x.device)
+    _lib.check(L.pseld_dwconv_wgrad(dtype_code(x), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, T, D, K, _lib.ptr(ws), ws.numel() * 4,
+                                    _lib.stream_ptr()), "pseld_dwconv_wgrad")
+
+
+def relattn_fwd(q, k, v, pos, u_bias, v_bias, B, T, heads, mask=None, mask_scale=1.0):
+    """RelativeMultiHeadAttention core: returns (context [B*T, D], attn f32 [B, heads, T, T])."""
+    _chk(q, k, v, pos, u_bias, v_bias, mask)
+    D = q.shape[1]
+    out = torch.empty_like(q)
+    attn = torch.empty((B, heads, T, T), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().pseld_relattn_fwd(dtype_code(q), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(pos), _lib.ptr(u_bias),
+                                            _lib.ptr(v_bias), _lib.ptr(mask), float(mask_scale), _lib.ptr(out),
+                                            _lib.ptr(attn), B, T, D, heads, _lib.stream_ptr()), "pseld_relattn_fwd")
+    return out, attn
+
+
+def relattn_bwd(q, k, v, pos, u_bias, v_bias, attn, dout, dpos, du_bias, dv_bias, B, T, heads, mask=None, mask_scale=1.0):
+    _chk(q, k, v, pos, u_bias, v_bias, attn, dout, dpos, du_bias, dv_bias, mask)
+    D = q.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.pseld_relattn_bwd_workspace(B, T, D), q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    _lib.check(L.pseld_relattn_bwd(dtype_code(q), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(pos), _lib.ptr(u_bias), _lib.ptr(v_bias),
+                                   _lib.ptr(mask), float(mask_scale), _lib.ptr(attn), _lib.ptr(dout), _lib.ptr(dq),
+                                   _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(dpos), _lib.ptr(du_bias), _lib.ptr(dv_bias), B, T, D, heads,
+                                   _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "pseld_relattn_bwd")
+    return dq, dk, dv

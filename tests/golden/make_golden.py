@@ -387,8 +387,84 @@ def gen_crnn():
     save('crnn.npz', **out)
 
 
+def gen_conformer():
+    """CRNN(encoder='CNN12', cfg.model.decoder='conformer', 1 layer — configs/model/crnn.yaml) and ConvConformer (2 layers).
+    Dropout: eval (identity), train with p forced to 0, and train with torch.nn.functional.dropout patched to the closed-form
+    keep mask of oracle/crnn.py:formula_keep_mask (dropout ACTIVE, reproducible). Gradients from FLOAT64 runs."""
+    import torch.nn.functional as Fn
+    C = 3
+    cfgc = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'),
+                      model=R.AttrDict(decoder='conformer', num_decoder_layers=1), adapt=dict())
+    out = {}
+    D = CRNN_TINY[-1]
+    sd = oc.add_conformer(oc.random_state('multi_accdoa', C, 7, 'CNN12', CRNN_TINY, seed=0), D, 1, seed=3)
+    x = oc.random_features(2, seed=1)
+    net = multi_accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    net.eval()
+    with torch.no_grad():
+        out['eval'] = net(x.clone())['multi_accdoa'].numpy()
+
+    real_dropout = Fn.dropout
+
+    def formula_dropout(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        return input * oc.formula_keep_mask(input.shape).to(input.dtype) / (1.0 - p)
+
+    def grads(net64, xin, tag):
+        net64.train()
+        pred = net64(xin.double().clone())
+        lab = synth.formula_adpit_label(xin.shape[0], 100, C)
+        ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab.double()})
+        ld['loss_all'].backward()
+        out[tag + '_pred'] = pred['multi_accdoa'].detach().numpy()
+        out[tag + '_loss'] = ld['loss_all'].item()
+        names, norms, heads = [], [], []
+        for n, p in net64.named_parameters():
+            if n.startswith('scalar.'):
+                continue
+            names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+        out[tag + '_grad_names'] = np.array(names)
+        out[tag + '_grad_norms'] = np.array(norms)
+        out[tag + '_grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+        sdn = net64.state_dict()
+        k = 'decoder.decoder.layers.0.sequential.2.module.sequential.5.'
+        if k + 'running_var' in sdn:
+            out[tag + '_bn1d_running_var'] = sdn[k + 'running_var'].numpy()
+            out[tag + '_bn1d_running_mean'] = sdn[k + 'running_mean'].numpy()
+
+    def fresh64(cls, state):
+        n = cls(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY).double()
+        n.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in state.items()})
+        return n
+
+    Fn.dropout = formula_dropout
+    try:
+        grads(fresh64(multi_accdoa.CRNN, sd), x, 'drop')             # dropout active (p = 0.1), formula masks
+    finally:
+        Fn.dropout = real_dropout
+    net64 = fresh64(multi_accdoa.CRNN, sd)
+    for m in net64.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    grads(net64, x, 'p0')
+    # ConvConformer: two layers under `decoder.layers.*`
+    sd2 = oc.add_conformer(oc.random_state('multi_accdoa', C, 7, 'CNN12', CRNN_TINY, seed=0), D, 2, seed=4, pre='decoder.')
+    net = multi_accdoa.ConvConformer(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY)
+    missing, unexpected = net.load_state_dict(sd2, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out['cc_state_keys'] = np.array(list(net.state_dict().keys()))
+    net.eval()
+    with torch.no_grad():
+        out['cc_eval'] = net(x.clone())['multi_accdoa'].numpy()
+    save('conformer.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -397,3 +473,4 @@ if __name__ == '__main__':
     if 'sampler' in which: gen_sampler()
     if 'passt' in which: gen_passt()
     if 'crnn' in which: gen_crnn()
+    if 'conformer' in which: gen_conformer()

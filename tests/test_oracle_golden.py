@@ -269,3 +269,49 @@ def test_crnn_full_size_golden():
     with torch.no_grad():
         y = oc.accdoa_crnn_forward(oh.formula_features(1), oc.formula_state('accdoa', 13, 7, 'CNN12', CRNN_FULL), 'CNN12')['accdoa']
     close(y, g['full_eval'], 5e-5)
+
+
+def _conformer_case(g, tag, dropout_p, masks, tol=1e-8):
+    from oracle import crnn as oc
+    D = CRNN_TINY[-1]
+    sd = oc.add_conformer(oc.random_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY, seed=0), D, 1, seed=3)
+    p = {k: (v.double().clone().requires_grad_('running' not in k and not k.endswith('.pe')) if v.is_floating_point() else v)
+         for k, v in sd.items()}
+    upd = {}
+    pred = oc.accdoa_crnn_forward(oc.random_features(2, seed=1).double(), p, 'CNN12', training=True, bn_update=upd, key='multi_accdoa',
+                                  decoder='conformer', num_decoder_layers=1, dropout_p=dropout_p, masks=masks)
+    assert np.abs(pred['multi_accdoa'].detach().numpy() - g[tag + '_pred']).max() < 1e-10
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3).double()})
+    assert abs(ld['loss_all'].item() - float(g[tag + '_loss'])) < 1e-10
+    ld['loss_all'].backward()
+    k = 'decoder.decoder.layers.0.sequential.2.module.sequential.5.'
+    assert np.abs(upd[k + 'running_var'].numpy() - g[tag + '_bn1d_running_var']).max() < 1e-10
+    assert np.abs(upd[k + 'running_mean'].numpy() - g[tag + '_bn1d_running_mean']).max() < 1e-10
+    for n, norm, head in zip(g[tag + '_grad_names'], g[tag + '_grad_norms'], g[tag + '_grad_heads']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= tol * max(norm, 1e-6) + 1e-14, n
+        kk = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:kk].numpy() - head[:kk]).max() <= tol * max(np.abs(head).max(), 1e-6) + 1e-14, n
+
+
+def test_conformer_decoder_golden():
+    """oracle/crnn.py conformer_blocks against the reference's CRNN(decoder='conformer') (configs/model/crnn.yaml) and
+    ConvConformer: eval output, float64 train output / loss / gradients / BatchNorm1d running statistics with dropout
+    off (p = 0) and with dropout ACTIVE (p = 0.1, torch.nn.functional.dropout patched to the closed-form keep mask)."""
+    from oracle import crnn as oc
+    g = gold('conformer.npz')
+    D = CRNN_TINY[-1]
+    x = oc.random_features(2, seed=1)
+    sd = oc.add_conformer(oc.random_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY, seed=0), D, 1, seed=3)
+    assert set(sd.keys()) == set(str(k) for k in g['state_keys'])
+    with torch.no_grad():
+        y = oc.accdoa_crnn_forward(x.clone(), sd, 'CNN12', key='multi_accdoa', decoder='conformer', num_decoder_layers=1)
+        close(y['multi_accdoa'], g['eval'], 5e-5)
+        sd2 = oc.add_conformer(oc.random_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY, seed=0), D, 2, seed=4, pre='decoder.')
+        assert set(sd2.keys()) == set(str(k) for k in g['cc_state_keys'])
+        y = oc.accdoa_crnn_forward(x.clone(), sd2, 'CNN12', key='multi_accdoa', decoder='conformer', num_decoder_layers=2,
+                                   decoder_prefix='decoder.')
+        close(y['multi_accdoa'], g['cc_eval'], 5e-5)
+    assert abs(float(g['drop_loss']) - float(g['p0_loss'])) > 1e-6          # the patched dropout really was active
+    _conformer_case(g, 'p0', 0.0, None)
+    _conformer_case(g, 'drop', 0.1, 'formula')
