@@ -42,13 +42,13 @@ def test_glue_kernels(dev, dtype, tol):
     m = (torch.rand(M, D, device=dev) > 0.1).to(dtype)
     assert rel(ops.mul(x, m, 1 / 0.9), x.float() * m.float() / 0.9) < tol
     # Swish
-    xr = x.float().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
     sr = xr * torch.sigmoid(xr)
     sr.backward(y.float())
     assert rel(ops.swish_fwd(x), sr) < tol and rel(ops.swish_bwd(x, y), xr.grad) < tol
     # GLU over the channel halves
     x2 = torch.randn(M, 2 * D, device=dev).to(dtype)
-    x2r = x2.float().requires_grad_(True)
+    x2r = x2.float().clone().requires_grad_(True)
     gr = F.glu(x2r, dim=1)
     gr.backward(y.float())
     assert rel(ops.glu_fwd(x2), gr) < tol and rel(ops.glu_bwd(x2, y), x2r.grad) < tol
