@@ -20,7 +20,7 @@ import torch  # noqa: E402
 
 CLIP_SECONDS, CHUNKS_PER_CLIP, FS, CLASSES = 60, 6, 24000, 170
 GFLOP_PER_CHUNK_TRAIN = 37.61       # 37.026 (net fwd+bwd) + 0.583 (features)
-GFLOP_PER_CHUNK_TRAIN_CRNN = 282.0   # 3 x 93.8 (conv stack + fc of the CNN14-Conformer probe's 94.94 without the Conformer) + features
+GFLOP_PER_CHUNK_TRAIN_CRNN = 285.4   # 3 x 94.94 (SURVEY §6 probe, CNN14-Conformer forward) + features
 GFLOP_PER_CHUNK_TRAIN_EINV2 = 72.28  # 3 x 23.90 (SURVEY §6 probe, EINV2-HTSAT forward) + features
 GFLOP_PER_CHUNK_TRAIN_PASST = 207.9  # 3 x (patch 1.65 + 7 blocks x (12 E^2 N + 4 N^2 E) = 67.8) + features; N=602, E=768
 PEAK_BF16_TFLOPS = 2516.6           # dense MFMA bf16 peak, MI355X_MICROARCH.md
@@ -212,7 +212,7 @@ def main():
         from pseldnets_amd.models import einv2
         net = einv2.HTSAT(cfg, CLASSES, 7, pretrained_path=None)             # einv2.py:189-327: SED + DOA encoders
     elif args.backbone == 'crnn':
-        cfg['model'] = AttrDict(decoder=None, num_decoder_layers=1)          # Identity decoder (Conformer not built yet)
+        cfg['model'] = AttrDict(decoder='conformer', num_decoder_layers=1)   # configs/model/crnn.yaml:5-6
         net = multi_accdoa.CRNN(cfg, CLASSES, 7, encoder='CNN12', pretrained_path=None,
                                 num_features=[64, 128, 256, 512, 1024, 2048])   # configs/model/crnn.yaml kwargs
     else:
@@ -269,7 +269,7 @@ def main():
     clips_per_s = args.clips * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
-    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'crnn': 'CNN14 (CRNN/CNN12, Identity decoder)'}[args.backbone]
+    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'crnn': 'CNN14-Conformer (CRNN: CNN12 + 1 Conformer block)'}[args.backbone]
     gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2,
                    'crnn': GFLOP_PER_CHUNK_TRAIN_CRNN}[args.backbone]
     out = {
@@ -278,7 +278,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
                                f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
-                               f"drop_path {0.0 if args.backbone in ('passt', 'crnn') else 0.1}, BN train mode, no augmentation",
+                               f"{'dropout 0.1' if args.backbone == 'crnn' else 'drop_path 0.0' if args.backbone == 'passt' else 'drop_path 0.1'}, BN train mode, no augmentation",
                    "global_clips": args.clips * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
     }

@@ -123,6 +123,105 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     if (wv == 0 && d < D) part[((long)blockIdx.z * D + d) * K + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+
+// ---- the kernel-31 case (ConformerBlocks' default): one workgroup per (sample, 128 channels) keeps the whole padded
+// sequence tile in LDS and the 31 taps of a thread's two channels in registers ----------------------------------------------
+constexpr int DW_K = 31, DW_CH = 128;
+template <typename T> __device__ __forceinline__ void pair_read(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void pair_read<float>(const float* p, float& a, float& b) { const float2 v = *(const float2*)p; a = v.x; b = v.y; }
+template <> __device__ __forceinline__ void pair_read<bf16_t>(const bf16_t* p, float& a, float& b) {
+    const unsigned u = *(const unsigned*)p;
+    a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void pair_write(T* p, float a, float b);
+template <> __device__ __forceinline__ void pair_write<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+template <> __device__ __forceinline__ void pair_write<bf16_t>(bf16_t* p, float a, float b) {
+    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v; v[0] = (bf16_t)a; v[1] = (bf16_t)b;
+    *(bf16x2*)p = v;
+}
+// rows r <-> time r - lead of sample b, channels c0..c0+127, zero outside the sequence / channel range
+template <typename T>
+__device__ __forceinline__ void dw_stage(T* dst, const T* src, int b, int Tn, int D, int c0, int lead, int rows, int tid) {
+    for (int e = tid; e < rows * (DW_CH / 8); e += 256) {
+        const int r = e >> 4, o = e & 15, t = r - lead;
+        Vec8<T> v = {};
+        if (t >= 0 && t < Tn && c0 + o * 8 < D) v = *(const Vec8<T>*)(src + ((long)b * Tn + t) * D + c0 + o * 8);
+        *(Vec8<T>*)(dst + r * DW_CH + o * 8) = v;
+    }
+}
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv31_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int Tn, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = (T*)smem;                                   // [Tn + 30][128]
+    const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * DW_CH;
+    dw_stage<T>(xs, x, b, Tn, D, c0, DW_K / 2, Tn + DW_K - 1, tid);
+    const int cp = tid & 63, lane = tid >> 6, ch = c0 + 2 * cp;
+    float w0[DW_K], w1[DW_K];
+#pragma unroll
+    for (int k = 0; k < DW_K; ++k) {
+        const int kk = FLIP ? DW_K - 1 - k : k;
+        w0[k] = ch < D ? w[ch * DW_K + kk] : 0.f;
+        w1[k] = ch + 1 < D ? w[(ch + 1) * DW_K + kk] : 0.f;
+    }
+    __syncthreads();
+    if (ch >= D) return;
+    for (int t = lane; t < Tn; t += 4) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < DW_K; ++k) {
+            float x0, x1;
+            pair_read<T>(xs + (t + k) * DW_CH + 2 * cp, x0, x1);
+            a0 = fmaf(w0[k], x0, a0); a1 = fmaf(w1[k], x1, a1);
+        }
+        pair_write<T>(y + ((long)b * Tn + t) * D + ch, a0, a1);
+    }
+}
+// dw partial of one sample: part[b][d][k] = sum_t dy[b,t,d] * x[b, t + k - 15, d]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv31_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                                             int Tn, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = (T*)smem;                                   // [Tn + 30][128]
+    T* ds = xs + (Tn + DW_K - 1) * DW_CH;               // [Tn][128]
+    const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * DW_CH;
+    dw_stage<T>(xs, x, b, Tn, D, c0, DW_K / 2, Tn + DW_K - 1, tid);
+    dw_stage<T>(ds, dy, b, Tn, D, c0, 0, Tn, tid);
+    __syncthreads();
+    const int cp = tid & 63, lane = tid >> 6;
+    float a0[DW_K], a1[DW_K];
+#pragma unroll
+    for (int k = 0; k < DW_K; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+    for (int t = lane; t < Tn; t += 4) {
+        float d0, d1;
+        pair_read<T>(ds + t * DW_CH + 2 * cp, d0, d1);
+#pragma unroll
+        for (int k = 0; k < DW_K; ++k) {
+            float x0, x1;
+            pair_read<T>(xs + (t + k) * DW_CH + 2 * cp, x0, x1);
+            a0[k] = fmaf(d0, x0, a0[k]); a1[k] = fmaf(d1, x1, a1[k]);
+        }
+    }
+    __syncthreads();
+    float* red = (float*)smem;                          // [4][128][31]
+#pragma unroll
+    for (int k = 0; k < DW_K; ++k) {
+        red[(lane * DW_CH + 2 * cp) * DW_K + k] = a0[k];
+        red[(lane * DW_CH + 2 * cp + 1) * DW_K + k] = a1[k];
+    }
+    __syncthreads();
+    for (int e = tid; e < DW_CH * DW_K; e += 256) {
+        const int c = e / DW_K;
+        if (c0 + c < D)
+            part[((long)b * D + c0) * DW_K + e] = red[e] + red[DW_CH * DW_K + e] + red[2 * DW_CH * DW_K + e] + red[3 * DW_CH * DW_K + e];
+    }
+}
+template <typename T> size_t dw31_lds(int Tn, bool wgrad) {
+    const size_t tiles = (size_t)((Tn + DW_K - 1) + (wgrad ? Tn : 0)) * DW_CH * sizeof(T);
+    const size_t red = wgrad ? (size_t)4 * DW_CH * DW_K * sizeof(float) : 0;
+    return tiles > red ? tiles : red;
+}
+
 }  // namespace
 
 #define CF_DISPATCH(name, CALL)                                                   \
@@ -174,18 +273,63 @@ extern "C" int pseld_dwconv_fwd(int dtype, const void* x, const float* w, void* 
     PSELD_CHECK_ARG(x && w && y && B > 0 && Tn > 0 && D % 8 == 0 && K % 2 == 1, "dwconv_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * Tn * (D / 8);
+    if (K == DW_K && D % 2 == 0) {
+        const dim3 grid(pseld_cdiv(D, DW_CH), B);
+        if (dtype == PSELD_BF16 && dw31_lds<bf16_t>(Tn, false) <= 160 * 1024) {
+            const size_t lds = dw31_lds<bf16_t>(Tn, false);
+            static bool set = false;
+            if (!set) {
+                (void)hipFuncSetAttribute((const void*)dwconv31_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)dwconv31_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                set = true;
+            }
+            if (flip) hipLaunchKernelGGL((dwconv31_kernel<bf16_t, true>), grid, dim3(256), lds, s, (const bf16_t*)x, w, (bf16_t*)y, Tn, D);
+            else hipLaunchKernelGGL((dwconv31_kernel<bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, w, (bf16_t*)y, Tn, D);
+            PSELD_LAUNCH_CHECK("dwconv");
+            return PSELD_OK;
+        }
+        if (dtype == PSELD_F32 && dw31_lds<float>(Tn, false) <= 160 * 1024) {
+            const size_t lds = dw31_lds<float>(Tn, false);
+            static bool set = false;
+            if (!set) {
+                (void)hipFuncSetAttribute((const void*)dwconv31_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)dwconv31_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                set = true;
+            }
+            if (flip) hipLaunchKernelGGL((dwconv31_kernel<float, true>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, Tn, D);
+            else hipLaunchKernelGGL((dwconv31_kernel<float, false>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, Tn, D);
+            PSELD_LAUNCH_CHECK("dwconv");
+            return PSELD_OK;
+        }
+    }
     if (flip) { CF_DISPATCH("dwconv", hipLaunchKernelGGL((dwconv_kernel<T, true>), dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)x, w, (T*)y, Tn, D, K, total)); }
     CF_DISPATCH("dwconv", hipLaunchKernelGGL((dwconv_kernel<T, false>), dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)x, w, (T*)y, Tn, D, K, total));
 }
 static const int DW_ROWS = 2048;
 extern "C" long pseld_dwconv_wgrad_workspace(int B, int Tn, int D, int K) {
-    return (long)pseld_cdiv((long)B * Tn, DW_ROWS) * D * K * (long)sizeof(float);
+    const long slabs = pseld_cdiv((long)B * Tn, DW_ROWS) > B ? pseld_cdiv((long)B * Tn, DW_ROWS) : B;      // tiled path: one slab per sample
+    return slabs * D * K * (long)sizeof(float);
 }
 extern "C" int pseld_dwconv_wgrad(int dtype, const void* x, const void* dy, float* dw, int B, int Tn, int D, int K,
                                   float* workspace, long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(x && dy && dw && workspace && B > 0 && Tn > 0 && D > 0 && K % 2 == 1, "dwconv_wgrad: bad argument");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_dwconv_wgrad_workspace(B, Tn, D, K), "dwconv_wgrad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    if (K == DW_K && D % 2 == 0 && (dtype == PSELD_BF16 ? dw31_lds<bf16_t>(Tn, true) : dw31_lds<float>(Tn, true)) <= 160 * 1024) {
+        const dim3 grid31(pseld_cdiv(D, DW_CH), B);
+        if (dtype == PSELD_BF16) {
+            static bool set = false;
+            if (!set) { (void)hipFuncSetAttribute((const void*)dwconv31_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+            hipLaunchKernelGGL(dwconv31_wgrad_kernel<bf16_t>, grid31, dim3(256), dw31_lds<bf16_t>(Tn, true), s, (const bf16_t*)x, (const bf16_t*)dy, workspace, Tn, D);
+        } else if (dtype == PSELD_F32) {
+            static bool set = false;
+            if (!set) { (void)hipFuncSetAttribute((const void*)dwconv31_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+            hipLaunchKernelGGL(dwconv31_wgrad_kernel<float>, grid31, dim3(256), dw31_lds<float>(Tn, true), s, (const float*)x, (const float*)dy, workspace, Tn, D);
+        } else { pseld_set_error("dwconv_wgrad: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+        pseld_reduce_slabs(workspace, dw, (long)D * K, B, (long)D * K, 0, s);
+        PSELD_LAUNCH_CHECK("dwconv_wgrad");
+        return PSELD_OK;
+    }
     const int nb = pseld_cdiv((long)B * Tn, DW_ROWS);
     const dim3 grid(pseld_cdiv(D, 64), K, nb);
     if (dtype == PSELD_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, workspace, B, Tn, D, K, DW_ROWS);
@@ -197,11 +341,18 @@ extern "C" int pseld_dwconv_wgrad(int dtype, const void* x, const void* dy, floa
 }
 
 // ---- relative-positional multi-head attention (attention.py:28-112) ------------------------------------------------------------
+// One workgroup (256 threads) per (sample, head); the sequence (<= 128 frames) is one 128 x 128 score tile. Every product
+// is register-tiled: thread (ti, tj) = (tid >> 4, tid & 15) owns the 8 x 8 outputs {ti + 16 r} x {tj + 16 c} (interleaved
+// rows / columns keep the LDS reads conflict-free), operand chunks come through LDS, and the two [128][129] fp32
+// matrices (scores / probabilities, raw positional scores and their gradients) stay in LDS for the whole kernel.
 namespace {
 
 constexpr int RA_TMAX = 128;       // sequence length limit (125 frames here)
-constexpr int RA_DC = 16;          // head-dim chunk staged in LDS
-constexpr int RA_NP = RA_TMAX * RA_TMAX / 256;
+constexpr int RA_LD = RA_TMAX + 1; // row stride of the LDS-resident matrices
+constexpr int RA_DC = 16;          // reduction chunk staged in LDS
+constexpr int RA_SLD = RA_DC + 1;  // row stride of a [128][16] staged chunk
+constexpr int RA_MAT = RA_TMAX * RA_LD;
+constexpr int RA_STG = RA_TMAX * RA_SLD;    // floats per staged chunk ([128][17]; a [16][128] chunk fits too)
 
 struct RelAttnArgs {
     const void *q, *k, *v, *mask, *dout;   // [B*T, D] (mask: [B, heads, T, T] 0/1 keep-mask, or null)
@@ -223,104 +374,202 @@ __device__ __forceinline__ bool rel_shift_src(int i, int j, int T, int& r, int& 
     c = flat - r * (T + 1) - 1;
     return c >= 0;
 }
+// its inverse: raw[r][c] is read by shifted[i][j] (false: by nobody — the first T - 1 entries fall off the front)
+__device__ __forceinline__ bool rel_shift_dst(int r, int c, int T, int& i, int& j) {
+    const int flat = r * (T + 1) + c + 1;
+    i = flat / T - 1;
+    j = flat - (i + 1) * T;
+    return i >= 0;
+}
+
+// rows [0, 128) x 16 columns d0.. of a [T][ld] matrix -> registers (zero outside T x ncols) -> S[128][17]
+template <typename T_>
+__device__ __forceinline__ void fetch_rows16(float (&r)[8], const T_* g, int ld, int T, int d0, int ncols, int tid) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int e = tid + 256 * n, row = e >> 4, dd = e & 15;
+        r[n] = (row < T && d0 + dd < ncols) ? to_f32<T_>(g[(long)row * ld + d0 + dd]) : 0.f;
+    }
+}
+__device__ __forceinline__ void put_rows16(float* S, const float (&r)[8], int tid) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { const int e = tid + 256 * n; S[(e >> 4) * RA_SLD + (e & 15)] = r[n]; }
+}
+// rows k0..k0+15 x columns c0..c0+127 of a [T][ld] matrix (+ a per-column bias) -> registers -> S[16][128]
+template <typename T_>
+__device__ __forceinline__ void fetch_cols128(float (&r)[8], const T_* g, int ld, int T, int k0, int c0, int ncols, const float* colbias,
+                                              int tid) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int e = tid + 256 * n, kk = e >> 7, col = e & 127;
+        const bool ok = k0 + kk < T && c0 + col < ncols;
+        r[n] = ok ? to_f32<T_>(g[(long)(k0 + kk) * ld + c0 + col]) + (colbias ? colbias[c0 + col] : 0.f) : 0.f;
+    }
+}
+__device__ __forceinline__ void put_cols128(float* S, const float (&r)[8], int tid) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) S[tid + 256 * n] = r[n];
+}
+__device__ __forceinline__ void zero_tile(float (&acc)[8][8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+}
+// acc[r][c] += sum_kk A(ti + 16 r, kk) * Bst[kk][tj + 16 c]; A(i, kk) = Mat[i][k0 + kk] or (TRANS) Mat[k0 + kk][i]
+template <bool TRANS>
+__device__ __forceinline__ void mat_times_chunk(float (&acc)[8][8], const float* Mat, const float* Bst, int k0, int ti, int tj) {
+#pragma unroll 4
+    for (int kk = 0; kk < RA_DC; ++kk) {
+        float a[8], b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = TRANS ? Mat[(k0 + kk) * RA_LD + ti + 16 * r] : Mat[(ti + 16 * r) * RA_LD + k0 + kk];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = Bst[kk * 128 + tj + 16 * c];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[r][c] = fmaf(a[r], b[c], acc[r][c]);
+    }
+}
+// out[ti + 16 r][c0 + tj + 16 c] = acc (rows < T, columns < ncols)
+template <typename TO>
+__device__ __forceinline__ void store_tile(TO* out, int ld, const float (&acc)[8][8], int T, int c0, int ncols, int ti, int tj) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = ti + 16 * r;
+        if (i >= T) continue;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int col = c0 + tj + 16 * c;
+            if (col < ncols) out[(long)i * ld + col] = from_f32<TO>(acc[r][c]);
+        }
+    }
+}
 
 template <typename T_>
 __global__ __launch_bounds__(256) void relattn_fwd_kernel(RelAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = a.T, hd = a.D / a.heads, LD = T + 1;
-    float* S = (float*)smem;                 // [T][LD] content, then probabilities
-    float* PR = S + T * LD;                  // [T][LD] raw positional scores
-    float* Qs = PR + T * LD;                 // [T][RA_DC + 1] x 3
-    float* Ks = Qs + T * (RA_DC + 1);
-    float* Ps = Ks + T * (RA_DC + 1);
-    const int tid = threadIdx.x, b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    const T_* q = (const T_*)a.q + (long)b * T * a.D + h * hd;
-    const T_* k = (const T_*)a.k + (long)b * T * a.D + h * hd;
-    const T_* v = (const T_*)a.v + (long)b * T * a.D + h * hd;
+    const int T = a.T, hd = a.D / a.heads;
+    float* S = (float*)smem;                 // [128][129] content scores, then probabilities (x dropout mask)
+    float* PR = S + RA_MAT;                  // [128][129] raw positional scores
+    float* Qs = PR + RA_MAT;                 // staged chunks
+    float* Ks = Qs + RA_STG;
+    float* Ps = Ks + RA_STG;
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const long base = (long)b * T * a.D + h * hd;
+    const T_* q = (const T_*)a.q + base;
+    const T_* k = (const T_*)a.k + base;
+    const T_* v = (const T_*)a.v + base;
     const float* p = a.pos + h * hd;
-    float accc[RA_NP], accp[RA_NP];
+    // content = (q + u) k^T and raw positional = (q + v) p^T over head-dim chunks
+    {
+        float accc[8][8], accp[8][8], rq[8], rk[8], rp[8];
+        zero_tile(accc); zero_tile(accp);
+        fetch_rows16<T_>(rq, q, a.D, T, 0, hd, tid);
+        fetch_rows16<T_>(rk, k, a.D, T, 0, hd, tid);
+        fetch_rows16<float>(rp, p, a.D, T, 0, hd, tid);
+        for (int d0 = 0; d0 < hd; d0 += RA_DC) {
+            __syncthreads();
+            put_rows16(Qs, rq, tid); put_rows16(Ks, rk, tid); put_rows16(Ps, rp, tid);
+            __syncthreads();
+            if (d0 + RA_DC < hd) {
+                fetch_rows16<T_>(rq, q, a.D, T, d0 + RA_DC, hd, tid);
+                fetch_rows16<T_>(rk, k, a.D, T, d0 + RA_DC, hd, tid);
+                fetch_rows16<float>(rp, p, a.D, T, d0 + RA_DC, hd, tid);
+            }
+#pragma unroll 2
+            for (int dd = 0; dd < RA_DC; ++dd) {
+                const float ub = d0 + dd < hd ? a.u_bias[h * hd + d0 + dd] : 0.f;
+                const float vb = d0 + dd < hd ? a.v_bias[h * hd + d0 + dd] : 0.f;
+                float qa[8], kb[8], pb[8];
 #pragma unroll
-    for (int n = 0; n < RA_NP; ++n) { accc[n] = 0.f; accp[n] = 0.f; }
-    for (int d0 = 0; d0 < hd; d0 += RA_DC) {
-        __syncthreads();
-        for (int e = tid; e < T * RA_DC; e += 256) {
-            const int row = e / RA_DC, dd = e - row * RA_DC;
-            const bool in = d0 + dd < hd;
-            Qs[row * (RA_DC + 1) + dd] = in ? to_f32<T_>(q[(long)row * a.D + d0 + dd]) : 0.f;
-            Ks[row * (RA_DC + 1) + dd] = in ? to_f32<T_>(k[(long)row * a.D + d0 + dd]) : 0.f;
-            Ps[row * (RA_DC + 1) + dd] = in ? p[(long)row * a.D + d0 + dd] : 0.f;
-        }
-        __syncthreads();
-        float ub[RA_DC], vb[RA_DC];
+                for (int r = 0; r < 8; ++r) qa[r] = Qs[(ti + 16 * r) * RA_SLD + dd];
 #pragma unroll
-        for (int dd = 0; dd < RA_DC; ++dd) {
-            const bool in = d0 + dd < hd;
-            ub[dd] = in ? a.u_bias[h * hd + d0 + dd] : 0.f;
-            vb[dd] = in ? a.v_bias[h * hd + d0 + dd] : 0.f;
-        }
+                for (int c = 0; c < 8; ++c) { kb[c] = Ks[(tj + 16 * c) * RA_SLD + dd]; pb[c] = Ps[(tj + 16 * c) * RA_SLD + dd]; }
 #pragma unroll
-        for (int n = 0; n < RA_NP; ++n) {
-            const int idx = tid + 256 * n;
-            if (idx < T * T) {
-                const int i = idx / T, j = idx - i * T;
-                float c = 0.f, pp = 0.f;
+                for (int r = 0; r < 8; ++r) {
+                    const float qu = qa[r] + ub, qv = qa[r] + vb;
 #pragma unroll
-                for (int dd = 0; dd < RA_DC; ++dd) {
-                    const float qv = Qs[i * (RA_DC + 1) + dd];
-                    c = fmaf(qv + ub[dd], Ks[j * (RA_DC + 1) + dd], c);
-                    pp = fmaf(qv + vb[dd], Ps[j * (RA_DC + 1) + dd], pp);
+                    for (int c = 0; c < 8; ++c) { accc[r][c] = fmaf(qu, kb[c], accc[r][c]); accp[r][c] = fmaf(qv, pb[c], accp[r][c]); }
                 }
-                accc[n] += c; accp[n] += pp;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                S[(ti + 16 * r) * RA_LD + tj + 16 * c] = accc[r][c];
+                PR[(ti + 16 * r) * RA_LD + tj + 16 * c] = accp[r][c];
+            }
+    }
+    __syncthreads();
+    // rows: add the shifted positional score, scale, softmax. Two threads per row (even / odd columns).
+    {
+        const int i = tid >> 1, half = tid & 1;
+        if (i < T) {
+            float m = -1e30f;
+            for (int j = half; j < T; j += 2) {
+                int r, c;
+                const float ps = rel_shift_src(i, j, T, r, c) ? PR[r * RA_LD + c] : 0.f;
+                const float s = (S[i * RA_LD + j] + ps) * a.scale;
+                S[i * RA_LD + j] = s;
+                m = fmaxf(m, s);
+            }
+            m = fmaxf(m, __shfl_xor(m, 1));
+            float l = 0.f;
+            for (int j = half; j < T; j += 2) { const float e = __expf(S[i * RA_LD + j] - m); S[i * RA_LD + j] = e; l += e; }
+            l += __shfl_xor(l, 1);
+            const float il = 1.f / l;
+            for (int j = half; j < T; j += 2) S[i * RA_LD + j] *= il;
+        }
+    }
+    __syncthreads();
+    // keep the probabilities for the backward, apply the dropout mask (coalesced over the T x T block); zero the padding
+    {
+        float* arow = a.attn + ((long)b * a.heads + h) * T * T;
+        const T_* mrow = a.mask ? (const T_*)a.mask + ((long)b * a.heads + h) * T * T : nullptr;
+        for (int idx = tid; idx < RA_TMAX * RA_TMAX; idx += 256) {
+            const int i = idx >> 7, j = idx & 127;
+            if (i < T && j < T) {
+                const float pr = S[i * RA_LD + j];
+                arow[i * T + j] = pr;
+                if (mrow) S[i * RA_LD + j] = pr * to_f32<T_>(mrow[i * T + j]) * a.mask_scale;
+            } else {
+                S[i * RA_LD + j] = 0.f;
             }
         }
     }
-#pragma unroll
-    for (int n = 0; n < RA_NP; ++n) {
-        const int idx = tid + 256 * n;
-        if (idx < T * T) { const int i = idx / T, j = idx - i * T; S[i * LD + j] = accc[n]; PR[i * LD + j] = accp[n]; }
-    }
-    __syncthreads();
-    // row-wise: add the shifted positional score, scale, softmax, keep the probabilities, apply the dropout mask
-    if (tid < T) {
-        const int i = tid;
-        float m = -1e30f;
-        for (int j = 0; j < T; ++j) {
-            int r, c;
-            const float ps = rel_shift_src(i, j, T, r, c) ? PR[r * LD + c] : 0.f;
-            const float s = (S[i * LD + j] + ps) * a.scale;
-            S[i * LD + j] = s;
-            m = fmaxf(m, s);
+    // context = P v, 128 head-dim columns per pass
+    T_* o = (T_*)a.out + base;
+    float* Bst = Qs;
+    for (int c0 = 0; c0 < hd; c0 += 128) {
+        float acc[8][8], rv[8];
+        zero_tile(acc);
+        fetch_cols128<T_>(rv, v, a.D, T, 0, c0, hd, nullptr, tid);
+        for (int k0 = 0; k0 < T; k0 += RA_DC) {
+            __syncthreads();
+            put_cols128(Bst, rv, tid);
+            __syncthreads();
+            if (k0 + RA_DC < T) fetch_cols128<T_>(rv, v, a.D, T, k0 + RA_DC, c0, hd, nullptr, tid);
+            mat_times_chunk<false>(acc, S, Bst, k0, ti, tj);
         }
-        float l = 0.f;
-        for (int j = 0; j < T; ++j) { const float e = __expf(S[i * LD + j] - m); S[i * LD + j] = e; l += e; }
-        const float il = 1.f / l;
-        float* arow = a.attn + (((long)b * a.heads + h) * T + i) * T;
-        const T_* mrow = a.mask ? (const T_*)a.mask + (((long)b * a.heads + h) * T + i) * T : nullptr;
-        for (int j = 0; j < T; ++j) {
-            const float pr = S[i * LD + j] * il;
-            arow[j] = pr;
-            S[i * LD + j] = mrow ? pr * to_f32<T_>(mrow[j]) * a.mask_scale : pr;
-        }
-    }
-    __syncthreads();
-    T_* o = (T_*)a.out + (long)b * T * a.D + h * hd;
-    for (int idx = tid; idx < T * hd; idx += 256) {
-        const int i = idx / hd, c = idx - i * hd;
-        float acc = 0.f;
-        for (int j = 0; j < T; ++j) acc = fmaf(S[i * LD + j], to_f32<T_>(v[(long)j * a.D + c]), acc);
-        o[(long)i * a.D + c] = from_f32<T_>(acc);
+        store_tile<T_>(o, a.D, acc, T, c0, hd, ti, tj);
     }
 }
 
 template <typename T_>
 __global__ __launch_bounds__(256) void relattn_bwd_kernel(RelAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = a.T, hd = a.D / a.heads, LD = T + 1;
-    float* M1 = (float*)smem;                // [T][LD]: A*mask, later the un-shifted positional-score gradient
-    float* M2 = M1 + T * LD;                 // [T][LD]: G = (dO V^T)*mask, later dS*scale
-    float* As = M2 + T * LD;                 // [T][RA_DC + 1] x 2 tiles
-    float* Bs = As + T * (RA_DC + 1);
-    const int tid = threadIdx.x, b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int T = a.T, hd = a.D / a.heads;
+    float* M1 = (float*)smem;                // [128][129]: A*mask -> A -> un-shifted positional-score gradient
+    float* M2 = M1 + RA_MAT;                 // [128][129]: G = (dO V^T)*mask -> dS*scale
+    float* St0 = M2 + RA_MAT;                // staged chunks
+    float* St1 = St0 + RA_STG;
+    float* colsum = St1 + RA_STG;            // [2][hd]: du_bias, dv_bias of this (sample, head)
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const long base = (long)b * T * a.D + h * hd;
     const T_* q = (const T_*)a.q + base;
     const T_* k = (const T_*)a.k + base;
@@ -329,108 +578,150 @@ __global__ __launch_bounds__(256) void relattn_bwd_kernel(RelAttnArgs a) {
     const float* p = a.pos + h * hd;
     const float* attn = a.attn + ((long)b * a.heads + h) * T * T;
     const T_* mask = a.mask ? (const T_*)a.mask + ((long)b * a.heads + h) * T * T : nullptr;
-    // G = (dO V^T) * mask (pairs in registers, head-dim chunks through LDS); M1 = A * mask
-    float acc[RA_NP];
-#pragma unroll
-    for (int n = 0; n < RA_NP; ++n) acc[n] = 0.f;
-    for (int d0 = 0; d0 < hd; d0 += RA_DC) {
-        __syncthreads();
-        for (int e = tid; e < T * RA_DC; e += 256) {
-            const int row = e / RA_DC, dd = e - row * RA_DC;
-            const bool in = d0 + dd < hd;
-            As[row * (RA_DC + 1) + dd] = in ? to_f32<T_>(dO[(long)row * a.D + d0 + dd]) : 0.f;
-            Bs[row * (RA_DC + 1) + dd] = in ? to_f32<T_>(v[(long)row * a.D + d0 + dd]) : 0.f;
+    for (int c = tid; c < 2 * hd; c += 256) colsum[c] = 0.f;
+    // M1 = A * mask (zero padding)
+    for (int idx = tid; idx < RA_TMAX * RA_TMAX; idx += 256) {
+        const int i = idx >> 7, j = idx & 127;
+        float val = 0.f;
+        if (i < T && j < T) val = attn[i * T + j] * (mask ? to_f32<T_>(mask[i * T + j]) * a.mask_scale : 1.f);
+        M1[i * RA_LD + j] = val;
+    }
+    // dV = (A*mask)^T dO
+    T_* dv = (T_*)a.dv + base;
+    for (int c0 = 0; c0 < hd; c0 += 128) {
+        float acc[8][8], rr[8];
+        zero_tile(acc);
+        fetch_cols128<T_>(rr, dO, a.D, T, 0, c0, hd, nullptr, tid);
+        for (int k0 = 0; k0 < T; k0 += RA_DC) {
+            __syncthreads();
+            put_cols128(St0, rr, tid);
+            __syncthreads();
+            if (k0 + RA_DC < T) fetch_cols128<T_>(rr, dO, a.D, T, k0 + RA_DC, c0, hd, nullptr, tid);
+            mat_times_chunk<true>(acc, M1, St0, k0, ti, tj);
         }
-        __syncthreads();
+        store_tile<T_>(dv, a.D, acc, T, c0, hd, ti, tj);
+    }
+    // G = dO V^T over head-dim chunks; then M2 = G * mask, M1 = A
+    {
+        float acc[8][8], ra[8], rb[8];
+        zero_tile(acc);
+        fetch_rows16<T_>(ra, dO, a.D, T, 0, hd, tid);
+        fetch_rows16<T_>(rb, v, a.D, T, 0, hd, tid);
+        for (int d0 = 0; d0 < hd; d0 += RA_DC) {
+            __syncthreads();
+            put_rows16(St0, ra, tid); put_rows16(St1, rb, tid);
+            __syncthreads();
+            if (d0 + RA_DC < hd) {
+                fetch_rows16<T_>(ra, dO, a.D, T, d0 + RA_DC, hd, tid);
+                fetch_rows16<T_>(rb, v, a.D, T, d0 + RA_DC, hd, tid);
+            }
+#pragma unroll 4
+            for (int dd = 0; dd < RA_DC; ++dd) {
+                float x[8], y[8];
 #pragma unroll
-        for (int n = 0; n < RA_NP; ++n) {
-            const int idx = tid + 256 * n;
-            if (idx < T * T) {
-                const int i = idx / T, j = idx - i * T;
-                float c = 0.f;
+                for (int r = 0; r < 8; ++r) x[r] = St0[(ti + 16 * r) * RA_SLD + dd];
 #pragma unroll
-                for (int dd = 0; dd < RA_DC; ++dd) c = fmaf(As[i * (RA_DC + 1) + dd], Bs[j * (RA_DC + 1) + dd], c);
-                acc[n] += c;
+                for (int c = 0; c < 8; ++c) y[c] = St1[(tj + 16 * c) * RA_SLD + dd];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[r][c] = fmaf(x[r], y[c], acc[r][c]);
             }
         }
-    }
+        __syncthreads();                       // every reader of M1 = A*mask (dV) is done
 #pragma unroll
-    for (int n = 0; n < RA_NP; ++n) {
-        const int idx = tid + 256 * n;
-        if (idx < T * T) {
-            const int i = idx / T, j = idx - i * T;
-            const float mk = mask ? to_f32<T_>(mask[idx]) * a.mask_scale : 1.f;
-            M2[i * LD + j] = acc[n] * mk;
-            M1[i * LD + j] = attn[idx] * mk;
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = ti + 16 * r, j = tj + 16 * c;
+                float g = 0.f, pa = 0.f;
+                if (i < T && j < T) {
+                    pa = attn[i * T + j];
+                    g = acc[r][c] * (mask ? to_f32<T_>(mask[i * T + j]) * a.mask_scale : 1.f);
+                }
+                M2[i * RA_LD + j] = g;
+                M1[i * RA_LD + j] = pa;
+            }
+    }
+    __syncthreads();
+    // softmax backward per row (two threads per row), scaled: M2 = dS
+    {
+        const int i = tid >> 1, half = tid & 1;
+        if (i < T) {
+            float dot = 0.f;
+            for (int j = half; j < T; j += 2) dot = fmaf(M2[i * RA_LD + j], M1[i * RA_LD + j], dot);
+            dot += __shfl_xor(dot, 1);
+            for (int j = half; j < T; j += 2) M2[i * RA_LD + j] = M1[i * RA_LD + j] * (M2[i * RA_LD + j] - dot) * a.scale;
         }
     }
     __syncthreads();
-    // dV[j][c] = sum_i (A*mask)[i][j] dO[i][c]
-    T_* dv = (T_*)a.dv + base;
-    for (int idx = tid; idx < T * hd; idx += 256) {
-        const int j = idx / hd, c = idx - j * hd;
-        float s = 0.f;
-        for (int i = 0; i < T; ++i) s = fmaf(M1[i * LD + j], to_f32<T_>(dO[(long)i * a.D + c]), s);
-        dv[(long)j * a.D + c] = from_f32<T_>(s);
+    // M1 = gradient of the RAW positional scores: the relative shift is a reshape, so this is a gather from dS
+    for (int idx = tid; idx < RA_TMAX * RA_TMAX; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        float val = 0.f;
+        int i, j;
+        if (r < T && c < T && rel_shift_dst(r, c, T, i, j)) val = M2[i * RA_LD + j];
+        M1[r * RA_LD + c] = val;
     }
     __syncthreads();
-    for (int e = tid; e < T * LD; e += 256) M1[e] = 0.f;
-    __syncthreads();
-    // softmax backward per row, scaled; scatter the positional part back through the relative shift
-    if (tid < T) {
-        const int i = tid;
-        float dot = 0.f;
-        for (int j = 0; j < T; ++j) dot = fmaf(M2[i * LD + j], attn[i * T + j], dot);
-        for (int j = 0; j < T; ++j) {
-            const float ds = attn[i * T + j] * (M2[i * LD + j] - dot) * a.scale;
-            M2[i * LD + j] = ds;
-            int r, c;
-            if (rel_shift_src(i, j, T, r, c)) M1[r * LD + c] = ds;     // the shift is a reshape: every source has one reader
-        }
-    }
-    __syncthreads();
-    // dq = DS k + DPR p ; du = sum_i DS k ; dvb = sum_i DPR p  (per batch partials) ; dk = DS^T (q + u) ; dp = DPR^T (q + vb)
+    // dq = dS k + dPR p (their column sums are the u / v bias gradients); dk = dS^T (q + u); dpos = dPR^T (q + v)
     T_* dq = (T_*)a.dq + base;
     T_* dk = (T_*)a.dk + base;
     float* dpos = a.dpos_part + (long)b * T * a.D + h * hd;
+    for (int c0 = 0; c0 < hd; c0 += 128) {
+        {
+            float accc[8][8], accp[8][8], rk[8], rp[8];
+            zero_tile(accc); zero_tile(accp);
+            fetch_cols128<T_>(rk, k, a.D, T, 0, c0, hd, nullptr, tid);
+            fetch_cols128<float>(rp, p, a.D, T, 0, c0, hd, nullptr, tid);
+            for (int k0 = 0; k0 < T; k0 += RA_DC) {
+                __syncthreads();
+                put_cols128(St0, rk, tid); put_cols128(St1, rp, tid);
+                __syncthreads();
+                if (k0 + RA_DC < T) {
+                    fetch_cols128<T_>(rk, k, a.D, T, k0 + RA_DC, c0, hd, nullptr, tid);
+                    fetch_cols128<float>(rp, p, a.D, T, k0 + RA_DC, c0, hd, nullptr, tid);
+                }
+                mat_times_chunk<false>(accc, M2, St0, k0, ti, tj);
+                mat_times_chunk<false>(accp, M1, St1, k0, ti, tj);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float su = 0.f, sv = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { su += accc[r][c]; sv += accp[r][c]; accc[r][c] += accp[r][c]; }
+                const int col = c0 + tj + 16 * c;
+                if (col < hd) { atomicAdd(&colsum[col], su); atomicAdd(&colsum[hd + col], sv); }
+            }
+            store_tile<T_>(dq, a.D, accc, T, c0, hd, ti, tj);
+        }
+        {
+            float acck[8][8], accq[8][8], ru[8], rv[8];
+            zero_tile(acck); zero_tile(accq);
+            fetch_cols128<T_>(ru, q, a.D, T, 0, c0, hd, a.u_bias + h * hd, tid);
+            fetch_cols128<T_>(rv, q, a.D, T, 0, c0, hd, a.v_bias + h * hd, tid);
+            for (int k0 = 0; k0 < T; k0 += RA_DC) {
+                __syncthreads();
+                put_cols128(St0, ru, tid); put_cols128(St1, rv, tid);
+                __syncthreads();
+                if (k0 + RA_DC < T) {
+                    fetch_cols128<T_>(ru, q, a.D, T, k0 + RA_DC, c0, hd, a.u_bias + h * hd, tid);
+                    fetch_cols128<T_>(rv, q, a.D, T, k0 + RA_DC, c0, hd, a.v_bias + h * hd, tid);
+                }
+                mat_times_chunk<true>(acck, M2, St0, k0, ti, tj);
+                mat_times_chunk<true>(accq, M1, St1, k0, ti, tj);
+            }
+            store_tile<T_>(dk, a.D, acck, T, c0, hd, ti, tj);
+            store_tile<float>(dpos, a.D, accq, T, c0, hd, ti, tj);
+        }
+    }
+    __syncthreads();
     float* dub = a.dbias_part + (long)b * 2 * a.D + h * hd;
-    for (int idx = tid; idx < T * hd; idx += 256) {
-        const int i = idx / hd, c = idx - i * hd;
-        float sc = 0.f, sp = 0.f;
-        for (int j = 0; j < T; ++j) {
-            sc = fmaf(M2[i * LD + j], to_f32<T_>(k[(long)j * a.D + c]), sc);
-            sp = fmaf(M1[i * LD + j], p[(long)j * a.D + c], sp);
-        }
-        dq[(long)i * a.D + c] = from_f32<T_>(sc + sp);
-        // reuse the loop index as (j, c) for the transposed products
-        const int j2 = i;
-        float sk = 0.f, spp = 0.f;
-        const float ub = a.u_bias[h * hd + c], vb = a.v_bias[h * hd + c];
-        for (int i2 = 0; i2 < T; ++i2) {
-            const float qv = to_f32<T_>(q[(long)i2 * a.D + c]);
-            sk = fmaf(M2[i2 * LD + j2], qv + ub, sk);
-            spp = fmaf(M1[i2 * LD + j2], qv + vb, spp);
-        }
-        dk[(long)j2 * a.D + c] = from_f32<T_>(sk);
-        dpos[(long)j2 * a.D + c] = spp;
-    }
-    // bias gradients: column sums over i of the two dq parts (recomputed per column by hd threads)
-    for (int c = tid; c < hd; c += 256) {
-        float su = 0.f, sv = 0.f;
-        // sum_i sum_j DS[i][j] k[j][c] = sum_j (sum_i DS[i][j]) k[j][c]
-        for (int j = 0; j < T; ++j) {
-            float cs = 0.f, cp = 0.f;
-            for (int i = 0; i < T; ++i) { cs += M2[i * LD + j]; cp += M1[i * LD + j]; }
-            su = fmaf(cs, to_f32<T_>(k[(long)j * a.D + c]), su);
-            sv = fmaf(cp, p[(long)j * a.D + c], sv);
-        }
-        dub[c] = su;
-        dub[a.D + c] = sv;
-    }
+    for (int c = tid; c < hd; c += 256) { dub[c] = colsum[c]; dub[a.D + c] = colsum[hd + c]; }
 }
 
-size_t relattn_lds(int T, bool bwd) {
-    return (size_t)(2 * T * (T + 1) + (bwd ? 2 : 3) * T * (RA_DC + 1)) * sizeof(float);
+size_t relattn_lds(int hd, bool bwd) {
+    return (size_t)(2 * RA_MAT + (bwd ? 2 : 3) * RA_STG + (bwd ? 2 * hd : 0)) * sizeof(float);
 }
 
 }  // namespace
@@ -444,7 +735,7 @@ extern "C" int pseld_relattn_fwd(int dtype, const void* q, const void* k, const 
     a.q = q; a.k = k; a.v = v; a.pos = pos; a.u_bias = u_bias; a.v_bias = v_bias; a.mask = mask; a.out = out; a.attn = attn;
     a.B = B; a.T = T; a.D = D; a.heads = heads; a.scale = 1.0f / sqrtf((float)D); a.mask_scale = mask_scale;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = relattn_lds(T, false);
+    const size_t lds = relattn_lds(D / heads, false);
     if (dtype == PSELD_BF16) {
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute((const void*)relattn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
@@ -467,14 +758,15 @@ extern "C" int pseld_relattn_bwd(int dtype, const void* q, const void* k, const 
                                  float* workspace, long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(q && k && v && pos && u_bias && v_bias && attn && dout && dq && dk && dv && dpos && du_bias && dv_bias && workspace,
                     "relattn_bwd: null pointer");
-    PSELD_CHECK_ARG(B > 0 && T > 0 && T <= RA_TMAX && heads > 0 && D % heads == 0, "relattn_bwd: bad geometry (T <= 128)");
+    PSELD_CHECK_ARG(B > 0 && T > 0 && T <= RA_TMAX && heads > 0 && D % heads == 0 && relattn_lds(D / heads, true) <= 160 * 1024,
+                    "relattn_bwd: bad geometry (T <= 128, head_dim <= 512)");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_relattn_bwd_workspace(B, T, D), "relattn_bwd: workspace too small");
     RelAttnArgs a; memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.pos = pos; a.u_bias = u_bias; a.v_bias = v_bias; a.mask = mask; a.attn = const_cast<float*>(attn);
     a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.dpos_part = workspace; a.dbias_part = workspace + (long)B * T * D;
     a.B = B; a.T = T; a.D = D; a.heads = heads; a.scale = 1.0f / sqrtf((float)D); a.mask_scale = mask_scale;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = relattn_lds(T, true);
+    const size_t lds = relattn_lds(D / heads, true);
     if (dtype == PSELD_BF16) {
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute((const void*)relattn_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }

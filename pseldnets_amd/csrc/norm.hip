@@ -218,7 +218,8 @@ int launch_ln(const LnArgs& a, bool bwd, int rows_per_block, int nblocks, hipStr
     else if (a.C <= 512) LN_CASE(64, 1);
     else if (a.C <= 1024) LN_CASE(64, 2);
     else if (a.C <= 1536) LN_CASE(64, 3);
-    else { pseld_set_error("layernorm: C=%d > 1536 not built", a.C); return PSELD_ERR_UNSUPPORTED; }
+    else if (a.C <= 2048) LN_CASE(64, 4);                 // the CNN14-Conformer decoder width
+    else { pseld_set_error("layernorm: C=%d > 2048 not built", a.C); return PSELD_ERR_UNSUPPORTED; }
 #undef LN_CASE
     PSELD_LAUNCH_CHECK("layernorm");
     return PSELD_OK;

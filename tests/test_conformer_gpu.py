@@ -52,19 +52,20 @@ def test_glue_kernels(dev, dtype, tol):
     gr = F.glu(x2r, dim=1)
     gr.backward(y.float())
     assert rel(ops.glu_fwd(x2), gr) < tol and rel(ops.glu_bwd(x2, y), x2r.grad) < tol
-    # depthwise Conv1d(k=31, 'same'), its input gradient (flip) and weight gradient
-    w = torch.randn(D, K, device=dev) * 0.2
-    xc = x.float().view(B, T, D).transpose(1, 2).contiguous().requires_grad_(True)
-    wr = w.clone().view(D, 1, K).requires_grad_(True)
-    cr = F.conv1d(xc, wr, padding=(K - 1) // 2, groups=D)
-    dyc = y.float().view(B, T, D).transpose(1, 2)
-    cr.backward(dyc)
+    # depthwise Conv1d('same'), its input gradient (flip) and weight gradient: k = 31 (LDS-tiled kernels) and the generic path
     rows = lambda t: t.transpose(1, 2).reshape(M, D)
-    assert rel(ops.dwconv_fwd(x, w, B, T), rows(cr)) < tol
-    assert rel(ops.dwconv_fwd(y, w, B, T, flip=True), rows(xc.grad)) < tol
-    dw = torch.empty(D, K, device=dev)
-    ops.dwconv_wgrad(x, y, dw, B, T)
-    assert rel(dw, wr.grad.view(D, K)) < (1e-4 if dtype == torch.float32 else tol)
+    dyc = y.float().view(B, T, D).transpose(1, 2)
+    for K in (31, 7):
+        w = torch.randn(D, K, device=dev) * 0.2
+        xc = x.float().view(B, T, D).transpose(1, 2).contiguous().requires_grad_(True)
+        wr = w.clone().view(D, 1, K).requires_grad_(True)
+        cr = F.conv1d(xc, wr, padding=(K - 1) // 2, groups=D)
+        cr.backward(dyc)
+        assert rel(ops.dwconv_fwd(x, w, B, T), rows(cr)) < tol, K
+        assert rel(ops.dwconv_fwd(y, w, B, T, flip=True), rows(xc.grad)) < tol, K
+        dw = torch.empty(D, K, device=dev)
+        ops.dwconv_wgrad(x, y, dw, B, T)
+        assert rel(dw, wr.grad.view(D, K)) < (1e-4 if dtype == torch.float32 else tol), K
     # BatchNorm1d (train) without activation, forward and backward
     gam, bet = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev)
     rm, rv, nb = torch.zeros(D, device=dev), torch.ones(D, device=dev), torch.zeros((), dtype=torch.long, device=dev)

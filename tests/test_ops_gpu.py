@@ -34,7 +34,7 @@ def check(name, got, ref, t):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,C", [(300, 96), (257, 192), (100, 384), (70, 768), (33, 1536), (64, 48)])
+@pytest.mark.parametrize("M,C", [(300, 96), (257, 192), (100, 384), (70, 768), (33, 1536), (64, 48), (41, 2048)])
 def test_layernorm(dev, dtype, M, C):
     from pseldnets_amd import ops
     x, g, b, dy = rnd((M, C), 1, dtype), 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3), rnd((M, C), 4, dtype)
