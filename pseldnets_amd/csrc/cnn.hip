@@ -213,36 +213,49 @@ __global__ void bn_relu_bwd_kernel(const T* __restrict__ X, const T* __restrict_
     store8<T>(dX + id * 8, o);
 }
 
-// AvgPool2d((pt, pf)) on [B, T, F, C] rows (floor mode, stride = kernel)
+// AvgPool2d((pt, pf)) on [B, T, F, C] rows (floor mode, stride = kernel); a thread moves 8 channels
 template <typename T>
-__global__ void avgpool_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, int Tn, int Fn, int C, int pt, int pf, long total) {
+__global__ void avgpool_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, int Tn, int Fn, int C, int pt, int pf, long total8) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int To = Tn / pt, Fo = Fn / pf;
-    const int c = (int)(id % C);
-    long rest = id / C;
+    if (id >= total8) return;
+    const int To = Tn / pt, Fo = Fn / pf, c8 = C >> 3;
+    const int c = (int)(id % c8) * 8;
+    long rest = id / c8;
     const int fo = (int)(rest % Fo); rest /= Fo;
     const int to = (int)(rest % To);
     const long b = rest / To;
-    float s = 0.f;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < pt; ++i)
-        for (int j = 0; j < pf; ++j) s += to_f32<T>(X[((b * Tn + to * pt + i) * Fn + fo * pf + j) * C + c]);
-    Y[id] = from_f32<T>(s / (pt * pf));
+        for (int j = 0; j < pf; ++j) {
+            float v[8];
+            load8<T>(X + ((b * Tn + to * pt + i) * Fn + fo * pf + j) * C + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += v[k];
+        }
+    const float inv = 1.f / (pt * pf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] *= inv;
+    store8<T>(Y + id * 8, s);
 }
 template <typename T>
-__global__ void avgpool_bwd_kernel(const T* __restrict__ dY, T* __restrict__ dX, int Tn, int Fn, int C, int pt, int pf, long total) {
+__global__ void avgpool_bwd_kernel(const T* __restrict__ dY, T* __restrict__ dX, int Tn, int Fn, int C, int pt, int pf, long total8) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int To = Tn / pt, Fo = Fn / pf;
-    const int c = (int)(id % C);
-    long rest = id / C;
+    if (id >= total8) return;
+    const int To = Tn / pt, Fo = Fn / pf, c8 = C >> 3;
+    const int c = (int)(id % c8) * 8;
+    long rest = id / c8;
     const int f = (int)(rest % Fn); rest /= Fn;
     const int t = (int)(rest % Tn);
     const long b = rest / Tn;
     const int to = t / pt, fo = f / pf;
-    float v = 0.f;
-    if (to < To && fo < Fo) v = to_f32<T>(dY[((b * To + to) * Fo + fo) * C + c]) / (pt * pf);
-    dX[id] = from_f32<T>(v);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (to < To && fo < Fo) {
+        load8<T>(dY + ((b * To + to) * Fo + fo) * C + c, v);
+        const float inv = 1.f / (pt * pf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= inv;
+    }
+    store8<T>(dX + id * 8, v);
 }
 
 // y[b, j, :] = sum_{k<3} w[j][k] * x[b, i0[j] + k, :]  (the 'repeat' x ratio + group-mean map of accdoa.py:86-87 in compact form)
@@ -281,6 +294,16 @@ __global__ void rows_pool_bwd_kernel(const T* __restrict__ dY, const int* __rest
 }
 
 constexpr int CNN_ROWS_PER_BLOCK = 1024;
+// BatchNorm2d column sums: rows per workgroup such that even the deep, short layers (12 000 rows x 2048 channels) put
+// about two workgroups on every CU, without more than 1024 rows per workgroup on the long ones
+static inline int bn2d_rows_per_block(long rows, int C) {
+    const int c8 = C / 8, colgroups = pseld_cdiv(c8, c8 < 256 ? c8 : 256);
+    const long target = 512 / colgroups > 1 ? 512 / colgroups : 1;
+    long r = (rows + target - 1) / target;
+    if (r < 16) r = 16;
+    if (r > CNN_ROWS_PER_BLOCK) r = CNN_ROWS_PER_BLOCK;
+    return (int)r;
+}
 
 }  // namespace
 
@@ -356,20 +379,20 @@ extern "C" int pseld_conv_wgrad_from_tap(const float* dWp, float* dW, int Cout, 
 
 /* BatchNorm2d statistics over the rows of an NHWC map: sums f32[C][2] = (sum x, sum x^2) */
 extern "C" long pseld_bn2d_workspace(long rows, int C) {
-    return ((long)pseld_cdiv(rows, CNN_ROWS_PER_BLOCK) + 1) * C * 2 * (long)sizeof(float);
+    return ((long)pseld_cdiv(rows, bn2d_rows_per_block(rows, C)) + 1) * C * 2 * (long)sizeof(float);
 }
 extern "C" int pseld_bn2d_stats(int dtype, const void* X, float* sums, long rows, int C, float* workspace, long workspace_bytes,
                                 void* stream) {
     PSELD_CHECK_ARG(X && sums && workspace && rows > 0 && C > 0, "bn2d_stats: bad argument");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn2d_stats: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = pseld_cdiv(rows, CNN_ROWS_PER_BLOCK);
+    const int rpb = bn2d_rows_per_block(rows, C), nb = pseld_cdiv(rows, rpb);
     PSELD_CHECK_ARG(C % 8 == 0, "bn2d_stats: C must be a multiple of 8");
     const dim3 grid(nb, pseld_cdiv(C / 8, C / 8 < 256 ? C / 8 : 256));
     if (dtype == PSELD_BF16)
-        hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, workspace, rows, C, CNN_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, workspace, rows, C, rpb);
     else if (dtype == PSELD_F32)
-        hipLaunchKernelGGL((bn2d_sums_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)X, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, rows, C, CNN_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL((bn2d_sums_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)X, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, rows, C, rpb);
     else { pseld_set_error("bn2d_stats: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     pseld_reduce_slabs(workspace, sums, (long)C * 2, nb, (long)C * 2, 0, s);
     PSELD_LAUNCH_CHECK("bn2d_stats");
@@ -400,17 +423,17 @@ extern "C" int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const 
     PSELD_CHECK_ARG(X && dY && mean_rstd && gamma && dX && dgamma && dbeta && workspace, "bn_relu_bwd: null pointer");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn_relu_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = pseld_cdiv(rows, CNN_ROWS_PER_BLOCK);
+    const int rpb = bn2d_rows_per_block(rows, C), nb = pseld_cdiv(rows, rpb);
     PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_bwd: C must be a multiple of 8");
     const dim3 grid(nb, pseld_cdiv(C / 8, C / 8 < 256 ? C / 8 : 256));
     float* total = workspace + (long)nb * C * 2;
     const long n = rows * C / 8;
     if (dtype == PSELD_BF16) {
-        hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, workspace, rows, C, CNN_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, workspace, rows, C, rpb);
         pseld_reduce_slabs(workspace, total, (long)C * 2, nb, (long)C * 2, 0, s);
         hipLaunchKernelGGL(bn_relu_bwd_kernel<bf16_t>, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, gamma, total, 1.f / (float)rows, (bf16_t*)dX, C, n);
     } else if (dtype == PSELD_F32) {
-        hipLaunchKernelGGL((bn2d_sums_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, (const float*)Y, (const float*)dY, mean_rstd, workspace, rows, C, CNN_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL((bn2d_sums_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, (const float*)Y, (const float*)dY, mean_rstd, workspace, rows, C, rpb);
         pseld_reduce_slabs(workspace, total, (long)C * 2, nb, (long)C * 2, 0, s);
         hipLaunchKernelGGL(bn_relu_bwd_kernel<float>, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, (const float*)X, (const float*)Y, (const float*)dY, mean_rstd, gamma, total, 1.f / (float)rows, (float*)dX, C, n);
     } else { pseld_set_error("bn_relu_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
@@ -422,14 +445,16 @@ extern "C" int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const 
 extern "C" int pseld_avgpool_fwd(int dtype, const void* X, void* Y, int B, int Tn, int Fn, int C, int pt, int pf, void* stream) {
     PSELD_CHECK_ARG(X && Y && B > 0 && pt > 0 && pf > 0 && Tn >= pt && Fn >= pf && C > 0, "avgpool_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * (Tn / pt) * (Fn / pf) * C;
+    PSELD_CHECK_ARG(C % 8 == 0, "avgpool_fwd: C must be a multiple of 8");
+    const long total = (long)B * (Tn / pt) * (Fn / pf) * (C / 8);
     CNN_DISPATCH("avgpool_fwd", hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)X, (T*)Y,
                                                    Tn, Fn, C, pt, pf, total));
 }
 extern "C" int pseld_avgpool_bwd(int dtype, const void* dY, void* dX, int B, int Tn, int Fn, int C, int pt, int pf, void* stream) {
     PSELD_CHECK_ARG(dY && dX && B > 0 && pt > 0 && pf > 0 && Tn >= pt && Fn >= pf && C > 0, "avgpool_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * Tn * Fn * C;
+    PSELD_CHECK_ARG(C % 8 == 0, "avgpool_bwd: C must be a multiple of 8");
+    const long total = (long)B * Tn * Fn * (C / 8);
     CNN_DISPATCH("avgpool_bwd", hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)dY, (T*)dX,
                                                    Tn, Fn, C, pt, pf, total));
 }

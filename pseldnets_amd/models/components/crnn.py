@@ -3,9 +3,9 @@
 Host-side mirror of the reference's `models/components/backbone.py` (CNN8 :6-31, CNN12 :33-60 = the conv stack of PANNs
 CNN14) and `models/components/model_utilities.py` ConvBlock :92-126. Activations are NHWC rows [B*T*F, C]; every 3x3
 convolution is im2col (tap-major columns, 16-byte copies) -> MFMA GEMM against a tap-major copy of the reference's
-[Cout, Cin, 3, 3] weight, its input gradient GEMM -> col2im, its weight gradient the split-K GEMM over the recomputed
-im2col matrix, permuted back into the reference layout. The im2col matrix is
-built per slice of the batch so that it stays bounded. BatchNorm2d (train-mode batch statistics) + ReLU and the
+[Cout, Cin, 3, 3] weight, its input gradient GEMM -> col2im, its weight gradient the split-K GEMM over the im2col
+matrix kept from the forward pass (HBM is large: 0.2 GB per chunk), permuted back into the reference layout. The
+im2col matrix is built per slice of the batch. BatchNorm2d (train-mode batch statistics) + ReLU and the
 average pools are per-column / per-pixel kernels (csrc/cnn.hip). No tensor arithmetic happens in this file.
 """
 import torch
@@ -32,6 +32,7 @@ class ConvEncoder:
         self.widths = list(num_features)
         self.num_features = self.widths[-1]
         self.bn_buffers = {}
+        self.keep_im2col = True            # training: keep the forward im2col matrices for the weight-gradient GEMMs
         cin = in_chans
         for i, cout in enumerate(self.widths):
             b = f'{prefix}conv_block{i + 1}.'
@@ -61,21 +62,26 @@ class ConvEncoder:
         per = max(1, CONV_SLICE_ELEMS // max(1, rows_per_sample * K))
         return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
 
-    def _conv_fwd(self, x, W, B, T, F):
+    def _conv_fwd(self, x, W, B, T, F, keep):
+        """Returns (y, the im2col slices when `keep`: the weight-gradient GEMM of the backward reads them again, and
+        288 GB of HBM hold them easily — 0.2 GB per ten-second chunk at the crnn.yaml widths)."""
         rows, K = T * F, W.shape[1]
         y = torch.empty((B * rows, W.shape[0]), dtype=x.dtype, device=x.device)
+        kept = [] if keep else None
         for b0, b1 in self._slices(B, rows, K):
             A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
             ops.linear_fwd(A, W, out=y[b0 * rows:b1 * rows])
-        return y
+            if keep:
+                kept.append(A)
+        return y, kept
 
-    def _conv_bwd(self, dy, x, W, dW, B, T, F, cin_p):
+    def _conv_bwd(self, dy, x, W, dW, B, T, F, cin_p, kept=None):
         """dW (reference layout, overwritten) and dx = col2im(dy @ Wp)."""
         rows, K = T * F, W.shape[1]
         dx = torch.empty((B * rows, cin_p), dtype=x.dtype, device=x.device)
         dWp = torch.empty((W.shape[0], K), dtype=torch.float32, device=x.device)
         for n, (b0, b1) in enumerate(self._slices(B, rows, K)):
-            A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
+            A = kept[n] if kept is not None else ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
             ops.linear_wgrad(dy[b0 * rows:b1 * rows], A, dWp, accumulate=n > 0)
             dA = ops.linear_dgrad(dy[b0 * rows:b1 * rows], W)
             ops.col2im3x3(dA, b1 - b0, T, F, cin_p, out=dx[b0 * rows:b1 * rows])
@@ -98,13 +104,14 @@ class ConvEncoder:
         for i, cout in enumerate(self.widths):
             b = f'{self.prefix}conv_block{i + 1}.'
             W1 = self._weight(b + 'conv1.weight', dtype, cin_p)
-            y1 = self._conv_fwd(x, W1, B, T, F)
+            keep = training and self.keep_im2col
+            y1, A1 = self._conv_fwd(x, W1, B, T, F, keep)
             z1, mr1 = self._bn(b, 1, y1, training, buffers)
             W2 = self._weight(b + 'conv2.weight', dtype, cout)
-            y2 = self._conv_fwd(z1, W2, B, T, F)
+            y2, A2 = self._conv_fwd(z1, W2, B, T, F, keep)
             z2, mr2 = self._bn(b, 2, y2, training, buffers)
             pt, pf = self.pools[i]
-            saved.append(dict(x=x, y1=y1, z1=z1, mr1=mr1, y2=y2, z2=z2, mr2=mr2, T=T, F=F, cin=cin, cin_p=cin_p))
+            saved.append(dict(x=x, y1=y1, z1=z1, mr1=mr1, y2=y2, z2=z2, mr2=mr2, T=T, F=F, cin=cin, cin_p=cin_p, A1=A1, A2=A2))
             x = ops.avgpool_fwd(z2, B, T, F, pt, pf)
             T, F, cin, cin_p = T // pt, F // pf, cout, cout
         if F > 1:
@@ -123,8 +130,10 @@ class ConvEncoder:
             dz2 = ops.avgpool_bwd(dx, B, s['T'], s['F'], pt, pf)
             dy2 = ops.bn_relu_bwd(s['y2'], s['z2'], dz2, s['mr2'], a.p(b + 'bn2.weight'), a.g(b + 'bn2.weight'), a.g(b + 'bn2.bias'))
             W2 = self._weight(b + 'conv2.weight', dtype, cout)
-            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout)
+            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout, s['A2'])
+            s['A2'] = None
             dy1 = ops.bn_relu_bwd(s['y1'], s['z1'], dz1, s['mr1'], a.p(b + 'bn1.weight'), a.g(b + 'bn1.weight'), a.g(b + 'bn1.bias'))
             W1 = self._weight(b + 'conv1.weight', dtype, s['cin_p'])
-            dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'])
+            dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'], s['A1'])
+            s['A1'] = None
         return dx
