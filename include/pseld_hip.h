@@ -166,6 +166,17 @@ int pseld_im2col3x3(int dtype, const void* X, void* A, int B, int T, int F, int 
 int pseld_col2im3x3(int dtype, const void* dA, void* dX, int B, int T, int F, int C, void* stream);
 int pseld_conv_weight_to_tap(int dtype, const void* W, void* Wp, int Cout, int Cin, int Cp, void* stream);
 int pseld_conv_wgrad_from_tap(const float* dWp, float* dW, int Cout, int Cin, int Cp, void* stream);
+/* Implicit 3x3 / pad 1 convolution on NHWC rows (model_utilities.py:92-126 ConvBlock's nn.Conv2d, bias-free): the
+ * im2col matrix is never built — the GEMM loaders read X[B*T*F, C] with shifted rows and zero the border.
+ * conv3x3_fwd: Y[B*T*F, N] = im2col(X) @ Wp[N, 9*C]^T (Wp from pseld_conv_weight_to_tap). The same call is the input
+ * gradient with X = dY (C = Cout) and Wp = pseld_conv_weight_to_tap_t(W) ([Cp, 9*Cout], taps flipped, N = Cp).
+ * conv3x3_wgrad: dWp[N, 9*C] f32 (+)= dY[B*T*F, N]^T @ im2col(X) (back to [Cout,Cin,3,3] with conv_wgrad_from_tap).
+ * C, N multiples of 8; B*T*F < 2^24 rows per call. */
+int pseld_conv_weight_to_tap_t(int dtype, const void* W, void* Wd, int Cout, int Cin, int Cp, void* stream);
+int pseld_conv3x3_fwd(int dtype, const void* X, const void* Wp, void* Y, int B, int T, int F, int C, int N, void* stream);
+long pseld_conv3x3_wgrad_workspace(int B, int T, int F, int C, int N);
+int pseld_conv3x3_wgrad(int dtype, const void* dY, const void* X, float* dWp, int B, int T, int F, int C, int N,
+                        int accumulate, float* workspace, long workspace_bytes, void* stream);
 long pseld_bn2d_workspace(long rows, int C);
 int pseld_bn2d_stats(int dtype, const void* X, float* sums, long rows, int C, float* workspace, long workspace_bytes,
                      void* stream);

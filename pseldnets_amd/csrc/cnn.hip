@@ -369,6 +369,26 @@ extern "C" int pseld_conv_weight_to_tap(int dtype, const void* W, void* Wp, int 
     PSELD_LAUNCH_CHECK("conv_weight_to_tap");
     return PSELD_OK;
 }
+// input-gradient weights of the implicit convolution: Wd[ci][8 - tap][co] = W[co][ci][tap], rows ci >= Cin zero ([Cp, 9*Cout])
+template <typename T>
+__global__ void conv_weight_t_kernel(const T* __restrict__ W, T* __restrict__ Wd, int Cout, int Cin, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int co = (int)(id % Cout);
+    const int tapd = (int)((id / Cout) % 9);
+    const long ci = id / (9L * Cout);
+    Wd[id] = ci < Cin ? W[((long)co * Cin + ci) * 9 + (8 - tapd)] : (T)0.f;
+}
+extern "C" int pseld_conv_weight_to_tap_t(int dtype, const void* W, void* Wd, int Cout, int Cin, int Cp, void* stream) {
+    PSELD_CHECK_ARG(W && Wd && Cout > 0 && Cin > 0 && Cp >= Cin && Cp % 8 == 0 && Cout % 8 == 0, "conv_weight_to_tap_t: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)Cp * 9 * Cout;
+    if (dtype == PSELD_BF16) hipLaunchKernelGGL(conv_weight_t_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)W, (bf16_t*)Wd, Cout, Cin, total);
+    else if (dtype == PSELD_F32) hipLaunchKernelGGL(conv_weight_t_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const float*)W, (float*)Wd, Cout, Cin, total);
+    else { pseld_set_error("conv_weight_to_tap_t: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    PSELD_LAUNCH_CHECK("conv_weight_to_tap_t");
+    return PSELD_OK;
+}
 extern "C" int pseld_conv_wgrad_from_tap(const float* dWp, float* dW, int Cout, int Cin, int Cp, void* stream) {
     PSELD_CHECK_ARG(dWp && dW && Cout > 0 && Cin > 0 && Cp >= Cin, "conv_wgrad_from_tap: bad argument");
     const long total = (long)Cout * Cin * 9;

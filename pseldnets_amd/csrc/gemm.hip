@@ -62,7 +62,19 @@ struct GemmArgs {
     unsigned long long* dbg;  // diagnostic build only: per-workgroup s_memtime stamps
     int nx, ny, nz;           // tile grid (N tiles, M tiles, K splits); the launch is 1-D and XCD-swizzled
     int xcd_swizzle;          // 0: plain x-fastest order (experiment knob PSELD_GEMM_XCD=0)
+    // CONV kernels: the non-weight operand is the 3x3 / pad 1 im2col view [B*T*F, 9*C] (column = tap*C + c) of an NHWC
+    // activation X[B*T*F, C]; it is never materialised, the loaders read X with shifted rows and zero the border
+    int cv_T, cv_F, cv_C;
+    float cv_rF, cv_rT;       // reciprocals for the row -> (t, f) decode
 };
+
+// x / d for 0 <= x < 2^24 through the reciprocal (exact after one fix-up step)
+__device__ __forceinline__ int div_by(int x, int d, float rd) {
+    int q = (int)((float)x * rd);
+    const int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -350,7 +362,7 @@ __device__ __forceinline__ bool tile_coords(const GemmArgs& g, int& bx, int& by,
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------
-template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
+template <typename T, typename OutT, int WM, int WN, bool TA, bool TB, bool CONV = false>
 __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void gemm_kernel(GemmArgs g) {
     constexpr int GEMM_THREADS = WM * WN * 64;
     constexpr int BM = WM * 64, BN = WN * 96;
@@ -396,6 +408,27 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (STAGED && tid < BN) bias_s[tid] = ((g.epi & EPI_BIAS) && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
 
+    // CONV, forward layout (A = im2col view): the (t, f) position of each of this thread's A rows, decoded once.
+    // CONV, weight-gradient layout (B = im2col view): the (tap, channel) of each of this thread's B column chunks.
+    int cva[CONV ? (TA ? NCH_B : NCH_A) : 1], cvb[CONV ? (TA ? NCH_B : NCH_A) : 1];
+    if constexpr (CONV && !TA) {
+#pragma unroll
+        for (int i = 0; i < NCH_A; ++i) {
+            const int m = min(m0 + (tid + GEMM_THREADS * i) / A_CPR, g.M - 1);
+            const int q = div_by(m, g.cv_F, g.cv_rF);
+            cvb[i] = m - q * g.cv_F;                                  // f
+            cva[i] = q - div_by(q, g.cv_T, g.cv_rT) * g.cv_T;         // t
+        }
+    }
+    if constexpr (CONV && TA) {
+#pragma unroll
+        for (int i = 0; i < NCH_B; ++i) {
+            const int n = n0 + ((tid + GEMM_THREADS * i) % B_CPR) * EPC;
+            const int tap = n / g.cv_C;
+            cva[i] = tap;                                             // tap (>= 9: beyond N)
+            cvb[i] = n - tap * g.cv_C;                                // channel
+        }
+    }
     // a K slice (BK tokens) lies inside one sample when samples are whole multiples of BK tokens: one uniform factor
     const bool slice_uniform = TA && (g.rows_per_scale % BK == 0) && (g.kchunk % BK == 0);
     auto load_regs = [&](int k0) {
@@ -405,6 +438,13 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
             const int row = c / A_CPR, cb = c % A_CPR;
             bool ok;
             long off;
+            if constexpr (CONV && !TA) {
+                const int k = k0 + cb * EPC, tap = k / g.cv_C, cc = k - tap * g.cv_C;
+                const int dt = tap / 3 - 1, df = tap - (tap / 3) * 3 - 1;
+                ok = (m0 + row < g.M) && (k < kend) && ((unsigned)(cva[i] + dt) < (unsigned)g.cv_T) &&
+                     ((unsigned)(cvb[i] + df) < (unsigned)g.cv_F);
+                off = ((long)(m0 + row + dt * g.cv_F + df) * g.cv_C + cc) * ES;
+            } else
             if (TA) {  // image row = contraction index, chunk runs along M
                 ok = (k0 + row < kend) && (m0 + cb * EPC < g.M);
                 off = ((long)(k0 + row) * g.lda + m0 + cb * EPC) * ES;
@@ -422,6 +462,14 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
             const int row = c / B_CPR, cb = c % B_CPR;
             bool ok;
             long off;
+            if constexpr (CONV && TA) {
+                const int tok = k0 + row, tap = cva[i];
+                const int q = div_by(tok, g.cv_F, g.cv_rF);
+                const int f = tok - q * g.cv_F, t = q - div_by(q, g.cv_T, g.cv_rT) * g.cv_T;
+                const int dt = tap / 3 - 1, df = tap - (tap / 3) * 3 - 1;
+                ok = (tok < kend) && (tap < 9) && ((unsigned)(t + dt) < (unsigned)g.cv_T) && ((unsigned)(f + df) < (unsigned)g.cv_F);
+                off = ((long)(tok + dt * g.cv_F + df) * g.cv_C + cvb[i]) * ES;
+            } else
             if (TB) {
                 ok = (k0 + row < kend) && (n0 + cb * EPC < g.N);
                 off = ((long)(k0 + row) * g.ldb + n0 + cb * EPC) * ES;
@@ -697,7 +745,7 @@ static int gemm_xcd_mode(bool wgrad) {
     return wgrad ? (v >> 1) & 1 : v & 1;
 }
 
-template <typename T, typename OutT, int WM, int WN, bool TA, bool TB>
+template <typename T, typename OutT, int WM, int WN, bool TA, bool TB, bool CONV = false>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
     constexpr int BM = WM * 64, BN = WN * 96, BK = Mma<T>::BK;
     constexpr int A_STRIDE = TA ? TStride<T, BM>::value : ROWB;
@@ -715,9 +763,9 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
     dim3 grid((unsigned)nblocks);
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, OutT, WM, WN, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, OutT, WM, WN, TA, TB, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     }
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB>), grid, dim3(WM * WN * 64), LDS, stream, ga);
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB, CONV>), grid, dim3(WM * WN * 64), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm");
     return PSELD_OK;
 }
@@ -728,18 +776,18 @@ static int gemm_big_tiles() {
     return v;
 }
 
-template <typename T, typename OutT, bool TA, bool TB>
+template <typename T, typename OutT, bool TA, bool TB, bool CONV = false>
 int dispatch_tile(const GemmArgs& g, int splits, hipStream_t stream) {
     // 256x96 when one 96-column tile covers N (or N is not worth a 192 tile), else 128x192
     if (g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288))
-        return launch_gemm<T, OutT, 4, 1, TA, TB>(g, splits, stream);
+        return launch_gemm<T, OutT, 4, 1, TA, TB, CONV>(g, splits, stream);
     if (sizeof(T) == 2 && TA && g.M >= 256) {
         const char* e = getenv("PSELD_WGRAD_TILE");          // experiment knob: 22 / 42
         const int force = e ? atoi(e) : 0;
         if (force == 42 || (force == 0 && gemm_big_tiles()))
-            return launch_gemm<T, OutT, 4, 2, TA, TB>(g, splits, stream);   // weight gradient: 256x192, 8 waves (measured +4 %)
+            return launch_gemm<T, OutT, 4, 2, TA, TB, CONV>(g, splits, stream);   // weight gradient: 256x192, 8 waves (measured +4 %)
     }
-    return launch_gemm<T, OutT, 2, 2, TA, TB>(g, splits, stream);
+    return launch_gemm<T, OutT, 2, 2, TA, TB, CONV>(g, splits, stream);
 }
 
 // ---- split-K slab reduction: out[i] (+)= sum_s slabs[s][i] ----------------------------------------------
@@ -843,6 +891,10 @@ static int wgrad_splits_for(int dtype, int Mtok, int N, int K) {
     else { bm = 128; bn = 192; slots = dtype == PSELD_BF16 ? 512 : 256; }
     const int tiles = pseld_cdiv(N, bm) * pseld_cdiv(K, bn);
     int splits = (int)((long)slots * wgrad_fill_percent() / 100 / tiles);
+    // a weight with more than half a round of output tiles (the CNN14 / Conformer matrices) would get ONE split and leave
+    // the tail of its single round idle: three rounds of shorter workgroups instead (tools/wgrad_sweep_crnn.py:
+    // 24000 x 1024 x 9216 1498 -> 685 us; the small weights stay with one resident round)
+    if (2 * tiles > slots) splits = (int)((long)slots * 3 / tiles);
     // XCD-swizzled launches give whole splits to one XCD: keep the 8 XCDs evenly loaded
     if (gemm_xcd_mode(true) && splits >= 8) splits = splits / 8 * 8;
     const int max_splits = pseld_cdiv(Mtok, wgrad_min_tokens());
@@ -923,5 +975,58 @@ extern "C" int pseld_colsum(int dtype, const void* X, float* out, int M, int N, 
     PSELD_LAUNCH_CHECK("colsum_partial");
     pseld_reduce_slabs(workspace, out, (long)N, nb, (long)N, accumulate, s);
     PSELD_LAUNCH_CHECK("colsum_reduce");
+    return PSELD_OK;
+}
+
+
+// ---- implicit 3x3 convolution (pad 1) on NHWC rows: the im2col matrix of cnn.hip is never built ------------------------------
+static void conv_geometry(GemmArgs& g, int T, int F, int C) {
+    g.cv_T = T; g.cv_F = F; g.cv_C = C; g.cv_rF = 1.0f / (float)F; g.cv_rT = 1.0f / (float)T;
+}
+// Y[B*T*F, N] = im2col(X)[B*T*F, 9*C] @ Wp[N, 9*C]^T. Forward: Wp = conv_weight_to_tap(W); input gradient: X = dY
+// (C = Cout) and Wp = conv_weight_to_tap_t(W) (N = Cin padded).
+extern "C" int pseld_conv3x3_fwd(int dtype, const void* X, const void* Wp, void* Y, int B, int T, int F, int C, int N, void* stream) {
+    PSELD_CHECK_ARG(X && Wp && Y && B > 0 && T > 0 && F > 0, "conv3x3_fwd: bad argument");
+    PSELD_CHECK_ARG(C % 8 == 0 && N % 8 == 0 && (long)B * T * F < (1L << 24), "conv3x3_fwd: C, N multiples of 8; rows < 2^24");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = X; g.B = Wp; g.C = Y;
+    g.M = B * T * F; g.N = N; g.K = 9 * C; g.lda = C; g.ldb = 9 * C; g.ldc = N;
+    g.rows_per_scale = 1; g.kchunk = g.K; g.epi = EPI_NONE; g.pro = PRO_NONE; g.dbg = nullptr;
+    conv_geometry(g, T, F, C);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PSELD_BF16) return dispatch_tile<bf16_t, bf16_t, false, false, true>(g, 1, s);
+    if (dtype == PSELD_F32) return dispatch_tile<float, float, false, false, true>(g, 1, s);
+    pseld_set_error("conv3x3_fwd: unknown dtype %d", dtype);
+    return PSELD_ERR_BAD_ARG;
+}
+extern "C" long pseld_conv3x3_wgrad_workspace(int B, int T, int F, int C, int N) { return pseld_gemm_wgrad_workspace(B * T * F, N, 9 * C, nullptr); }
+// dWp[N, 9*C] (fp32, tap-major) (+)= dY[B*T*F, N]^T @ im2col(X)
+extern "C" int pseld_conv3x3_wgrad(int dtype, const void* dY, const void* X, float* dWp, int B, int T, int F, int C, int N,
+                                   int accumulate, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(dY && X && dWp && workspace && B > 0 && T > 0 && F > 0, "conv3x3_wgrad: bad argument");
+    PSELD_CHECK_ARG(C % 8 == 0 && N % 8 == 0 && (long)B * T * F < (1L << 24), "conv3x3_wgrad: C, N multiples of 8; rows < 2^24");
+    const int Mtok = B * T * F, K = 9 * C;
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr), "conv3x3_wgrad: workspace too small");
+    int splits = wgrad_splits_for(dtype, Mtok, N, K);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dY; g.B = X; g.C = workspace;
+    g.M = N; g.N = K; g.K = Mtok; g.lda = N; g.ldb = C; g.ldc = K;
+    g.rows_per_scale = 1;
+    const int bk = (dtype == PSELD_BF16) ? 64 : 32;
+    int kchunk = pseld_cdiv(Mtok, splits);
+    kchunk = pseld_cdiv(kchunk, bk) * bk;
+    splits = pseld_cdiv(Mtok, kchunk);
+    g.kchunk = kchunk; g.slab_stride = (long)N * K; g.epi = EPI_NONE; g.pro = PRO_NONE;
+    conv_geometry(g, T, F, C);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true, true>(g, splits, s);
+    else if (dtype == PSELD_F32) rc = dispatch_tile<float, float, true, true, true>(g, splits, s);
+    else { pseld_set_error("conv3x3_wgrad: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
+    if (rc != PSELD_OK) return rc;
+    pseld_reduce_slabs(workspace, dWp, (long)N * K, splits, g.slab_stride, accumulate, s);
+    PSELD_LAUNCH_CHECK("conv3x3_wgrad");
     return PSELD_OK;
 }

@@ -8,6 +8,8 @@ matrix kept from the forward pass (HBM is large: 0.2 GB per chunk), permuted bac
 im2col matrix is built per slice of the batch. BatchNorm2d (train-mode batch statistics) + ReLU and the
 average pools are per-column / per-pixel kernels (csrc/cnn.hip). No tensor arithmetic happens in this file.
 """
+import os
+
 import torch
 
 from ... import ops
@@ -33,6 +35,9 @@ class ConvEncoder:
         self.num_features = self.widths[-1]
         self.bn_buffers = {}
         self.keep_im2col = True            # training: keep the forward im2col matrices for the weight-gradient GEMMs
+        # layers with at most this many input channels run as implicit convolutions (no im2col / col2im at all): they are
+        # the HBM-bound ones; the deep layers keep the explicit matrix and the LDS-DMA GEMM feeder
+        self.implicit_max_channels = int(os.environ.get('PSELD_CONV_IMPLICIT_MAXC', 256))
         cin = in_chans
         for i, cout in enumerate(self.widths):
             b = f'{prefix}conv_block{i + 1}.'
@@ -62,11 +67,23 @@ class ConvEncoder:
         per = max(1, CONV_SLICE_ELEMS // max(1, rows_per_sample * K))
         return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
 
+    def _implicit(self, cin_p):
+        return cin_p <= self.implicit_max_channels
+
+    @staticmethod
+    def _row_slices(B, rows_per_sample):
+        per = max(1, ((1 << 24) - 1) // rows_per_sample)           # the implicit loaders decode rows below 2^24
+        return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+
     def _conv_fwd(self, x, W, B, T, F, keep):
         """Returns (y, the im2col slices when `keep`: the weight-gradient GEMM of the backward reads them again, and
         288 GB of HBM hold them easily — 0.2 GB per ten-second chunk at the crnn.yaml widths)."""
         rows, K = T * F, W.shape[1]
         y = torch.empty((B * rows, W.shape[0]), dtype=x.dtype, device=x.device)
+        if self._implicit(x.shape[1]):
+            for b0, b1 in self._row_slices(B, rows):
+                ops.conv3x3_fwd(x[b0 * rows:b1 * rows], W, b1 - b0, T, F, out=y[b0 * rows:b1 * rows])
+            return y, None
         kept = [] if keep else None
         for b0, b1 in self._slices(B, rows, K):
             A = ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
@@ -75,11 +92,19 @@ class ConvEncoder:
                 kept.append(A)
         return y, kept
 
-    def _conv_bwd(self, dy, x, W, dW, B, T, F, cin_p, kept=None):
-        """dW (reference layout, overwritten) and dx = col2im(dy @ Wp)."""
+    def _conv_bwd(self, dy, x, W, dW, B, T, F, cin_p, kept=None, name=None):
+        """dW (reference layout, overwritten) and dx = col2im(dy @ Wp) — or, for the implicit layers, dx = the 3x3
+        convolution of dy with the flipped, transposed weight."""
         rows, K = T * F, W.shape[1]
         dx = torch.empty((B * rows, cin_p), dtype=x.dtype, device=x.device)
         dWp = torch.empty((W.shape[0], K), dtype=torch.float32, device=x.device)
+        if self._implicit(cin_p):
+            Wd = ops.conv_weight_to_tap_t(self.arena.w(name, x.dtype), cin_p)
+            for n, (b0, b1) in enumerate(self._row_slices(B, rows)):
+                ops.conv3x3_wgrad(dy[b0 * rows:b1 * rows], x[b0 * rows:b1 * rows], dWp, b1 - b0, T, F, accumulate=n > 0)
+                ops.conv3x3_fwd(dy[b0 * rows:b1 * rows], Wd, b1 - b0, T, F, out=dx[b0 * rows:b1 * rows])
+            ops.conv_wgrad_from_tap(dWp, dW, cin_p)
+            return dx
         for n, (b0, b1) in enumerate(self._slices(B, rows, K)):
             A = kept[n] if kept is not None else ops.im2col3x3(x[b0 * rows:b1 * rows], b1 - b0, T, F)
             ops.linear_wgrad(dy[b0 * rows:b1 * rows], A, dWp, accumulate=n > 0)
@@ -130,10 +155,10 @@ class ConvEncoder:
             dz2 = ops.avgpool_bwd(dx, B, s['T'], s['F'], pt, pf)
             dy2 = ops.bn_relu_bwd(s['y2'], s['z2'], dz2, s['mr2'], a.p(b + 'bn2.weight'), a.g(b + 'bn2.weight'), a.g(b + 'bn2.bias'))
             W2 = self._weight(b + 'conv2.weight', dtype, cout)
-            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout, s['A2'])
+            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout, s['A2'], b + 'conv2.weight')
             s['A2'] = None
             dy1 = ops.bn_relu_bwd(s['y1'], s['z1'], dz1, s['mr1'], a.p(b + 'bn1.weight'), a.g(b + 'bn1.weight'), a.g(b + 'bn1.bias'))
             W1 = self._weight(b + 'conv1.weight', dtype, s['cin_p'])
-            dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'], s['A1'])
+            dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'], s['A1'], b + 'conv1.weight')
             s['A1'] = None
         return dx

@@ -573,6 +573,39 @@ def conv_wgrad_from_tap(dwp, dw, cp):
                "pseld_conv_wgrad_from_tap")
 
 
+def conv_weight_to_tap_t(w, cp):
+    """[Cout, Cin, 3, 3] -> [cp, 9*Cout] with flipped taps: the weight of the input gradient as an implicit convolution."""
+    _chk(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    wd = torch.empty((cp, 9 * Cout), dtype=w.dtype, device=w.device)
+    _lib.check(_lib.lib().pseld_conv_weight_to_tap_t(dtype_code(w), _lib.ptr(w), _lib.ptr(wd), Cout, Cin, cp, _lib.stream_ptr()),
+               "pseld_conv_weight_to_tap_t")
+    return wd
+
+
+def conv3x3_fwd(X, Wp, B, T, F, out=None):
+    """Y[B*T*F, N] = im2col(X) @ Wp^T without the im2col matrix (Wp [N, 9*C] tap-major)."""
+    _chk(X, Wp, out)
+    C, N = X.shape[1], Wp.shape[0]
+    assert Wp.shape[1] == 9 * C and X.shape[0] == B * T * F
+    Y = torch.empty((B * T * F, N), dtype=X.dtype, device=X.device) if out is None else out
+    _lib.check(_lib.lib().pseld_conv3x3_fwd(dtype_code(X), _lib.ptr(X), _lib.ptr(Wp), _lib.ptr(Y), B, T, F, C, N, _lib.stream_ptr()),
+               "pseld_conv3x3_fwd")
+    return Y
+
+
+def conv3x3_wgrad(dY, X, dWp, B, T, F, accumulate=False):
+    """dWp f32 [N, 9*C] (+)= dY^T @ im2col(X)."""
+    _chk(dY, X, dWp)
+    C, N = X.shape[1], dY.shape[1]
+    assert dWp.shape == (N, 9 * C) and dWp.dtype == torch.float32
+    L = _lib.lib()
+    ws = workspace(L.pseld_conv3x3_wgrad_workspace(B, T, F, C, N), X.device)
+    _lib.check(L.pseld_conv3x3_wgrad(dtype_code(X), _lib.ptr(dY), _lib.ptr(X), _lib.ptr(dWp), B, T, F, C, N, int(accumulate), _lib.ptr(ws),
+                                     ws.numel() * 4, _lib.stream_ptr()), "pseld_conv3x3_wgrad")
+    return dWp
+
+
 def bn2d_stats(X):
     _chk(X)
     rows, C = X.shape

@@ -117,6 +117,37 @@ def test_conv_encoder_kernels(dev, dtype, tol):
     assert rel(dwf, (d04 * xh).sum(dim=(0, 2)).reshape(-1)) < 1e-4 and rel(dbf, d04.sum(dim=(0, 2)).reshape(-1)) < 1e-4
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("B,C,T,Fq,Co", [(2, 16, 21, 12, 24), (3, 64, 33, 8, 64), (1, 8, 50, 64, 16), (2, 128, 9, 2, 200)])
+def test_implicit_conv3x3(dev, dtype, tol, B, C, T, Fq, Co):
+    """conv3x3_fwd / its use as the input gradient / conv3x3_wgrad (no im2col matrix) against F.conv2d autograd."""
+    from pseldnets_amd import ops
+    torch.manual_seed(9)
+    x = torch.randn(B, C, T, Fq, device=dev)
+    w = torch.randn(Co, C, 3, 3, device=dev) * (2.0 / (9 * C)) ** 0.5
+    xr, wq = nhwc(x).to(dtype), w.to(dtype)
+    x4 = xr.float().view(B, T, Fq, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    w4 = wq.float().clone().requires_grad_(True)
+    yr = F.conv2d(x4, w4, padding=1)
+    y = ops.conv3x3_fwd(xr, ops.conv_weight_to_tap(wq, C), B, T, Fq)
+    assert rel(y, nhwc(yr)) < tol
+    dy = torch.randn(B, Co, T, Fq, device=dev)
+    dyr = nhwc(dy).to(dtype)
+    yr.backward(dyr.float().view(B, T, Fq, Co).permute(0, 3, 1, 2))
+    Cop = (Co + 7) // 8 * 8
+    assert Cop == Co
+    dx = ops.conv3x3_fwd(dyr, ops.conv_weight_to_tap_t(wq, C), B, T, Fq)
+    assert rel(dx, nhwc(x4.grad)) < tol
+    dwp = torch.empty(Co, 9 * C, device=dev)
+    ops.conv3x3_wgrad(dyr, xr, dwp, B, T, Fq)
+    dw = torch.empty(Co, C, 3, 3, device=dev)
+    ops.conv_wgrad_from_tap(dwp, dw, C)
+    assert rel(dw, w4.grad) < (1e-4 if dtype == torch.float32 else tol)
+    ops.conv3x3_wgrad(dyr, xr, dwp, B, T, Fq, accumulate=True)
+    ops.conv_wgrad_from_tap(dwp, dw, C)
+    assert rel(dw, 2 * w4.grad) < (1e-4 if dtype == torch.float32 else tol)
+
+
 def build(mod, kind, C, encoder, feats, dev, dtype=torch.float32):
     net = mod.CRNN(CFG, C, 7, encoder=encoder, pretrained_path=None, num_features=feats)
     net.load_state_dict(oc.formula_state(kind, C, 7, encoder, feats), strict=True)
