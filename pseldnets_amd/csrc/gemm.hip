@@ -632,16 +632,21 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
 // staging of the epilogue is the larger user), so THREE workgroups fit per CU instead of two — that occupancy, not
 // the DMA itself, is what pays (a 3-slice / 2-workgroup version measured equal to the register-staged kernel;
 // this one is 7 % faster over the HTS-AT forward shapes: tools/gemm_shapes.py, one session, 4.06 -> 3.77 ms).
+// STAGES > 2 turns the two slices into a ring (STAGES - 1 slices in flight, vmcnt distance kept constant by dummy
+// loads in the tail). Measured (tools/gemm_deep.py, tools/experiments/loop_ceiling.hip): ring depth 2..6 changes nothing and
+// a 256x192 / 8-wave / 4-slice variant is no faster — the slice loop is bound by the THROUGHPUT of global_load_lds
+// (about 30 B/clk/CU even on cache hits: 1.37 PFLOP/s for this tile with fragment reads, barrier and MFMAs in place,
+// 2.1 PFLOP/s without the DMA), not by its latency, the LDS reads or the barrier. Only STAGES = 2 is instantiated.
 // One raw s_barrier per slice; the next slice's DMA is issued right after it. Images are lane-linear 64-byte rows; the
 // 16-byte chunk each lane FETCHES is XOR-ed with (row>>2)&3 so every ds_read_b128 lane group is bank-conflict free.
 // PSELD_GEMM_DMA=0 falls back to gemm_kernel (A/B knob).
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
-template <int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 3) void gemm_dma_kernel(GemmArgs g) {
+template <int WM, int WN, int STAGES = 2>
+__global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 1) void gemm_dma_kernel(GemmArgs g) {
     constexpr int THREADS = WM * WN * 64, WAVES = WM * WN, BM = WM * 64, BN = WN * 96;
-    constexpr int BKD = 32, STAGES = 2;
+    constexpr int BKD = 32;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = A_BYTES / 1024, TOTAL = STAGE / 1024;
     constexpr int LPW = (TOTAL + WAVES - 1) / WAVES;          // DMA instructions per wave per slice (padded with dummies)
@@ -664,7 +669,8 @@ __global__ __launch_bounds__(WM * WN * 64, 3) void gemm_dma_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
             const int i = wave + WAVES * j;                  // wave-uniform instruction index inside the slice
-            if (i < TOTAL) {
+            if (i < TOTAL && s < nslices) {                  // (deep pipeline: slices past the end are dummies, so that
+                                                             //  the vmcnt distance stays constant in the tail)
                 const bool isA = i < A_INSTR;
                 const int ii = isA ? i : i - A_INSTR;
                 const int row = ii * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
@@ -688,11 +694,13 @@ __global__ __launch_bounds__(WM * WN * 64, 3) void gemm_dma_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    if (nslices > 0) issue(0);
+    // STAGES - 1 slices are in flight; the wait leaves the STAGES - 2 younger ones outstanding
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p) issue(p);
     for (int s = 0; s < nslices; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPW) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + 1 < nslices) issue(s + 1);
+        if (STAGES > 2 || s + 1 < nslices) issue(s + STAGES - 1);
         const char* As = smem + (s % STAGES) * STAGE;
         const char* Bs = As + A_BYTES;
 #pragma unroll
@@ -721,19 +729,19 @@ __global__ __launch_bounds__(WM * WN * 64, 3) void gemm_dma_kernel(GemmArgs g) {
     else staged_epilogue<EM_GENERIC, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int STAGES = 2>
 int launch_gemm_dma(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = WM * 64, BN = WN * 96;
     constexpr int STAGE = (BM + BN) * 64;
     constexpr int CS_BYTES = BM * (BN * 2 + 16);
-    constexpr int LDS = (2 * STAGE + 1024 > CS_BYTES) ? 2 * STAGE + 1024 : CS_BYTES;
+    constexpr int LDS = (STAGES * STAGE + 1024 > CS_BYTES) ? STAGES * STAGE + 1024 : CS_BYTES;
     GemmArgs ga = g;
     ga.nx = pseld_cdiv(g.N, BN); ga.ny = pseld_cdiv(g.M, BM); ga.nz = 1;
     ga.xcd_swizzle = 1;
     const long nblocks = (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-    hipLaunchKernelGGL((gemm_dma_kernel<WM, WN>), dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, stream, ga);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, STAGES>), dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm_dma");
     return PSELD_OK;
 }
