@@ -57,5 +57,13 @@ int main() {
             if (rep) printf("16x16x32 bf16, %4d blocks x 4 waves, 8 chains: %7.3f ms  %7.1f TFLOP/s\n", blocks, ms, flops / ms / 1e9);
         }
     }
+    // sustained: 400 back-to-back launches (about 1.2 s of pure MFMA issue) — does the rate hold once the power limit reacts?
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(mfma_loop<6>, dim3(2048), dim3(256), 0, 0, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("sustained chunk %d: %8.1f ms  %7.1f TFLOP/s\n", chunk, ms, 100.0 * 2048 * 4 * iters * 6 * 32768.0 / ms / 1e9);
+    }
     return 0;
 }
