@@ -224,6 +224,31 @@ int pseld_relattn_bwd(int dtype, const void* q, const void* k, const void* v, co
                       void* dk, void* dv, float* dpos, float* du_bias, float* dv_bias, int B, int T, int D, int heads,
                       float* workspace, long workspace_bytes, void* stream);
 
+/* ---- on-device augmentations -----------------------------------------------------------------
+ * src/augment/specaug.py:14-63, crop.py:10-32, freqshift.py:17-38, rotate.py:10-101, trackmix.py:15-75,
+ * wavmix.py:16-116; called from models/model_module.py:47-68 and components/model_module.py:83-121. The host mirror
+ * draws the random parameters with the reference's generator calls; these entry points apply them to the batch.
+ * All data fp32. rect_fill: x [N,C,T,F] in place, rects int32 [N*C][R][4] = (t0,t1,f0,f1) half-open (SpecAugment time
+ * and iid frequency masks, Crop). time_fill: label [N,Ty,inner] in place, spans int32 [N][R][2]. freqshift: shift int32
+ * [N], > 0 = 'up' (F.pad(x,(s,0),'reflect')[..., :F]), < 0 = 'down' (F.pad(x,(0,-s),'reflect')[..., -s:]). rotate_wave:
+ * y[n,0] = x[n,0], y[n,1+j] = sign[n][j] * x[n, src[n][j]] (FOA [N,4,L], L % 4 == 0). rotate_label: label viewed
+ * [N, outer, A, inner], y[..,a0+j,:] = sign[n][j] * x[..,a0+src[n][j],:], other positions of the axis copied.
+ * mix: y[dst[p]] = lam[p]*x[dst[p]] + (1-lam[p])*x[src[p]] for P pairs of `elems` elements (y holds a copy of x).
+ * mix_adpit: the ADPIT label surgery on [N,T,6,4,C]; mode 1 = partner with one source (TrackMix, WavMix add_ov '1'),
+ * mode 2 = partner with up to two (WavMix add_ov '2'). mix_tracks: sed [N,T,3,C] / doa [N,T,3,3] track stacking
+ * (wavmix = 0: third track zero; 1: third track = the partner's second). Outputs hold copies of the inputs. */
+int pseld_aug_rect_fill(float* x, const int* rects, int N, int C, int T, int F, int R, float value, void* stream);
+int pseld_aug_time_fill(float* y, const int* spans, int N, int Ty, long inner, int R, float value, void* stream);
+int pseld_aug_freqshift(const float* x, float* y, const int* shift, int N, int C, int T, int F, void* stream);
+int pseld_aug_rotate_wave(const float* x, float* y, const int* src, const float* sign, int N, long L, void* stream);
+int pseld_aug_rotate_label(const float* x, float* y, const int* src, const float* sign, int N, long outer, int A, long inner,
+                           int a0, void* stream);
+int pseld_aug_mix(const float* x, float* y, const int* dst, const int* src, const float* lam, int P, long elems, void* stream);
+int pseld_aug_mix_adpit(const float* lab, float* out, const int* dst, const int* src, const float* lam, int P, int T, int C, int mode,
+                        void* stream);
+int pseld_aug_mix_tracks(const float* sed, const float* doa, float* sed_out, float* doa_out, const int* dst, const int* src,
+                         const float* lam, int P, int T, int C, int wavmix, void* stream);
+
 /* ---- output head ---------------------------------------------------------------------------------------------------
  * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):
  * tok [B,64,C] -> A [B*32, C*6] (k = c*6 + cf*3 + dt, matching the conv weight's [D, C, 2, 3] flattening).

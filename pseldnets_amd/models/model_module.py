@@ -5,6 +5,8 @@ can be driven either hook-by-hook (autograd + torch optimiser, as Lightning woul
 (FusedTrainer: backward, bucketed all-reduce, clip and AdamW inside the MI355X path).
 Validation-epoch aggregation / SELD metrics (model_module.py:83-179) are out of scope."""
 import importlib
+import random
+from itertools import combinations
 
 import torch
 
@@ -35,7 +37,7 @@ def instantiate(node):
     (`loss.multi_accdoa.Losses`, ...) are mapped onto this package."""
     kwargs = {k: v for k, v in dict(node).items() if k != '_target_'}
     target = node['_target_']
-    if target.startswith('loss.'):
+    if target.startswith('loss.') or target.startswith('augment.'):
         target = 'pseldnets_amd.' + target
     mod, cls = target.rsplit('.', 1)
     return getattr(importlib.import_module(mod), cls)(**kwargs)
@@ -50,10 +52,23 @@ class SELDModelModule:
         self.training = True
         self.af_extractor = get_afextractor(cfg)
         self.loss = instantiate(_get(cfg, 'model.loss'))
-        aug = _get(cfg, 'augment.type', [])
-        if aug or _get(cfg, 'augment.AugMix', False):
-            raise NotImplementedError("augmentations are not built on the MI355X path yet (SURVEY.md §8f rank 1): "
-                                      "run with augment.type=[] and AugMix=false")
+        # Data augmentations (components/model_module.py:61-78): instantiated only when configured
+        self.label_res = 0.1
+        xy_ratio = _get(cfg, 'data.sample_rate') / _get(cfg, 'data.hoplen') * self.label_res
+        types = list(_get(cfg, 'augment.type', []) or [])
+        self.data_aug = {'type': types, 'AugMix': bool(_get(cfg, 'augment.AugMix', False))}
+        for name in ('trackmix', 'wavmix', 'rotate', 'freqshift', 'crop', 'specaug'):
+            node = _get(cfg, 'augment.' + name)
+            if node is not None:
+                extra = {'xy_ratio': xy_ratio} if name == 'specaug' else {}
+                self.data_aug[name] = instantiate(dict(node, **extra))
+        missing = [t for t in types if t not in self.data_aug]
+        if missing:
+            raise KeyError(f"augment.type lists {missing} but cfg.augment has no such node")
+        aug_TF = [t for t in types if t not in ('rotate', 'wavmix')]
+        self.aug_TF_comb = []
+        for n in range(1, len(aug_TF) + 1):
+            self.aug_TF_comb += combinations(aug_TF, n)
         self._trainer = None
 
     def setup(self, stage='fit', device='cuda'):
@@ -75,8 +90,56 @@ class SELDModelModule:
     def forward(self, x):
         return self.net(x)
 
-    def common_step(self, batch_x, batch_y=None):
+    # -- augmentation plumbing (components/model_module.py:83-121) ------------------------------------------------------
+    def data_copy(self, batch_x, batch_target):
+        batch_x = torch.cat([batch_x] * 3, dim=0)
+        batch_target = dict(batch_target)
+        for key, value in batch_target.items():
+            batch_target[key] = torch.cat([value] * 3, dim=0) if isinstance(value, torch.Tensor) else list(value) * 3
+        return batch_x, batch_target
+
+    def augmix_data(self, batch_x, batch_target):
+        N = len(batch_x) // 3
+        parts_x, parts_t = [batch_x[:N]], [{k: v[:N] for k, v in batch_target.items()}]
+        for i in (1, 2):
+            x, t = self.augment_data(batch_x[i * N:(i + 1) * N], {k: v[i * N:(i + 1) * N] for k, v in batch_target.items()})
+            parts_x.append(x); parts_t.append(t)
+        out = {}
+        for key in batch_target:
+            if 'label' in key:
+                out[key] = torch.cat([t[key] for t in parts_t], dim=0)
+            else:
+                out[key] = list(parts_t[0][key]) + list(parts_t[1][key]) + list(parts_t[2][key])
+        return torch.cat(parts_x, dim=0), out
+
+    def augment_data(self, batch_x, batch_y=None):
+        if self.data_aug['type'] and self.aug_TF_comb:
+            aug_methods = list(random.choice(self.aug_TF_comb))
+            random.shuffle(aug_methods)
+            for aug_method in aug_methods:
+                batch_x, batch_y = self.data_aug[aug_method](batch_x, batch_y)
+        return batch_x, batch_y
+
+    def augment_step(self, batch_x, batch_y):
+        """The part of common_step (models/model_module.py:47-65) in front of the network: waveform augmentations, feature
+        extraction, feature augmentations. Returns (features, targets)."""
+        if self.training:
+            if self.data_aug['AugMix']:
+                batch_x, batch_y = self.data_copy(batch_x, batch_y)
+            if 'rotate' in self.data_aug['type']:
+                batch_x, batch_y = self.data_aug['rotate'](batch_x, batch_y)
+            if 'wavmix' in self.data_aug['type']:
+                batch_x, batch_y = self.data_aug['wavmix'](batch_x, batch_y)
         batch_x = self.standardize(batch_x)
+        if self.training:
+            if self.data_aug['AugMix']:
+                batch_x, batch_y = self.augmix_data(batch_x, batch_y)
+            else:
+                batch_x, batch_y = self.augment_data(batch_x, batch_y)
+        return batch_x, batch_y
+
+    def common_step(self, batch_x, batch_y=None):
+        batch_x, batch_y = self.augment_step(batch_x, batch_y)
         return self.forward(batch_x), batch_y
 
     def training_step(self, batch_sample, batch_idx=0):
@@ -109,4 +172,8 @@ class SELDModelModule:
 
     def fused_training_step(self, batch_sample, process_group=None):
         batch_target = {k: v for k, v in batch_sample.items() if 'data' not in k}
+        if self.data_aug['type'] or self.data_aug['AugMix']:
+            self.training = True
+            feats, batch_target = self.augment_step(batch_sample['data'], batch_target)
+            return self.fused_trainer(process_group).training_step(feats, batch_target, is_features=True)
         return self.fused_trainer(process_group).training_step(batch_sample['data'], batch_target)

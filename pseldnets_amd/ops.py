@@ -800,3 +800,79 @@ def relattn_bwd(q, k, v, pos, u_bias, v_bias, attn, dout, dpos, du_bias, dv_bias
                                    _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(dpos), _lib.ptr(du_bias), _lib.ptr(dv_bias), B, T, D, heads,
                                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "pseld_relattn_bwd")
     return dq, dk, dv
+
+
+# ---------------------------------------------------------------------------------------------------------
+# on-device augmentations (csrc/augment.hip); fp32 data, int32 parameter tensors on the same device
+def _f32(*ts):
+    _chk(*ts)
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.PseldError("augmentations run on fp32 data")
+
+
+def aug_rect_fill(x, rects, value=0.0):
+    """x [N,C,T,F] in place; rects int32 [N,C,R,4] = (t0,t1,f0,f1)."""
+    _f32(x); _chk(rects)
+    N, C, T, F = x.shape
+    _lib.check(_lib.lib().pseld_aug_rect_fill(_lib.ptr(x), _lib.ptr(rects), N, C, T, F, rects.shape[2], float(value), _lib.stream_ptr()),
+               "pseld_aug_rect_fill")
+    return x
+
+
+def aug_time_fill(y, spans, value=0.0):
+    """y [N,Ty,...] in place; spans int32 [N,R,2]."""
+    _f32(y); _chk(spans)
+    N, Ty = y.shape[:2]
+    _lib.check(_lib.lib().pseld_aug_time_fill(_lib.ptr(y), _lib.ptr(spans), N, Ty, y[0, 0].numel(), spans.shape[1], float(value),
+                                              _lib.stream_ptr()), "pseld_aug_time_fill")
+    return y
+
+
+def aug_freqshift(x, shift):
+    _f32(x); _chk(shift)
+    N, C, T, F = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pseld_aug_freqshift(_lib.ptr(x), _lib.ptr(y), _lib.ptr(shift), N, C, T, F, _lib.stream_ptr()), "pseld_aug_freqshift")
+    return y
+
+
+def aug_rotate_wave(x, src, sign):
+    _f32(x, sign); _chk(src)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pseld_aug_rotate_wave(_lib.ptr(x), _lib.ptr(y), _lib.ptr(src), _lib.ptr(sign), x.shape[0], x.shape[2], _lib.stream_ptr()),
+               "pseld_aug_rotate_wave")
+    return y
+
+
+def aug_rotate_label(x, src, sign, outer, A, inner, a0):
+    _f32(x, sign); _chk(src)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pseld_aug_rotate_label(_lib.ptr(x), _lib.ptr(y), _lib.ptr(src), _lib.ptr(sign), x.shape[0], outer, A, inner, a0,
+                                                 _lib.stream_ptr()), "pseld_aug_rotate_label")
+    return y
+
+
+def aug_mix(x, dst, src, lam):
+    """Returns a copy of x with rows dst[p] replaced by lam*x[dst[p]] + (1-lam)*x[src[p]]."""
+    _f32(x, lam); _chk(dst, src)
+    y = x.clone()
+    _lib.check(_lib.lib().pseld_aug_mix(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dst), _lib.ptr(src), _lib.ptr(lam), dst.numel(), x[0].numel(),
+                                        _lib.stream_ptr()), "pseld_aug_mix")
+    return y
+
+
+def aug_mix_adpit(lab, dst, src, lam, mode):
+    _f32(lab, lam); _chk(dst, src)
+    out = lab.clone()
+    _lib.check(_lib.lib().pseld_aug_mix_adpit(_lib.ptr(lab), _lib.ptr(out), _lib.ptr(dst), _lib.ptr(src), _lib.ptr(lam), dst.numel(), lab.shape[1],
+                                              lab.shape[4], mode, _lib.stream_ptr()), "pseld_aug_mix_adpit")
+    return out
+
+
+def aug_mix_tracks(sed, doa, dst, src, lam, wavmix):
+    _f32(sed, doa, lam); _chk(dst, src)
+    so, do = sed.clone(), doa.clone()
+    _lib.check(_lib.lib().pseld_aug_mix_tracks(_lib.ptr(sed), _lib.ptr(doa), _lib.ptr(so), _lib.ptr(do), _lib.ptr(dst), _lib.ptr(src), _lib.ptr(lam),
+                                               dst.numel(), sed.shape[1], sed.shape[3], int(wavmix), _lib.stream_ptr()), "pseld_aug_mix_tracks")
+    return so, do

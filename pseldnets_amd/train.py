@@ -22,10 +22,21 @@ DEFAULT_CFG = {
               'loss': {'_target_': 'loss.multi_accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'},
               'optimizer': {'method': 'AdamW', 'kwargs': {'lr': 1e-4, 'amsgrad': False}},
               'lr_scheduler': {'method': 'StepLR', 'kwargs': {'step_size': 20, 'gamma': 0.1}}},
-    'augment': {'type': [], 'AugMix': False},
+    # configs/augment/default.yaml (the `augment=augmix` group option = configs/augment/augmix.yaml)
+    'augment': {'type': [], 'AugMix': False,
+                'trackmix': {'_target_': 'augment.TrackMix', 'alpha': 0.5},
+                'wavmix': {'_target_': 'augment.WavMix', 'alpha': 0.5, 'p': 0.5},
+                'rotate': {'_target_': 'augment.Rotation', 'p': 0.8, 'rotation_type': 48},
+                'specaug': {'_target_': 'augment.SpecAugment', 'T': 40, 'F': 8, 'mT': 4, 'mF': 2},
+                'crop': {'_target_': 'augment.Crop', 'T': 8, 'F': 4, 'mC': 4},
+                'freqshift': {'_target_': 'augment.FreqShift', 'p': 0.5, 'shift_range': 15, 'direction': 'None', 'mode': 'reflect'}},
     'trainer': {'max_epochs': 1, 'gradient_clip_val': 1.0, 'precision': 'bf16-mixed', 'sync_batchnorm': False,
                 'limit_train_batches': 10},
     'adapt': {},
+}
+AUGMENT_GROUPS = {
+    'default': {},
+    'augmix': {'type': ['specaug', 'crop', 'freqshift', 'rotate', 'trackmix', 'wavmix'], 'AugMix': True},
 }
 EXPERIMENTS = {
     'synth_maccdoa': {},
@@ -57,6 +68,9 @@ def compose(argv):
         if key == 'experiment':
             _merge(cfg, copy.deepcopy(EXPERIMENTS[val]))
             continue
+        if key == 'augment':
+            _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS[val]))
+            continue
         try:
             val = json.loads(val)
         except json.JSONDecodeError:
@@ -87,8 +101,10 @@ def synthetic_batch(cfg, method, device, gen):
         lab = torch.zeros(B, 100, 6, 4, C, device=device)
         lab[:, :, 0, 0], lab[:, :, 0, 1:] = act, doa
         batch['adpit_label'] = lab
+        batch['ov'] = ['1'] * B                      # one source per synthetic chunk (TrackMix / WavMix pair these)
     elif method == 'accdoa':
         batch['accdoa_label'] = doa.reshape(B, 100, 3 * C)
+        batch['ov'] = ['1'] * B
     else:
         raise NotImplementedError(method)
     return batch

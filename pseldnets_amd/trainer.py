@@ -56,12 +56,13 @@ class FusedTrainer:
             return l3[0:1], (dsed, ddoa), {'loss_all': l3[0:1], 'loss_sed': l3[1:2], 'loss_doa': l3[2:3]}
         raise ValueError(self.loss_kind)
 
-    def training_step(self, batch_x, batch_target):
+    def training_step(self, batch_x, batch_target, is_features=False):
         """features -> net -> loss -> backward -> (bucketed all-reduce) -> clip -> AdamW. Returns the loss dict
-        (device tensors; nothing here synchronises with the host)."""
+        (device tensors; nothing here synchronises with the host). is_features: batch_x already is the feature tensor
+        (the augmentation path extracts features itself, models/model_module.py:47-65)."""
         net = self.net
         net.train()
-        x = self.af(batch_x) if self.af is not None else batch_x
+        x = self.af(batch_x) if (self.af is not None and not is_features) else batch_x
         net._check_input(x)
         net._materialize(x.device)
         outs, saved = net._forward_impl(x.contiguous().float(), True)

@@ -57,8 +57,11 @@ def install():
         def forward(self, x):
             return of.amplitude_to_db_power(x)
 
+    # functional.mask_along_axis_iid (augment/specaug.py:61): the published algorithm, oracle/augment.py
+    from oracle import augment as oa
     _mod('torchaudio', transforms=_mod('torchaudio.transforms', Spectrogram=Spectrogram, MelScale=MelScale,
-                                       AmplitudeToDB=AmplitudeToDB))
+                                       AmplitudeToDB=AmplitudeToDB),
+         functional=_mod('torchaudio.functional', mask_along_axis_iid=oa.mask_along_axis_iid))
 
 
 class AttrDict(dict):

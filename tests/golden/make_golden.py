@@ -463,8 +463,45 @@ def gen_conformer():
     save('conformer.npz', **out)
 
 
+from tests.golden.aug_inputs import aug_inputs  # noqa: E402
+
+
+def gen_augment():
+    """The reference's own augmentation classes (augment/*.py) on the seeded inputs, torch / numpy / random seeded per case.
+    SpecAugment runs with oracle/augment.py:mask_along_axis_iid standing in for the absent torchaudio function."""
+    import random
+    import augment as ref_aug
+    out = {}
+
+    def seed(s):
+        torch.manual_seed(s); np.random.seed(s); random.seed(s)
+
+    def put(tag, x, tgt):
+        out[tag + '_x'] = x.numpy().copy()
+        for k, v in tgt.items():
+            out[tag + '_' + k] = v.numpy().copy() if isinstance(v, torch.Tensor) else np.array(v)
+
+    def clone(t):
+        return {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in t.items()}
+
+    for kind in ('adpit', 'accdoa', 'tracks'):
+        feat, wave, tgt = aug_inputs(kind)
+        seed(11); x, t = ref_aug.SpecAugment(xy_ratio=10.0, T=20, F=4, mT=2, mF=2)(feat.clone(), clone(tgt)); put(f'specaug_{kind}', x, t)
+        seed(13); x, t = ref_aug.Rotation(p=0.8, rotation_type=48)(wave.clone(), clone(tgt)); put(f'rotate48_{kind}', x, t)
+        seed(14); x, t = ref_aug.Rotation(p=0.8, rotation_type=16)(wave.clone(), clone(tgt)); put(f'rotate16_{kind}', x, t)
+        seed(15); x, t = ref_aug.TrackMix(alpha=0.5)(feat.clone(), clone(tgt)); put(f'trackmix_{kind}', x, t)
+        for s in (16, 17, 18, 19, 20, 21):          # covers p-skip, add_ov '1' and add_ov '2'
+            seed(s); x, t = ref_aug.WavMix(alpha=0.5, p=0.9)(wave.clone(), clone(tgt)); put(f'wavmix{s}_{kind}', x, t)
+    feat, wave, tgt = aug_inputs('adpit')
+    seed(12); x, t = ref_aug.Crop(T=8, F=4, mC=3)(feat.clone(), clone(tgt)); put('crop', x, t)
+    seed(22); x, t = ref_aug.FreqShift(p=0.7, shift_range=5, direction=None, mode='reflect')(feat.clone(), clone(tgt)); put('freqshift_none', x, t)
+    seed(23); x, t = ref_aug.FreqShift(p=0.7, shift_range=5, direction='None', mode='reflect')(feat.clone(), clone(tgt)); put('freqshift_str', x, t)
+    seed(24); x, t = ref_aug.FreqShift(p=0.7, shift_range=5, direction='up', mode='reflect')(feat.clone(), clone(tgt)); put('freqshift_up', x, t)
+    save('augment.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -474,3 +511,4 @@ if __name__ == '__main__':
     if 'passt' in which: gen_passt()
     if 'crnn' in which: gen_crnn()
     if 'conformer' in which: gen_conformer()
+    if 'augment' in which: gen_augment()

@@ -315,3 +315,42 @@ def test_conformer_decoder_golden():
     assert abs(float(g['drop_loss']) - float(g['p0_loss'])) > 1e-6          # the patched dropout really was active
     _conformer_case(g, 'p0', 0.0, None)
     _conformer_case(g, 'drop', 0.1, 'formula')
+
+
+def _aug_check(g, tag, x, tgt):
+    assert np.array_equal(x.numpy(), g[tag + '_x']), tag
+    for k, v in tgt.items():
+        want = g[tag + '_' + k]
+        if isinstance(v, torch.Tensor):
+            assert np.abs(v.numpy() - want).max() <= 1e-7 * max(1.0, np.abs(want).max()), (tag, k)
+        else:
+            assert [str(a) for a in v] == [str(a) for a in want], (tag, k)
+
+
+def test_augment_golden():
+    """oracle/augment.py against the reference's augmentation classes (tests/golden/make_golden.py:gen_augment): equal seeds
+    (torch / numpy / random) give the same masks, shifts, rotations, pairings and mixed labels."""
+    import random
+    from oracle import augment as oa
+    from tests.golden.aug_inputs import aug_inputs
+    g = gold('augment.npz')
+
+    def seed(s):
+        torch.manual_seed(s); np.random.seed(s); random.seed(s)
+
+    for kind in ('adpit', 'accdoa', 'tracks'):
+        feat, wave, tgt = aug_inputs(kind)
+        seed(11); _aug_check(g, f'specaug_{kind}', *oa.specaug(feat, tgt, 10.0, T=20, Fq=4, mT=2, mF=2))
+        seed(13); _aug_check(g, f'rotate48_{kind}', *oa.rotation(wave, tgt, 0.8, 48))
+        seed(14); _aug_check(g, f'rotate16_{kind}', *oa.rotation(wave, tgt, 0.8, 16))
+        seed(15); _aug_check(g, f'trackmix_{kind}', *oa.trackmix(feat, tgt, 0.5))
+        for s in (16, 17, 18, 19, 20, 21):
+            seed(s); _aug_check(g, f'wavmix{s}_{kind}', *oa.wavmix(wave, tgt, 0.5, 0.9))
+    feat, wave, tgt = aug_inputs('adpit')
+    seed(12); _aug_check(g, 'crop', *oa.crop(feat, tgt, T=8, Fq=4, mC=3))
+    seed(22); _aug_check(g, 'freqshift_none', *oa.freqshift(feat, tgt, 0.7, 5, None))
+    seed(23); _aug_check(g, 'freqshift_str', *oa.freqshift(feat, tgt, 0.7, 5, 'None'))
+    seed(24); _aug_check(g, 'freqshift_up', *oa.freqshift(feat, tgt, 0.7, 5, 'up'))
+    # the wavmix seeds cover the skip, add_ov '1' and add_ov '2' branches
+    ovs = {tuple(str(a) for a in g[f'wavmix{s}_adpit_ov']) for s in (16, 17, 18, 19, 20, 21)}
+    assert len(ovs) >= 3, ovs
