@@ -62,6 +62,8 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
+            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_passt_grid_t'):
+                continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn
 
@@ -315,7 +317,7 @@ def main():
                                "unit": "GB/s" if hbm else "TFLOP/s",
                                "frac": round((gbs / PEAK_HBM_GBS) if hbm else (ach / PEAK_FLOPS), 4),
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "gemm_kernel<T,WM,WN,TA=0,TB> (forward + input-gradient launches)",
+                               "kernel": "pseld_gemm forward + input-gradient launches (gemm_dma_kernel<WM,WN> for bf16 NT products, gemm_kernel<T,..,TA=0,TB> otherwise)",
                                "launches": n // 2, "avg_launch_ms": round(tms / n, 4),
                                "flops_per_launch_avg": round(fl / n, 1), "bytes_per_launch_avg": round(nb / n, 1),
                                "achieved_tflops": round(ach, 2), "achieved_gbs": round(gbs, 1),
