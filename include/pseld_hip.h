@@ -249,6 +249,20 @@ int pseld_aug_mix_adpit(const float* lab, float* out, const int* dst, const int*
 int pseld_aug_mix_tracks(const float* sed, const float* doa, float* sed_out, float* doa_out, const int* dst, const int* src,
                          const float* lam, int P, int T, int C, int wavmix, void* stream);
 
+/* ---- inference-side decoding (device part) --------------------------------------------------------
+ * utils/data_utilities.py:234-244 get_accdoa_labels, :273-300 get_multi_accdoa_labels + :302-388
+ * multi_accdoa_to_dcase_format (15-degree unification of same-class tracks), components/model_module.py:302-329
+ * (moving average over overlapping test chunks). decode_maccdoa: pred f32 [rows, 9C] -> events f32 [rows, C, 3, 3]
+ * (xyz of up to three events per frame and class, in the reference's order) and counts int32 [rows, C].
+ * decode_accdoa: pred f32 [rows, 3C] -> sed u8 [rows, C] (among the max_ov largest norms and above the threshold).
+ * move_avg: preds f32 [num_chunks, chunk_frames, D] of ONE recording -> out f32 [out_frames, D]; output block
+ * i (hop_frames frames) = mean of the chunks covering it, frames >= valid_frames are zero. */
+int pseld_decode_maccdoa(const float* pred, float* events, int* counts, long rows, int C, float sed_threshold, float unify_deg,
+                         void* stream);
+int pseld_decode_accdoa(const float* pred, unsigned char* sed, long rows, int C, float sed_threshold, int max_ov, void* stream);
+int pseld_move_avg(const float* preds, float* out, int num_chunks, int chunk_frames, int hop_frames, int valid_frames, int out_frames,
+                   long D, void* stream);
+
 /* ---- output head ---------------------------------------------------------------------------------------------------
  * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):
  * tok [B,64,C] -> A [B*32, C*6] (k = c*6 + cf*3 + dt, matching the conv weight's [D, C, 2, 3] flattening).

@@ -16,9 +16,13 @@ namespace {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <typename T>
-__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, float a, float b, long n8) {
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, float a, float b, long n8, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
+    if (i == n8) {                                       // scalar tail (n % 8 elements)
+        for (long e = n8 * 8; e < n; ++e) out[e] = from_f32<T>(a * to_f32<T>(x[e]) + b * to_f32<T>(y[e]));
+        return;
+    }
+    if (i > n8) return;
     float u[8], v[8];
     load8<T>(x + i * 8, u);
     load8<T>(y + i * 8, v);
@@ -232,10 +236,10 @@ template <typename T> size_t dw31_lds(int Tn, bool wgrad) {
     return PSELD_OK
 
 extern "C" int pseld_axpby(int dtype, const void* x, const void* y, void* out, float a, float b, long n, void* stream) {
-    PSELD_CHECK_ARG(x && y && out && n > 0 && n % 8 == 0, "axpby: bad argument");
+    PSELD_CHECK_ARG(x && y && out && n > 0, "axpby: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    CF_DISPATCH("axpby", hipLaunchKernelGGL(axpby_kernel<T>, dim3(pseld_cdiv(n / 8, 256)), dim3(256), 0, s, (const T*)x, (const T*)y, (T*)out,
-                                            a, b, n / 8));
+    CF_DISPATCH("axpby", hipLaunchKernelGGL(axpby_kernel<T>, dim3(pseld_cdiv(n / 8 + 1, 256)), dim3(256), 0, s, (const T*)x, (const T*)y, (T*)out,
+                                            a, b, n / 8, n));
 }
 extern "C" int pseld_mul(int dtype, const void* x, const void* m, void* y, float scale, long n, void* stream) {
     PSELD_CHECK_ARG(x && m && y && n > 0 && n % 8 == 0, "mul: bad argument");

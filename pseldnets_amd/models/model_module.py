@@ -3,7 +3,8 @@ common_step :47-68, training_step :70-81) and `models/components/model_module.py
 configure_optimizers :128-146, configure_loss :171-175), without Lightning: the object exposes the same hooks and
 can be driven either hook-by-hook (autograd + torch optimiser, as Lightning would) or through `fused_training_step`
 (FusedTrainer: backward, bucketed all-reduce, clip and AdamW inside the MI355X path).
-Validation-epoch aggregation / SELD metrics (model_module.py:83-179) are out of scope."""
+The device part of the validation / test path (prediction incl. ACS, rank gather, moving average, thresholding and
+15-degree unification -> DCASE dictionaries) is mirrored too; the SELD metrics (utils/SELD_metrics.py) are not."""
 import importlib
 import random
 from itertools import combinations
@@ -70,6 +71,7 @@ class SELDModelModule:
         for n in range(1, len(aug_TF) + 1):
             self.aug_TF_comb += combinations(aug_TF, n)
         self._trainer = None
+        self.step_system_outputs = []
 
     def setup(self, stage='fit', device='cuda'):
         feature = _get(self.cfg, 'data.audio_feature')
@@ -149,6 +151,56 @@ class SELDModelModule:
         pred, target = self.common_step(batch_sample['data'], batch_target)
         loss_dict = self.loss(pred, target)
         return loss_dict[self.loss.loss_type]
+
+    # -- validation / test (models/model_module.py:83-145, components/model_module.py:177-241) ---------------------------
+    def predict(self, batch_data):
+        """Eval-mode prediction of one batch; cfg.post_processing == 'ACS' runs the 16-pass test-time augmentation."""
+        from .. import inference
+        self.net.eval()
+        self.training = False
+        with torch.no_grad():
+            if _get(self.cfg, 'post_processing') == 'ACS':
+                return inference.acs_predict(batch_data, self.standardize, self.forward, output_format=self.method)
+            return self.common_step(batch_data)[0]
+
+    def validation_step(self, batch_sample, batch_idx=0):
+        batch_target = {k: v for k, v in batch_sample.items() if 'label' in k}
+        batch_pred = self.predict(batch_sample['data'])
+        self.step_system_outputs.append(batch_pred)
+        with torch.no_grad():
+            return self.loss({k: v.float() for k, v in batch_pred.items()}, batch_target)
+
+    def test_step(self, batch_sample, batch_idx=0):
+        self.step_system_outputs.append(self.predict(batch_sample['data']))
+
+    def pred_aggregation(self, process_group=None, paths_dict=None):
+        """All ranks' step outputs in the sampler's order (rank-interleaved, components/model_module.py:178-184), optionally
+        stitched by the moving average; returns the prediction tensor(s) on the device, [frames, D] per output key."""
+        from .. import inference
+        outs, self.step_system_outputs = self.step_system_outputs, []
+        merged = {k: torch.cat([o[k].float() for o in outs], dim=0) for k in outs[0]}
+        if process_group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(process_group)
+            for k, v in merged.items():
+                parts = [torch.empty_like(v) for _ in range(world)]
+                dist.all_gather(parts, v.contiguous(), group=process_group)
+                merged[k] = torch.stack(parts, 0).transpose(0, 1).reshape(-1, *v.shape[1:])
+        if self.method == 'multi_accdoa' and _get(self.cfg, 'post_processing') == 'move_avg':
+            merged['multi_accdoa'] = inference.move_avg(merged['multi_accdoa'], list((paths_dict or {}).values()),
+                                                        _get(self.cfg, 'data.test_chunklen_sec'), _get(self.cfg, 'data.test_hoplen_sec'),
+                                                        self.label_res)
+        return {k: v.reshape(-1, v.shape[-1]) if k in ('accdoa', 'multi_accdoa') else v.reshape(-1, *v.shape[2:]) for k, v in merged.items()}
+
+    def convert_to_dcase_format_polar(self, pred_frames):
+        """{frame: [[class, azimuth_deg, elevation_deg], ...]} for a slice of aggregated prediction frames (one recording)."""
+        from .. import inference
+        thr = _get(self.cfg, 'sed_threshold', 0.5)
+        if self.method == 'multi_accdoa':
+            return inference.multi_accdoa_to_dcase_polar(pred_frames, self.num_classes, thr)
+        if self.method == 'accdoa':
+            return inference.accdoa_to_dcase_polar(pred_frames, self.num_classes, thr)
+        raise NotImplementedError(f"decoding of '{self.method}' outputs is not built on the MI355X path yet")
 
     def configure_optimizers(self):
         opt_cfg, sch_cfg = _get(self.cfg, 'model.optimizer'), _get(self.cfg, 'model.lr_scheduler')

@@ -876,3 +876,38 @@ def aug_mix_tracks(sed, doa, dst, src, lam, wavmix):
     _lib.check(_lib.lib().pseld_aug_mix_tracks(_lib.ptr(sed), _lib.ptr(doa), _lib.ptr(so), _lib.ptr(do), _lib.ptr(dst), _lib.ptr(src), _lib.ptr(lam),
                                                dst.numel(), sed.shape[1], sed.shape[3], int(wavmix), _lib.stream_ptr()), "pseld_aug_mix_tracks")
     return so, do
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inference-side decoding (csrc/decode.hip)
+def decode_maccdoa(pred, nb_classes, sed_threshold=0.5, unify_deg=15.0):
+    """pred f32 [rows, 9C] -> (events f32 [rows, C, 3, 3], counts int32 [rows, C])."""
+    _f32(pred)
+    rows = pred.shape[0]
+    assert pred.shape[1] == 9 * nb_classes
+    events = torch.empty((rows, nb_classes, 3, 3), dtype=torch.float32, device=pred.device)
+    counts = torch.empty((rows, nb_classes), dtype=torch.int32, device=pred.device)
+    _lib.check(_lib.lib().pseld_decode_maccdoa(_lib.ptr(pred), _lib.ptr(events), _lib.ptr(counts), rows, nb_classes, float(sed_threshold),
+                                               float(unify_deg), _lib.stream_ptr()), "pseld_decode_maccdoa")
+    return events, counts
+
+
+def decode_accdoa(pred, nb_classes, sed_threshold=0.5, max_ov=3):
+    """pred f32 [rows, 3C] -> sed bool [rows, C]."""
+    _f32(pred)
+    rows = pred.shape[0]
+    assert pred.shape[1] == 3 * nb_classes
+    sed = torch.empty((rows, nb_classes), dtype=torch.uint8, device=pred.device)
+    _lib.check(_lib.lib().pseld_decode_accdoa(_lib.ptr(pred), _lib.ptr(sed), rows, nb_classes, float(sed_threshold), max_ov, _lib.stream_ptr()),
+               "pseld_decode_accdoa")
+    return sed.bool()
+
+
+def move_avg(preds, hop_frames, valid_frames, out_frames):
+    """preds f32 [num_chunks, chunk_frames, D] of one recording -> f32 [out_frames, D]."""
+    _f32(preds)
+    n, cf, D = preds.shape
+    out = torch.empty((out_frames, D), dtype=torch.float32, device=preds.device)
+    _lib.check(_lib.lib().pseld_move_avg(_lib.ptr(preds), _lib.ptr(out), n, cf, hop_frames, valid_frames, out_frames, D, _lib.stream_ptr()),
+               "pseld_move_avg")
+    return out

@@ -24,6 +24,7 @@ def install():
          utilities=_mod('lightning.pytorch.utilities', rank_zero_only=ident))
     L.pytorch = sys.modules['lightning.pytorch']
     _mod('omegaconf', DictConfig=dict, OmegaConf=object)
+    _mod('torchmetrics', MeanMetric=object)            # imported by models/components/model_module.py, unused by the goldens
     _mod('librosa')
     # torchaudio 2.2.1 stand-in built from oracle/feature.py (its published algorithm), so the reference's OWN
     # LogmelIV_Extractor / intensityvector code (utils/feature.py) can run here.

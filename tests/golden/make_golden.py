@@ -500,8 +500,51 @@ def gen_augment():
     save('augment.npz', **out)
 
 
+from tests.golden.decode_inputs import decode_inputs, toy_forward  # noqa: E402
+
+
+def gen_decode():
+    """The reference's decoding functions (utils/data_utilities.py) and BaseModelModule.post_processing (ACS, move_avg; called
+    unbound with a stand-in `self`)."""
+    import utils.data_utilities as du
+    from models.components.model_module import BaseModelModule
+    pred, acc, C = decode_inputs()
+    out = {}
+    sed, doa = du.get_multi_accdoa_labels(pred[None], C, torch.tensor(0.5))
+    sed = sed.reshape(sed.shape[0], sed.shape[1] * sed.shape[2], -1).transpose(0, 1).numpy()
+    doa = doa.reshape(doa.shape[0], doa.shape[1] * doa.shape[2], -1).transpose(0, 1).float().numpy()
+    d = du.multi_accdoa_to_dcase_format(sed.transpose(1, 0, 2), doa.transpose(1, 0, 2), nb_classes=C)
+    rows = [[f, e[0], e[1], e[2], e[3]] for f in sorted(d) for e in d[f]]
+    out['maccdoa_events'] = np.array(rows, np.float64)
+    pol = du.convert_output_format_cartesian_to_polar(d)
+    out['maccdoa_polar'] = np.array([[f, e[0], e[1], e[2]] for f in sorted(pol) for e in pol[f]], np.float64)
+    s, _ = du.get_accdoa_labels(acc[None], C, torch.tensor(0.5))
+    out['accdoa_sed'] = s.numpy().reshape(-1, C)
+    da = du.accdoa_label_to_dcase_format(s.numpy().reshape(-1, C), acc.numpy(), C)
+    out['accdoa_events'] = np.array([[f, e[0], e[1], e[2], e[3]] for f in sorted(da) for e in da[f]], np.float64)
+    # post-processing with a stand-in self
+    fake = R.AttrDict()
+    fake_obj = type('S', (), {})()
+    fake_obj.standardize = lambda x: x * 1.5
+    fake_obj.forward = lambda x: toy_forward(x, C)
+    wave = torch.randn(3, 4, 40, generator=torch.Generator().manual_seed(2))
+    out['acs_wave'] = wave.numpy()
+    out['acs_maccdoa'] = BaseModelModule.post_processing(fake_obj, wave, method='ACS', output_format='multi_accdoa')['multi_accdoa'].numpy()
+    out['acs_accdoa'] = BaseModelModule.post_processing(fake_obj, wave, method='ACS', output_format='accdoa')['accdoa'].numpy()
+    fake_obj.cfg = R.AttrDict(data=dict(test_chunklen_sec=10, test_hoplen_sec=2))
+    fake_obj.label_res = 0.1
+    fake_obj.get_num_frames = lambda x: int(np.ceil(x / 100) * 100)
+    seg = {'a': 330, 'b': 100, 'c': 215}
+    n_chunks = sum(int(np.ceil((v - 100) / 20)) + 1 for v in seg.values())
+    preds = torch.randn(n_chunks, 100, 7, generator=torch.Generator().manual_seed(3))
+    out['mavg_preds'] = preds.numpy()
+    res = BaseModelModule.post_processing(fake_obj, preds=preds, method='move_avg', paths_dict=seg)
+    out['mavg_out'] = res.numpy()                        # [1, sum of padded recording lengths, D]
+    save('decode.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -512,3 +555,4 @@ if __name__ == '__main__':
     if 'crnn' in which: gen_crnn()
     if 'conformer' in which: gen_conformer()
     if 'augment' in which: gen_augment()
+    if 'decode' in which: gen_decode()

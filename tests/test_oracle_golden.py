@@ -354,3 +354,30 @@ def test_augment_golden():
     # the wavmix seeds cover the skip, add_ov '1' and add_ov '2' branches
     ovs = {tuple(str(a) for a in g[f'wavmix{s}_adpit_ov']) for s in (16, 17, 18, 19, 20, 21)}
     assert len(ovs) >= 3, ovs
+
+
+def _events(d):
+    return np.array([[f, *e] for f in sorted(d) for e in d[f]], np.float64)
+
+
+def test_decode_golden():
+    """oracle/decode.py against the reference's decoding functions and BaseModelModule.post_processing (ACS, move_avg)."""
+    from oracle import decode as od
+    from tests.golden.decode_inputs import decode_inputs, toy_forward
+    g = gold('decode.npz')
+    pred, acc, C = decode_inputs()
+    d = od.decode_multi_accdoa(pred.numpy(), C)
+    ev = _events(d)
+    assert ev.shape == g['maccdoa_events'].shape and np.abs(ev - g['maccdoa_events']).max() < 1e-6
+    assert len({len(v) for v in d.values()}) >= 3                     # frames with different event counts are present
+    pol = _events(od.cartesian_to_polar(d))
+    assert np.abs(pol - g['maccdoa_polar']).max() < 1e-4
+    sed = od.decode_accdoa(acc[None], C)[0]
+    assert np.array_equal(sed, g['accdoa_sed']) and 0 < sed.sum() < sed.size
+    wave = torch.as_tensor(g['acs_wave'])
+    for fmt in ('multi_accdoa', 'accdoa'):
+        y = od.acs(wave, lambda x: x * 1.5, lambda x: toy_forward(x, C), fmt)[fmt]
+        assert np.abs(y.numpy() - g['acs_' + ('maccdoa' if fmt == 'multi_accdoa' else 'accdoa')]).max() < 1e-6
+    outs = od.move_avg(torch.as_tensor(g['mavg_preds']), [330, 100, 215], 10, 2)
+    assert [o.shape[0] for o in outs] == [400, 100, 300]
+    assert np.abs(torch.cat(outs, 0)[None].numpy() - g['mavg_out']).max() < 1e-6
