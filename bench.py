@@ -174,6 +174,10 @@ def main():
     ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2', 'crnn'],
                     help='htsat = the headline workload (BASELINE.json configs[1]); htsat_einv2 = configs[2] (dual-branch, tPIT); '
                          'passt = the PaSST backbone, same data')
+    ap.add_argument('--augment', default='none', choices=['none', 'augmix'],
+                    help="augmix = configs/augment/augmix.yaml (every shipped synth_* experiment trains with it): the batch is "
+                         "tripled, rotated / mixed as waveforms and masked / shifted as features on the device; `value` still counts "
+                         "the ORIGINAL clips. Not the headline configuration.")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
@@ -239,6 +243,21 @@ def main():
         doa[:, :, 0] = (lab[:, :, 0, 1:] * first.unsqueeze(2)).sum(-1)
         target = {'sed_label': sed, 'doa_label': doa}
 
+    step = lambda: trainer.training_step(wave, target)
+    if args.augment == 'augmix':
+        if einv2_mode:
+            raise SystemExit("--augment augmix is wired for the ADPIT workloads")
+        from pseldnets_amd.models.model_module import SELDModelModule
+        from pseldnets_amd.train import SyntheticDataset, compose
+        acfg = compose(['experiment=synth_maccdoa', 'augment=augmix'])
+        aug = SELDModelModule(acfg, SyntheticDataset(acfg))
+        aug.af_extractor = trainer.af
+        target['ov'] = ['1'] * wave.shape[0]
+
+        def step():
+            feats, tgt = aug.augment_step(wave, target)
+            return trainer.training_step(feats, tgt, is_features=True)
+
     lib = _lib.lib()
     global PEAK_FLOPS, ESIZE
     PEAK_FLOPS = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3
@@ -255,11 +274,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        loss = trainer.training_step(wave, target)
+        loss = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.training_step(wave, target)
+        loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -275,15 +294,17 @@ def main():
     gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2,
                    'crnn': GFLOP_PER_CHUNK_TRAIN_CRNN}[args.backbone]
     out = {
-        "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA"), "value": round(clips_per_s, 2), "unit": "clips/s",
+        "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA") + (" + AugMix" if args.augment == 'augmix' else ""), "value": round(clips_per_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
                                f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
-                               f"{'dropout 0.1' if args.backbone == 'crnn' else 'drop_path 0.0' if args.backbone == 'passt' else 'drop_path 0.1'}, BN train mode, no augmentation",
+                               f"{'dropout 0.1' if args.backbone == 'crnn' else 'drop_path 0.0' if args.backbone == 'passt' else 'drop_path 0.1'}, BN train mode, {'AugMix augmentations (x3 chunks through the network)' if args.augment == 'augmix' else 'no augmentation'}",
                    "global_clips": args.clips * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
     }
+    if args.augment == 'augmix':
+        gflop_chunk = 3 * gflop_chunk                     # every original chunk goes through the network three times
     step_tflops = clips_per_s * CHUNKS_PER_CLIP * gflop_chunk / 1e3
     out["roofline_step"] = {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4)}
@@ -293,7 +314,7 @@ def main():
         if timer is not None:
             timer.on = True
         for _ in range(2):
-            trainer.training_step(wave, target)
+            step()
         barrier()
     if rank == 0 and timer is not None:
         agg = timer.summary()

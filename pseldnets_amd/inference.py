@@ -86,6 +86,24 @@ def accdoa_to_dcase_polar(pred, nb_classes, sed_threshold=0.5, max_ov=3):
     return out
 
 
+def einv2_to_dcase(pred_sed, pred_doa, sed_threshold=0.5):
+    """pred_aggregation's einv2 branch (components/model_module.py:191-204) + convert_to_dcase_format_polar (:229-233) +
+    track_to_dcase_format (utils/data_utilities.py:154-177): sed logits [frames, 3, C], doa [frames, 3, 3] ->
+    {frame: [[class, azimuth_deg, elevation_deg], ...]} (integer degrees, tracks in order). The sigmoid / arg-max / threshold
+    are evaluated on the device; per track only the top class can be active."""
+    p = torch.sigmoid(pred_sed.float())
+    top_v, top_i = p.max(dim=-1)                                         # [frames, 3]
+    active = (top_v > sed_threshold).cpu().numpy()
+    cls = top_i.cpu().numpy()
+    d = pred_doa.float().cpu().numpy()
+    azi = np.arctan2(d[..., 1], d[..., 0])
+    ele = np.arctan2(d[..., 2], np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2))
+    out = {}
+    for f, t in zip(*np.nonzero(active)):
+        out.setdefault(int(f), []).append([int(cls[f, t]), int(np.around(azi[f, t] * 180 / np.pi)), int(np.around(ele[f, t] * 180 / np.pi))])
+    return out
+
+
 def write_output_format_file(path, output_dict):
     """utils/data_utilities.py:91-104: DCASE CSV rows `frame,class,azimuth,elevation` (integers). Frames are written in
     ascending order (the reference writes them in its dictionary's insertion order)."""

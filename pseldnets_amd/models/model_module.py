@@ -193,14 +193,16 @@ class SELDModelModule:
         return {k: v.reshape(-1, v.shape[-1]) if k in ('accdoa', 'multi_accdoa') else v.reshape(-1, *v.shape[2:]) for k, v in merged.items()}
 
     def convert_to_dcase_format_polar(self, pred_frames):
-        """{frame: [[class, azimuth_deg, elevation_deg], ...]} for a slice of aggregated prediction frames (one recording)."""
+        """{frame: [[class, azimuth_deg, elevation_deg], ...]} for a slice of aggregated prediction frames (one recording);
+        einv2: pred_frames = (sed logits [frames, 3, C], doa [frames, 3, 3])."""
         from .. import inference
         thr = _get(self.cfg, 'sed_threshold', 0.5)
         if self.method == 'multi_accdoa':
             return inference.multi_accdoa_to_dcase_polar(pred_frames, self.num_classes, thr)
         if self.method == 'accdoa':
             return inference.accdoa_to_dcase_polar(pred_frames, self.num_classes, thr)
-        raise NotImplementedError(f"decoding of '{self.method}' outputs is not built on the MI355X path yet")
+        sed, doa = pred_frames
+        return inference.einv2_to_dcase(sed, doa, thr)
 
     def configure_optimizers(self):
         opt_cfg, sch_cfg = _get(self.cfg, 'model.optimizer'), _get(self.cfg, 'model.lr_scheduler')

@@ -522,6 +522,19 @@ def gen_decode():
     out['accdoa_sed'] = s.numpy().reshape(-1, C)
     da = du.accdoa_label_to_dcase_format(s.numpy().reshape(-1, C), acc.numpy(), C)
     out['accdoa_events'] = np.array([[f, e[0], e[1], e[2], e[3]] for f in sorted(da) for e in da[f]], np.float64)
+    # einv2: the sigmoid / top-1 / threshold of pred_aggregation (components/model_module.py:191-204) + track_to_dcase_format
+    ge = torch.Generator().manual_seed(9)
+    sed_logit = torch.randn(40, 3, C, generator=ge) * 2.0
+    doa_t = torch.randn(40, 3, 3, generator=ge)
+    out['einv2_sed_logit'], out['einv2_doa'] = sed_logit.numpy(), doa_t.numpy()
+    ps = sed_logit.clone().sigmoid_()
+    tv, ti = torch.topk(ps, 1, dim=-1, largest=True)
+    ps = torch.zeros_like(ps).scatter_(-1, ti, tv)
+    ps = (ps > torch.tensor(0.5)).numpy()
+    dn = doa_t.numpy()
+    azi = np.arctan2(dn[..., 1], dn[..., 0]); elev = np.arctan2(dn[..., 2], np.sqrt(dn[..., 0] ** 2 + dn[..., 1] ** 2))
+    de = du.track_to_dcase_format(ps, np.stack((azi, elev), axis=-1))
+    out['einv2_events'] = np.array([[f, e[0], e[1], e[2]] for f in sorted(de) for e in de[f]], np.float64)
     # post-processing with a stand-in self
     fake = R.AttrDict()
     fake_obj = type('S', (), {})()

@@ -30,6 +30,9 @@ def test_decoding_against_reference_goldens(dev, tmp_path):
     assert np.array_equal(sed, g['accdoa_sed'])
     da = inf.accdoa_to_dcase_polar(acc.to(dev), C)
     assert sum(len(v) for v in da.values()) == g['accdoa_events'].shape[0]
+    de = inf.einv2_to_dcase(torch.as_tensor(g['einv2_sed_logit']).to(dev), torch.as_tensor(g['einv2_doa']).to(dev))
+    ge = np.array([[f, *e] for f in sorted(de) for e in de[f]], np.float64)
+    assert ge.shape == g['einv2_events'].shape and np.array_equal(ge, g['einv2_events'])
     inf.write_output_format_file(tmp_path / 'x.csv', pol)
     lines = open(tmp_path / 'x.csv').read().strip().split('\n')
     assert len(lines) == gp.shape[0] and all(len(l.split(',')) == 4 for l in lines)
