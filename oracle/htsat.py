@@ -106,11 +106,22 @@ def attention_core(qkv, table, heads, mask, rel_index):
     return (attn @ v).transpose(1, 2).reshape(Bw, N, C)
 
 
+def adapter(x, sd, pre, scale):
+    """model_utilities_adapt.py:7-44 Adapter: fc2(gelu(fc1(x))) * scale (present when the state holds `pre`fc1.weight)."""
+    return F.linear(F.gelu(F.linear(x, sd[pre + 'fc1.weight'], sd[pre + 'fc1.bias'])), sd[pre + 'fc2.weight'], sd[pre + 'fc2.bias']) * scale
+
+
+ADAPTER_SCALE = 0.1          # configs/adapt/adapter.yaml adapter_scalar (the oracle's adapters are keyed off the state dict)
+
+
 def window_attention(xw, sd, pre, heads, mask, rel_index):
     """htsat.py:112-145 on windows xw [nWin_total, N, C]."""
     qkv = F.linear(xw, sd[pre + 'qkv.weight'], sd[pre + 'qkv.bias'])
     out = attention_core(qkv, sd[pre + 'relative_position_bias_table'], heads, mask, rel_index)
-    return F.linear(out, sd[pre + 'proj.weight'], sd[pre + 'proj.bias'])
+    y = F.linear(out, sd[pre + 'proj.weight'], sd[pre + 'proj.bias'])
+    if pre + 'adapter.fc1.weight' in sd:                    # htsat.py:141-143 SpatialAdapter
+        y = adapter(y, sd, pre + 'adapter.', ADAPTER_SCALE) + y
+    return y
 
 
 def to_windows(x, res, ws, shift):
@@ -158,8 +169,9 @@ def swin_block(x, sd, pre, res, heads, ws, shift, rel_index, keep=None):
 
     x = x + dp(y, 0)
     z = F.layer_norm(x, (C,), sd[pre + 'norm2.weight'], sd[pre + 'norm2.bias'], 1e-5)
+    zs = adapter(z, sd, pre + 'mlp.adapter.', ADAPTER_SCALE) if pre + 'mlp.adapter.fc1.weight' in sd else 0.   # model_utilities.py:160-170
     z = F.linear(z, sd[pre + 'mlp.fc1.weight'], sd[pre + 'mlp.fc1.bias'])
-    z = F.linear(F.gelu(z), sd[pre + 'mlp.fc2.weight'], sd[pre + 'mlp.fc2.bias'])
+    z = F.linear(F.gelu(z), sd[pre + 'mlp.fc2.weight'], sd[pre + 'mlp.fc2.bias']) + zs
     return x + dp(z, 1)
 
 
@@ -407,3 +419,24 @@ def formula_features(B, T=1001, mel=64, in_chans=7):
     base = torch.sin(0.013 * t * (1 + 0.1 * c) + 0.21 * f + 0.7 * b) + 0.5 * torch.cos(0.0041 * t * f / 8 + c + 0.3 * b)
     x = torch.where(c < 4, -40.0 + 12.0 * base - 0.2 * f, 0.45 * base)
     return x.to(torch.float32)
+
+
+def add_adapters(sd, cfg=None, mlp_ratio=0.5, seed=5, pre='encoder.', attn=True, mlp=True):
+    """Seeded non-trivial adapter weights (the reference initialises fc2 to zero, which would make the branch vanish) for
+    every Swin block of `pre`: keys `...blocks.{b}.attn.adapter.{fc1,fc2}.*` / `...mlp.adapter.{fc1,fc2}.*`."""
+    cfg = _norm_cfg(cfg)
+    g = torch.Generator().manual_seed(seed)
+    E = cfg['embed_dim']
+    for li, depth in enumerate(cfg['depths']):
+        C = E * 2 ** li
+        ah = int(C * mlp_ratio)
+        for bi in range(depth):
+            for site, on in (('attn', attn), ('mlp', mlp)):
+                if not on:
+                    continue
+                b = f'{pre}layers.{li}.blocks.{bi}.{site}.adapter.'
+                sd[b + 'fc1.weight'] = torch.randn(ah, C, generator=g) * (1.0 / C) ** 0.5
+                sd[b + 'fc1.bias'] = torch.randn(ah, generator=g) * 0.1
+                sd[b + 'fc2.weight'] = torch.randn(C, ah, generator=g) * (4.0 / ah) ** 0.5
+                sd[b + 'fc2.bias'] = torch.randn(C, generator=g) * 0.5
+    return sd

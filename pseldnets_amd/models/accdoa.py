@@ -21,11 +21,33 @@ class HTSAT(HTSATNetBase):
         super().__init__()
         self.num_classes = num_classes
         self._init_common(cfg, in_channels)
-        self.enc = SwinEncoder(self.arena, 'encoder.', in_channels, mel_bins=self.mel_bins, **kwargs)
+        cfg_adapt = cfg.adapt if hasattr(cfg, 'adapt') else (cfg.get('adapt', {}) if isinstance(cfg, dict) else {})
+        cfg_adapt = dict(cfg_adapt or {})
+        self.enc = SwinEncoder(self.arena, 'encoder.', in_channels, mel_bins=self.mel_bins, cfg_adapt=cfg_adapt, **kwargs)
         self.head = TscamHead(self.arena, 'tscam_conv.', self.enc.num_features, num_classes * self.tracks_axes, True)
         self._finish_init()
         if pretrained_path:
             self.load_ckpts(pretrained_path, audioset_pretrain)
+        self.freeze_layers_if_needed(str(cfg_adapt.get('method', '') or ''))
+        for n_, p_ in self.named_parameters():
+            if n_.startswith('tscam_conv.'):
+                p_.requires_grad_(True)                       # accdoa.py:146
+
+    def freeze_layers_if_needed(self, adapt_method):
+        """accdoa.py:148-170: adapter fine-tuning trains the biases (every parameter whose name contains 'bias', the
+        relative-position bias tables included), the adapters and the head; 'mono_adapter' without adapters trains all."""
+        if 'adapter' not in adapt_method:
+            return
+        found = False
+        self.requires_grad_(False)
+        for name, param in self.named_parameters():
+            if 'bias' in name:
+                param.requires_grad_(True)
+            if 'adapter' in name or 'lora' in name:
+                found = True
+                param.requires_grad_(True)
+        if adapt_method == 'mono_adapter' and not found:
+            self.requires_grad_(True)
 
     def load_ckpts(self, pretrained_path, audioset_pretrain=True):
         """accdoa.py:172-202: AudioSet HTS-AT checkpoints (1-channel patch-embed replicated / in_channels, bn0 copied

@@ -29,7 +29,7 @@ DEFAULTS = dict(spec_size=256, patch_size=4, patch_stride=(4, 4), embed_dim=96, 
 class SwinEncoder:
     """One HTSAT_Swin_Transformer whose parameters live in `arena` under `prefix` (reference key names)."""
 
-    def __init__(self, arena, prefix, in_chans, mel_bins=64, **kw):
+    def __init__(self, arena, prefix, in_chans, mel_bins=64, cfg_adapt=None, **kw):
         cfg = dict(DEFAULTS)
         cfg.update({k: v for k, v in kw.items() if k in DEFAULTS})
         if cfg['window_size'] != 8 or cfg['patch_size'] != 4 or tuple(cfg['patch_stride']) != (4, 4) \
@@ -48,6 +48,25 @@ class SwinEncoder:
         self.SF = 2
         self.grid = 64
         self.rates = [v.item() for v in torch.linspace(0, cfg['drop_path_rate'], sum(self.depths))]
+        # Adapter fine-tuning (configs/adapt/adapter.yaml; htsat.py:105-110,142-143, model_utilities.py:149-168,
+        # model_utilities_adapt.py:7-44): bottleneck MLPs behind attention.proj ('SpatialAdapter') and beside the block MLP
+        # ('MlpAdapter'): x -> fc2(gelu(fc1(x))) * adapter_scalar
+        ad = dict(cfg_adapt or {})
+        method = str(ad.get('method', '') or '')
+        if 'lora' in method:
+            raise NotImplementedError("adapt.method=lora (model_utilities_adapt.py:47-158) is not built on the MI355X path yet")
+        akw = dict(ad.get('adapt_kwargs', {}) or {})
+        pos = akw.get('position', []) or []
+        self.attn_adapter = 'adapter' in method and 'SpatialAdapter' in pos
+        self.mlp_adapter = 'adapter' in method and 'MlpAdapter' in pos
+        self.adapter_ratio = float(akw.get('mlp_ratio', 0.25))
+        self.adapter_scale = akw.get('adapter_scalar', 1)
+        self._ad_scale = None
+        if self.attn_adapter or self.mlp_adapter:
+            if akw.get('type', 'adapter') != 'adapter' or akw.get('act_layer', 'gelu') != 'gelu' or akw.get('new_adapter'):
+                raise NotImplementedError("adapters: only type=adapter, act_layer=gelu, no new_adapter (configs/adapt/adapter.yaml)")
+            if isinstance(self.adapter_scale, str):
+                raise NotImplementedError("adapter_scalar=learnable_scalar is not built; use the numeric scalar of adapter.yaml")
         a, p, E = arena, prefix, self.E
         a.add(p + 'patch_embed.proj.weight', (E, in_chans, 4, 4))
         a.add(p + 'patch_embed.proj.bias', (E,))
@@ -62,9 +81,16 @@ class SwinEncoder:
                 a.add(b + 'attn.relative_position_bias_table', (225, h))
                 a.add(b + 'attn.qkv.weight', (3 * C, C)); a.add(b + 'attn.qkv.bias', (3 * C,))
                 a.add(b + 'attn.proj.weight', (C, C)); a.add(b + 'attn.proj.bias', (C,))
+                ah = int(C * self.adapter_ratio)
+                if self.attn_adapter:
+                    a.add(b + 'attn.adapter.fc1.weight', (ah, C)); a.add(b + 'attn.adapter.fc1.bias', (ah,))
+                    a.add(b + 'attn.adapter.fc2.weight', (C, ah)); a.add(b + 'attn.adapter.fc2.bias', (C,))
                 a.add(b + 'norm2.weight', (C,)); a.add(b + 'norm2.bias', (C,))
                 a.add(b + 'mlp.fc1.weight', (hid, C)); a.add(b + 'mlp.fc1.bias', (hid,))
                 a.add(b + 'mlp.fc2.weight', (C, hid)); a.add(b + 'mlp.fc2.bias', (C,))
+                if self.mlp_adapter:
+                    a.add(b + 'mlp.adapter.fc1.weight', (ah, C)); a.add(b + 'mlp.adapter.fc1.bias', (ah,))
+                    a.add(b + 'mlp.adapter.fc2.weight', (C, ah)); a.add(b + 'mlp.adapter.fc2.bias', (C,))
             if li < self.nl - 1:
                 d = f'{p}layers.{li}.downsample.'
                 a.add(d + 'reduction.weight', (2 * C, 4 * C))
@@ -123,6 +149,28 @@ class SwinEncoder:
         dA0 = ops.linear_dgrad(dP0, W)
         ops.bn_scalar_bwd(feat, mean_rstd, dA0, bn_dw, bn_db, saved['c_first'], accumulate=accumulate_bn)
 
+    # -- Adapter (model_utilities_adapt.py:7-44): fc2(gelu(fc1(x))) * scale (+ resid) --------------------------------------
+    def _scale_vec(self, device):
+        if self._ad_scale is None or self._ad_scale.device != device:
+            self._ad_scale = torch.full((1,), float(self.adapter_scale), dtype=torch.float32, device=device)
+        return self._ad_scale
+
+    def _adapter_fwd(self, x, pre, resid=None):
+        a, dtype, M = self.arena, x.dtype, x.shape[0]
+        h, g = ops.linear_fwd(x, a.w(pre + 'fc1.weight', dtype), a.p(pre + 'fc1.bias'), gelu_dual=True)
+        y = ops.linear_fwd(h, a.w(pre + 'fc2.weight', dtype), a.p(pre + 'fc2.bias'), resid=resid, rowscale=self._scale_vec(x.device),
+                           rows_per_scale=M)
+        return y, dict(h=h, g=g)
+
+    def _adapter_bwd(self, dy, x, sv, pre, dresid=None):
+        """dy = gradient of the adapter output; returns the gradient wrt its input (+ dresid for the 'adapter(x) + x' form)."""
+        a, dtype, M = self.arena, dy.dtype, dy.shape[0]
+        sc = self._scale_vec(dy.device)
+        ops.linear_wgrad(dy, sv['h'], a.g(pre + 'fc2.weight'), dbias=a.g(pre + 'fc2.bias'), rowscale=sc, rows_per_scale=M)
+        dh = ops.linear_dgrad(dy, a.w(pre + 'fc2.weight', dtype), wt=a.wt(pre + 'fc2.weight', dtype), mul=sv['g'], rowscale=sc, rows_per_scale=M)
+        ops.linear_wgrad(dh, x, a.g(pre + 'fc1.weight'), dbias=a.g(pre + 'fc1.bias'))
+        return ops.linear_dgrad(dh, a.w(pre + 'fc1.weight', dtype), wt=a.wt(pre + 'fc1.weight', dtype), resid=dresid)
+
     def forward_layer(self, li, x, B, drop_scale=None):
         """BasicLayer li (htsat.py:364-378): its blocks, then PatchMerging. drop_scale: f32[n_blocks_total, 2, B]."""
         a, p, dtype = self.arena, self.prefix, x.dtype
@@ -139,22 +187,36 @@ class SwinEncoder:
             xh1 = ops.layernorm_fwd(x, a.p(b + 'norm1.weight'), a.p(b + 'norm1.bias'))
             qkv = ops.linear_fwd(xh1, a.w(b + 'attn.qkv.weight', dtype), a.p(b + 'attn.qkv.bias'))
             ao = ops.window_attn_fwd(qkv, a.p(b + 'attn.relative_position_bias_table'), B, res, heads, shift)
-            x_mid = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
-                                   rowscale=s1, rows_per_scale=L)
+            ad = {}
+            if self.attn_adapter:
+                # x = adapter(proj(attn)) + proj(attn) (htsat.py:141-143), then the block's DropPath + residual
+                a0 = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'))
+                a1, ad['attn'] = self._adapter_fwd(a0, b + 'attn.adapter.', resid=a0)
+                ad['a0'] = a0
+                x_mid = ops.add(x, ops.rowscale(a1, s1, L * C)) if s1 is not None else ops.add(x, a1)
+            else:
+                x_mid = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
+                                       rowscale=s1, rows_per_scale=L)
             xh2 = ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
+            if self.mlp_adapter:
+                xs, ad['mlp'] = self._adapter_fwd(xh2, b + 'mlp.adapter.')          # xs = adapter(x) (model_utilities.py:160-170)
             if GELU_DUAL:
                 # fc1 epilogue emits h = gelu(u) and g = gelu'(u): erf is evaluated once per element, not in fc2/dW2/dU
                 hact, gact = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), gelu_dual=True)
                 x_out = ops.linear_fwd(hact, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
                                        rowscale=s2, rows_per_scale=L)
+                if self.mlp_adapter:
+                    x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
                 saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1,
-                                         s2=s2, shift=shift))
+                                         s2=s2, shift=shift, ad=ad))
             else:
                 u = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'))
                 x_out = ops.linear_fwd(u, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
                                        rowscale=s2, rows_per_scale=L, gelu_in=True)
+                if self.mlp_adapter:
+                    x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
                 saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, u=u, s1=s1, s2=s2,
-                                         shift=shift))
+                                         shift=shift, ad=ad))
             x = x_out
         saved = dict(blocks=saved_blocks)
         if li < self.nl - 1:
@@ -185,12 +247,22 @@ class SwinEncoder:
                 ops.linear_wgrad(dx, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L)
                 du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
             ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
-            dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype), wt=a.wt(b + 'mlp.fc1.weight', dtype))
+            dxh2_ad = None
+            if self.mlp_adapter:            # the adapter branch sees the same DropPath-scaled gradient
+                dxs = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
+                dxh2_ad = self._adapter_bwd(dxs, s['xh2'], s['ad']['mlp'], b + 'mlp.adapter.')
+            dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype), wt=a.wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
                                        a.g(b + 'norm2.bias'), dres=dx)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
-            ops.linear_wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=L)
-            dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
+            if self.attn_adapter:
+                da1 = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
+                da0 = self._adapter_bwd(da1, s['ad']['a0'], s['ad']['attn'], b + 'attn.adapter.', dresid=da1)
+                ops.linear_wgrad(da0, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'))
+                dao = ops.linear_dgrad(da0, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype))
+            else:
+                ops.linear_wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=L)
+                dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
             ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
@@ -250,6 +322,8 @@ def default_init(name, shape):
     leaf = name.rsplit('.', 1)[-1]
     if 'relative_position_bias_table' in name:
         torch.nn.init.trunc_normal_(t, std=.02)
+    elif '.adapter.fc2.' in name:                                       # model_utilities_adapt.py:26-30: the adapter starts as identity
+        t.zero_()
     elif name.startswith('stitch'):
         t.uniform_(0.1, 0.9)
     elif '.sequential.' in name and 'layers.' in name:                 # Conformer decoder (conformer/modules.py:41-47, attention.py:69-70)

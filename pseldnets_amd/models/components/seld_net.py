@@ -193,6 +193,9 @@ class HTSATNetBase(nn.Module):
         a = self.arena
         a.ensure_opt_state()
         a.step += 1
+        frozen = self._frozen_state()
+        if frozen is not None:                 # adapter fine-tuning: frozen parameters take no part in the clip norm or the update
+            a.grad.copy_(ops.mul(a.grad, frozen['mask']))
         if max_norm and grad_norm is None:
             grad_norm = ops.grad_norm(a.grad)
         shadow = None
@@ -206,4 +209,24 @@ class HTSATNetBase(nn.Module):
             a.shadow_valid = True
             a.shadow_t_valid = False       # the transposed copies follow lazily (arena.wt)
             self.shadow_trusted = True
+        if frozen is not None:                 # undo the weight decay on the frozen entries: p = p * mask + p_frozen * (1 - mask)
+            a.flat.copy_(ops.axpby(ops.mul(a.flat, frozen['mask']), frozen['keep'], 1.0, 1.0))
+            a.shadow_valid = False
         return grad_norm
+
+    def _frozen_state(self):
+        """None when every parameter trains; else {'mask': 1 for trainable arena elements, 'keep': the frozen values * (1 - mask)}.
+        Built once per materialisation from the parameters' requires_grad flags (accdoa.py:148-170 freeze_layers_if_needed)."""
+        st = getattr(self, '_frozen_cache', None)
+        if st is not None and st['device'] == self.arena.flat.device and st['flat'] is self.arena.flat:
+            return st['state']
+        flags = {n: _get(self, n).requires_grad for n in self.arena.entries}
+        state = None
+        if not all(flags.values()):
+            mask = torch.zeros_like(self.arena.flat)
+            for n, f in flags.items():
+                if f:
+                    self.arena.view(mask, n, padded=True).fill_(1.0)
+            state = {'mask': mask, 'keep': self.arena.flat * (1.0 - mask)}
+        self._frozen_cache = {'device': self.arena.flat.device, 'flat': self.arena.flat, 'state': state}
+        return state

@@ -34,6 +34,13 @@ DEFAULT_CFG = {
                 'limit_train_batches': 10},
     'adapt': {},
 }
+ADAPT_GROUPS = {      # configs/adapt/{default,adapter,mono_adapter}.yaml
+    'default': {'method': 'none'},
+    'adapter': {'method': 'adapter', 'adapt_kwargs': {'position': ['MlpAdapter', 'SpatialAdapter'], 'type': 'adapter', 'mlp_ratio': 0.5,
+                                                      'adapter_scalar': 0.1, 'act_layer': 'gelu'}},
+    'mono_adapter': {'method': 'mono_adapter', 'adapt_kwargs': {'position': ['MlpAdapter', 'SpatialAdapter'], 'type': 'adapter',
+                                                                'mlp_ratio': 0.5, 'act_layer': 'gelu', 'adapter_scalar': 0.1}},
+}
 AUGMENT_GROUPS = {
     'default': {},
     'augmix': {'type': ['specaug', 'crop', 'freqshift', 'rotate', 'trackmix', 'wavmix'], 'AugMix': True},
@@ -70,6 +77,9 @@ def compose(argv):
             continue
         if key == 'augment':
             _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS[val]))
+            continue
+        if key == 'adapt':
+            cfg['adapt'] = copy.deepcopy(ADAPT_GROUPS[val])
             continue
         try:
             val = json.loads(val)

@@ -556,8 +556,57 @@ def gen_decode():
     save('decode.npz', **out)
 
 
+ADAPT_CFG = dict(method='adapter', adapt_kwargs=dict(position=['MlpAdapter', 'SpatialAdapter'], type='adapter', mlp_ratio=0.5,
+                                                     adapter_scalar=0.1, act_layer='gelu'))
+
+
+def gen_adapter():
+    """multi_accdoa.HTSAT with configs/adapt/adapter.yaml (MlpAdapter + SpatialAdapter, AdapterBit freezing): eval output,
+    the trainable-parameter set, train-step loss and the gradients of every trainable parameter. The adapters get seeded
+    non-zero weights (oracle/htsat.py:add_adapters; the reference's zero fc2 init would make them vanish)."""
+    C = 3
+    cfga = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'), adapt=ADAPT_CFG)
+    out = {}
+    x = oh.formula_features(2)
+    net = multi_accdoa.HTSAT(cfga, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    sd = oh.add_adapters(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(('relative_position_index' in k) or ('attn_mask' in k) for k in missing), (missing, unexpected)
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    out['trainable'] = np.array([n for n, p in net.named_parameters() if p.requires_grad])
+    net.eval()
+    with torch.no_grad():
+        out['eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net.train()
+    pred = net(x.clone())
+    lab = synth.formula_adpit_label(2, 100, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab})
+    ld['loss_all'].backward()
+    out['train'] = pred['multi_accdoa'].detach().numpy()
+    out['loss'] = ld['loss_all'].item()
+    names, norms, heads = [], [], []
+    for n, p in net.named_parameters():
+        if not p.requires_grad or n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    # one AdamW step (lr 1e-3, clip 1.0) over the trainable parameters: which tensors moved
+    opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+    opt.step()
+    moved = [n for n, p in net.named_parameters() if not torch.equal(p.detach(), before[n])]
+    out['moved'] = np.array(moved)
+    pick = ['encoder.layers.2.blocks.1.mlp.adapter.fc2.weight', 'encoder.layers.0.blocks.0.attn.qkv.bias', 'tscam_conv.weight']
+    out['after_names'] = np.array(pick)
+    out['after_heads'] = np.stack([dict(net.named_parameters())[n].detach().reshape(-1)[:8].numpy() for n in pick])
+    save('adapter.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -569,3 +618,4 @@ if __name__ == '__main__':
     if 'conformer' in which: gen_conformer()
     if 'augment' in which: gen_augment()
     if 'decode' in which: gen_decode()
+    if 'adapter' in which: gen_adapter()

@@ -236,3 +236,63 @@ def test_einv2_full_size_forward_and_fused_step(dev):
     sl, dl = synth.formula_einv2_label(2, 100, 170)
     out = tr.training_step(oh.formula_features(2).to(dev), {'sed_label': sl.to(dev), 'doa_label': dl.to(dev)})
     assert torch.isfinite(out['loss_all']).all() and torch.isfinite(net.arena.flat).all()
+
+
+ADAPT = A(method='adapter', adapt_kwargs=A(position=['MlpAdapter', 'SpatialAdapter'], type='adapter', mlp_ratio=0.5,
+                                           adapter_scalar=0.1, act_layer='gelu'))
+
+
+def test_adapter_fine_tuning_vs_reference(dev):
+    """configs/adapt/adapter.yaml (MlpAdapter + SpatialAdapter, AdapterBit freezing: biases, adapters and the head train):
+    state-dict keys, trainable set, eval / train output, ADPIT loss, the gradient of every trainable parameter, and one fused
+    clip + AdamW step that must move exactly the parameters the reference's optimiser moves."""
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'adapter.npz'))
+    C = 3
+    cfg = A(data=CFG.data, adapt=ADAPT)
+    net = multi_accdoa.HTSAT(cfg, C, 7, pretrained_path=None, **kw(TINY))
+    sd = oh.add_adapters(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all('relative_position_index' in k or 'attn_mask' in k for k in missing)
+    assert set(net.state_dict().keys()) == set(str(k) for k in g['state_keys'])
+    assert set(n for n, p in net.named_parameters() if p.requires_grad) == set(str(n) for n in g['trainable'])
+    net.to(dev)
+    x = oh.formula_features(2).to(dev)
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(x.clone())['multi_accdoa'], g['eval']) < 1e-3
+    net.train()
+    pred = net(x.clone())
+    assert rel(pred['multi_accdoa'], g['train']) < 1e-3
+    ld = Losses('mse', 'loss_all')(pred, {'adpit_label': synth.formula_adpit_label(2, 100, C).to(dev)})
+    assert abs(ld['loss_all'].item() - float(g['loss'])) < 1e-4 * abs(float(g['loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        n = str(n)
+        gr = params[n].grad
+        e = abs(gr.norm().item() - norm) / max(norm, 1e-12)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        k = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:k].cpu().numpy() - head[:k]).max() <= 5e-3 * max(np.abs(head).max(), norm / np.sqrt(gr.numel())), n
+    print('adapter fine-tuning: worst trainable grad-norm rel err', worst)
+    assert worst[1] < 5e-3, worst
+    assert all(p.grad is None for n, p in params.items() if not p.requires_grad)
+    # fused step: the arena gradients are those of the backward above
+    before = {n: p.detach().clone() for n, p in params.items()}
+    net.fused_adamw_step(1e-3, max_norm=1.0)
+    moved = set(n for n, p in net.named_parameters() if not torch.equal(p.detach(), before[n]))
+    assert moved == set(str(n) for n in g['moved'])
+    after = dict(net.named_parameters())
+    for n, head in zip(g['after_names'], g['after_heads']):
+        got = after[str(n)].detach().reshape(-1)[:8].cpu().numpy()
+        assert np.abs(got - head).max() <= 2e-4 * max(1.0, np.abs(head).max()), n
+    # bf16 throughput mode runs the same graph
+    netb = multi_accdoa.HTSAT(cfg, C, 7, pretrained_path=None, **kw(TINY))
+    netb.load_state_dict(sd, strict=False)
+    netb.compute_dtype = torch.bfloat16
+    netb.to(dev).eval()
+    with torch.no_grad():
+        assert rel(netb(x.clone())['multi_accdoa'], g['eval']) < 1.5e-1

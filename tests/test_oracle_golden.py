@@ -381,3 +381,25 @@ def test_decode_golden():
     outs = od.move_avg(torch.as_tensor(g['mavg_preds']), [330, 100, 215], 10, 2)
     assert [o.shape[0] for o in outs] == [400, 100, 300]
     assert np.abs(torch.cat(outs, 0)[None].numpy() - g['mavg_out']).max() < 1e-6
+
+
+def test_adapter_golden():
+    """oracle/htsat.py adapter branches against the reference's HTSAT with configs/adapt/adapter.yaml (eval and train-mode
+    output, ADPIT loss; the gradients of the trainable set are checked through autograd of the oracle)."""
+    g = gold('adapter.npz')
+    C = 3
+    x = oh.formula_features(2)
+    sd = oh.add_adapters(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+    with torch.no_grad():
+        close(oh.accdoa_htsat_forward(x.clone(), sd, TINY, key='multi_accdoa')['multi_accdoa'], g['eval'], 2e-5)
+    trainable = set(str(n) for n in g['trainable'])
+    assert all(('bias' in n) or ('adapter' in n) or n.startswith('tscam_conv.') for n in trainable)
+    p = {k: (v.clone().requires_grad_(k in trainable) if v.is_floating_point() else v) for k, v in sd.items()}
+    pred = oh.accdoa_htsat_forward(x.clone(), p, TINY, training=True, key='multi_accdoa')
+    close(pred['multi_accdoa'], g['train'], 2e-5)
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, C)})
+    assert abs(ld['loss_all'].item() - float(g['loss'])) < 1e-6
+    ld['loss_all'].backward()
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= 2e-3 * max(norm, 1e-6), n
