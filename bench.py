@@ -178,6 +178,8 @@ def main():
                     help="augmix = configs/augment/augmix.yaml (every shipped synth_* experiment trains with it): the batch is "
                          "tripled, rotated / mixed as waveforms and masked / shifted as features on the device; `value` still counts "
                          "the ORIGINAL clips. Not the headline configuration.")
+    ap.add_argument('--adapt', default='none', choices=['none', 'adapter'],
+                    help="adapter = configs/adapt/adapter.yaml fine-tuning (HTS-AT only): adapters + biases + head train. Not the headline.")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
@@ -211,6 +213,9 @@ def main():
     from pseldnets_amd.utils.config import get_afextractor
 
     cfg = make_cfg()
+    if args.adapt == 'adapter':
+        from pseldnets_amd.train import ADAPT_GROUPS
+        cfg['adapt'] = ADAPT_GROUPS['adapter']
     torch.manual_seed(2024)
     if args.backbone == 'htsat':
         net = multi_accdoa.HTSAT(cfg, CLASSES, 7, pretrained_path=None)      # configs/model/htsat.yaml geometry
@@ -294,7 +299,7 @@ def main():
     gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2,
                    'crnn': GFLOP_PER_CHUNK_TRAIN_CRNN}[args.backbone]
     out = {
-        "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA") + (" + AugMix" if args.augment == 'augmix' else ""), "value": round(clips_per_s, 2), "unit": "clips/s",
+        "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA") + (" + AugMix" if args.augment == 'augmix' else "") + (" (adapter fine-tuning)" if args.adapt == 'adapter' else ""), "value": round(clips_per_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "

@@ -48,6 +48,8 @@ class HTSAT(HTSATNetBase):
                 param.requires_grad_(True)
         if adapt_method == 'mono_adapter' and not found:
             self.requires_grad_(True)
+        else:
+            self.enc.frozen_weights = True     # the backward skips the frozen weight-gradient GEMMs (bias gradients stay)
 
     def load_ckpts(self, pretrained_path, audioset_pretrain=True):
         """accdoa.py:172-202: AudioSet HTS-AT checkpoints (1-channel patch-embed replicated / in_channels, bn0 copied

@@ -62,6 +62,7 @@ class SwinEncoder:
         self.adapter_ratio = float(akw.get('mlp_ratio', 0.25))
         self.adapter_scale = akw.get('adapter_scalar', 1)
         self._ad_scale = None
+        self.frozen_weights = False            # set by the network when freeze_layers_if_needed froze the backbone weights
         if self.attn_adapter or self.mlp_adapter:
             if akw.get('type', 'adapter') != 'adapter' or akw.get('act_layer', 'gelu') != 'gelu' or akw.get('new_adapter'):
                 raise NotImplementedError("adapters: only type=adapter, act_layer=gelu, no new_adapter (configs/adapt/adapter.yaml)")
@@ -143,11 +144,24 @@ class SwinEncoder:
         dtype = dx.dtype
         dP0 = ops.layernorm_bwd(dx, saved['P0'], a.p(p + 'patch_embed.norm.weight'), a.g(p + 'patch_embed.norm.weight'),
                                 a.g(p + 'patch_embed.norm.bias'))
-        ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 16),
-                         dbias=a.g(p + 'patch_embed.proj.bias'))
+        if self.frozen_weights:
+            ops.colsum(dP0, a.g(p + 'patch_embed.proj.bias'))
+        else:
+            ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 16),
+                             dbias=a.g(p + 'patch_embed.proj.bias'))
         W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 16)
         dA0 = ops.linear_dgrad(dP0, W)
         ops.bn_scalar_bwd(feat, mean_rstd, dA0, bn_dw, bn_db, saved['c_first'], accumulate=accumulate_bn)
+
+    def _wgrad(self, dy, x, wname, bname=None, gelu_on_x=False, rowscale=None, rows_per_scale=1, per_scale_elems=0):
+        """dW (+ dbias). With the backbone frozen (adapter fine-tuning) only the bias gradient is formed: a column sum of the
+        (DropPath-scaled) output gradient instead of the split-K weight-gradient GEMM."""
+        a = self.arena
+        if not self.frozen_weights:
+            ops.linear_wgrad(dy, x, a.g(wname), dbias=a.g(bname) if bname else None, gelu_on_x=gelu_on_x, rowscale=rowscale,
+                             rows_per_scale=rows_per_scale)
+        elif bname is not None:
+            ops.colsum(dy if rowscale is None else ops.rowscale(dy, rowscale, per_scale_elems), a.g(bname))
 
     # -- Adapter (model_utilities_adapt.py:7-44): fc2(gelu(fc1(x))) * scale (+ resid) --------------------------------------
     def _scale_vec(self, device):
@@ -232,7 +246,7 @@ class SwinEncoder:
         L = res * res
         if li < self.nl - 1:
             d = f'{p}layers.{li}.downsample.'
-            ops.linear_wgrad(dx, saved['xm'], a.g(d + 'reduction.weight'))
+            self._wgrad(dx, saved['xm'], d + 'reduction.weight')
             dxm = ops.linear_dgrad(dx, a.w(d + 'reduction.weight', dtype), wt=a.wt(d + 'reduction.weight', dtype))
             dx = ops.layernorm_bwd(dxm, saved['x_pre'], a.p(d + 'norm.weight'), a.g(d + 'norm.weight'),
                                    a.g(d + 'norm.bias'), merge_res=res)
@@ -241,12 +255,12 @@ class SwinEncoder:
             s = saved['blocks'][bi]
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
             if 'h' in s:
-                ops.linear_wgrad(dx, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), rowscale=s['s2'], rows_per_scale=L)
+                self._wgrad(dx, s['h'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
                 du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
             else:
-                ops.linear_wgrad(dx, s['u'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L)
+                self._wgrad(dx, s['u'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
                 du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
-            ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
+            self._wgrad(du, s['xh2'], b + 'mlp.fc1.weight', b + 'mlp.fc1.bias')
             dxh2_ad = None
             if self.mlp_adapter:            # the adapter branch sees the same DropPath-scaled gradient
                 dxs = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
@@ -258,14 +272,14 @@ class SwinEncoder:
             if self.attn_adapter:
                 da1 = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
                 da0 = self._adapter_bwd(da1, s['ad']['a0'], s['ad']['attn'], b + 'attn.adapter.', dresid=da1)
-                ops.linear_wgrad(da0, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'))
+                self._wgrad(da0, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias')
                 dao = ops.linear_dgrad(da0, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype))
             else:
-                ops.linear_wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=L)
+                self._wgrad(dx_mid, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias', rowscale=s['s1'], rows_per_scale=L, per_scale_elems=L * C)
                 dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
-            ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
+            self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
             dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype), wt=a.wt(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
                                    a.g(b + 'norm1.bias'), dres=dx_mid)
