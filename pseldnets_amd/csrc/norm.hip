@@ -395,21 +395,25 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     for (int z = 0; z < splits; ++z) s += slabs[z * slab_stride + i];
     out[i] = s;
 }
-// many slabs, few columns: 16 columns x 16 slab groups per workgroup, fixed-order tree in LDS (deterministic)
+// many slabs, few columns: CW columns x (256 / CW) slab groups per workgroup, fixed-order sum in LDS (deterministic).
+// CW = 16 for up to a few dozen slabs; CW = 4 (64 slab groups, four times the workgroups) for the per-row-block partials of
+// the LayerNorm / BatchNorm backward passes, where a launch used to be 12 workgroups each walking 64 slabs serially.
+template <int CW>
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 long n, int splits, long slab_stride, int accumulate) {
-    __shared__ float red[16][17];
-    const int c = threadIdx.x & 15, sg = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + c;
+    constexpr int SG = 256 / CW;
+    __shared__ float red[SG][CW + 1];
+    const int c = threadIdx.x % CW, sg = threadIdx.x / CW;
+    const long i = (long)blockIdx.x * CW + c;
     float s = 0.f;
     if (i < n)
-        for (int z = sg; z < splits; z += 16) s += slabs[z * slab_stride + i];
+        for (int z = sg; z < splits; z += SG) s += slabs[z * slab_stride + i];
     red[sg][c] = s;
     __syncthreads();
     if (sg == 0 && i < n) {
         float t = accumulate ? out[i] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][c];
+#pragma unroll 16
+        for (int k = 0; k < SG; ++k) t += red[k][c];
         out[i] = t;
     }
 }
@@ -543,8 +547,11 @@ void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long
     if (splits >= 4 && n >= 4096 && n % 4 == 0 && slab_stride % 4 == 0 && ((unsigned long)slabs & 15) == 0 && ((unsigned long)out & 15) == 0)
         hipLaunchKernelGGL(reduce_slabs_vec4_kernel, dim3(pseld_cdiv(n / 4, 64)), dim3(256), 0, stream, slabs, out, n / 4, splits,
                            slab_stride, accumulate);
+    else if (splits > 128)
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel<4>, dim3(pseld_cdiv(n, 4)), dim3(256), 0, stream, slabs, out, n, splits,
+                           slab_stride, accumulate);
     else if (splits > 32)
-        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3(pseld_cdiv(n, 16)), dim3(256), 0, stream, slabs, out, n, splits,
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel<16>, dim3(pseld_cdiv(n, 16)), dim3(256), 0, stream, slabs, out, n, splits,
                            slab_stride, accumulate);
     else
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, stream, slabs, out, n, splits,
