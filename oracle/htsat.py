@@ -440,3 +440,42 @@ def add_adapters(sd, cfg=None, mlp_ratio=0.5, seed=5, pre='encoder.', attn=True,
                 sd[b + 'fc2.weight'] = torch.randn(C, ah, generator=g) * (4.0 / ah) ** 0.5
                 sd[b + 'fc2.bias'] = torch.randn(C, generator=g) * 0.5
     return sd
+
+
+def add_lora(sd, cfg=None, in_chans=7, r=16, seed=6, pre='encoder.'):
+    """Seeded non-trivial LoRA factors (the reference initialises lora_B to zero) for every get_linear_layer / get_conv2d_layer
+    site of `pre` (model_utilities_adapt.py:66-158): keys `...{qkv,proj,fc1,fc2,reduction}.lora_{A,B}`,
+    `patch_embed.proj.lora_{A,B}.weight`."""
+    cfg = _norm_cfg(cfg)
+    g = torch.Generator().manual_seed(seed)
+    E = cfg['embed_dim']
+
+    def put(base, out_f, in_f):
+        sd[base + 'lora_A'] = torch.randn(r, in_f, generator=g) * (1.0 / in_f) ** 0.5
+        sd[base + 'lora_B'] = torch.randn(out_f, r, generator=g) * 0.3
+    sd[pre + 'patch_embed.proj.lora_A.weight'] = torch.randn(r, in_chans, 4, 4, generator=g) * (1.0 / (in_chans * 16)) ** 0.5
+    sd[pre + 'patch_embed.proj.lora_B.weight'] = torch.randn(E, r, 1, 1, generator=g) * 0.3
+    for li, depth in enumerate(cfg['depths']):
+        C = E * 2 ** li
+        for bi in range(depth):
+            b = f'{pre}layers.{li}.blocks.{bi}.'
+            put(b + 'attn.qkv.', 3 * C, C); put(b + 'attn.proj.', C, C)
+            put(b + 'mlp.fc1.', 4 * C, C); put(b + 'mlp.fc2.', C, 4 * C)
+        if li < len(cfg['depths']) - 1:
+            put(f'{pre}layers.{li}.downsample.reduction.', 2 * C, 4 * C)
+    return sd
+
+
+def merge_lora(sd, r_scale=1.0 / 16, pre='encoder.'):
+    """State with the LoRA factors merged into the base weights (W + s * B A; model_utilities_adapt.py:103-118 / :150-158) and
+    the factor keys removed: the plain forward on it equals the reference's LoRA forward."""
+    out = {k: v for k, v in sd.items() if 'lora_' not in k}
+    for k in sd:
+        if k.endswith('lora_A'):
+            base = k[:-len('lora_A')]
+            out[base + 'weight'] = sd[base + 'weight'] + (sd[base + 'lora_B'] @ sd[k]) * r_scale
+        elif k.endswith('lora_A.weight'):
+            base = k[:-len('lora_A.weight')]
+            A, B = sd[k], sd[base + 'lora_B.weight']
+            out[base + 'weight'] = sd[base + 'weight'] + ((B.flatten(1) @ A.flatten(1)) * r_scale).view_as(sd[base + 'weight'])
+    return out

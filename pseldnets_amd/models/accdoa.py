@@ -36,6 +36,11 @@ class HTSAT(HTSATNetBase):
     def freeze_layers_if_needed(self, adapt_method):
         """accdoa.py:148-170: adapter fine-tuning trains the biases (every parameter whose name contains 'bias', the
         relative-position bias tables included), the adapters and the head; 'mono_adapter' without adapters trains all."""
+        if 'lora' in adapt_method:             # model_utilities_adapt.py:91,141: the base weight of every LoRA layer is frozen
+            for name, param in self.named_parameters():
+                if name.endswith('.weight') and (name[:-len('weight')] + 'lora_A' in self.arena.offsets
+                                                 or name[:-len('weight')] + 'lora_A.weight' in self.arena.offsets):
+                    param.requires_grad_(False)
         if 'adapter' not in adapt_method:
             return
         found = False

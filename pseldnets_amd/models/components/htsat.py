@@ -53,8 +53,16 @@ class SwinEncoder:
         # ('MlpAdapter'): x -> fc2(gelu(fc1(x))) * adapter_scalar
         ad = dict(cfg_adapt or {})
         method = str(ad.get('method', '') or '')
-        if 'lora' in method:
-            raise NotImplementedError("adapt.method=lora (model_utilities_adapt.py:47-158) is not built on the MI355X path yet")
+        # LoRA (configs/adapt/lora.yaml; model_utilities_adapt.py:47-158): every get_linear_layer / get_conv2d_layer site
+        # (qkv, proj, fc1, fc2, reduction, patch-embed conv) gets rank-r factors, its base weight is frozen
+        self.lora = 'lora' in method
+        lk, ck = dict(ad.get('linear_kwargs', {}) or {}), dict(ad.get('conv_kwargs', {}) or {})
+        self.lora_r, self.lora_rc = int(lk.get('r', 0)), int(ck.get('r', 0))
+        if self.lora:
+            if self.lora_r <= 0 or self.lora_rc <= 0 or self.lora_r % 8 or self.lora_rc % 8 or lk.get('lora_dropout', 0.) or lk.get('fan_in_fan_out', False):
+                raise NotImplementedError("LoRA: r a positive multiple of 8 for linear and conv layers, no dropout, no fan_in_fan_out")
+            self.lora_s, self.lora_sc = lk.get('lora_alpha', 1) / self.lora_r, ck.get('lora_alpha', 1) / self.lora_rc
+        self._weff, self._lora_names = {}, []
         akw = dict(ad.get('adapt_kwargs', {}) or {})
         pos = akw.get('position', []) or []
         self.attn_adapter = 'adapter' in method and 'SpatialAdapter' in pos
@@ -69,8 +77,16 @@ class SwinEncoder:
             if isinstance(self.adapter_scale, str):
                 raise NotImplementedError("adapter_scalar=learnable_scalar is not built; use the numeric scalar of adapter.yaml")
         a, p, E = arena, prefix, self.E
+
+        def lora_entries(base, out_f, in_f):
+            if self.lora:
+                a.add(base + 'lora_A', (self.lora_r, in_f)); a.add(base + 'lora_B', (out_f, self.lora_r))
+                self._lora_names.append(base)
         a.add(p + 'patch_embed.proj.weight', (E, in_chans, 4, 4))
         a.add(p + 'patch_embed.proj.bias', (E,))
+        if self.lora:
+            a.add(p + 'patch_embed.proj.lora_A.weight', (self.lora_rc, in_chans, 4, 4))
+            a.add(p + 'patch_embed.proj.lora_B.weight', (E, self.lora_rc, 1, 1))
         a.add(p + 'patch_embed.norm.weight', (E,))
         a.add(p + 'patch_embed.norm.bias', (E,))
         for li in range(self.nl):
@@ -80,21 +96,21 @@ class SwinEncoder:
                 b = f'{p}layers.{li}.blocks.{bi}.'
                 a.add(b + 'norm1.weight', (C,)); a.add(b + 'norm1.bias', (C,))
                 a.add(b + 'attn.relative_position_bias_table', (225, h))
-                a.add(b + 'attn.qkv.weight', (3 * C, C)); a.add(b + 'attn.qkv.bias', (3 * C,))
-                a.add(b + 'attn.proj.weight', (C, C)); a.add(b + 'attn.proj.bias', (C,))
+                a.add(b + 'attn.qkv.weight', (3 * C, C)); a.add(b + 'attn.qkv.bias', (3 * C,)); lora_entries(b + 'attn.qkv.', 3 * C, C)
+                a.add(b + 'attn.proj.weight', (C, C)); a.add(b + 'attn.proj.bias', (C,)); lora_entries(b + 'attn.proj.', C, C)
                 ah = int(C * self.adapter_ratio)
                 if self.attn_adapter:
                     a.add(b + 'attn.adapter.fc1.weight', (ah, C)); a.add(b + 'attn.adapter.fc1.bias', (ah,))
                     a.add(b + 'attn.adapter.fc2.weight', (C, ah)); a.add(b + 'attn.adapter.fc2.bias', (C,))
                 a.add(b + 'norm2.weight', (C,)); a.add(b + 'norm2.bias', (C,))
-                a.add(b + 'mlp.fc1.weight', (hid, C)); a.add(b + 'mlp.fc1.bias', (hid,))
-                a.add(b + 'mlp.fc2.weight', (C, hid)); a.add(b + 'mlp.fc2.bias', (C,))
+                a.add(b + 'mlp.fc1.weight', (hid, C)); a.add(b + 'mlp.fc1.bias', (hid,)); lora_entries(b + 'mlp.fc1.', hid, C)
+                a.add(b + 'mlp.fc2.weight', (C, hid)); a.add(b + 'mlp.fc2.bias', (C,)); lora_entries(b + 'mlp.fc2.', C, hid)
                 if self.mlp_adapter:
                     a.add(b + 'mlp.adapter.fc1.weight', (ah, C)); a.add(b + 'mlp.adapter.fc1.bias', (ah,))
                     a.add(b + 'mlp.adapter.fc2.weight', (C, ah)); a.add(b + 'mlp.adapter.fc2.bias', (C,))
             if li < self.nl - 1:
                 d = f'{p}layers.{li}.downsample.'
-                a.add(d + 'reduction.weight', (2 * C, 4 * C))
+                a.add(d + 'reduction.weight', (2 * C, 4 * C)); lora_entries(d + 'reduction.', 2 * C, 4 * C)
                 a.add(d + 'norm.weight', (4 * C,)); a.add(d + 'norm.bias', (4 * C,))
         a.add(p + 'norm.weight', (self.num_features,)); a.add(p + 'norm.bias', (self.num_features,))
 
@@ -133,8 +149,9 @@ class SwinEncoder:
     def forward_patch(self, feat, scale_shift, dtype, c_first=0):
         """model_utilities.py:205-213 on bn->pad->fold->patches (htsat.py:547-553 forward_patch)."""
         a, p = self.arena, self.prefix
+        self.lora_refresh(dtype)
         A0 = ops.bn_fold_patchify(feat, scale_shift, dtype, c_first, self.in_chans)
-        W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 16)
+        W = self._w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 16)
         P0 = ops.linear_fwd(A0, W, a.p(p + 'patch_embed.proj.bias'))
         x = ops.layernorm_fwd(P0, a.p(p + 'patch_embed.norm.weight'), a.p(p + 'patch_embed.norm.bias'))
         return x, dict(A0=A0, P0=P0, c_first=c_first)
@@ -149,9 +166,54 @@ class SwinEncoder:
         else:
             ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 16),
                              dbias=a.g(p + 'patch_embed.proj.bias'))
-        W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 16)
+            if self.lora:
+                self._lora_grads(p + 'patch_embed.proj.weight')
+        W = self._w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 16)
         dA0 = ops.linear_dgrad(dP0, W)
         ops.bn_scalar_bwd(feat, mean_rstd, dA0, bn_dw, bn_db, saved['c_first'], accumulate=accumulate_bn)
+
+    # -- LoRA: the GEMMs run on the effective weight W + s * B A; its gradient is folded back onto the factors ----------------
+    def _w(self, name, dtype):
+        return self._weff[name] if self.lora else self.arena.w(name, dtype)
+
+    def _wt(self, name, dtype):
+        return None if self.lora else self.arena.wt(name, dtype)
+
+    def _lora_factors(self, wname):
+        a = self.arena
+        if wname.endswith('patch_embed.proj.weight'):
+            base = wname[:-len('weight')]
+            K = self.in_chans * 16
+            return (a.p(base + 'lora_A.weight').view(self.lora_rc, K), a.p(base + 'lora_B.weight').view(self.E, self.lora_rc),
+                    a.g(base + 'lora_A.weight').view(self.lora_rc, K), a.g(base + 'lora_B.weight').view(self.E, self.lora_rc), self.lora_sc, K)
+        base = wname[:-len('weight')]
+        return a.p(base + 'lora_A'), a.p(base + 'lora_B'), a.g(base + 'lora_A'), a.g(base + 'lora_B'), self.lora_s, a.p(base + 'lora_A').shape[1]
+
+    def lora_refresh(self, dtype):
+        """W_eff = W + s * B @ A for every LoRA site (fp32 product, one GEMM with the base weight as its residual), in the
+        compute dtype. Equals the reference's unmerged train-mode sum x W^T + s (x A^T) B^T and its merged eval-mode weight."""
+        if not self.lora:
+            return
+        a, p = self.arena, self.prefix
+        dev = a.flat.device
+        for wname in [p + 'patch_embed.proj.weight'] + [b + 'weight' for b in self._lora_names]:
+            A, Bm, _, _, sc, K = self._lora_factors(wname)
+            W = a.p(wname).view(Bm.shape[0], K)
+            sv = torch.full((1,), float(sc), dtype=torch.float32, device=dev)
+            weff = ops.linear_dgrad(Bm.contiguous(), A.contiguous(), rowscale=sv, rows_per_scale=Bm.shape[0], resid=W)
+            if dtype == torch.bfloat16:
+                wb = torch.empty(weff.numel(), dtype=torch.bfloat16, device=dev)
+                ops.cast_bf16(weff.view(-1), wb)
+                weff = wb.view(weff.shape)
+            self._weff[wname] = weff.view(a.p(wname).shape) if not wname.endswith('patch_embed.proj.weight') else weff
+
+    def _lora_grads(self, wname):
+        """dW_eff sits in the (frozen) base weight's gradient slot: dA = s * B^T dW_eff, dB = s * dW_eff A^T."""
+        A, Bm, dA, dB, sc, K = self._lora_factors(wname)
+        G = self.arena.g(wname).view(Bm.shape[0], K)
+        sv = torch.full((1,), float(sc), dtype=torch.float32, device=G.device)
+        ops.linear_wgrad(Bm.contiguous(), G, dA, rowscale=sv, rows_per_scale=Bm.shape[0])
+        dB.copy_(ops.linear_fwd(G, A.contiguous(), rowscale=sv, rows_per_scale=G.shape[0]))
 
     def _wgrad(self, dy, x, wname, bname=None, gelu_on_x=False, rowscale=None, rows_per_scale=1, per_scale_elems=0):
         """dW (+ dbias). With the backbone frozen (adapter fine-tuning) only the bias gradient is formed: a column sum of the
@@ -160,6 +222,8 @@ class SwinEncoder:
         if not self.frozen_weights:
             ops.linear_wgrad(dy, x, a.g(wname), dbias=a.g(bname) if bname else None, gelu_on_x=gelu_on_x, rowscale=rowscale,
                              rows_per_scale=rows_per_scale)
+            if self.lora:
+                self._lora_grads(wname)
         elif bname is not None:
             ops.colsum(dy if rowscale is None else ops.rowscale(dy, rowscale, per_scale_elems), a.g(bname))
 
@@ -199,33 +263,33 @@ class SwinEncoder:
             if drop_scale is not None and self.rates[gi] > 0:
                 s1, s2 = drop_scale[gi, 0], drop_scale[gi, 1]
             xh1 = ops.layernorm_fwd(x, a.p(b + 'norm1.weight'), a.p(b + 'norm1.bias'))
-            qkv = ops.linear_fwd(xh1, a.w(b + 'attn.qkv.weight', dtype), a.p(b + 'attn.qkv.bias'))
+            qkv = ops.linear_fwd(xh1, self._w(b + 'attn.qkv.weight', dtype), a.p(b + 'attn.qkv.bias'))
             ao = ops.window_attn_fwd(qkv, a.p(b + 'attn.relative_position_bias_table'), B, res, heads, shift)
             ad = {}
             if self.attn_adapter:
                 # x = adapter(proj(attn)) + proj(attn) (htsat.py:141-143), then the block's DropPath + residual
-                a0 = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'))
+                a0 = ops.linear_fwd(ao, self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'))
                 a1, ad['attn'] = self._adapter_fwd(a0, b + 'attn.adapter.', resid=a0)
                 ad['a0'] = a0
                 x_mid = ops.add(x, ops.rowscale(a1, s1, L * C)) if s1 is not None else ops.add(x, a1)
             else:
-                x_mid = ops.linear_fwd(ao, a.w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
+                x_mid = ops.linear_fwd(ao, self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
                                        rowscale=s1, rows_per_scale=L)
             xh2 = ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
             if self.mlp_adapter:
                 xs, ad['mlp'] = self._adapter_fwd(xh2, b + 'mlp.adapter.')          # xs = adapter(x) (model_utilities.py:160-170)
             if GELU_DUAL:
                 # fc1 epilogue emits h = gelu(u) and g = gelu'(u): erf is evaluated once per element, not in fc2/dW2/dU
-                hact, gact = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), gelu_dual=True)
-                x_out = ops.linear_fwd(hact, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
+                hact, gact = ops.linear_fwd(xh2, self._w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), gelu_dual=True)
+                x_out = ops.linear_fwd(hact, self._w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
                                        rowscale=s2, rows_per_scale=L)
                 if self.mlp_adapter:
                     x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
                 saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1,
                                          s2=s2, shift=shift, ad=ad))
             else:
-                u = ops.linear_fwd(xh2, a.w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'))
-                x_out = ops.linear_fwd(u, a.w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
+                u = ops.linear_fwd(xh2, self._w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'))
+                x_out = ops.linear_fwd(u, self._w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,
                                        rowscale=s2, rows_per_scale=L, gelu_in=True)
                 if self.mlp_adapter:
                     x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
@@ -237,7 +301,7 @@ class SwinEncoder:
             d = f'{p}layers.{li}.downsample.'
             xm = ops.layernorm_fwd(x, a.p(d + 'norm.weight'), a.p(d + 'norm.bias'), merge_res=res)
             saved.update(x_pre=x, xm=xm)
-            x = ops.linear_fwd(xm, a.w(d + 'reduction.weight', dtype))
+            x = ops.linear_fwd(xm, self._w(d + 'reduction.weight', dtype))
         return x, saved
 
     def backward_layer(self, li, dx, saved, B):
@@ -247,7 +311,7 @@ class SwinEncoder:
         if li < self.nl - 1:
             d = f'{p}layers.{li}.downsample.'
             self._wgrad(dx, saved['xm'], d + 'reduction.weight')
-            dxm = ops.linear_dgrad(dx, a.w(d + 'reduction.weight', dtype), wt=a.wt(d + 'reduction.weight', dtype))
+            dxm = ops.linear_dgrad(dx, self._w(d + 'reduction.weight', dtype), wt=self._wt(d + 'reduction.weight', dtype))
             dx = ops.layernorm_bwd(dxm, saved['x_pre'], a.p(d + 'norm.weight'), a.g(d + 'norm.weight'),
                                    a.g(d + 'norm.bias'), merge_res=res)
         for bi in reversed(range(self.depths[li])):
@@ -256,16 +320,16 @@ class SwinEncoder:
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
             if 'h' in s:
                 self._wgrad(dx, s['h'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
-                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
+                du = ops.linear_dgrad(dx, self._w(b + 'mlp.fc2.weight', dtype), wt=self._wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
             else:
                 self._wgrad(dx, s['u'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
-                du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
+                du = ops.linear_dgrad(dx, self._w(b + 'mlp.fc2.weight', dtype), wt=self._wt(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
             self._wgrad(du, s['xh2'], b + 'mlp.fc1.weight', b + 'mlp.fc1.bias')
             dxh2_ad = None
             if self.mlp_adapter:            # the adapter branch sees the same DropPath-scaled gradient
                 dxs = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
                 dxh2_ad = self._adapter_bwd(dxs, s['xh2'], s['ad']['mlp'], b + 'mlp.adapter.')
-            dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype), wt=a.wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
+            dxh2 = ops.linear_dgrad(du, self._w(b + 'mlp.fc1.weight', dtype), wt=self._wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
                                        a.g(b + 'norm2.bias'), dres=dx)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
@@ -273,14 +337,14 @@ class SwinEncoder:
                 da1 = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
                 da0 = self._adapter_bwd(da1, s['ad']['a0'], s['ad']['attn'], b + 'attn.adapter.', dresid=da1)
                 self._wgrad(da0, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias')
-                dao = ops.linear_dgrad(da0, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype))
+                dao = ops.linear_dgrad(da0, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype))
             else:
                 self._wgrad(dx_mid, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias', rowscale=s['s1'], rows_per_scale=L, per_scale_elems=L * C)
-                dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
+                dao = ops.linear_dgrad(dx_mid, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
             self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
-            dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype), wt=a.wt(b + 'attn.qkv.weight', dtype))
+            dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=self._wt(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
                                    a.g(b + 'norm1.bias'), dres=dx_mid)
         return dx
@@ -336,6 +400,10 @@ def default_init(name, shape):
     leaf = name.rsplit('.', 1)[-1]
     if 'relative_position_bias_table' in name:
         torch.nn.init.trunc_normal_(t, std=.02)
+    elif 'lora_B' in name:                                               # model_utilities_adapt.py:99-100,147-148: LoRA starts as identity
+        t.zero_()
+    elif 'lora_A' in name:
+        torch.nn.init.kaiming_uniform_(t.view(shape[0], -1), a=math.sqrt(5))
     elif '.adapter.fc2.' in name:                                       # model_utilities_adapt.py:26-30: the adapter starts as identity
         t.zero_()
     elif name.startswith('stitch'):

@@ -38,6 +38,8 @@ ADAPT_GROUPS = {      # configs/adapt/{default,adapter,mono_adapter}.yaml
     'default': {'method': 'none'},
     'adapter': {'method': 'adapter', 'adapt_kwargs': {'position': ['MlpAdapter', 'SpatialAdapter'], 'type': 'adapter', 'mlp_ratio': 0.5,
                                                       'adapter_scalar': 0.1, 'act_layer': 'gelu'}},
+    'lora': {'method': 'lora', 'linear_kwargs': {'r': 16, 'lora_alpha': 1, 'lora_dropout': 0., 'fan_in_fan_out': False, 'merge_weights': True},
+             'conv_kwargs': {'r': 16, 'lora_alpha': 1}},
     'mono_adapter': {'method': 'mono_adapter', 'adapt_kwargs': {'position': ['MlpAdapter', 'SpatialAdapter'], 'type': 'adapter',
                                                                 'mlp_ratio': 0.5, 'act_layer': 'gelu', 'adapter_scalar': 0.1}},
 }

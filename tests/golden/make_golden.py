@@ -605,8 +605,46 @@ def gen_adapter():
     save('adapter.npz', **out)
 
 
+LORA_CFG = dict(method='lora', linear_kwargs=dict(r=16, lora_alpha=1, lora_dropout=0., fan_in_fan_out=False, merge_weights=True),
+                conv_kwargs=dict(r=16, lora_alpha=1))
+
+
+def gen_lora():
+    """multi_accdoa.HTSAT with configs/adapt/lora.yaml: eval (merged) and train (unmerged) output, trainable set, loss and the
+    gradients of the LoRA factors and a few other trainable parameters. Factors seeded non-zero (oracle/htsat.py:add_lora)."""
+    C = 3
+    cfgl = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'), adapt=LORA_CFG)
+    out = {}
+    x = oh.formula_features(2)
+    net = multi_accdoa.HTSAT(cfgl, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    sd = oh.add_lora(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(('relative_position_index' in k) or ('attn_mask' in k) for k in missing), (missing, unexpected)
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    out['trainable'] = np.array([n for n, p in net.named_parameters() if p.requires_grad])
+    net.eval()                               # merges W += s * B A (model_utilities_adapt.py:113-118); before the train pass moves the BN statistics
+    with torch.no_grad():
+        out['eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net.train()                              # un-merges again
+    pred = net(x.clone())
+    lab = synth.formula_adpit_label(2, 100, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab})
+    ld['loss_all'].backward()
+    out['train'] = pred['multi_accdoa'].detach().numpy()
+    out['loss'] = ld['loss_all'].item()
+    names, norms, heads = [], [], []
+    for n, p in net.named_parameters():
+        if not p.requires_grad or n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    save('lora.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -619,3 +657,4 @@ if __name__ == '__main__':
     if 'augment' in which: gen_augment()
     if 'decode' in which: gen_decode()
     if 'adapter' in which: gen_adapter()
+    if 'lora' in which: gen_lora()

@@ -296,3 +296,60 @@ def test_adapter_fine_tuning_vs_reference(dev):
     netb.to(dev).eval()
     with torch.no_grad():
         assert rel(netb(x.clone())['multi_accdoa'], g['eval']) < 1.5e-1
+
+
+LORA = A(method='lora', linear_kwargs=A(r=16, lora_alpha=1, lora_dropout=0., fan_in_fan_out=False, merge_weights=True),
+         conv_kwargs=A(r=16, lora_alpha=1))
+
+
+def test_lora_fine_tuning_vs_reference(dev):
+    """configs/adapt/lora.yaml: rank-16 factors on every linear / patch-embed layer with frozen base weights. State-dict keys,
+    trainable set, eval / train output, loss and the gradient of every trainable parameter (the factors included) against the
+    reference; one fused step leaves the frozen base weights untouched."""
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'lora.npz'))
+    C = 3
+    cfg = A(data=CFG.data, adapt=LORA)
+    net = multi_accdoa.HTSAT(cfg, C, 7, pretrained_path=None, **kw(TINY))
+    sd = oh.add_lora(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all('relative_position_index' in k or 'attn_mask' in k for k in missing)
+    assert set(net.state_dict().keys()) == set(str(k) for k in g['state_keys'])
+    assert set(n for n, p in net.named_parameters() if p.requires_grad) == set(str(n) for n in g['trainable'])
+    net.to(dev)
+    x = oh.formula_features(2).to(dev)
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(x.clone())['multi_accdoa'], g['eval']) < 1e-3
+    net.train()
+    pred = net(x.clone())
+    assert rel(pred['multi_accdoa'], g['train']) < 1e-3
+    ld = Losses('mse', 'loss_all')(pred, {'adpit_label': synth.formula_adpit_label(2, 100, C).to(dev)})
+    assert abs(ld['loss_all'].item() - float(g['loss'])) < 1e-4 * abs(float(g['loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        n = str(n)
+        gr = params[n].grad
+        e = abs(gr.norm().item() - norm) / max(norm, 1e-12)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        k = min(8, gr.numel())
+        assert np.abs(gr.reshape(-1)[:k].cpu().numpy() - head[:k]).max() <= 5e-3 * max(np.abs(head).max(), norm / np.sqrt(gr.numel())), n
+    print('LoRA fine-tuning: worst trainable grad-norm rel err', worst)
+    assert worst[1] < 5e-3, worst
+    frozen = [n for n, p in params.items() if not p.requires_grad]
+    assert len(frozen) == 36                                        # 4 x 8 block linears + 3 reductions + the patch-embed conv
+    before = {n: params[n].detach().clone() for n in frozen}
+    lb = params['encoder.layers.1.blocks.0.mlp.fc1.lora_B'].detach().clone()
+    net.fused_adamw_step(1e-3, max_norm=1.0)
+    after = dict(net.named_parameters())
+    assert all(torch.equal(after[n].detach(), before[n]) for n in frozen)
+    assert not torch.equal(after['encoder.layers.1.blocks.0.mlp.fc1.lora_B'].detach(), lb)
+    netb = multi_accdoa.HTSAT(cfg, C, 7, pretrained_path=None, **kw(TINY))
+    netb.load_state_dict(sd, strict=False)
+    netb.compute_dtype = torch.bfloat16
+    netb.to(dev).eval()
+    with torch.no_grad():
+        assert rel(netb(x.clone())['multi_accdoa'], g['eval']) < 1.5e-1

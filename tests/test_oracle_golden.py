@@ -403,3 +403,18 @@ def test_adapter_golden():
     for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
         gr = p[str(n)].grad
         assert abs(gr.norm().item() - norm) <= 2e-3 * max(norm, 1e-6), n
+
+
+def test_lora_golden():
+    """oracle: the plain HTS-AT forward on the LoRA-merged state (oracle/htsat.py:merge_lora) against the reference's LoRA network
+    (configs/adapt/lora.yaml) in eval (merged) and train (unmerged) mode."""
+    g = gold('lora.npz')
+    C = 3
+    x = oh.formula_features(2)
+    sd = oh.merge_lora(oh.add_lora(oh.formula_state('multi_accdoa', C, 7, TINY), TINY))
+    with torch.no_grad():
+        close(oh.accdoa_htsat_forward(x.clone(), sd, TINY, key='multi_accdoa')['multi_accdoa'], g['eval'], 5e-5)
+        close(oh.accdoa_htsat_forward(x.clone(), sd, TINY, training=True, key='multi_accdoa')['multi_accdoa'], g['train'], 5e-5)
+    tr = set(str(n) for n in g['trainable'])
+    assert not any(n.endswith(('qkv.weight', 'proj.weight', 'fc1.weight', 'fc2.weight', 'reduction.weight')) for n in tr)
+    assert sum('lora_' in n for n in tr) == 72
