@@ -598,7 +598,10 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     // backward: 2 heads per workgroup (50 KB LDS, 3 workgroups per CU) wins from 8 heads up, 4 at stage 0 (tools/attn_bench.py)
     const int hgv = (dtype == PSELD_BF16 && !getenv("PSELD_ATTN_HG")) ? (heads >= 8 ? 2 : 4) : attn_hg(dtype);
     const int nhg = pseld_cdiv(heads, hgv);
-    int slots = 1024 / nhg;
+    const char* es = getenv("PSELD_ATTN_BWD_WGS");                  // experiment knob: total workgroups of the persistent loop
+    // one resident round: the kernel needs > 256 registers, so a CU holds 4 waves = one 4-head or two 2-head workgroups
+    // (tools/attn_bench.py WGS sweep: 256 / 512 total are the fastest, 768 — not a multiple of the capacity — the slowest)
+    int slots = (es ? atoi(es) : (hgv == 4 ? 256 : 512)) / nhg;
     if (slots > a.n_win_total) slots = a.n_win_total;
     if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);

@@ -17,6 +17,7 @@ def timeit(fn, n=6):
 
 
 masks = [int(m) for m in os.environ.get('MASKS', '0').split(',')]
+wgs = os.environ.get('WGS', '').split(',') if os.environ.get('WGS') else []      # sweep PSELD_ATTN_BWD_WGS (read per call)
 for li, (C, heads) in enumerate(((96, 4), (192, 8), (384, 16), (768, 32))):
     res = 64 >> li
     B = 192
@@ -33,4 +34,8 @@ for li, (C, heads) in enumerate(((96, 4), (192, 8), (384, 16), (768, 32))):
         tb = timeit(lambda: ops.window_attn_bwd(qkv, bt, dout, dbt, B, res, heads, shift))
         out.append(f"bwd[skip={m}] {tb:6.1f}")
     os.environ['PSELD_ATTN_SKIP'] = '0'
+    for w in wgs:
+        os.environ['PSELD_ATTN_BWD_WGS'] = w
+        out.append(f"bwd[wgs={w}] {timeit(lambda: ops.window_attn_bwd(qkv, bt, dout, dbt, B, res, heads, shift)):6.1f}")
+    os.environ.pop('PSELD_ATTN_BWD_WGS', None)
     print('  '.join(out) + f"  (bwd floor {7 * u:5.1f})")
