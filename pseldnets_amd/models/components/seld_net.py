@@ -218,9 +218,10 @@ class HTSATNetBase(nn.Module):
         """None when every parameter trains; else {'mask': 1 for trainable arena elements, 'keep': the frozen values * (1 - mask)}.
         Built once per materialisation from the parameters' requires_grad flags (accdoa.py:148-170 freeze_layers_if_needed)."""
         st = getattr(self, '_frozen_cache', None)
-        if st is not None and st['device'] == self.arena.flat.device and st['flat'] is self.arena.flat:
-            return st['state']
         flags = {n: _get(self, n).requires_grad for n in self.arena.entries}
+        sig = tuple(flags.values())            # re-built when a caller toggles requires_grad between steps
+        if st is not None and st['flat'] is self.arena.flat and st['sig'] == sig:
+            return st['state']
         state = None
         if not all(flags.values()):
             mask = torch.zeros_like(self.arena.flat)
@@ -228,5 +229,5 @@ class HTSATNetBase(nn.Module):
                 if f:
                     self.arena.view(mask, n, padded=True).fill_(1.0)
             state = {'mask': mask, 'keep': self.arena.flat * (1.0 - mask)}
-        self._frozen_cache = {'device': self.arena.flat.device, 'flat': self.arena.flat, 'state': state}
+        self._frozen_cache = {'flat': self.arena.flat, 'sig': sig, 'state': state}
         return state
