@@ -56,6 +56,35 @@ __device__ __forceinline__ void load_rows(char* tile, const T* g, long ld, int g
         else zero16<T>(l);
     }
 }
+// The streamed 64-row tiles are requested one iteration ahead into registers (2 chunks per thread and tile with 256
+// threads) and dropped into LDS after the barrier: their latency hides behind the MFMA work of the current tile instead
+// of sitting between two barriers (PaSST, 192 chunks: attention backward 15.0 -> 10.2 ms, forward 4.0 -> 3.4 ms per step).
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16_t> { f32x4 a; };
+template <> struct Chunk<float> { f32x4 a, b; };
+template <typename T>
+__device__ __forceinline__ void fetch_tile64(Chunk<T> (&reg)[2], const T* g, long ld, int gcol, int r0, int N) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + 256 * i, t = c >> 3, k = c & 7;
+        const T* src = g + (long)min(r0 + t, N - 1) * ld + gcol + k * 8;       // clamped: rows past N are zeroed in put_tile64
+        reg[i].a = ((const f32x4*)src)[0];
+        if constexpr (sizeof(T) == 4) reg[i].b = ((const f32x4*)src)[1];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void put_tile64(char* tile, const Chunk<T> (&reg)[2], int r0, int N) {
+    constexpr int SB = RowS<T>::value;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + 256 * i, t = c >> 3, k = c & 7;
+        char* l = tile + t * SB + k * 8 * (int)sizeof(T);
+        const bool in = r0 + t < N;
+        ((f32x4*)l)[0] = in ? reg[i].a : z;
+        if constexpr (sizeof(T) == 4) ((f32x4*)l)[1] = in ? reg[i].b : z;
+    }
+}
 // the calling wave's 32 LDS rows -> global rows [r0, r0+32) (those below N), 64 columns at gcol
 template <typename T>
 __device__ __forceinline__ void store_wave_rows(const char* rows, T* g, long ld, int gcol, int r0, int N, int lane) {
@@ -125,11 +154,18 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a) {
     zero_tiles(ot);
     float m = -1e30f, l = 0.f;
     const int nkt = (N + 63) >> 6;
+    Chunk<T> rk[2], rv[2];
+    fetch_tile64<T>(rk, base, ld, a.E + head * HD, 0, N);
+    fetch_tile64<T>(rv, base, ld, 2 * a.E + head * HD, 0, N);
     for (int ki = 0; ki < nkt; ++ki) {
         __syncthreads();
-        load_rows<T>(kt, base, ld, a.E + head * HD, ki * 64, 64, N);
-        load_rows<T>(vt, base, ld, 2 * a.E + head * HD, ki * 64, 64, N);
+        put_tile64<T>(kt, rk, ki * 64, N);
+        put_tile64<T>(vt, rv, ki * 64, N);
         __syncthreads();
+        if (ki + 1 < nkt) {
+            fetch_tile64<T>(rk, base, ld, a.E + head * HD, (ki + 1) * 64, N);
+            fetch_tile64<T>(rv, base, ld, 2 * a.E + head * HD, (ki + 1) * 64, N);
+        }
         f32x16 st[2];
         zero_tiles(st);
 #pragma unroll
@@ -227,11 +263,18 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(MhsaArgs a) {
     f32x16 dq[2];
     zero_tiles(dq);
     const int nkt = (N + 63) >> 6;
+    Chunk<T> rk[2], rv[2];
+    fetch_tile64<T>(rk, base, ld, a.E + head * HD, 0, N);
+    fetch_tile64<T>(rv, base, ld, 2 * a.E + head * HD, 0, N);
     for (int ki = 0; ki < nkt; ++ki) {
         __syncthreads();
-        load_rows<T>(kt, base, ld, a.E + head * HD, ki * 64, 64, N);
-        load_rows<T>(vt, base, ld, 2 * a.E + head * HD, ki * 64, 64, N);
+        put_tile64<T>(kt, rk, ki * 64, N);
+        put_tile64<T>(vt, rv, ki * 64, N);
         __syncthreads();
+        if (ki + 1 < nkt) {
+            fetch_tile64<T>(rk, base, ld, a.E + head * HD, (ki + 1) * 64, N);
+            fetch_tile64<T>(rv, base, ld, 2 * a.E + head * HD, (ki + 1) * 64, N);
+        }
         f32x16 st[2], dp[2];
         zero_tiles(st);
         zero_tiles(dp);
@@ -288,10 +331,17 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkv_kernel(MhsaArgs a) {
     zero_tiles(dk);
     zero_tiles(dv);
     const int nqt = (N + 63) >> 6;
+    Chunk<T> rq[2], rd[2];
+    fetch_tile64<T>(rq, base, ld, head * HD, 0, N);
+    fetch_tile64<T>(rd, dob, a.E, head * HD, 0, N);
     for (int qi = 0; qi < nqt; ++qi) {
         __syncthreads();
-        load_rows<T>(qt, base, ld, head * HD, qi * 64, 64, N);
-        load_rows<T>(dot, dob, a.E, head * HD, qi * 64, 64, N);
+        put_tile64<T>(qt, rq, qi * 64, N);
+        put_tile64<T>(dot, rd, qi * 64, N);
+        if (qi + 1 < nqt) {
+            fetch_tile64<T>(rq, base, ld, head * HD, (qi + 1) * 64, N);
+            fetch_tile64<T>(rd, dob, a.E, head * HD, (qi + 1) * 64, N);
+        }
         if (threadIdx.x < 64) {
             const int q = qi * 64 + threadIdx.x;
             lse_s[threadIdx.x] = q < N ? a.lse[sbase + q] : 1e30f;   // exp(s - 1e30) = 0 switches padded queries off
