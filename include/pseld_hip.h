@@ -249,6 +249,16 @@ int pseld_aug_mix_adpit(const float* lab, float* out, const int* dst, const int*
 int pseld_aug_mix_tracks(const float* sed, const float* doa, float* sed_out, float* doa_out, const int* dst, const int* src,
                          const float* lam, int P, int T, int C, int wavmix, void* stream);
 
+/* ---- device-side ingest (device part) --------------------------------------------------------------
+ * src/data/data.py:7-15 load_audio + :75-77 np.pad for the index rows of utils/data_utilities.py:6-64 segment_index, and the
+ * label synthesis of data.py:87-93,207-213. pcm: int16 interleaved frames [total_frames][C] of all clips back to back
+ * (resident in HBM); seg int64 [n][5] = (first frame of the clip, begin, end, pad_before, pad_after);
+ * out f32 [n][C][chunk_len] = PCM / 32768, zero in the pads. polar_labels: se u8, azi i16, ele i8 (degrees), each
+ * [rows*tracks][C] -> out f32 [rows*tracks][4][C] = (se, cos(az)cos(el)se, sin(az)cos(el)se, sin(el)se). */
+int pseld_pcm16_chunks(const short* pcm, const long* seg, float* out, long n, int C, int chunk_len, void* stream);
+int pseld_polar_labels(const unsigned char* se, const short* azi, const signed char* ele, float* out, long rows_tracks, int C,
+                       void* stream);
+
 /* ---- inference-side decoding (device part) --------------------------------------------------------
  * utils/data_utilities.py:234-244 get_accdoa_labels, :273-300 get_multi_accdoa_labels + :302-388
  * multi_accdoa_to_dcase_format (15-degree unification of same-class tracks), components/model_module.py:302-329

@@ -1,0 +1,124 @@
+"""HBM-resident clip store and device-side chunking — the device part of the reference's data layer:
+`utils/data_utilities.py:6-64` segment_index (the index rows `begin,end,pad_before,pad_after` of the chunk CSVs),
+`data/data.py:7-15` load_audio + the padding of :75-77, and the label synthesis of :87-93 / :207-213.
+
+The reference reads a float32 slice per chunk from FLAC/WAV files through soundfile in DataLoader workers; at the MI355X
+step rate (≈ 7 500 ten-second chunks/s per GPU) that is ≈ 29 GB/s of fp32 audio per GPU. Here the clips are decoded ONCE
+to 16-bit PCM and kept in HBM (STARSS23 dev: 5 GB); a training batch is cut, padded and converted by one kernel launch
+from a table of index rows. HDF5 / FLAC readers are not rebuilt (h5py / soundfile are absent from this image); a RIFF PCM16
+reader is included for WAV clips.
+"""
+import struct
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def segment_index(x_len, chunklen, hoplen, last_frame_always_paddding=False):
+    """utils/data_utilities.py:6-64 on a length instead of an array: ([(begin, end), ...], [(pad_before, pad_after), ...]).
+    Full chunks at multiples of hoplen; a trailing remainder of at least half a chunk becomes a zero-padded chunk, a
+    shorter one is covered by a last chunk aligned to the end (unless `last_frame_always_paddding`)."""
+    if x_len < chunklen:
+        return [(0, x_len)], [(0, chunklen - x_len)]
+    n_frames = 1 + (x_len - chunklen) // hoplen
+    idx = [(n * hoplen, n * hoplen + chunklen) for n in range(n_frames)]
+    pad = [(0, 0)] * n_frames
+    if (n_frames - 1) * hoplen + chunklen == x_len:
+        return idx, pad
+    rest = x_len - n_frames * hoplen
+    if last_frame_always_paddding or rest >= chunklen // 2:
+        idx.append((n_frames * hoplen, x_len)); pad.append((0, chunklen - rest))
+    else:
+        idx.append((x_len - chunklen, x_len)); pad.append((0, 0))
+    return idx, pad
+
+
+def read_wav_pcm16(path):
+    """Minimal RIFF/WAVE reader for 16-bit PCM: (int16 [frames, channels], sample_rate)."""
+    with open(path, 'rb') as f:
+        data = f.read()
+    if data[:4] != b'RIFF' or data[8:12] != b'WAVE':
+        raise ValueError(f'{path}: not a RIFF/WAVE file')
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack('<I', data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b'fmt ':
+            fmt = struct.unpack('<HHIIHH', body[:16])
+        elif cid == b'data':
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError(f'{path}: missing fmt / data chunk')
+    tag, channels, rate, _, _, bits = fmt
+    if tag not in (1, 0xFFFE) or bits != 16:
+        raise NotImplementedError(f'{path}: only 16-bit PCM is supported (format tag {tag}, {bits} bits)')
+    return np.frombuffer(pcm, dtype='<i2').reshape(-1, channels).copy(), rate
+
+
+class DeviceClipStore:
+    """All clips of a dataset split as ONE int16 tensor [total_frames, channels] in HBM plus per-clip frame offsets."""
+
+    def __init__(self, device, channels=4):
+        self.device, self.channels = torch.device(device), channels
+        self._parts, self.offsets, self.lengths, self.names = [], [], [], {}
+        self._total, self.pcm = 0, None
+
+    def add_clip(self, name, pcm):
+        """pcm: int16 array / tensor [frames, channels]."""
+        pcm = torch.as_tensor(np.ascontiguousarray(pcm) if isinstance(pcm, np.ndarray) else pcm)
+        if pcm.dtype != torch.int16 or pcm.ndim != 2 or pcm.shape[1] != self.channels:
+            raise ValueError(f'clip must be int16 [frames, {self.channels}]')
+        self.names[name] = len(self.offsets)
+        self.offsets.append(self._total); self.lengths.append(pcm.shape[0])
+        self._parts.append(pcm)
+        self._total += pcm.shape[0]
+        self.pcm = None
+
+    def add_wav(self, path):
+        pcm, _ = read_wav_pcm16(path)
+        self.add_clip(str(path), pcm)
+
+    def finalize(self):
+        if self.pcm is None:
+            _lib.require_gpu()
+            self.pcm = torch.cat([p.to(self.device) for p in self._parts], 0).contiguous()
+            self._parts = [self.pcm]
+        return self
+
+    def index_rows(self, chunklen, hoplen, last_frame_always_paddding=False):
+        """The rows of the reference's `{dataset}_{chunk}sChunklen_{hop}sHoplen_*.csv`: (clip name, begin, end, pad_before,
+        pad_after) for every clip of the store."""
+        rows = []
+        for name, i in self.names.items():
+            idx, pad = segment_index(self.lengths[i], chunklen, hoplen, last_frame_always_paddding)
+            rows += [(name, b, e, pb, pa) for (b, e), (pb, pa) in zip(idx, pad)]
+        return rows
+
+    def chunks(self, rows, chunk_len):
+        """rows: [(clip name, begin, end, pad_before, pad_after), ...] -> f32 [n, channels, chunk_len] on the device."""
+        self.finalize()
+        seg = torch.tensor([[self.offsets[self.names[r[0]]], r[1], r[2], r[3], r[4]] for r in rows], dtype=torch.int64, device=self.device)
+        for r in rows:
+            if r[3] + (r[2] - r[1]) + r[4] != chunk_len or r[1] < 0 or r[2] > self.lengths[self.names[r[0]]]:
+                raise ValueError(f'bad index row {r} for chunk length {chunk_len}')
+        out = torch.empty((len(rows), self.channels, chunk_len), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().pseld_pcm16_chunks(_lib.ptr(self.pcm), _lib.ptr(seg), _lib.ptr(out), len(rows), self.channels, chunk_len,
+                                                 _lib.stream_ptr()), "pseld_pcm16_chunks")
+        return out
+
+
+def polar_labels(se, azi, ele):
+    """(se bool/u8, azi int16, ele int8) of shape [T, tracks, C] (ADPIT) or [T, C] (ACCDOA) on the device ->
+    f32 [T, tracks, 4, C] (data.py:207-213) or [T, 4*C] (data.py:87-93: concatenation of se, x, y, z)."""
+    if not se.is_cuda:
+        raise _lib.PseldError("labels must live on the MI355X (no CPU fallback)")
+    se8, a16, e8 = se.to(torch.uint8).contiguous(), azi.to(torch.int16).contiguous(), ele.to(torch.int8).contiguous()
+    C = se.shape[-1]
+    rows_tracks = se.numel() // C
+    out = torch.empty((rows_tracks, 4, C), dtype=torch.float32, device=se.device)
+    _lib.check(_lib.lib().pseld_polar_labels(_lib.ptr(se8), _lib.ptr(a16), _lib.ptr(e8), _lib.ptr(out), rows_tracks, C, _lib.stream_ptr()),
+               "pseld_polar_labels")
+    return out.view(*se.shape[:-1], 4, C) if se.ndim == 3 else out.view(se.shape[0], 4 * C)

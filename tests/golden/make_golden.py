@@ -643,8 +643,24 @@ def gen_lora():
     save('lora.npz', **out)
 
 
+SEG_CASES = [(240000, 240000, 240000, False), (1440000, 240000, 240000, False), (1500000, 240000, 240000, False),
+             (1390000, 240000, 240000, False), (1390000, 240000, 240000, True), (100000, 240000, 240000, False),
+             (700000, 240000, 48000, False), (733333, 240000, 48000, False), (612345, 240000, 120000, True), (1001, 100, 30, False)]
+
+
+def gen_data():
+    """utils/data_utilities.py:segment_index on the cases above (x is only asked for its shape)."""
+    import utils.data_utilities as du
+    out = {}
+    for i, (n, cl, hl, flag) in enumerate(SEG_CASES):
+        idx, pad = du.segment_index(np.zeros((1, n), np.int8), cl, hl, flag)
+        out[f'case{i}'] = np.array([[b, e, pb, pa] for (b, e), (pb, pa) in zip(idx, pad)], np.int64)
+    out['cases'] = np.array([[n, cl, hl, int(f)] for n, cl, hl, f in SEG_CASES], np.int64)
+    save('data.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -658,3 +674,4 @@ if __name__ == '__main__':
     if 'decode' in which: gen_decode()
     if 'adapter' in which: gen_adapter()
     if 'lora' in which: gen_lora()
+    if 'data' in which: gen_data()

@@ -113,3 +113,16 @@ def test_pool_taps_equal_the_oracle_interpolate_mean_map():
             if t['i0'][f] + j < 32:
                 dense[f, t['i0'][f] + j] += t['w'][3 * f + j]
     assert torch.allclose(dense, t['dense'])
+
+
+def test_segment_index_matches_the_reference():
+    """pseldnets_amd.data.ingest.segment_index against utils/data_utilities.py:segment_index (tests/golden/data.npz)."""
+    import os
+    import numpy as np
+    from pseldnets_amd.data.ingest import segment_index
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'data.npz'))
+    for i, (n, cl, hl, flag) in enumerate(g['cases']):
+        idx, pad = segment_index(int(n), int(cl), int(hl), bool(flag))
+        got = np.array([[b, e, pb, pa] for (b, e), (pb, pa) in zip(idx, pad)], np.int64)
+        assert np.array_equal(got, g[f'case{i}']), (i, got, g[f'case{i}'])
+        assert all(pb + (e - b) + pa == cl for b, e, pb, pa in got)
