@@ -353,3 +353,23 @@ def test_lora_fine_tuning_vs_reference(dev):
     netb.to(dev).eval()
     with torch.no_grad():
         assert rel(netb(x.clone())['multi_accdoa'], g['eval']) < 1.5e-1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_bench_size_batch_independence(dev, dtype):
+    """Size-independent property at the BASELINE workload (full HTS-AT, 192 ten-second chunks): in eval mode every chunk's
+    prediction is independent of the rest of the batch, so the 192-chunk launch geometry (tile tails, XCD swizzle, persistent
+    grids) must reproduce, bit for bit, what the same chunks give in batches of 7."""
+    from pseldnets_amd.models import multi_accdoa
+    torch.manual_seed(7)
+    net = multi_accdoa.HTSAT(CFG, 170, 7, pretrained_path=None, **kw(FULL))
+    net.compute_dtype = dtype
+    net.to(dev).eval()
+    B = 192 if dtype == torch.bfloat16 else 48
+    x = torch.randn(B, 7, 1001, 64, device=dev)
+    with torch.no_grad():
+        big = net(x.clone())['multi_accdoa']
+        for b0 in (0, 7 * (B // 14), B - 7):
+            small = net(x[b0:b0 + 7].clone())['multi_accdoa']
+            assert torch.equal(big[b0:b0 + 7], small), (dtype, b0, (big[b0:b0 + 7] - small).abs().max().item())
+    assert big.shape == (B, 100, 9 * 170) and torch.isfinite(big).all()
