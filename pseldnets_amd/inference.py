@@ -4,7 +4,7 @@ over overlapping test chunks, models/components/model_module.py:269-329), `pred_
 the ACCDOA / multi-ACCDOA outputs) and `convert_to_dcase_format_polar` (:223-241 with utils/data_utilities.py:197-388).
 The rotations, the averaging, the activity thresholds and the 15-degree unification run as HIP kernels on the gathered
 predictions; only the final, variable-length DCASE dictionaries ({frame: [[class, azimuth, elevation], ...]}) and the CSV
-files are assembled on the host. SELD metrics (utils/SELD_metrics.py) are not built.
+files are assembled on the host; the SELD scores on them are `pseldnets_amd.utils.seld_scores`.
 """
 import math
 

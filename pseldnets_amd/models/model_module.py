@@ -4,7 +4,8 @@ configure_optimizers :128-146, configure_loss :171-175), without Lightning: the 
 can be driven either hook-by-hook (autograd + torch optimiser, as Lightning would) or through `fused_training_step`
 (FusedTrainer: backward, bucketed all-reduce, clip and AdamW inside the MI355X path).
 The device part of the validation / test path (prediction incl. ACS, rank gather, moving average, thresholding and
-15-degree unification -> DCASE dictionaries) is mirrored too; the SELD metrics (utils/SELD_metrics.py) are not."""
+15-degree unification -> DCASE dictionaries) is mirrored too, and `update_metrics` accumulates the SELD scores
+(pseldnets_amd/utils/seld_scores.py, host numpy as in the reference)."""
 import importlib
 import random
 from itertools import combinations
@@ -203,6 +204,17 @@ class SELDModelModule:
             return inference.accdoa_to_dcase_polar(pred_frames, self.num_classes, thr)
         sed, doa = pred_frames
         return inference.einv2_to_dcase(sed, doa, thr)
+
+    def update_metrics(self, pred_dcase_format, gt_dcase_format, num_frames, metrics=None):
+        """components/model_module.py:243-262: accumulate the SELD scores of one recording (DCASE dictionaries in degrees)."""
+        from ..utils.seld_scores import SeldScores
+        if metrics is None:
+            if getattr(self, 'metrics', None) is None:
+                self.metrics = SeldScores(doa_threshold=_get(self.cfg, 'doa_threshold', 20), nb_classes=self.num_classes,
+                                          label_resolution=self.label_res)
+            metrics = self.metrics
+        metrics.update(pred_dcase_format, gt_dcase_format, num_frames)
+        return metrics
 
     def configure_optimizers(self):
         opt_cfg, sch_cfg = _get(self.cfg, 'model.optimizer'), _get(self.cfg, 'model.lr_scheduler')

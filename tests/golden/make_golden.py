@@ -659,8 +659,31 @@ def gen_data():
     save('data.npz', **out)
 
 
+from tests.golden.metric_inputs import metric_inputs  # noqa: E402
+
+
+def gen_metrics():
+    """utils/SELD_metrics.py:SELDMetrics (through utils/data_utilities.py:to_metrics_format) on seeded random dictionaries."""
+    import utils.data_utilities as du
+    from utils.SELD_metrics import SELDMetrics
+    out = {}
+    m = SELDMetrics(doa_threshold=20, nb_classes=5)
+    rows = []
+    for seed in (1, 2, 3):
+        pred, gt, nf = metric_inputs(seed)
+        m.update_seld_scores(du.to_metrics_format(pred, nf), du.to_metrics_format(gt, nf))
+        for avg in ('macro', 'micro'):
+            d = m.compute_seld_scores(avg)[0]
+            rows.append([d['ER'], d['F'], d['LE'], d['LR'], d['SELD_scr']])
+    out['scores'] = np.array(rows)                       # cumulative after each recording: macro, micro
+    m.reset()
+    empty = m.compute_seld_scores('macro')[0]
+    out['empty_macro'] = np.array([empty['ER'], empty['F'], empty['LE'], empty['LR'], empty['SELD_scr']])
+    save('metrics.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -675,3 +698,4 @@ if __name__ == '__main__':
     if 'adapter' in which: gen_adapter()
     if 'lora' in which: gen_lora()
     if 'data' in which: gen_data()
+    if 'metrics' in which: gen_metrics()

@@ -126,3 +126,25 @@ def test_segment_index_matches_the_reference():
         got = np.array([[b, e, pb, pa] for (b, e), (pb, pa) in zip(idx, pad)], np.int64)
         assert np.array_equal(got, g[f'case{i}']), (i, got, g[f'case{i}'])
         assert all(pb + (e - b) + pa == cl for b, e, pb, pa in got)
+
+
+def test_seld_scores_match_the_reference_class():
+    """pseldnets_amd.utils.seld_scores.SeldScores against utils/SELD_metrics.py:SELDMetrics fed through to_metrics_format
+    (tests/golden/metrics.npz): cumulative macro / micro scores over three seeded recordings, and the empty case."""
+    import os
+    import numpy as np
+    from pseldnets_amd.utils.seld_scores import SeldScores
+    from tests.golden.metric_inputs import metric_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'metrics.npz'))
+    m = SeldScores(doa_threshold=20, nb_classes=5)
+    rows = []
+    for seed in (1, 2, 3):
+        pred, gt, nf = metric_inputs(seed)
+        m.update(pred, gt, nf)
+        for avg in ('macro', 'micro'):
+            d = m.compute(avg)
+            rows.append([d['ER'], d['F'], d['LE'], d['LR'], d['SELD_scr']])
+    assert np.abs(np.array(rows) - g['scores']).max() < 1e-6          # summation order differs from the reference's pair list
+    m.reset()
+    e = m.compute('macro')
+    assert np.allclose([e['ER'], e['F'], e['LE'], e['LR'], e['SELD_scr']], g['empty_macro'])
