@@ -178,6 +178,8 @@ def main():
                     help="augmix = configs/augment/augmix.yaml (every shipped synth_* experiment trains with it): the batch is "
                          "tripled, rotated / mixed as waveforms and masked / shifted as features on the device; `value` still counts "
                          "the ORIGINAL clips. Not the headline configuration.")
+    ap.add_argument('--decoder', default='conformer', choices=['conformer', 'gru', 'none'],
+                    help="--backbone crnn only: configs/model/crnn.yaml's conformer (1 block), configs/model/default.yaml's gru (2 layers) or Identity")
     ap.add_argument('--adapt', default='none', choices=['none', 'adapter'],
                     help="adapter = configs/adapt/adapter.yaml fine-tuning (HTS-AT only): adapters + biases + head train. Not the headline.")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -223,7 +225,8 @@ def main():
         from pseldnets_amd.models import einv2
         net = einv2.HTSAT(cfg, CLASSES, 7, pretrained_path=None)             # einv2.py:189-327: SED + DOA encoders
     elif args.backbone == 'crnn':
-        cfg['model'] = AttrDict(decoder='conformer', num_decoder_layers=1)   # configs/model/crnn.yaml:5-6
+        cfg['model'] = AttrDict(decoder=None if args.decoder == 'none' else args.decoder,
+                                num_decoder_layers=2 if args.decoder == 'gru' else 1)   # configs/model/{crnn,default}.yaml:5-6
         net = multi_accdoa.CRNN(cfg, CLASSES, 7, encoder='CNN12', pretrained_path=None,
                                 num_features=[64, 128, 256, 512, 1024, 2048])   # configs/model/crnn.yaml kwargs
     else:
@@ -295,7 +298,7 @@ def main():
     clips_per_s = args.clips * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
-    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'crnn': 'CNN14-Conformer (CRNN: CNN12 + 1 Conformer block)'}[args.backbone]
+    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'crnn': {'conformer': 'CNN14-Conformer (CRNN: CNN12 + 1 Conformer block)', 'gru': 'CNN14-GRU (CRNN: CNN12 + 2-layer BiGRU)', 'none': 'CNN14 (CRNN: CNN12, Identity decoder)'}[args.decoder]}[args.backbone]
     gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2,
                    'crnn': GFLOP_PER_CHUNK_TRAIN_CRNN}[args.backbone]
     out = {

@@ -273,6 +273,18 @@ int pseld_decode_accdoa(const float* pred, unsigned char* sed, long rows, int C,
 int pseld_move_avg(const float* preds, float* out, int num_chunks, int chunk_frames, int hop_frames, int valid_frames, int out_frames,
                    long D, void* stream);
 
+/* ---- GRU decoder cell (CRNN decoder='gru': components/model_utilities.py:249-252 nn.GRU, configs/model/default.yaml) ------
+ * Gate order r | z | n. The input projections of all timesteps, the recurrent product h_{t-1} W_hh^T + b_hh of a step and every
+ * weight gradient are pseld_gemm / pseld_gemm_wgrad calls; these two kernels are the element-wise part of one timestep.
+ * gate_fwd: gi rows at gi + b*gi_stride (3H wide), gh [B,3H], hprev rows at hp_stride (NULL = zeros) -> h rows at h_stride and
+ * gates [B,4H] = (r | z | n | gh_n) kept for the backward. gate_bwd: dh rows at dh_stride (+ carry [B,H] or NULL) ->
+ * dgi rows at dgi_stride = (dr | dz | dn) pre-activation gradients, dgh [B,3H] = (dr | dz | dn*r), dhprev [B,H] = dh*z
+ * (the caller adds dgh W_hh). */
+int pseld_gru_gate_fwd(int dtype, const void* gi, long gi_stride, const void* gh, const void* hprev, long hp_stride, void* h,
+                       long h_stride, void* gates, int B, int H, void* stream);
+int pseld_gru_gate_bwd(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
+                       long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, int B, int H, void* stream);
+
 /* ---- output head ---------------------------------------------------------------------------------------------------
  * htsat.py:526-534 (token -> [C,2,32] map) + im2col of accdoa.py:230 tscam_conv((2,3), pad (0,1)):
  * tok [B,64,C] -> A [B*32, C*6] (k = c*6 + cf*3 + dt, matching the conv weight's [D, C, 2, 3] flattening).

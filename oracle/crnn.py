@@ -142,6 +142,46 @@ def conformer_blocks(x, sd, pre, num_layers, heads=8, training=False, dropout_p=
     return x
 
 
+def gru_decoder(x, sd, pre, num_layers):
+    """nn.GRU(num_feats, num_feats // 2, num_layers, bidirectional=True, batch_first=True) restated (model_utilities.py:249-252;
+    gate order r | z | n): x [B, T, I] -> [B, T, 2H]."""
+    B, T, _ = x.shape
+    for layer in range(num_layers):
+        outs = []
+        for sfx in ('', '_reverse'):
+            w_ih, w_hh = sd[f'{pre}weight_ih_l{layer}{sfx}'], sd[f'{pre}weight_hh_l{layer}{sfx}']
+            b_ih, b_hh = sd[f'{pre}bias_ih_l{layer}{sfx}'], sd[f'{pre}bias_hh_l{layer}{sfx}']
+            H = w_hh.shape[1]
+            gi = F.linear(x, w_ih, b_ih)
+            h = x.new_zeros(B, H)
+            hs = [None] * T
+            for t in (range(T) if sfx == '' else range(T - 1, -1, -1)):
+                gh = F.linear(h, w_hh, b_hh)
+                r = torch.sigmoid(gi[:, t, :H] + gh[:, :H])
+                z = torch.sigmoid(gi[:, t, H:2 * H] + gh[:, H:2 * H])
+                n = torch.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:])
+                h = (1 - z) * n + z * h
+                hs[t] = h
+            outs.append(torch.stack(hs, 1))
+        x = torch.cat(outs, -1)
+    return x
+
+
+def add_gru(sd, D, num_layers, seed=8, pre='decoder.decoder.'):
+    """Seeded nn.GRU-style parameters (U(-1/sqrt(H), 1/sqrt(H)) scaled up a little so that the gates leave the linear regime)."""
+    g = torch.Generator().manual_seed(seed)
+    H = D // 2
+    for layer in range(num_layers):
+        for sfx in ('', '_reverse'):
+            n_in = D if layer == 0 else 2 * H
+            k = 2.0 / H ** 0.5
+            sd[f'{pre}weight_ih_l{layer}{sfx}'] = (torch.rand(3 * H, n_in, generator=g) * 2 - 1) * k
+            sd[f'{pre}weight_hh_l{layer}{sfx}'] = (torch.rand(3 * H, H, generator=g) * 2 - 1) * k
+            sd[f'{pre}bias_ih_l{layer}{sfx}'] = (torch.rand(3 * H, generator=g) * 2 - 1) * k
+            sd[f'{pre}bias_hh_l{layer}{sfx}'] = (torch.rand(3 * H, generator=g) * 2 - 1) * k
+    return sd
+
+
 def accdoa_crnn_forward(x, sd, encoder='CNN12', training=False, bn_update=None, key='accdoa', decoder=None, num_decoder_layers=1,
                         dropout_p=0.1, masks=None, decoder_prefix='decoder.decoder.'):
     """accdoa.py:65-95. decoder None (Identity) or 'conformer' (ConvConformer, accdoa.py:98-104: decoder_prefix 'decoder.',
@@ -153,6 +193,8 @@ def accdoa_crnn_forward(x, sd, encoder='CNN12', training=False, bn_update=None, 
     x = x.mean(dim=3).permute(0, 2, 1)                                      # (N, T', C)
     if decoder == 'conformer':
         x = conformer_blocks(x, sd, decoder_prefix, num_decoder_layers, 8, training, dropout_p, masks, bn_update)
+    elif decoder == 'gru':
+        x = gru_decoder(x, sd, decoder_prefix, num_decoder_layers)
     elif decoder is not None:
         raise NotImplementedError(decoder)
     x = x[:, :, None, :].repeat(1, 1, 8, 1).reshape(N, x.shape[1] * 8, -1)  # interpolate(x, 8) 'repeat'

@@ -787,3 +787,73 @@ extern "C" int pseld_relattn_bwd(int dtype, const void* q, const void* k, const 
     PSELD_LAUNCH_CHECK("relattn_bwd");
     return PSELD_OK;
 }
+
+// ---- GRU decoder cell (CRNN decoder='gru', models/components/model_utilities.py:249-252 nn.GRU) ------------------------------------
+// The input projections of ALL timesteps and the weight gradients are ordinary GEMMs; per timestep only the recurrent
+// product h_{t-1} W_hh^T (a GEMM with B rows) and this gate kernel run. Gate order r | z | n (torch.nn.GRU):
+//   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h = (1 - z) * n + z * h_prev
+namespace {
+
+template <typename T>
+__global__ void gru_gate_fwd_kernel(const T* __restrict__ gi, long gi_stride, const T* __restrict__ gh, const T* __restrict__ hprev, long hp_stride,
+                                    T* __restrict__ h, long h_stride, T* __restrict__ gates, int H, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;        // over (b, j < H)
+    if (id >= total) return;
+    const int j = (int)(id % H);
+    const long b = id / H;
+    const T* gib = gi + b * gi_stride;
+    const T* ghb = gh + b * 3 * H;
+    const float r = sigmoidf_(to_f32<T>(gib[j]) + to_f32<T>(ghb[j]));
+    const float z = sigmoidf_(to_f32<T>(gib[H + j]) + to_f32<T>(ghb[H + j]));
+    const float ghn = to_f32<T>(ghb[2 * H + j]);
+    const float n = tanhf(to_f32<T>(gib[2 * H + j]) + r * ghn);
+    const float hp = hprev ? to_f32<T>(hprev[b * hp_stride + j]) : 0.f;
+    h[b * h_stride + j] = from_f32<T>((1.f - z) * n + z * hp);
+    T* g = gates + b * 4 * H;                                            // kept for the backward: r | z | n | gh_n
+    g[j] = from_f32<T>(r); g[H + j] = from_f32<T>(z); g[2 * H + j] = from_f32<T>(n); g[3 * H + j] = from_f32<T>(ghn);
+}
+// dh: gradient wrt h_t (output gradient + the carry from t+1). Writes dgi_t = (dr_pre | dz_pre | dn_pre), dgh_t =
+// (dr_pre | dz_pre | dn_pre * r) and the direct part of the carry, dh * z (the W_hh part is added by the caller's GEMM).
+template <typename T>
+__global__ void gru_gate_bwd_kernel(const T* __restrict__ dh, long dh_stride, const T* __restrict__ carry, const T* __restrict__ gates,
+                                    const T* __restrict__ hprev, long hp_stride, T* __restrict__ dgi, long dgi_stride, T* __restrict__ dgh,
+                                    T* __restrict__ dhprev, int H, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int j = (int)(id % H);
+    const long b = id / H;
+    const T* g = gates + b * 4 * H;
+    const float r = to_f32<T>(g[j]), z = to_f32<T>(g[H + j]), n = to_f32<T>(g[2 * H + j]), ghn = to_f32<T>(g[3 * H + j]);
+    const float hp = hprev ? to_f32<T>(hprev[b * hp_stride + j]) : 0.f;
+    const float d = to_f32<T>(dh[b * dh_stride + j]) + (carry ? to_f32<T>(carry[b * H + j]) : 0.f);
+    const float dn = d * (1.f - z) * (1.f - n * n);
+    const float dz = d * (hp - n) * z * (1.f - z);
+    const float dr = dn * ghn * r * (1.f - r);
+    T* a = dgi + b * dgi_stride;
+    a[j] = from_f32<T>(dr); a[H + j] = from_f32<T>(dz); a[2 * H + j] = from_f32<T>(dn);
+    T* c = dgh + b * 3 * H;
+    c[j] = from_f32<T>(dr); c[H + j] = from_f32<T>(dz); c[2 * H + j] = from_f32<T>(dn * r);
+    dhprev[b * H + j] = from_f32<T>(d * z);
+}
+
+}  // namespace
+
+/* gi rows b at gi + b*gi_stride (3H wide: the slice of timestep t of the all-timestep input projection), gh [B, 3H] =
+ * h_prev W_hh^T + b_hh, hprev rows at hp_stride (NULL: zeros), h rows at h_stride (the output sequence), gates [B, 4H] */
+extern "C" int pseld_gru_gate_fwd(int dtype, const void* gi, long gi_stride, const void* gh, const void* hprev, long hp_stride, void* h,
+                                  long h_stride, void* gates, int B, int H, void* stream) {
+    PSELD_CHECK_ARG(gi && gh && h && gates && B > 0 && H > 0, "gru_gate_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * H;
+    CF_DISPATCH("gru_gate_fwd", hipLaunchKernelGGL(gru_gate_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)gi, gi_stride,
+                                                   (const T*)gh, (const T*)hprev, hp_stride, (T*)h, h_stride, (T*)gates, H, total));
+}
+extern "C" int pseld_gru_gate_bwd(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
+                                  long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, int B, int H, void* stream) {
+    PSELD_CHECK_ARG(dh && gates && dgi && dgh && dhprev && B > 0 && H > 0, "gru_gate_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * H;
+    CF_DISPATCH("gru_gate_bwd", hipLaunchKernelGGL(gru_gate_bwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)dh, dh_stride,
+                                                   (const T*)carry, (const T*)gates, (const T*)hprev, hp_stride, (T*)dgi, dgi_stride, (T*)dgh,
+                                                   (T*)dhprev, H, total));
+}

@@ -8,6 +8,7 @@ from .components.htsat import SwinEncoder, TscamHead
 from .components.passt import FcTanhHead, PasstEncoder
 from .components.crnn import ConvEncoder
 from .components.conformer import ConformerDecoder
+from .components.gru import GRUDecoder
 from .. import ops
 from .components.seld_net import HTSATNetBase
 
@@ -230,16 +231,20 @@ class CRNN(HTSATNetBase):
         else:
             n_layers = (model.num_decoder_layers if hasattr(model, 'num_decoder_layers') else model.get('num_decoder_layers', 2)) \
                 if model is not None else 2
-        if decoder not in (None, 'conformer'):
+        if decoder not in (None, 'conformer', 'gru'):
             raise NotImplementedError(f"decoder '{decoder}' (model_utilities.py:245-269) is not built on the MI355X path yet; "
-                                      "set model.decoder: conformer or null")
+                                      "set model.decoder: conformer, gru or null")
         self.num_classes = num_classes
         self.interpolate_time_ratio = 2 ** 3
         self._init_common(cfg, in_channels)
         self.conv_enc = ConvEncoder(self.arena, 'convs.', in_channels, encoder, list(num_features))
         self.num_features = list(num_features)
-        self.dec_blocks = ConformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers) \
-            if decoder == 'conformer' else None
+        if decoder == 'conformer':
+            self.dec_blocks = ConformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
+        elif decoder == 'gru':
+            self.dec_blocks = GRUDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
+        else:
+            self.dec_blocks = None
         self.head = FcTanhHead(self.arena, 'fc.', self.num_features[-1], num_classes * self.tracks_axes)
         self._finish_init()
         self._taps = None

@@ -44,8 +44,10 @@ def workspace(nbytes, device):
 
 def linear_fwd(x, w, bias=None, resid=None, rowscale=None, rows_per_scale=1, gelu_in=False, out=None, gelu_dual=False):
     """y[M,N] = (gelu(x) if gelu_in else x)[M,K] @ w[N,K]^T (+ bias) (* rowscale[m // rows_per_scale]) (+ resid).
-    gelu_dual: returns (gelu(y), gelu'(y)) instead of y."""
-    _chk(x, w, bias, resid, rowscale)
+    gelu_dual: returns (gelu(y), gelu'(y)) instead of y. x may be a row-strided view (unit stride along K)."""
+    _chk(w, bias, resid, rowscale)
+    if not x.is_cuda or x.stride(1) != 1:
+        raise _lib.PseldError("linear_fwd: x must live on the MI355X with unit stride along its columns")
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and w.dtype == x.dtype
@@ -911,3 +913,21 @@ def move_avg(preds, hop_frames, valid_frames, out_frames):
     _lib.check(_lib.lib().pseld_move_avg(_lib.ptr(preds), _lib.ptr(out), n, cf, hop_frames, valid_frames, out_frames, D, _lib.stream_ptr()),
                "pseld_move_avg")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GRU decoder cell (csrc/conformer.hip)
+def gru_gate_fwd(gi_t, gh, hprev, h_t, gates):
+    """gi_t [B, 3H] (row-strided view of timestep t), gh [B, 3H], hprev [B, H] view or None, h_t [B, H] view (written),
+    gates [B, 4H] (written)."""
+    B, H = h_t.shape
+    _lib.check(_lib.lib().pseld_gru_gate_fwd(dtype_code(gh), _lib.ptr(gi_t), gi_t.stride(0), _lib.ptr(gh), _lib.ptr(hprev),
+                                             hprev.stride(0) if hprev is not None else 0, _lib.ptr(h_t), h_t.stride(0), _lib.ptr(gates), B, H,
+                                             _lib.stream_ptr()), "pseld_gru_gate_fwd")
+
+
+def gru_gate_bwd(dh_t, carry, gates, hprev, dgi_t, dgh, dhprev):
+    B, H = dhprev.shape
+    _lib.check(_lib.lib().pseld_gru_gate_bwd(dtype_code(dgh), _lib.ptr(dh_t), dh_t.stride(0), _lib.ptr(carry), _lib.ptr(gates), _lib.ptr(hprev),
+                                             hprev.stride(0) if hprev is not None else 0, _lib.ptr(dgi_t), dgi_t.stride(0), _lib.ptr(dgh),
+                                             _lib.ptr(dhprev), B, H, _lib.stream_ptr()), "pseld_gru_gate_bwd")

@@ -198,3 +198,62 @@ def test_train_step_vs_float64_reference(dev, tag):
         assert np.abs(gr.reshape(-1)[:k].cpu().numpy() - head[:k]).max() <= 5e-3 * max(np.abs(head).max(), norm / np.sqrt(gr.numel())), n
     print(f'CRNN+Conformer [{tag}] worst decoder grad-norm rel err vs float64 reference:', worst)
     assert worst[1] < 5e-3, worst
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_gru_decoder_kernels(dev, dtype, tol):
+    """GRUDecoder (2 layers, bidirectional) forward and BPTT backward against torch.nn.GRU autograd."""
+    from pseldnets_amd.models.components.arena import ParamArena
+    from pseldnets_amd.models.components.gru import GRUDecoder
+    torch.manual_seed(2)
+    B, T, D = 3, 17, 64
+    arena = ParamArena()
+    dec = GRUDecoder(arena, 'g.', D, 2)
+    ref = torch.nn.GRU(D, D // 2, num_layers=2, bidirectional=True, batch_first=True).to(dev)
+    init = {f'g.{n}': p.detach().clone() for n, p in ref.named_parameters()}
+    arena.materialize(dev, init)
+    x = torch.randn(B, T, D, device=dev).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    y, saved = dec.forward(x.reshape(B * T, D).contiguous(), B, T)
+    assert rel(y.view(B, T, D), yr) < tol
+    dy = torch.randn(B, T, D, device=dev).to(dtype)
+    yr.backward(dy.float())
+    dx = dec.backward(dy.reshape(B * T, D).contiguous(), saved, B)
+    big = 10 * tol if dtype == torch.bfloat16 else 2e-4
+    assert rel(dx.view(B, T, D), xr.grad) < big
+    for n, p in ref.named_parameters():
+        assert rel(arena.g(f'g.{n}'), p.grad) < big, n
+
+
+def test_gru_network_vs_reference_goldens(dev):
+    """CRNN with cfg.model.decoder='gru' (configs/model/default.yaml): eval output, loss and decoder / fc gradients against the
+    reference's float64 run."""
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'gru.npz'))
+    D = TINY[-1]
+    cfg = A(data=CFG.data, model=A(decoder='gru', num_decoder_layers=2), adapt=A())
+    sd = oc.add_gru(oc.random_state('multi_accdoa', 3, 7, 'CNN12', TINY, seed=0), D, 2, seed=8)
+    net = multi_accdoa.CRNN(cfg, 3, 7, encoder='CNN12', pretrained_path=None, num_features=TINY)
+    net.load_state_dict(sd, strict=True)
+    assert set(net.state_dict().keys()) == set(str(k) for k in g['state_keys'])
+    net.to(dev).eval()
+    x = oc.random_features(2, seed=1)
+    with torch.no_grad():
+        assert rel(net(x.to(dev))['multi_accdoa'], g['eval']) < 1e-3
+    net.train()
+    pred = net(x.to(dev))
+    assert rel(pred['multi_accdoa'], g['train']) < 1e-3
+    ld = Losses('mse', 'loss_all')(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3).to(dev)})
+    assert abs(ld['loss_all'].item() - float(g['loss'])) < 1e-4 * abs(float(g['loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        n = str(n)
+        gr = params[n].grad
+        e = abs(gr.norm().item() - norm) / max(norm, 1e-12)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+    print('CRNN+GRU worst decoder grad-norm rel err vs float64 reference:', worst)
+    assert worst[1] < 5e-3, worst
