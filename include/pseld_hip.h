@@ -282,6 +282,15 @@ int pseld_move_avg(const float* preds, float* out, int num_chunks, int chunk_fra
  * (the caller adds dgh W_hh). */
 int pseld_gru_gate_fwd(int dtype, const void* gi, long gi_stride, const void* gh, const void* hprev, long hp_stride, void* h,
                        long h_stride, void* gates, int B, int H, void* stream);
+/* The recurrence of one layer and direction in one call (T x (B-row GEMM + gate kernel) launched from C): gi [B,T,3H] input
+ * projections, w_hh [3H,H] (compute dtype), b_hh f32; seq points at this direction's H columns of the layer output
+ * [B,T,ld_seq]; gates [T,B,4H]; gh scratch [B,3H]. seq_bwd: dseq / seq as above, w_hh_t [H,3H] (transposed copy) or NULL,
+ * writes dgi [B,T,3H], dgh [T,B,3H], hprev_all [T,B,H] (pre-zeroed by the caller); carry / direct scratch [B,H]. */
+int pseld_gru_seq_fwd(int dtype, const void* gi, const void* w_hh, const float* b_hh, void* seq, long ld_seq, void* gates, void* gh,
+                      int B, int T, int H, int reverse, void* stream);
+int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, long ld_seq, const void* gates, const void* w_hh,
+                      const void* w_hh_t, void* dgi, void* dgh, void* hprev_all, void* carry, void* direct, int B, int T, int H,
+                      int reverse, void* stream);
 int pseld_gru_gate_bwd(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
                        long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, int B, int H, void* stream);
 

@@ -817,7 +817,7 @@ __global__ void gru_gate_fwd_kernel(const T* __restrict__ gi, long gi_stride, co
 template <typename T>
 __global__ void gru_gate_bwd_kernel(const T* __restrict__ dh, long dh_stride, const T* __restrict__ carry, const T* __restrict__ gates,
                                     const T* __restrict__ hprev, long hp_stride, T* __restrict__ dgi, long dgi_stride, T* __restrict__ dgh,
-                                    T* __restrict__ dhprev, int H, long total) {
+                                    T* __restrict__ dhprev, T* __restrict__ hprev_out, int H, long total) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
     const int j = (int)(id % H);
@@ -834,6 +834,7 @@ __global__ void gru_gate_bwd_kernel(const T* __restrict__ dh, long dh_stride, co
     T* c = dgh + b * 3 * H;
     c[j] = from_f32<T>(dr); c[H + j] = from_f32<T>(dz); c[2 * H + j] = from_f32<T>(dn * r);
     dhprev[b * H + j] = from_f32<T>(d * z);
+    if (hprev_out) hprev_out[b * H + j] = from_f32<T>(hp);            // contiguous copy of h_{t-1} for the W_hh weight-gradient GEMM
 }
 
 }  // namespace
@@ -848,12 +849,102 @@ extern "C" int pseld_gru_gate_fwd(int dtype, const void* gi, long gi_stride, con
     CF_DISPATCH("gru_gate_fwd", hipLaunchKernelGGL(gru_gate_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)gi, gi_stride,
                                                    (const T*)gh, (const T*)hprev, hp_stride, (T*)h, h_stride, (T*)gates, H, total));
 }
-extern "C" int pseld_gru_gate_bwd(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
-                                  long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, int B, int H, void* stream) {
+static int gru_gate_bwd_impl(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
+                             long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, void* hprev_out, int B, int H, void* stream) {
     PSELD_CHECK_ARG(dh && gates && dgi && dgh && dhprev && B > 0 && H > 0, "gru_gate_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * H;
     CF_DISPATCH("gru_gate_bwd", hipLaunchKernelGGL(gru_gate_bwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)dh, dh_stride,
                                                    (const T*)carry, (const T*)gates, (const T*)hprev, hp_stride, (T*)dgi, dgi_stride, (T*)dgh,
-                                                   (T*)dhprev, H, total));
+                                                   (T*)dhprev, (T*)hprev_out, H, total));
+}
+extern "C" int pseld_gru_gate_bwd(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
+                                  long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, int B, int H, void* stream) {
+    return gru_gate_bwd_impl(dtype, dh, dh_stride, carry, gates, hprev, hp_stride, dgi, dgi_stride, dgh, dhprev, nullptr, B, H, stream);
+}
+
+namespace {
+template <typename T>
+__global__ void gru_bias_rows_kernel(const float* __restrict__ b, T* __restrict__ out, int N, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < total) out[id] = from_f32<T>(b[id % N]);
+}
+}  // namespace
+static int pseld_gru_bias_rows(int dtype, const float* b, void* out, int B, int N, void* stream) {
+    const long total = (long)B * N;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PSELD_BF16) hipLaunchKernelGGL(gru_bias_rows_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, b, (bf16_t*)out, N, total);
+    else hipLaunchKernelGGL(gru_bias_rows_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, b, (float*)out, N, total);
+    PSELD_LAUNCH_CHECK("gru_bias_rows");
+    return PSELD_OK;
+}
+// ---- the whole recurrence of one GRU layer and direction in ONE C-ABI call: the T x (B-row GEMM + gate kernel) launches are
+// issued from here instead of from a Python loop (the host dispatch, not the GPU, was the limit: 2 000 launches per step) ------------
+extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                          int ldc, const float* bias, const void* resid, int ldr, const float* rowscale, int rows_per_scale, const void* aux,
+                          int ldaux, int epi, int pro, void* c2, void* stream);
+
+/* gi [B, T, 3H] (input projections incl. b_ih), w_hh [3H, H] in the compute dtype, b_hh f32 [3H]; seq = the layer's output
+ * [B, T, ld_seq] with this direction's H columns starting at seq (caller offsets the pointer); gates [T, B, 4H]; gh scratch
+ * [B, 3H]; reverse != 0 walks t = T-1 .. 0. */
+extern "C" int pseld_gru_seq_fwd(int dtype, const void* gi, const void* w_hh, const float* b_hh, void* seq, long ld_seq, void* gates, void* gh,
+                                 int B, int T, int H, int reverse, void* stream) {
+    PSELD_CHECK_ARG(gi && w_hh && b_hh && seq && gates && gh && B > 0 && T > 0 && H > 0 && H % 8 == 0 && ld_seq % 8 == 0, "gru_seq_fwd: bad argument");
+    PSELD_CHECK_ARG(dtype == PSELD_BF16 || dtype == PSELD_F32, "gru_seq_fwd: unknown dtype");
+    const size_t es = dtype == PSELD_BF16 ? 2 : 4;
+    const long row = (long)T * ld_seq;                      // elements between consecutive samples of seq
+    int prev = -1;
+    for (int k = 0; k < T; ++k) {
+        const int t = reverse ? T - 1 - k : k;
+        const char* hprev = prev >= 0 ? (const char*)seq + (size_t)prev * ld_seq * es : nullptr;
+        int rc;
+        if (hprev) {
+            rc = pseld_gemm(dtype, 0, 0, hprev, w_hh, gh, B, 3 * H, H, (int)row, H, 3 * H, b_hh, nullptr, 0, nullptr, 1, nullptr, 0, 1 /*EPI_BIAS*/,
+                            0, nullptr, stream);
+            if (rc != PSELD_OK) return rc;
+        } else {
+            // h_0 = 0: gh = b_hh (a GEMM against a zero row would do; the gate kernel reads gh, so broadcast the bias instead)
+            rc = pseld_gru_bias_rows(dtype, b_hh, gh, B, 3 * H, stream);
+            if (rc != PSELD_OK) return rc;
+        }
+        rc = pseld_gru_gate_fwd(dtype, (const char*)gi + (size_t)t * 3 * H * es, (long)T * 3 * H, gh, hprev, row, (char*)seq + (size_t)t * ld_seq * es, row,
+                                (char*)gates + (size_t)t * B * 4 * H * es, B, H, stream);
+        if (rc != PSELD_OK) return rc;
+        prev = t;
+    }
+    return PSELD_OK;
+}
+
+/* BPTT of the same recurrence. dseq: gradient wrt this direction's slice of the output [B, T, ld_seq]; w_hh_t [H, 3H] (the
+ * transposed copy: dh_prev = dgh W_hh is then an NT product) or NULL with w_hh [3H, H]; writes dgi [B, T, 3H], dgh [T, B, 3H] and
+ * hprev_all [T, B, H] (the h_{t-1} of every step, zeros for the first) for the weight-gradient GEMMs; carry / direct scratch [B, H]. */
+extern "C" int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, long ld_seq, const void* gates, const void* w_hh,
+                                 const void* w_hh_t, void* dgi, void* dgh, void* hprev_all, void* carry, void* direct, int B, int T, int H,
+                                 int reverse, void* stream) {
+    PSELD_CHECK_ARG(dseq && seq && gates && w_hh && dgi && dgh && hprev_all && carry && direct && B > 0 && T > 0 && H > 0 && H % 8 == 0,
+                    "gru_seq_bwd: bad argument");
+    PSELD_CHECK_ARG(dtype == PSELD_BF16 || dtype == PSELD_F32, "gru_seq_bwd: unknown dtype");
+    const size_t es = dtype == PSELD_BF16 ? 2 : 4;
+    const long row = (long)T * ld_seq;
+    bool have_carry = false;
+    for (int k = T - 1; k >= 0; --k) {                       // reverse of the processing order
+        const int t = reverse ? T - 1 - k : k;
+        const int tp = k > 0 ? (reverse ? T - k : k - 1) : -1;
+        const char* hprev = tp >= 0 ? (const char*)seq + (size_t)tp * ld_seq * es : nullptr;
+        char* dgh_t = (char*)dgh + (size_t)t * B * 3 * H * es;
+        int rc = gru_gate_bwd_impl(dtype, (const char*)dseq + (size_t)t * ld_seq * es, row, have_carry ? carry : nullptr,
+                                   (const char*)gates + (size_t)t * B * 4 * H * es, hprev, row, (char*)dgi + (size_t)t * 3 * H * es, (long)T * 3 * H,
+                                   dgh_t, direct, tp >= 0 ? (char*)hprev_all + (size_t)t * B * H * es : nullptr, B, H, stream);
+        if (rc != PSELD_OK) return rc;
+        if (tp >= 0) {
+            // carry = direct + dgh_t W_hh
+            if (w_hh_t) rc = pseld_gemm(dtype, 0, 0, dgh_t, w_hh_t, carry, B, H, 3 * H, 3 * H, 3 * H, H, nullptr, direct, H, nullptr, 1, nullptr, 0,
+                                        2 /*EPI_RESID*/, 0, nullptr, stream);
+            else rc = pseld_gemm(dtype, 0, 1, dgh_t, w_hh, carry, B, H, 3 * H, 3 * H, H, H, nullptr, direct, H, nullptr, 1, nullptr, 0, 2, 0, nullptr,
+                                 stream);
+            if (rc != PSELD_OK) return rc;
+            have_carry = true;
+        }
+    }
+    return PSELD_OK;
 }

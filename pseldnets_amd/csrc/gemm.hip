@@ -856,6 +856,77 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ X
     }
 }
 
+// ---- skinny forward GEMM: C[M <= 64, N] = A[M, K] B[N, K]^T (+ bias) (+ resid), bf16 ------------------------------------------------
+// The recurrent products of the GRU decoder (48 rows x 3072 x 1024, a thousand of them per step) put ONE row tile = 16
+// workgroups on the chip with the tiled kernels. Here a workgroup owns 32 output columns (N / 32 workgroups), its four waves
+// split K, and the MFMA operands are read straight from global memory (a lane's fragment is 8 consecutive k of one row =
+// one 16-byte load; B rows are the weight rows, A rows the few activations rows, which every workgroup re-reads from L2);
+// the four partial tiles meet in LDS. C^T tiles are computed (weight rows in registers, activation rows in lanes).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(GemmArgs g) {
+    __shared__ float red[WAVES - 1][2][16][64];
+    const bf16_t* A = (const bf16_t*)g.A;        // [M, lda]
+    const bf16_t* B = (const bf16_t*)g.B;        // [N, ldb]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const bf16_t* brow = B + (long)min(n0 + r, g.N - 1) * g.ldb + 8 * h2;
+    const bf16_t* arow0 = A + (long)min(r, g.M - 1) * g.lda + 8 * h2;
+    const bf16_t* arow1 = A + (long)min(32 + r, g.M - 1) * g.lda + 8 * h2;
+    const bool two = g.M > 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const int ksteps = g.K >> 4;
+    for (int ks = wave; ks < ksteps; ks += 8 * WAVES) {      // 8 steps of this wave per batch: their 24 loads are in flight together
+        bf16x8 fb[8], fa0[8], fa1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = (ks + WAVES * u) << 4;
+            const bool in = ks + WAVES * u < ksteps;
+            const int kc = in ? k : 0;
+            fb[u] = *(const bf16x8*)(brow + kc);
+            fa0[u] = *(const bf16x8*)(arow0 + kc);
+            if (two) fa1[u] = *(const bf16x8*)(arow1 + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ks + WAVES * u < ksteps) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u], fa0[u], acc[0], 0, 0, 0);
+                if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u], fa1[u], acc[1], 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave - 1][t][e][lane] = acc[t][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        bf16_t* C = (bf16_t*)g.C;
+        const bf16_t* R = (const bf16_t*)g.resid;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int m = t * 32 + r;                        // activation row of this lane
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+                if (n >= g.N) continue;
+                float v = acc[t][e];
+#pragma unroll
+                for (int w = 0; w < WAVES - 1; ++w) v += red[w][t][e][lane];
+                if (g.epi & EPI_BIAS) v += g.bias[n];
+                if (g.epi & EPI_RESID) v += (float)R[(long)m * g.ldr + n];
+                C[(long)m * g.ldc + n] = (bf16_t)v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static unsigned long long* g_gemm_dbg = nullptr;
@@ -886,6 +957,13 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     g.kchunk = K; g.slab_stride = 0; g.epi = epi; g.pro = pro; g.colsum = nullptr; g.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && M <= 64 && K % 16 == 0 && N >= 512 && !rowscale &&
+        (epi & ~(EPI_BIAS | EPI_RESID)) == 0) {
+        if (K >= 2048) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(pseld_cdiv(N, 32)), dim3(512), 0, s, g);   // long K, few column tiles
+        else hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(pseld_cdiv(N, 32)), dim3(256), 0, s, g);
+        PSELD_LAUNCH_CHECK("gemm_skinny");
+        return PSELD_OK;
+    }
     if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0 && M >= 128) {
         const char* e = getenv("PSELD_GEMM_DMA");
         if (!(e && e[0] == '0')) {

@@ -4,7 +4,9 @@ Host-side mirror of `Decoder('gru')` (reference models/components/model_utilitie
 num_layers, bidirectional, batch_first); configs/model/default.yaml). Parameters keep nn.GRU's state-dict names under `prefix`
 (`weight_ih_l0`, `weight_hh_l0_reverse`, ...; gate order r | z | n). The input projections of all timesteps, every weight
 gradient and the input gradient are single GEMMs over [B*T, .]; the recurrence itself is one B-row GEMM (h_{t-1} W_hh^T) and
-one gate kernel per timestep and direction (125 steps here), and the same pair in reverse for the backward.
+one gate kernel per timestep and direction (125 steps here), and the same pair in reverse for the backward, all launched by
+ONE C-ABI call per layer and direction (pseld_gru_seq_fwd / _bwd); in bf16 the B-row GEMMs take the skinny kernel of gemm.hip
+(32 output columns per workgroup, K split over the waves).
 """
 import torch
 
@@ -39,14 +41,7 @@ class GRUDecoder:
                 p = f'{self.prefix}%s_l{layer}{sfx}'
                 gi = ops.linear_fwd(x, a.w(p % 'weight_ih', dt), a.p(p % 'bias_ih')).view(B, T, 3 * H)
                 gates = torch.empty((T, B, 4 * H), dtype=dt, device=x.device)
-                w_hh, b_hh = a.w(p % 'weight_hh', dt), a.p(p % 'bias_hh')
-                order = range(T) if d == 0 else range(T - 1, -1, -1)
-                prev = None
-                for t in order:
-                    hprev = o3[:, prev, d * H:(d + 1) * H] if prev is not None else None
-                    gh = ops.linear_fwd(hprev, w_hh, b_hh) if hprev is not None else b_hh.to(dt).expand(B, 3 * H).contiguous()
-                    ops.gru_gate_fwd(gi[:, t], gh, hprev, o3[:, t, d * H:(d + 1) * H], gates[t])
-                    prev = t
+                ops.gru_seq_fwd(gi, a.w(p % 'weight_hh', dt), a.p(p % 'bias_hh'), o3[:, :, d * H:(d + 1) * H], gates, reverse=d == 1)
                 per_dir.append(gates)
             saved.append(dict(x=x, out=out, gates=per_dir))
             x = out
@@ -61,22 +56,10 @@ class GRUDecoder:
             dx = None
             for d, sfx in enumerate(('', '_reverse')):
                 p = f'{self.prefix}%s_l{layer}{sfx}'
-                w_hh = a.w(p % 'weight_hh', dt)
+                w_hh, w_hh_t = a.w(p % 'weight_hh', dt), a.wt(p % 'weight_hh', dt)
                 gates = sv['gates'][d]
-                dgi = torch.empty((B, T, 3 * H), dtype=dt, device=dout.device)
-                dgh = torch.empty((T, B, 3 * H), dtype=dt, device=dout.device)
-                hprev_all = torch.zeros((T, B, H), dtype=dt, device=dout.device)
-                order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
-                carry = None
-                for k in range(T - 1, -1, -1):                      # reverse of the processing order
-                    t = order[k]
-                    tp = order[k - 1] if k > 0 else None
-                    hprev = o3[:, tp, d * H:(d + 1) * H] if tp is not None else None
-                    direct = torch.empty((B, H), dtype=dt, device=dout.device)
-                    ops.gru_gate_bwd(d3[:, t, d * H:(d + 1) * H], carry, gates[t], hprev, dgi[:, t], dgh[t], direct)
-                    carry = ops.linear_dgrad(dgh[t], w_hh, resid=direct) if tp is not None else None
-                    if tp is not None:
-                        hprev_all[t].copy_(hprev)
+                dgi, dgh, hprev_all = ops.gru_seq_bwd(d3[:, :, d * H:(d + 1) * H], o3[:, :, d * H:(d + 1) * H], gates, w_hh, w_hh_t,
+                                                      reverse=d == 1)
                 dgi2 = dgi.view(B * T, 3 * H)
                 ops.linear_wgrad(dgh.view(T * B, 3 * H), hprev_all.view(T * B, H), a.g(p % 'weight_hh'), dbias=a.g(p % 'bias_hh'))
                 ops.linear_wgrad(dgi2, x, a.g(p % 'weight_ih'), dbias=a.g(p % 'bias_ih'))

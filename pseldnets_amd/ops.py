@@ -931,3 +931,30 @@ def gru_gate_bwd(dh_t, carry, gates, hprev, dgi_t, dgh, dhprev):
     _lib.check(_lib.lib().pseld_gru_gate_bwd(dtype_code(dgh), _lib.ptr(dh_t), dh_t.stride(0), _lib.ptr(carry), _lib.ptr(gates), _lib.ptr(hprev),
                                              hprev.stride(0) if hprev is not None else 0, _lib.ptr(dgi_t), dgi_t.stride(0), _lib.ptr(dgh),
                                              _lib.ptr(dhprev), B, H, _lib.stream_ptr()), "pseld_gru_gate_bwd")
+
+
+def gru_seq_fwd(gi, w_hh, b_hh, seq_dir, gates, reverse):
+    """One layer / direction of the GRU recurrence (all T steps launched from C). gi [B,T,3H]; seq_dir: the [B,T,H] column slice
+    of the layer output this direction writes; gates [T,B,4H]."""
+    _chk(gi, w_hh, b_hh, gates)
+    B, T, H = seq_dir.shape
+    gh = torch.empty((B, 3 * H), dtype=gi.dtype, device=gi.device)
+    _lib.check(_lib.lib().pseld_gru_seq_fwd(dtype_code(gi), _lib.ptr(gi), _lib.ptr(w_hh), _lib.ptr(b_hh), _lib.ptr(seq_dir), seq_dir.stride(1),
+                                            _lib.ptr(gates), _lib.ptr(gh), B, T, H, int(reverse), _lib.stream_ptr()), "pseld_gru_seq_fwd")
+
+
+def gru_seq_bwd(dseq_dir, seq_dir, gates, w_hh, w_hh_t, reverse):
+    """BPTT of gru_seq_fwd: returns (dgi [B,T,3H], dgh [T,B,3H], hprev_all [T,B,H])."""
+    _chk(gates, w_hh, w_hh_t)
+    B, T, H = seq_dir.shape
+    dt, dev = gates.dtype, gates.device
+    dgi = torch.empty((B, T, 3 * H), dtype=dt, device=dev)
+    dgh = torch.empty((T, B, 3 * H), dtype=dt, device=dev)
+    hprev_all = torch.zeros((T, B, H), dtype=dt, device=dev)
+    carry = torch.empty((B, H), dtype=dt, device=dev)
+    direct = torch.empty((B, H), dtype=dt, device=dev)
+    assert dseq_dir.stride(1) == seq_dir.stride(1) and dseq_dir.stride(0) == seq_dir.stride(0)
+    _lib.check(_lib.lib().pseld_gru_seq_bwd(dtype_code(gates), _lib.ptr(dseq_dir), _lib.ptr(seq_dir), seq_dir.stride(1), _lib.ptr(gates),
+                                            _lib.ptr(w_hh), _lib.ptr(w_hh_t), _lib.ptr(dgi), _lib.ptr(dgh), _lib.ptr(hprev_all), _lib.ptr(carry),
+                                            _lib.ptr(direct), B, T, H, int(reverse), _lib.stream_ptr()), "pseld_gru_seq_bwd")
+    return dgi, dgh, hprev_all

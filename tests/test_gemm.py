@@ -173,3 +173,21 @@ def test_input_gradient_through_transposed_weight_copies(dev):
             b = ops.linear_dgrad(dy, w, wt=wt)
             _check(f"dX via W^T copy {r}x{c}", b, a.double().cpu(), dtype)
         off += r * c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,bias,resid", [(48, 3072, 1024, True, False), (3, 1024, 3072, False, True), (64, 544, 48, True, True),
+                                                (33, 520, 16, False, False), (1, 2048, 2048, True, False)])
+def test_skinny_forward_gemm(dev, M, N, K, bias, resid):
+    """The M <= 64 bf16 path of pseld_gemm (gemm_skinny_kernel: the GRU decoder's recurrent products), also on a row-strided A."""
+    from pseldnets_amd import ops
+    torch.manual_seed(M + N)
+    big = torch.randn(M, 3 * K, device=dev).to(torch.bfloat16)
+    x = big[:, K:2 * K]                                     # row-strided view
+    w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev) if bias else None
+    r = torch.randn(M, N, device=dev).to(torch.bfloat16) if resid else None
+    y = ops.linear_fwd(x, w, b, resid=r)
+    want = x.double() @ w.double().t() + (b.double() if bias else 0) + (r.double() if resid else 0)
+    err = ((y.double() - want).abs().max() / want.abs().max()).item()
+    assert err < 1e-2, err
