@@ -878,6 +878,142 @@ static int pseld_gru_bias_rows(int dtype, const float* b, void* out, int B, int 
     PSELD_LAUNCH_CHECK("gru_bias_rows");
     return PSELD_OK;
 }
+// ---- fused GRU timestep kernels (bf16): recurrent product + gates in ONE launch per step -------------------------------------------------
+// Dependent tiny launches cost ~8 us each here, so the step count, not the arithmetic, sets the time. Forward: a workgroup owns 8 hidden
+// units = the rows (j, H+j, 2H+j) of W_hh; the MFMA tile is [32 weight rows (gate-major, 8 padded)] x [64 samples], K split over the
+// four waves, operands straight from global; after the LDS reduction lane (sample, half) holds r/z/n pre-activations of four units and
+// finishes the cell. Backward: a workgroup owns 32 hidden units = rows of W_hh^T; it forms the carry dh_{t} += dgh_{t+1} W_hh for its
+// units and immediately runs the gate backward of step t for them (everything it needs is unit-local).
+namespace {
+
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+
+struct GruStepArgs {
+    const bf16_t *gi, *w, *hprev, *gates_in, *dseq, *dgh_next, *direct_in;   // w: W_hh [3H,H] (fwd) or W_hh^T [H,3H] (bwd)
+    const float* b_hh;
+    bf16_t *h, *gates, *dgi, *dgh, *direct_out, *hprev_out;
+    long gi_stride, row;                 // sample strides of gi / seq-like tensors
+    int B, H, first;                     // first: no previous hidden state (fwd) / no carry yet (bwd)
+};
+
+__device__ __forceinline__ void skinny_accumulate(f32x16_ (&acc)[2], const bf16_t* wrow, const bf16_t* a0, const bf16_t* a1, bool two, int ksteps,
+                                                  int wave, int waves) {
+    for (int ks = wave; ks < ksteps; ks += 8 * waves) {
+        bf16x8_ fb[8], fa0[8], fa1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = ks + waves * u < ksteps;
+            const int kc = in ? (ks + waves * u) << 4 : 0;
+            fb[u] = *(const bf16x8_*)(wrow + kc);
+            fa0[u] = *(const bf16x8_*)(a0 + kc);
+            if (two) fa1[u] = *(const bf16x8_*)(a1 + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ks + waves * u < ksteps) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u], fa0[u], acc[0], 0, 0, 0);
+                if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u], fa1[u], acc[1], 0, 0, 0);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs a) {
+    __shared__ float red[4][2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
+    const int H = a.H, j0 = blockIdx.x * 8;
+    if (!a.first) {
+        f32x16_ acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        const int gate = min(r >> 3, 2), unit = r & 7;                         // fragment row r -> W_hh row gate*H + j0 + unit
+        const bf16_t* wrow = a.w + (long)(gate * H + j0 + unit) * H + 8 * h2;
+        const bf16_t* a0 = a.hprev + (long)min(r, a.B - 1) * a.row + 8 * h2;
+        const bf16_t* a1 = a.hprev + (long)min(32 + r, a.B - 1) * a.row + 8 * h2;
+        skinny_accumulate(acc, wrow, a0, a1, a.B > 32, H >> 4, wave, 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t][e][lane] = acc[t][e];
+        __syncthreads();
+    }
+    // the cell update of the 8 units x B samples of this workgroup, spread over all 256 threads (unit fastest)
+    for (int idx = threadIdx.x; idx < 8 * a.B; idx += 256) {
+        const int u = idx & 7, b = idx >> 3, j = j0 + u;
+        float g3[3];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            float v = a.b_hh[gt * H + j];
+            if (!a.first) {
+                const int t = b >> 5, e = 4 * gt + (u & 3), ln = (b & 31) + 32 * (u >> 2);          // tile row gt*8 + u
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += red[w][t][e][ln];
+            }
+            g3[gt] = v;
+        }
+        const bf16_t* gib = a.gi + b * a.gi_stride;
+        const float rr = sigmoidf_((float)gib[j] + g3[0]);
+        const float zz = sigmoidf_((float)gib[H + j] + g3[1]);
+        const float nn = tanhf((float)gib[2 * H + j] + rr * g3[2]);
+        const float hp = a.first ? 0.f : (float)a.hprev[b * a.row + j];
+        a.h[b * a.row + j] = (bf16_t)((1.f - zz) * nn + zz * hp);
+        bf16_t* gs = a.gates + (long)b * 4 * H;
+        gs[j] = (bf16_t)rr; gs[H + j] = (bf16_t)zz; gs[2 * H + j] = (bf16_t)nn; gs[3 * H + j] = (bf16_t)g3[2];
+    }
+}
+
+__global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruStepArgs a) {
+    __shared__ float red[8][2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
+    const int H = a.H, j0 = blockIdx.x * 32;
+    if (!a.first) {                                                             // carry = direct(t+1) + dgh(t+1) W_hh for units j0..j0+31
+        f32x16_ acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        const bf16_t* wrow = a.w + (long)min(j0 + r, H - 1) * 3 * H + 8 * h2;    // W_hh^T row j
+        const bf16_t* a0 = a.dgh_next + (long)min(r, a.B - 1) * 3 * H + 8 * h2;
+        const bf16_t* a1 = a.dgh_next + (long)min(32 + r, a.B - 1) * 3 * H + 8 * h2;
+        skinny_accumulate(acc, wrow, a0, a1, a.B > 32, (3 * H) >> 4, wave, 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t][e][lane] = acc[t][e];
+        __syncthreads();
+    }
+    // the gate backward of step t for the 32 units x B samples of this workgroup, spread over all 512 threads (unit fastest)
+    for (int idx = threadIdx.x; idx < 32 * a.B; idx += 512) {
+        const int jl = idx & 31, b = idx >> 5, j = j0 + jl;
+        if (j >= H) continue;
+        float carry = 0.f;
+        if (!a.first) {
+            const int t = b >> 5, e = (jl & 3) + 4 * (jl >> 3), ln = (b & 31) + 32 * ((jl >> 2) & 1);   // where the MFMA tile keeps (j, b)
+            carry = (float)a.direct_in[(long)b * H + j];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) carry += red[w][t][e][ln];
+            carry = (float)(bf16_t)carry;                                      // the unfused path stores the carry in bf16
+        }
+        const bf16_t* g = a.gates_in + (long)b * 4 * H;
+        const float rr = (float)g[j], zz = (float)g[H + j], nn = (float)g[2 * H + j], ghn = (float)g[3 * H + j];
+        const float hp = a.hprev ? (float)a.hprev[b * a.row + j] : 0.f;
+        const float d = (float)a.dseq[b * a.row + j] + carry;
+        const float dn = d * (1.f - zz) * (1.f - nn * nn);
+        const float dz = d * (hp - nn) * zz * (1.f - zz);
+        const float dr = dn * ghn * rr * (1.f - rr);
+        bf16_t* gi_ = a.dgi + b * a.gi_stride;
+        gi_[j] = (bf16_t)dr; gi_[H + j] = (bf16_t)dz; gi_[2 * H + j] = (bf16_t)dn;
+        bf16_t* gh_ = a.dgh + (long)b * 3 * H;
+        gh_[j] = (bf16_t)dr; gh_[H + j] = (bf16_t)dz; gh_[2 * H + j] = (bf16_t)(dn * rr);
+        a.direct_out[(long)b * H + j] = (bf16_t)(d * zz);
+        if (a.hprev_out) a.hprev_out[(long)b * H + j] = (bf16_t)hp;
+    }
+}
+
+}  // namespace
+
 // ---- the whole recurrence of one GRU layer and direction in ONE C-ABI call: the T x (B-row GEMM + gate kernel) launches are
 // issued from here instead of from a Python loop (the host dispatch, not the GPU, was the limit: 2 000 launches per step) ------------
 extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
@@ -894,10 +1030,20 @@ extern "C" int pseld_gru_seq_fwd(int dtype, const void* gi, const void* w_hh, co
     const size_t es = dtype == PSELD_BF16 ? 2 : 4;
     const long row = (long)T * ld_seq;                      // elements between consecutive samples of seq
     int prev = -1;
+    const bool fused = dtype == PSELD_BF16 && B <= 64 && H % 16 == 0;
     for (int k = 0; k < T; ++k) {
         const int t = reverse ? T - 1 - k : k;
         const char* hprev = prev >= 0 ? (const char*)seq + (size_t)prev * ld_seq * es : nullptr;
         int rc;
+        if (fused) {
+            GruStepArgs a; memset(&a, 0, sizeof(a));
+            a.gi = (const bf16_t*)gi + (size_t)t * 3 * H; a.gi_stride = (long)T * 3 * H; a.w = (const bf16_t*)w_hh; a.b_hh = b_hh;
+            a.hprev = (const bf16_t*)hprev; a.h = (bf16_t*)seq + (size_t)t * ld_seq; a.row = row;
+            a.gates = (bf16_t*)gates + (size_t)t * B * 4 * H; a.B = B; a.H = H; a.first = hprev == nullptr;
+            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, a);
+            prev = t;
+            continue;
+        }
         if (hprev) {
             rc = pseld_gemm(dtype, 0, 0, hprev, w_hh, gh, B, 3 * H, H, (int)row, H, 3 * H, b_hh, nullptr, 0, nullptr, 1, nullptr, 0, 1 /*EPI_BIAS*/,
                             0, nullptr, stream);
@@ -927,11 +1073,25 @@ extern "C" int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, l
     const size_t es = dtype == PSELD_BF16 ? 2 : 4;
     const long row = (long)T * ld_seq;
     bool have_carry = false;
+    const bool fused = dtype == PSELD_BF16 && B <= 64 && H % 32 == 0 && w_hh_t != nullptr;
     for (int k = T - 1; k >= 0; --k) {                       // reverse of the processing order
         const int t = reverse ? T - 1 - k : k;
         const int tp = k > 0 ? (reverse ? T - k : k - 1) : -1;
         const char* hprev = tp >= 0 ? (const char*)seq + (size_t)tp * ld_seq * es : nullptr;
         char* dgh_t = (char*)dgh + (size_t)t * B * 3 * H * es;
+        if (fused) {
+            // step k consumes the dgh / direct of step k+1 (the time index processed just before in this loop) and ping-pongs `direct`
+            const int tn = k < T - 1 ? (reverse ? T - 2 - k : k + 1) : -1;
+            GruStepArgs a; memset(&a, 0, sizeof(a));
+            a.w = (const bf16_t*)w_hh_t; a.first = tn < 0; a.B = B; a.H = H; a.row = row; a.gi_stride = (long)T * 3 * H;
+            a.dgh_next = tn >= 0 ? (const bf16_t*)dgh + (size_t)tn * B * 3 * H : nullptr;
+            a.direct_in = (const bf16_t*)((k & 1) ? carry : direct); a.direct_out = (bf16_t*)((k & 1) ? direct : carry);
+            a.gates_in = (const bf16_t*)gates + (size_t)t * B * 4 * H; a.dseq = (const bf16_t*)dseq + (size_t)t * ld_seq;
+            a.hprev = (const bf16_t*)hprev; a.dgi = (bf16_t*)dgi + (size_t)t * 3 * H; a.dgh = (bf16_t*)dgh_t;
+            a.hprev_out = tp >= 0 ? (bf16_t*)hprev_all + (size_t)t * B * H : nullptr;
+            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / 32), dim3(512), 0, (hipStream_t)stream, a);
+            continue;
+        }
         int rc = gru_gate_bwd_impl(dtype, (const char*)dseq + (size_t)t * ld_seq * es, row, have_carry ? carry : nullptr,
                                    (const char*)gates + (size_t)t * B * 4 * H * es, hprev, row, (char*)dgi + (size_t)t * 3 * H * es, (long)T * 3 * H,
                                    dgh_t, direct, tp >= 0 ? (char*)hprev_all + (size_t)t * B * H * es : nullptr, B, H, stream);
@@ -948,3 +1108,4 @@ extern "C" int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, l
     }
     return PSELD_OK;
 }
+
