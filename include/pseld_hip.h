@@ -273,6 +273,18 @@ int pseld_decode_accdoa(const float* pred, unsigned char* sed, long rows, int C,
 int pseld_move_avg(const float* preds, float* out, int num_chunks, int chunk_frames, int hop_frames, int valid_frames, int out_frames,
                    long D, void* stream);
 
+/* ---- Transformer decoder glue (CRNN decoder='transformer': components/model_utilities.py:256-259 nn.TransformerEncoder) ------
+ * relu: y = max(u, 0) and its backward. sdpa_small: nn.MultiheadAttention's softmax(q k^T / sqrt(head_dim)) (x dropout mask) v
+ * for T <= 128 on the relative-attention kernels with a zero positional table; zeros = f32 buffer of >= T*D zeros;
+ * attn f32 [B,heads,T,T] kept for the backward; scratch f32 [T*D + 2*D]; workspace = pseld_relattn_bwd_workspace. */
+int pseld_relu_fwd(int dtype, const void* u, void* y, long n, void* stream);
+int pseld_relu_bwd(int dtype, const void* u, const void* dy, void* du, long n, void* stream);
+int pseld_sdpa_small_fwd(int dtype, const void* q, const void* k, const void* v, const float* zeros, const void* mask, float mask_scale,
+                         void* out, float* attn, int B, int T, int D, int heads, void* stream);
+int pseld_sdpa_small_bwd(int dtype, const void* q, const void* k, const void* v, const float* zeros, const void* mask, float mask_scale,
+                         const float* attn, const void* dout, void* dq, void* dk, void* dv, float* scratch, int B, int T, int D,
+                         int heads, float* workspace, long workspace_bytes, void* stream);
+
 /* ---- GRU decoder cell (CRNN decoder='gru': components/model_utilities.py:249-252 nn.GRU, configs/model/default.yaml) ------
  * Gate order r | z | n. The input projections of all timesteps, the recurrent product h_{t-1} W_hh^T + b_hh of a step and every
  * weight gradient are pseld_gemm / pseld_gemm_wgrad calls; these two kernels are the element-wise part of one timestep.

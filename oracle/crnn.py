@@ -167,6 +167,41 @@ def gru_decoder(x, sd, pre, num_layers):
     return x
 
 
+def transformer_blocks(x, sd, pre, num_layers, heads=8, training=False, dropout_p=0.1, masks=None):
+    """nn.TransformerEncoder of post-norm nn.TransformerEncoderLayer(d_model, nhead=8, batch_first=True) restated
+    (model_utilities.py:256-259; torch defaults: dim_feedforward 2048, ReLU, LayerNorm 1e-5): x [B, T, D] -> [B, T, D]."""
+    B, T, D = x.shape
+    hd = D // heads
+    for li in range(num_layers):
+        b = f'{pre}layers.{li}.'
+        qkv = F.linear(x, sd[b + 'self_attn.in_proj_weight'], sd[b + 'self_attn.in_proj_bias'])
+        q, k, v = (t.view(B, T, heads, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        attn = _drop(F.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1), dropout_p, training, masks, b + 'attn_drop')
+        ctx = (attn @ v).transpose(1, 2).reshape(B, T, D)
+        o = _drop(F.linear(ctx, sd[b + 'self_attn.out_proj.weight'], sd[b + 'self_attn.out_proj.bias']), dropout_p, training, masks, b + 'dropout1')
+        x = F.layer_norm(x + o, (D,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'])
+        h = _drop(F.relu(F.linear(x, sd[b + 'linear1.weight'], sd[b + 'linear1.bias'])), dropout_p, training, masks, b + 'dropout')
+        f = _drop(F.linear(h, sd[b + 'linear2.weight'], sd[b + 'linear2.bias']), dropout_p, training, masks, b + 'dropout2')
+        x = F.layer_norm(x + f, (D,), sd[b + 'norm2.weight'], sd[b + 'norm2.bias'])
+    return x
+
+
+def add_transformer(sd, D, num_layers, ff=2048, seed=9, pre='decoder.decoder.'):
+    """Seeded parameters of the Transformer decoder (Xavier-scaled matrices, LayerNorm gains 1 +- 0.25, small biases)."""
+    g = torch.Generator().manual_seed(seed)
+    for li in range(num_layers):
+        b = f'{pre}layers.{li}.'
+        for name, shp in ((b + 'self_attn.in_proj_weight', (3 * D, D)), (b + 'self_attn.out_proj.weight', (D, D)),
+                          (b + 'linear1.weight', (ff, D)), (b + 'linear2.weight', (D, ff))):
+            sd[name] = torch.randn(shp, generator=g) * (1.0 / shp[1]) ** 0.5
+        for name, n in ((b + 'self_attn.in_proj_bias', 3 * D), (b + 'self_attn.out_proj.bias', D), (b + 'linear1.bias', ff),
+                        (b + 'linear2.bias', D), (b + 'norm1.bias', D), (b + 'norm2.bias', D)):
+            sd[name] = torch.randn(n, generator=g) * 0.1
+        for name in (b + 'norm1.weight', b + 'norm2.weight'):
+            sd[name] = 1.0 + 0.25 * (2 * torch.rand(D, generator=g) - 1)
+    return sd
+
+
 def add_gru(sd, D, num_layers, seed=8, pre='decoder.decoder.'):
     """Seeded nn.GRU-style parameters (U(-1/sqrt(H), 1/sqrt(H)) scaled up a little so that the gates leave the linear regime)."""
     g = torch.Generator().manual_seed(seed)
@@ -195,6 +230,8 @@ def accdoa_crnn_forward(x, sd, encoder='CNN12', training=False, bn_update=None, 
         x = conformer_blocks(x, sd, decoder_prefix, num_decoder_layers, 8, training, dropout_p, masks, bn_update)
     elif decoder == 'gru':
         x = gru_decoder(x, sd, decoder_prefix, num_decoder_layers)
+    elif decoder == 'transformer':
+        x = transformer_blocks(x, sd, decoder_prefix, num_decoder_layers, 8, training, dropout_p, masks)
     elif decoder is not None:
         raise NotImplementedError(decoder)
     x = x[:, :, None, :].repeat(1, 1, 8, 1).reshape(N, x.shape[1] * 8, -1)  # interpolate(x, 8) 'repeat'

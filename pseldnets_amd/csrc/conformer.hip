@@ -56,6 +56,18 @@ __global__ void swish_kernel(const T* __restrict__ u, const T* __restrict__ g, T
     }
     store8<T>(y + i * 8, a);
 }
+// BWD = false: y = max(u, 0); BWD = true: y = dy * (u > 0)
+template <typename T, bool BWD>
+__global__ void relu_kernel(const T* __restrict__ u, const T* __restrict__ g, T* __restrict__ y, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float a[8], d[8];
+    load8<T>(u + i * 8, a);
+    if (BWD) load8<T>(g + i * 8, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = BWD ? (a[k] > 0.f ? d[k] : 0.f) : fmaxf(a[k], 0.f);
+    store8<T>(y + i * 8, a);
+}
 // x [M, 2D] = (a | g): y = a * sigmoid(g); backward: dx = (dy * sigmoid(g) | dy * a * sigmoid(g) * (1 - sigmoid(g)))
 template <typename T, bool BWD>
 __global__ void glu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int D, long total8) {
@@ -257,6 +269,18 @@ extern "C" int pseld_swish_bwd(int dtype, const void* u, const void* dy, void* d
     hipStream_t s = (hipStream_t)stream;
     CF_DISPATCH("swish_bwd", hipLaunchKernelGGL((swish_kernel<T, true>), dim3(pseld_cdiv(n / 8, 256)), dim3(256), 0, s, (const T*)u,
                                                 (const T*)dy, (T*)du, n / 8));
+}
+extern "C" int pseld_relu_fwd(int dtype, const void* u, void* y, long n, void* stream) {
+    PSELD_CHECK_ARG(u && y && n > 0 && n % 8 == 0, "relu_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    CF_DISPATCH("relu_fwd", hipLaunchKernelGGL((relu_kernel<T, false>), dim3(pseld_cdiv(n / 8, 256)), dim3(256), 0, s, (const T*)u,
+                                               (const T*)nullptr, (T*)y, n / 8));
+}
+extern "C" int pseld_relu_bwd(int dtype, const void* u, const void* dy, void* du, long n, void* stream) {
+    PSELD_CHECK_ARG(u && dy && du && n > 0 && n % 8 == 0, "relu_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    CF_DISPATCH("relu_bwd", hipLaunchKernelGGL((relu_kernel<T, true>), dim3(pseld_cdiv(n / 8, 256)), dim3(256), 0, s, (const T*)u, (const T*)dy,
+                                               (T*)du, n / 8));
 }
 extern "C" int pseld_glu_fwd(int dtype, const void* x, void* y, long M, int D, void* stream) {
     PSELD_CHECK_ARG(x && y && M > 0 && D > 0 && D % 8 == 0, "glu_fwd: bad argument");
@@ -730,6 +754,9 @@ size_t relattn_lds(int hd, bool bwd) {
 
 }  // namespace
 
+// plain scaled-dot-product attention of short sequences (nn.MultiheadAttention inside the Transformer decoder): the same kernels with a
+// zero positional table / zero biases and scale = 1 / sqrt(head_dim)
+static thread_local float g_relattn_scale_override = 0.f;
 extern "C" int pseld_relattn_fwd(int dtype, const void* q, const void* k, const void* v, const float* pos, const float* u_bias,
                                  const float* v_bias, const void* mask, float mask_scale, void* out, float* attn, int B, int T, int D,
                                  int heads, void* stream) {
@@ -737,7 +764,7 @@ extern "C" int pseld_relattn_fwd(int dtype, const void* q, const void* k, const 
     PSELD_CHECK_ARG(B > 0 && T > 0 && T <= RA_TMAX && heads > 0 && D % heads == 0, "relattn_fwd: bad geometry (T <= 128)");
     RelAttnArgs a; memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.pos = pos; a.u_bias = u_bias; a.v_bias = v_bias; a.mask = mask; a.out = out; a.attn = attn;
-    a.B = B; a.T = T; a.D = D; a.heads = heads; a.scale = 1.0f / sqrtf((float)D); a.mask_scale = mask_scale;
+    a.B = B; a.T = T; a.D = D; a.heads = heads; a.scale = g_relattn_scale_override > 0.f ? g_relattn_scale_override : 1.0f / sqrtf((float)D); a.mask_scale = mask_scale;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = relattn_lds(D / heads, false);
     if (dtype == PSELD_BF16) {
@@ -768,7 +795,7 @@ extern "C" int pseld_relattn_bwd(int dtype, const void* q, const void* k, const 
     RelAttnArgs a; memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.pos = pos; a.u_bias = u_bias; a.v_bias = v_bias; a.mask = mask; a.attn = const_cast<float*>(attn);
     a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.dpos_part = workspace; a.dbias_part = workspace + (long)B * T * D;
-    a.B = B; a.T = T; a.D = D; a.heads = heads; a.scale = 1.0f / sqrtf((float)D); a.mask_scale = mask_scale;
+    a.B = B; a.T = T; a.D = D; a.heads = heads; a.scale = g_relattn_scale_override > 0.f ? g_relattn_scale_override : 1.0f / sqrtf((float)D); a.mask_scale = mask_scale;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = relattn_lds(D / heads, true);
     if (dtype == PSELD_BF16) {
@@ -1109,3 +1136,26 @@ extern "C" int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, l
     return PSELD_OK;
 }
 
+
+
+/* nn.MultiheadAttention core for sequences of up to 128 frames (components/model_utilities.py:256-259 nn.TransformerEncoderLayer):
+ * softmax(q k^T / sqrt(head_dim)) (x dropout mask) v on the relative-attention kernels with a zero positional table. zeros: f32
+ * buffer of at least T*D zeros; scratch (backward): f32 [T*D + 2*D] that receives the (meaningless) positional gradients. */
+extern "C" int pseld_sdpa_small_fwd(int dtype, const void* q, const void* k, const void* v, const float* zeros, const void* mask, float mask_scale,
+                                    void* out, float* attn, int B, int T, int D, int heads, void* stream) {
+    PSELD_CHECK_ARG(zeros && heads > 0 && D % heads == 0, "sdpa_small_fwd: bad argument");
+    g_relattn_scale_override = 1.0f / sqrtf((float)(D / heads));
+    const int rc = pseld_relattn_fwd(dtype, q, k, v, zeros, zeros, zeros, mask, mask_scale, out, attn, B, T, D, heads, stream);
+    g_relattn_scale_override = 0.f;
+    return rc;
+}
+extern "C" int pseld_sdpa_small_bwd(int dtype, const void* q, const void* k, const void* v, const float* zeros, const void* mask, float mask_scale,
+                                    const float* attn, const void* dout, void* dq, void* dk, void* dv, float* scratch, int B, int T, int D,
+                                    int heads, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(zeros && scratch && heads > 0 && D % heads == 0, "sdpa_small_bwd: bad argument");
+    g_relattn_scale_override = 1.0f / sqrtf((float)(D / heads));
+    const int rc = pseld_relattn_bwd(dtype, q, k, v, zeros, zeros, zeros, mask, mask_scale, attn, dout, dq, dk, dv, scratch, scratch + (long)T * D,
+                                     scratch + (long)T * D + D, B, T, D, heads, workspace, workspace_bytes, stream);
+    g_relattn_scale_override = 0.f;
+    return rc;
+}

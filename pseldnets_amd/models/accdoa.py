@@ -9,6 +9,7 @@ from .components.passt import FcTanhHead, PasstEncoder
 from .components.crnn import ConvEncoder
 from .components.conformer import ConformerDecoder
 from .components.gru import GRUDecoder
+from .components.transformer import TransformerDecoder
 from .. import ops
 from .components.seld_net import HTSATNetBase
 
@@ -231,9 +232,8 @@ class CRNN(HTSATNetBase):
         else:
             n_layers = (model.num_decoder_layers if hasattr(model, 'num_decoder_layers') else model.get('num_decoder_layers', 2)) \
                 if model is not None else 2
-        if decoder not in (None, 'conformer', 'gru'):
-            raise NotImplementedError(f"decoder '{decoder}' (model_utilities.py:245-269) is not built on the MI355X path yet; "
-                                      "set model.decoder: conformer, gru or null")
+        if decoder not in (None, 'conformer', 'gru', 'transformer'):
+            raise NotImplementedError(f"{decoder} is not implemented")          # model_utilities.py:262-263
         self.num_classes = num_classes
         self.interpolate_time_ratio = 2 ** 3
         self._init_common(cfg, in_channels)
@@ -243,6 +243,8 @@ class CRNN(HTSATNetBase):
             self.dec_blocks = ConformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
         elif decoder == 'gru':
             self.dec_blocks = GRUDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
+        elif decoder == 'transformer':
+            self.dec_blocks = TransformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
         else:
             self.dec_blocks = None
         self.head = FcTanhHead(self.arena, 'fc.', self.num_features[-1], num_classes * self.tracks_axes)

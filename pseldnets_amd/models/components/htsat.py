@@ -400,6 +400,10 @@ def default_init(name, shape):
     leaf = name.rsplit('.', 1)[-1]
     if 'relative_position_bias_table' in name:
         torch.nn.init.trunc_normal_(t, std=.02)
+    elif leaf == 'in_proj_weight':                                       # nn.MultiheadAttention: xavier_uniform
+        torch.nn.init.xavier_uniform_(t)
+    elif leaf == 'in_proj_bias' or name.endswith('out_proj.bias'):
+        t.zero_()
     elif leaf.startswith(('weight_ih_l', 'weight_hh_l', 'bias_ih_l', 'bias_hh_l')):   # nn.GRU: U(-1/sqrt(H), 1/sqrt(H))
         k = 1.0 / math.sqrt(shape[0] / 3)
         t.uniform_(-k, k)

@@ -958,3 +958,55 @@ def gru_seq_bwd(dseq_dir, seq_dir, gates, w_hh, w_hh_t, reverse):
                                             _lib.ptr(w_hh), _lib.ptr(w_hh_t), _lib.ptr(dgi), _lib.ptr(dgh), _lib.ptr(hprev_all), _lib.ptr(carry),
                                             _lib.ptr(direct), B, T, H, int(reverse), _lib.stream_ptr()), "pseld_gru_seq_bwd")
     return dgi, dgh, hprev_all
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Transformer decoder glue (csrc/conformer.hip)
+def relu_fwd(u):
+    _chk(u)
+    y = torch.empty_like(u)
+    _lib.check(_lib.lib().pseld_relu_fwd(dtype_code(u), _lib.ptr(u), _lib.ptr(y), u.numel(), _lib.stream_ptr()), "pseld_relu_fwd")
+    return y
+
+
+def relu_bwd(u, dy):
+    _chk(u, dy)
+    du = torch.empty_like(u)
+    _lib.check(_lib.lib().pseld_relu_bwd(dtype_code(u), _lib.ptr(u), _lib.ptr(dy), _lib.ptr(du), u.numel(), _lib.stream_ptr()), "pseld_relu_bwd")
+    return du
+
+
+_zeros_cache = {}
+
+
+def _zeros_f32(n, device):
+    key = (device.index, )
+    z = _zeros_cache.get(key)
+    if z is None or z.numel() < n:
+        z = _zeros_cache[key] = torch.zeros(max(n, 1 << 18), dtype=torch.float32, device=device)
+    return z
+
+
+def sdpa_small_fwd(q, k, v, B, T, heads, mask=None, mask_scale=1.0):
+    """q, k, v [B*T, D] -> (context [B*T, D], attn f32 [B, heads, T, T]); T <= 128."""
+    _chk(q, k, v, mask)
+    D = q.shape[1]
+    out = torch.empty_like(q)
+    attn = torch.empty((B, heads, T, T), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().pseld_sdpa_small_fwd(dtype_code(q), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(_zeros_f32(T * D, q.device)),
+                                               _lib.ptr(mask), float(mask_scale), _lib.ptr(out), _lib.ptr(attn), B, T, D, heads,
+                                               _lib.stream_ptr()), "pseld_sdpa_small_fwd")
+    return out, attn
+
+
+def sdpa_small_bwd(q, k, v, attn, dout, B, T, heads, mask=None, mask_scale=1.0):
+    _chk(q, k, v, attn, dout, mask)
+    D = q.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.pseld_relattn_bwd_workspace(B, T, D), q.device)
+    scratch = torch.empty(T * D + 2 * D, dtype=torch.float32, device=q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    _lib.check(L.pseld_sdpa_small_bwd(dtype_code(q), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(_zeros_f32(T * D, q.device)), _lib.ptr(mask),
+                                      float(mask_scale), _lib.ptr(attn), _lib.ptr(dout), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(scratch),
+                                      B, T, D, heads, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "pseld_sdpa_small_bwd")
+    return dq, dk, dv

@@ -719,8 +719,51 @@ def gen_gru():
     save('gru.npz', **out)
 
 
+def gen_transformer():
+    """multi_accdoa.CRNN(encoder='CNN12', cfg.model.decoder='transformer', 2 layers): eval output, and float64 train output / loss /
+    decoder + fc gradients with every dropout probability set to 0 (the fused scaled_dot_product_attention draws its dropout
+    internally, so an active-dropout run is not reproducible)."""
+    C = 3
+    cfgc = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'),
+                      model=R.AttrDict(decoder='transformer', num_decoder_layers=2), adapt=dict())
+    out = {}
+    D = CRNN_TINY[-1]
+    sd = oc.add_transformer(oc.random_state('multi_accdoa', C, 7, 'CNN12', CRNN_TINY, seed=0), D, 2)
+    x = oc.random_features(2, seed=1)
+    net = multi_accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    net.eval()
+    with torch.no_grad():
+        out['eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net64 = multi_accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY).double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sd.items()})
+    for m in net64.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    net64.train()
+    pred = net64(x.double().clone())
+    lab = synth.formula_adpit_label(2, 100, C)
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab.double()})
+    ld['loss_all'].backward()
+    out['train'] = pred['multi_accdoa'].detach().numpy()
+    out['loss'] = ld['loss_all'].item()
+    names, norms, heads = [], [], []
+    for n, p in net64.named_parameters():
+        if not (n.startswith('decoder.') or n.startswith('fc.')):
+            continue
+        names.append(n); norms.append(p.grad.norm().item()); heads.append(p.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    save('transformer.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -737,3 +780,4 @@ if __name__ == '__main__':
     if 'data' in which: gen_data()
     if 'metrics' in which: gen_metrics()
     if 'gru' in which: gen_gru()
+    if 'transformer' in which: gen_transformer()

@@ -257,3 +257,58 @@ def test_gru_network_vs_reference_goldens(dev):
         worst = max(worst, (n, e), key=lambda t: t[1])
     print('CRNN+GRU worst decoder grad-norm rel err vs float64 reference:', worst)
     assert worst[1] < 5e-3, worst
+
+
+@pytest.mark.parametrize("tag", ['p0', 'drop'])
+def test_transformer_network_vs_reference_goldens(dev, tag):
+    """CRNN with cfg.model.decoder='transformer' (nn.TransformerEncoder, 2 post-norm layers): eval output, loss and decoder / fc
+    gradients against the reference's float64 run (dropout 0); 'drop': dropout active with closed-form masks against the oracle
+    (the reference's fused attention draws its dropout internally and cannot be seeded per site)."""
+    from oracle import losses as ol
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'transformer.npz'))
+    D, B = TINY[-1], 2
+    cfg = A(data=CFG.data, model=A(decoder='transformer', num_decoder_layers=2), adapt=A())
+    sd = oc.add_transformer(oc.random_state('multi_accdoa', 3, 7, 'CNN12', TINY, seed=0), D, 2)
+    net = multi_accdoa.CRNN(cfg, 3, 7, encoder='CNN12', pretrained_path=None, num_features=TINY)
+    net.load_state_dict(sd, strict=True)
+    assert set(net.state_dict().keys()) == set(str(k) for k in g['state_keys'])
+    net.to(dev)
+    x = oc.random_features(B, seed=1)
+    lab = synth.formula_adpit_label(B, 100, 3)
+    if tag == 'p0':
+        net.eval()
+        with torch.no_grad():
+            assert rel(net(x.to(dev))['multi_accdoa'], g['eval']) < 1e-3
+        net.dec_blocks.p = 0.0
+        want_pred, want_loss = g['train'], float(g['loss'])
+        want_grads = {str(n): v for n, v in zip(g['grad_names'], g['grad_norms'])}
+    else:
+        net.dec_blocks.masks = lambda name, shape: oc.formula_keep_mask(shape if len(shape) == 4 else (B, shape[0] // B, shape[1]))
+        p = {k: (v.double().clone().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+        pred64 = oc.accdoa_crnn_forward(x.double(), p, 'CNN12', training=True, key='multi_accdoa', decoder='transformer',
+                                        num_decoder_layers=2, dropout_p=0.1, masks='formula')
+        l64 = ol.adpit(pred64, {'adpit_label': lab.double()})['loss_all']
+        l64.backward()
+        want_pred, want_loss = pred64['multi_accdoa'].detach().numpy(), l64.item()
+        want_grads = {k: v.grad.norm().item() for k, v in p.items() if k.startswith(('decoder.', 'fc.'))}
+    net.train()
+    pred = net(x.to(dev))
+    assert rel(pred['multi_accdoa'], want_pred) < 1e-3
+    ld = Losses('mse', 'loss_all')(pred, {'adpit_label': lab.to(dev)})
+    assert abs(ld['loss_all'].item() - want_loss) < 1e-4 * abs(want_loss)
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for n, norm in want_grads.items():
+        e = abs(params[n].grad.norm().item() - norm) / max(norm, 1e-12)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+    print(f'CRNN+Transformer [{tag}] worst decoder grad-norm rel err:', worst)
+    assert worst[1] < 5e-3, worst
+    netb = multi_accdoa.CRNN(cfg, 3, 7, encoder='CNN12', pretrained_path=None, num_features=TINY)
+    netb.load_state_dict(sd, strict=True)
+    netb.compute_dtype = torch.bfloat16
+    netb.to(dev).eval()
+    with torch.no_grad():
+        assert rel(netb(x.to(dev))['multi_accdoa'], g['eval']) < 1.5e-1

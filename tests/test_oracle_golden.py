@@ -441,3 +441,27 @@ def test_gru_decoder_golden():
     for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
         gr = p[str(n)].grad
         assert abs(gr.norm().item() - norm) <= 1e-8 * max(norm, 1e-6) + 1e-14, n
+
+
+def test_transformer_decoder_golden():
+    """oracle/crnn.py transformer_blocks against the reference's CRNN(decoder='transformer', 2 layers): eval output, float64 train
+    output (dropout probabilities 0), loss and decoder / fc gradients."""
+    from oracle import crnn as oc
+    g = gold('transformer.npz')
+    D = CRNN_TINY[-1]
+    x = oc.random_features(2, seed=1)
+    sd = oc.add_transformer(oc.random_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY, seed=0), D, 2)
+    assert set(sd.keys()) == set(str(k) for k in g['state_keys'])
+    with torch.no_grad():
+        y = oc.accdoa_crnn_forward(x.clone(), sd, 'CNN12', key='multi_accdoa', decoder='transformer', num_decoder_layers=2)
+        close(y['multi_accdoa'], g['eval'], 5e-5)
+    p = {k: (v.double().clone().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    pred = oc.accdoa_crnn_forward(x.double(), p, 'CNN12', training=True, key='multi_accdoa', decoder='transformer', num_decoder_layers=2,
+                                  dropout_p=0.0)
+    assert np.abs(pred['multi_accdoa'].detach().numpy() - g['train']).max() < 1e-10
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3).double()})
+    assert abs(ld['loss_all'].item() - float(g['loss'])) < 1e-10
+    ld['loss_all'].backward()
+    for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= 1e-8 * max(norm, 1e-6) + 1e-14, n
