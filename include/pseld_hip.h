@@ -128,15 +128,17 @@ int pseld_mhsa_bwd(int dtype, const void* qkv, const void* out, const void* dout
  * accdoa.py:320-327 scalar BN + im2col of model_utilities.py:174-213 PatchEmbed (Conv2d k16 s10 pad 3 on the
  * [C, mel, T] image): feat f32[B,Cin,T,64] -> A [B*6*Tg, Cin*256] (k = c*256 + kf*16 + kt = the conv weight's
  * flattening), Tg = pseld_passt_grid_t(T); bn_bwd folds dA back through the overlapping patches into the BN
- * weight/bias gradients. assemble: passt.py:219-247, X[b] = [cls+npos0, dist+npos1, P[b] + tpos[:,tg] + fpos[:,fg]]
+ * weight/bias gradients (added to them when `accumulate`). Ctot >= Cin is the channel count of `feat` itself: the SED
+ * encoder of einv2.PASST (einv2.py:543) reads the first Cin = 4 of its 7 channels. assemble: passt.py:219-247, X[b] = [cls+npos0, dist+npos1, P[b] + tpos[:,tg] + fpos[:,fg]]
  * ([B, 6*Tg+2, E]); its backward emits dP and the five positional/token gradients (summed over the batch).
  * pool: passt.py:296-300 mean over the 6 frequency rows, [B, 6*Tg+2, E] -> [B, Tg, E]. tanh: accdoa.py:328. */
 int pseld_passt_grid_t(int T);
-int pseld_passt_patchify(int dtype, const float* feat, const float* scale_shift, void* A, int B, int Cin, int T,
-                         void* stream);
+int pseld_passt_patchify(int dtype, const float* feat, const float* scale_shift, void* A, int B, int Cin, int Ctot,
+                         int T, void* stream);
 long pseld_passt_bn_bwd_workspace(int B, int Cin, int T);
 int pseld_passt_bn_bwd(int dtype, const float* feat, const float* mean_rstd, const void* dA, float* dweight,
-                       float* dbias, int B, int Cin, int T, float* workspace, long workspace_bytes, void* stream);
+                       float* dbias, int B, int Cin, int Ctot, int T, int accumulate, float* workspace,
+                       long workspace_bytes, void* stream);
 int pseld_passt_assemble_fwd(int dtype, const void* P, const float* tpos, const float* fpos, const float* cls,
                              const float* dist, const float* npos, void* X, int B, int E, int Tg, void* stream);
 long pseld_passt_assemble_bwd_workspace(int E, int Tg);
@@ -147,6 +149,12 @@ int pseld_passt_pool_fwd(int dtype, const void* X, void* Y, int B, int E, int Tg
 int pseld_passt_pool_bwd(int dtype, const void* dY, void* dX, int B, int E, int Tg, void* stream);
 int pseld_tanh_fwd(int dtype, const void* z, int ldz, float* y, long rows, int D, void* stream);
 int pseld_tanh_bwd(int dtype, const float* dy, const float* y, void* dz, int ldz, long rows, int D, void* stream);
+/* einv2.py:562-573 (and :166-174): the per-track Linear outputs of the EINV2 networks leave the padded GEMM buffer as
+ * y f32[rows, D] (row stride ldy: track t of a [rows, 3, D] tensor has ldy = 3*D) = act(z[rows, :D]), act 0 = identity (SED logits, final_act_sed is empty) or 1 = tanh (DOA); bwd writes
+ * dz[rows, ldz] with zeros in the padding columns (y may be NULL when act == 0). */
+int pseld_fc_out_fwd(int dtype, const void* z, int ldz, float* y, int ldy, long rows, int D, int act, void* stream);
+int pseld_fc_out_bwd(int dtype, const float* dy, const float* y, int ldy, void* dz, int ldz, long rows, int D, int act,
+                     void* stream);
 
 /* ---- convolutional encoder of the CRNN networks (CNN8 / CNN12 = the PANNs CNN14 conv stack) ------------------------------
  * accdoa.py:72-90, backbone.py:6-60, model_utilities.py:92-126 (ConvBlock), utils.py:25-52 (interpolate 'repeat').

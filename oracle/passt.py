@@ -26,11 +26,10 @@ def grid_size(cfg):
     return tuple((s + 2 * pad - c['patch_size']) // c['stride'] + 1 for s in c['img_size'])
 
 
-def encoder_forward(x, sd, pre, cfg):
-    """passt.py:214-312 with distilled=True: x [B, C, T, F] (already normalised) -> (feature_map [B, T', E] after the
-    head LayerNorm, features [B, E])."""
+def encoder_before(x, sd, pre, cfg):
+    """passt.py:314-357 (forward_before; = :216-247 of forward_features) with no patch-out: x [B, C, T, F] (already
+    normalised) -> ([B, 2 + Fg*Tg, E] tokens, (Fg, Tg))."""
     c = _cfg(cfg)
-    E, heads = c['embed_dim'], c['num_heads']
     pad = (c['patch_size'] - c['stride']) // 2
     x = F.conv2d(x.transpose(-1, -2), sd[pre + 'patch_embed.proj.weight'], sd[pre + 'patch_embed.proj.bias'],
                  stride=c['stride'], padding=pad)                                   # [B, E, Fg, Tg]
@@ -39,24 +38,44 @@ def encoder_forward(x, sd, pre, cfg):
     x = x.flatten(2).transpose(1, 2)                                                # [B, Fg*Tg, E]
     cls = sd[pre + 'cls_token'].expand(B, -1, -1) + sd[pre + 'new_pos_embed'][:, :1]
     dist = sd[pre + 'dist_token'].expand(B, -1, -1) + sd[pre + 'new_pos_embed'][:, 1:]
-    x = torch.cat((cls, dist, x), dim=1)
+    return torch.cat((cls, dist, x), dim=1), (Fg, Tg)
+
+
+def encoder_block(x, sd, b, cfg):
+    """passt.py:85-101 (Block) over :50-82 (Attention); b = '<pre>blocks.<i>.'."""
+    c = _cfg(cfg)
+    E, heads = c['embed_dim'], c['num_heads']
     hd = E // heads
-    for i in range(c['depth']):
-        b = f'{pre}blocks.{i}.'
-        y = F.layer_norm(x, (E,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'], 1e-6)
-        N = y.shape[1]
-        qkv = F.linear(y, sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias']).reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
-        attn = ((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
-        y = (attn @ qkv[2]).transpose(1, 2).reshape(B, N, E)
-        x = x + F.linear(y, sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'])
-        y = F.layer_norm(x, (E,), sd[b + 'norm2.weight'], sd[b + 'norm2.bias'], 1e-6)
-        y = F.linear(F.gelu(F.linear(y, sd[b + 'mlp.fc1.weight'], sd[b + 'mlp.fc1.bias'])), sd[b + 'mlp.fc2.weight'], sd[b + 'mlp.fc2.bias'])
-        x = x + y
+    B, N = x.shape[:2]
+    y = F.layer_norm(x, (E,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'], 1e-6)
+    qkv = F.linear(y, sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias']).reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = ((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    y = (attn @ qkv[2]).transpose(1, 2).reshape(B, N, E)
+    x = x + F.linear(y, sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'])
+    y = F.layer_norm(x, (E,), sd[b + 'norm2.weight'], sd[b + 'norm2.bias'], 1e-6)
+    y = F.linear(F.gelu(F.linear(y, sd[b + 'mlp.fc1.weight'], sd[b + 'mlp.fc1.bias'])), sd[b + 'mlp.fc2.weight'], sd[b + 'mlp.fc2.bias'])
+    return x + y
+
+
+def encoder_after(x, sd, pre, cfg, grid):
+    """passt.py:359-380 (forward_after; = :271-312): -> (feature_map [B, Tg, E] after the head LayerNorm, features [B, E])."""
+    E = _cfg(cfg)['embed_dim']
+    Fg, Tg = grid
+    B = x.shape[0]
     x = F.layer_norm(x, (E,), sd[pre + 'norm.weight'], sd[pre + 'norm.bias'], 1e-6)
     features = x[:, :2].mean(dim=1)
     fmap = x[:, 2:].transpose(-1, -2).reshape(B, E, Fg, Tg).mean(2).permute(0, 2, 1)   # [B, Tg, E]
     fmap = F.layer_norm(fmap, (E,), sd[pre + 'head.0.weight'], sd[pre + 'head.0.bias'], 1e-5)
     return fmap, features
+
+
+def encoder_forward(x, sd, pre, cfg):
+    """passt.py:214-312 with distilled=True: x [B, C, T, F] (already normalised) -> (feature_map [B, T', E] after the
+    head LayerNorm, features [B, E])."""
+    x, grid = encoder_before(x, sd, pre, cfg)
+    for i in range(_cfg(cfg)['depth']):
+        x = encoder_block(x, sd, f'{pre}blocks.{i}.', cfg)
+    return encoder_after(x, sd, pre, cfg, grid)
 
 
 def accdoa_passt_forward(x, sd, cfg=None, training=False, bn_update=None, key='accdoa'):

@@ -16,7 +16,8 @@ constexpr int PS = 16, STR = 10, PAD = 3, MEL = 64, FG = 6;   // patch 16, strid
 // one thread = 8 consecutive kt.
 template <typename T>
 __global__ __launch_bounds__(256) void passt_patchify_kernel(const float* __restrict__ feat, const float* __restrict__ ss,
-                                                             T* __restrict__ A, int Cin, int Tn, int Tg, long chunks) {
+                                                             T* __restrict__ A, int Cin, int Ctot, int Tn, int Tg,
+                                                             long chunks) {
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= chunks) return;
     const int cpr = Cin * 32;                       // 8-element chunks per row
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void passt_patchify_kernel(const float* __rest
     float v[8];
     if (f >= 0 && f < MEL) {
         const float sc = ss[2 * (c * MEL + f)], sh = ss[2 * (c * MEL + f) + 1];
-        const float* src = feat + ((b * Cin + c) * Tn) * MEL + f;
+        const float* src = feat + ((b * Ctot + c) * Tn) * MEL + f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int t = tg * STR - PAD + kt0 + j;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void passt_patchify_kernel(const float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void passt_bn_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ mean_rstd,
                                                            const T* __restrict__ dA, float* __restrict__ part, int B, int Cin,
-                                                           int Tn, int Tg, int rows_per_block) {
+                                                           int Ctot, int Tn, int Tg, int rows_per_block) {
     __shared__ float red[4][64][2];
     const int f = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.y;
     const long total = (long)B * Tn;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void passt_bn_bwd_kernel(const float* __restri
             if (g < Tg) gsum += to_f32<T>(dA[(rowbase + g) * lda + col + kt]);
             if (kt + STR < PS && g >= 1 && g - 1 < Tg) gsum += to_f32<T>(dA[(rowbase + g - 1) * lda + col + kt + STR]);
         }
-        const float xh = (feat[((b * Cin + c) * Tn + t) * MEL + f] - mean) * rstd;
+        const float xh = (feat[((b * Ctot + c) * Tn + t) * MEL + f] - mean) * rstd;
         dw += gsum * xh;
         db += gsum;
     }
@@ -87,11 +88,13 @@ __global__ __launch_bounds__(256) void passt_bn_bwd_kernel(const float* __restri
         o[1] = red[0][f][1] + red[1][f][1] + red[2][f][1] + red[3][f][1];
     }
 }
-__global__ void passt_bn_finish_kernel(const float* __restrict__ part, int nblocks, int n, float* dweight, float* dbias) {
+__global__ void passt_bn_finish_kernel(const float* __restrict__ part, int nblocks, int n, float* dweight, float* dbias,
+                                       int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float dw = 0.f, db = 0.f;
     for (int k = 0; k < nblocks; ++k) { dw += part[((long)k * n + i) * 2]; db += part[((long)k * n + i) * 2 + 1]; }
+    if (accumulate) { dw += dweight[i]; db += dbias[i]; }
     dweight[i] = dw; dbias[i] = db;
 }
 
@@ -210,23 +213,28 @@ __global__ __launch_bounds__(256) void passt_pool_bwd_kernel(const T* __restrict
     store8<T>(dX + id * 8, v);
 }
 
-template <typename T>
-__global__ void tanh_fwd_kernel(const T* __restrict__ z, int ldz, float* __restrict__ y, long rows, int D) {
+// y f32[rows, D] = act(z[rows, :D]) out of the padded GEMM output (ldz >= D); TANH=false: the plain f32 copy (SED logits)
+template <typename T, bool TANH = true>
+__global__ void tanh_fwd_kernel(const T* __restrict__ z, int ldz, float* __restrict__ y, int ldy, long rows, int D) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= rows * D) return;
     const long r = id / D;
     const int d = (int)(id - r * D);
-    y[id] = tanhf(to_f32<T>(z[r * ldz + d]));
+    const float v = to_f32<T>(z[r * ldz + d]);
+    y[r * ldy + d] = TANH ? tanhf(v) : v;
 }
-template <typename T>
-__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* __restrict__ dz, int ldz, long rows,
-                                int D) {
+template <typename T, bool TANH = true>
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ldy, T* __restrict__ dz, int ldz,
+                                long rows, int D) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= rows * ldz) return;
     const long r = id / ldz;
     const int d = (int)(id - r * ldz);
     float g = 0.f;
-    if (d < D) { const float t = y[r * D + d]; g = dy[r * D + d] * (1.f - t * t); }
+    if (d < D) {
+        g = dy[r * ldy + d];
+        if (TANH) { const float t = y[r * ldy + d]; g *= 1.f - t * t; }
+    }
     dz[id] = from_f32<T>(g);
 }
 
@@ -243,34 +251,36 @@ constexpr int BN_ROWS_PER_BLOCK = 512;
 
 extern "C" int pseld_passt_grid_t(int T) { return (T + 2 * PAD - PS) / STR + 1; }
 
-extern "C" int pseld_passt_patchify(int dtype, const float* feat, const float* scale_shift, void* A, int B, int Cin, int Tn,
-                                    void* stream) {
+extern "C" int pseld_passt_patchify(int dtype, const float* feat, const float* scale_shift, void* A, int B, int Cin, int Ctot,
+                                    int Tn, void* stream) {
     PSELD_CHECK_ARG(feat && scale_shift && A, "passt_patchify: null pointer");
-    PSELD_CHECK_ARG(B > 0 && Cin > 0 && Tn >= PS, "passt_patchify: bad geometry");
+    PSELD_CHECK_ARG(B > 0 && Cin > 0 && Ctot >= Cin && Tn >= PS, "passt_patchify: bad geometry");
     hipStream_t s = (hipStream_t)stream;
     const int Tg = pseld_passt_grid_t(Tn);
     const long chunks = (long)B * FG * Tg * Cin * 32;
     PASST_DISPATCH("passt_patchify", hipLaunchKernelGGL(passt_patchify_kernel<T>, dim3(pseld_cdiv(chunks, 256)), dim3(256), 0, s,
-                                                         feat, scale_shift, (T*)A, Cin, Tn, Tg, chunks));
+                                                         feat, scale_shift, (T*)A, Cin, Ctot, Tn, Tg, chunks));
 }
 
 extern "C" long pseld_passt_bn_bwd_workspace(int B, int Cin, int T) {
     return (long)pseld_cdiv((long)B * T, BN_ROWS_PER_BLOCK) * Cin * 64 * 2 * (long)sizeof(float);
 }
 extern "C" int pseld_passt_bn_bwd(int dtype, const float* feat, const float* mean_rstd, const void* dA, float* dweight,
-                                  float* dbias, int B, int Cin, int T, float* workspace, long workspace_bytes, void* stream) {
+                                  float* dbias, int B, int Cin, int Ctot, int T, int accumulate, float* workspace,
+                                  long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(feat && mean_rstd && dA && dweight && dbias && workspace, "passt_bn_bwd: null pointer");
+    PSELD_CHECK_ARG(Ctot >= Cin, "passt_bn_bwd: Ctot < Cin");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_passt_bn_bwd_workspace(B, Cin, T), "passt_bn_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int Tg = pseld_passt_grid_t(T);
     const int nb = pseld_cdiv((long)B * T, BN_ROWS_PER_BLOCK);
     if (dtype == PSELD_BF16)
-        hipLaunchKernelGGL(passt_bn_bwd_kernel<bf16_t>, dim3(nb, Cin), dim3(256), 0, s, feat, mean_rstd, (const bf16_t*)dA, workspace, B, Cin, T, Tg, BN_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(passt_bn_bwd_kernel<bf16_t>, dim3(nb, Cin), dim3(256), 0, s, feat, mean_rstd, (const bf16_t*)dA, workspace, B, Cin, Ctot, T, Tg, BN_ROWS_PER_BLOCK);
     else if (dtype == PSELD_F32)
-        hipLaunchKernelGGL(passt_bn_bwd_kernel<float>, dim3(nb, Cin), dim3(256), 0, s, feat, mean_rstd, (const float*)dA, workspace, B, Cin, T, Tg, BN_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(passt_bn_bwd_kernel<float>, dim3(nb, Cin), dim3(256), 0, s, feat, mean_rstd, (const float*)dA, workspace, B, Cin, Ctot, T, Tg, BN_ROWS_PER_BLOCK);
     else { pseld_set_error("passt_bn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     const int n = Cin * 64;
-    hipLaunchKernelGGL(passt_bn_finish_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, workspace, nb, n, dweight, dbias);
+    hipLaunchKernelGGL(passt_bn_finish_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, workspace, nb, n, dweight, dbias, accumulate);
     PSELD_LAUNCH_CHECK("passt_bn_bwd");
     return PSELD_OK;
 }
@@ -320,15 +330,28 @@ extern "C" int pseld_passt_pool_bwd(int dtype, const void* dY, void* dX, int B, 
                                                          (const T*)dY, (T*)dX, E, Tg, chunks));
 }
 
-extern "C" int pseld_tanh_fwd(int dtype, const void* z, int ldz, float* y, long rows, int D, void* stream) {
-    PSELD_CHECK_ARG(z && y && rows > 0 && D > 0 && ldz >= D, "tanh_fwd: bad argument");
+extern "C" int pseld_fc_out_fwd(int dtype, const void* z, int ldz, float* y, int ldy, long rows, int D, int act, void* stream) {
+    PSELD_CHECK_ARG(z && y && rows > 0 && D > 0 && ldz >= D && ldy >= D, "fc_out_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    PASST_DISPATCH("tanh_fwd", hipLaunchKernelGGL(tanh_fwd_kernel<T>, dim3(pseld_cdiv(rows * D, 256)), dim3(256), 0, s, (const T*)z,
-                                                   ldz, y, rows, D));
+    const dim3 grid(pseld_cdiv(rows * D, 256));
+    if (act) {
+        PASST_DISPATCH("fc_out_fwd", hipLaunchKernelGGL((tanh_fwd_kernel<T, true>), grid, dim3(256), 0, s, (const T*)z, ldz, y, ldy, rows, D));
+    }
+    PASST_DISPATCH("fc_out_fwd", hipLaunchKernelGGL((tanh_fwd_kernel<T, false>), grid, dim3(256), 0, s, (const T*)z, ldz, y, ldy, rows, D));
+}
+extern "C" int pseld_fc_out_bwd(int dtype, const float* dy, const float* y, int ldy, void* dz, int ldz, long rows, int D, int act,
+                                void* stream) {
+    PSELD_CHECK_ARG(dy && dz && (y || !act) && rows > 0 && D > 0 && ldz >= D && ldy >= D, "fc_out_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(pseld_cdiv(rows * ldz, 256));
+    if (act) {
+        PASST_DISPATCH("fc_out_bwd", hipLaunchKernelGGL((tanh_bwd_kernel<T, true>), grid, dim3(256), 0, s, dy, y, ldy, (T*)dz, ldz, rows, D));
+    }
+    PASST_DISPATCH("fc_out_bwd", hipLaunchKernelGGL((tanh_bwd_kernel<T, false>), grid, dim3(256), 0, s, dy, y, ldy, (T*)dz, ldz, rows, D));
+}
+extern "C" int pseld_tanh_fwd(int dtype, const void* z, int ldz, float* y, long rows, int D, void* stream) {
+    return pseld_fc_out_fwd(dtype, z, ldz, y, D, rows, D, 1, stream);
 }
 extern "C" int pseld_tanh_bwd(int dtype, const float* dy, const float* y, void* dz, int ldz, long rows, int D, void* stream) {
-    PSELD_CHECK_ARG(dy && y && dz && rows > 0 && D > 0 && ldz >= D, "tanh_bwd: bad argument");
-    hipStream_t s = (hipStream_t)stream;
-    PASST_DISPATCH("tanh_bwd", hipLaunchKernelGGL(tanh_bwd_kernel<T>, dim3(pseld_cdiv(rows * ldz, 256)), dim3(256), 0, s, dy, y,
-                                                   (T*)dz, ldz, rows, D));
+    return pseld_fc_out_bwd(dtype, dy, y, D, dz, ldz, rows, D, 1, stream);
 }

@@ -126,6 +126,24 @@ class HTSAT(HTSATNetBase):
         return {self.out_key: self._run(x)}
 
 
+def copy_passt_entry(dst, src, ck, in_channels):
+    """accdoa.py:273-300 for one encoder entry `src` of an AudioSet PaSST checkpoint `ck`."""
+    if src == 'patch_embed.proj.weight':
+        dst.copy_(ck[src].repeat(1, in_channels, 1, 1) / in_channels)
+    elif src in ('time_new_pos_embed', 'freq_new_pos_embed'):
+        axis = -1 if src.startswith('time') else -2
+        have, want = ck[src].shape[axis], dst.shape[axis]
+        if have >= want:
+            dst.copy_(ck[src].narrow(axis, int((have - want) / 2), want))
+        else:
+            dst.copy_(torch.nn.functional.interpolate(ck[src], size=(1, want), mode='bilinear'))
+    elif 'head' in src:
+        if src in ('head.0.weight', 'head.0.bias'):
+            dst.copy_(ck[src])
+    else:
+        dst.copy_(ck[src])
+
+
 class PASST(HTSATNetBase):
     """models/accdoa.py:249-329: scalar BatchNorms -> PaSST -> Linear(E, 3*C) -> tanh."""
     out_key = 'accdoa'
@@ -149,23 +167,8 @@ class PASST(HTSATNetBase):
         if audioset_pretrain:
             ck = torch.load(pretrained_path, map_location='cpu')
             for key in own:
-                if not key.startswith('encoder.'):
-                    continue
-                src = key[len('encoder.'):]
-                if src == 'patch_embed.proj.weight':
-                    own[key].copy_(ck[src].repeat(1, self.in_channels, 1, 1) / self.in_channels)
-                elif src in ('time_new_pos_embed', 'freq_new_pos_embed'):
-                    axis = -1 if src.startswith('time') else -2
-                    have, want = ck[src].shape[axis], own[key].shape[axis]
-                    if have >= want:
-                        own[key].copy_(ck[src].narrow(axis, int((have - want) / 2), want))
-                    else:
-                        own[key].copy_(torch.nn.functional.interpolate(ck[src], size=(1, want), mode='bilinear'))
-                elif 'head' in src:
-                    if src in ('head.0.weight', 'head.0.bias'):
-                        own[key].copy_(ck[src])
-                else:
-                    own[key].copy_(ck[src])
+                if key.startswith('encoder.'):
+                    copy_passt_entry(own[key], key[len('encoder.'):], ck, self.in_channels)
         else:
             ck = torch.load(pretrained_path, map_location='cpu')['state_dict']
             ck = {k.replace('net.', '').replace('_orig_mod.', ''): v for k, v in ck.items()}
@@ -212,11 +215,55 @@ class PASST(HTSATNetBase):
         return {self.out_key: self._run(x)}
 
 
-class CRNN(HTSATNetBase):
+def decoder_config(cfg):
+    """(cfg.model.decoder, cfg.model.num_decoder_layers) of an attribute- or dict-style config."""
+    model = cfg.model if hasattr(cfg, 'model') else cfg.get('model', {})
+    if model is None:
+        return None, 2
+    decoder = model.decoder if hasattr(model, 'decoder') else model.get('decoder')
+    n_layers = model.num_decoder_layers if hasattr(model, 'num_decoder_layers') else model.get('num_decoder_layers', 2)
+    return decoder, n_layers
+
+
+def make_decoder(arena, prefix, decoder, num_feats, n_layers):
+    """model_utilities.py:245-263 `Decoder`: the block stack behind `prefix` (= '<name>.decoder.'), None for nn.Identity."""
+    if decoder == 'conformer':
+        return ConformerDecoder(arena, prefix, num_feats, n_layers)
+    if decoder == 'gru':
+        return GRUDecoder(arena, prefix, num_feats, n_layers)
+    if decoder == 'transformer':
+        return TransformerDecoder(arena, prefix, num_feats, n_layers)
+    if decoder is None:
+        return None
+    raise NotImplementedError(f"{decoder} is not implemented")          # model_utilities.py:262-263
+
+
+class StaticBufferMixin:
+    """Moves the non-arena buffers of the encoders / decoders (BatchNorm running statistics, positional tables) onto the
+    device when the arena is materialised and keeps them addressable by their reference names in `self._bn_bufs`."""
+    _bn_bufs = None
+
+    def _materialize(self, device):
+        fresh = self._materialized_on != device
+        super()._materialize(device)
+        if fresh:
+            from .components.seld_net import _get
+            self._bn_bufs = {}
+            names = [n for e in self._encoders() for n in e.static_buffers()]
+            for name in names:
+                node = _get(self, name.rsplit('.', 1)[0])
+                leaf = name.rsplit('.', 1)[1]
+                t = node._buffers[leaf].detach().to(device)
+                t = (t.float() if t.is_floating_point() else t.long()).contiguous()
+                node._buffers[leaf] = t
+                self._bn_bufs[name] = t
+
+
+class CRNN(StaticBufferMixin, HTSATNetBase):
     """models/accdoa.py:12-95: scalar BatchNorms -> CNN8 / CNN12 (the PANNs CNN14 conv stack) -> frequency mean ->
     decoder -> 'repeat' x8 interpolation + 10-frame mean -> Linear -> tanh. Built on the MI355X path with
     `cfg.model.decoder` = 'conformer' (configs/model/crnn.yaml:5; ConformerBlocks, model_utilities.py:254-255) or None
-    (nn.Identity, :260-261); the GRU / Transformer decoders are not built yet and raise."""
+    (nn.Identity, :260-261), 'gru' or 'transformer'."""
     out_key = 'accdoa'
     tracks_axes = 3
     decoder_prefix = 'decoder.decoder.'          # Decoder(...).decoder = ConformerBlocks
@@ -225,13 +272,9 @@ class CRNN(HTSATNetBase):
     def __init__(self, cfg, num_classes, in_channels=7, encoder='CNN8', pretrained_path=None, audioset_pretrain=True,
                  num_features=[32, 64, 128, 256]):
         super().__init__()
-        model = cfg.model if hasattr(cfg, 'model') else cfg.get('model', {})
-        decoder = (model.decoder if hasattr(model, 'decoder') else model.get('decoder')) if model is not None else None
+        decoder, n_layers = decoder_config(cfg)
         if self.forced_decoder_layers is not None:
             decoder, n_layers = 'conformer', self.forced_decoder_layers
-        else:
-            n_layers = (model.num_decoder_layers if hasattr(model, 'num_decoder_layers') else model.get('num_decoder_layers', 2)) \
-                if model is not None else 2
         if decoder not in (None, 'conformer', 'gru', 'transformer'):
             raise NotImplementedError(f"{decoder} is not implemented")          # model_utilities.py:262-263
         self.num_classes = num_classes
@@ -239,14 +282,7 @@ class CRNN(HTSATNetBase):
         self._init_common(cfg, in_channels)
         self.conv_enc = ConvEncoder(self.arena, 'convs.', in_channels, encoder, list(num_features))
         self.num_features = list(num_features)
-        if decoder == 'conformer':
-            self.dec_blocks = ConformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
-        elif decoder == 'gru':
-            self.dec_blocks = GRUDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
-        elif decoder == 'transformer':
-            self.dec_blocks = TransformerDecoder(self.arena, self.decoder_prefix, self.num_features[-1], n_layers)
-        else:
-            self.dec_blocks = None
+        self.dec_blocks = make_decoder(self.arena, self.decoder_prefix, decoder, self.num_features[-1], n_layers)
         self.head = FcTanhHead(self.arena, 'fc.', self.num_features[-1], num_classes * self.tracks_axes)
         self._finish_init()
         self._taps = None
@@ -281,21 +317,6 @@ class CRNN(HTSATNetBase):
 
     def _encoders(self):
         return [self.conv_enc] + ([self.dec_blocks] if self.dec_blocks is not None else [])
-
-    def _materialize(self, device):
-        fresh = self._materialized_on != device
-        super()._materialize(device)
-        if fresh:
-            from .components.seld_net import _get
-            self._bn_bufs = {}
-            names = [n for e in self._encoders() for n in e.static_buffers()]
-            for name in names:
-                node = _get(self, name.rsplit('.', 1)[0])
-                leaf = name.rsplit('.', 1)[1]
-                t = node._buffers[leaf].detach().to(device)
-                t = (t.float() if t.is_floating_point() else t.long()).contiguous()
-                node._buffers[leaf] = t
-                self._bn_bufs[name] = t
 
     def _pool(self, device, n_in):
         if self._taps is None or self._taps['i0'].device != device or self._taps['n_in'] != n_in:

@@ -121,44 +121,57 @@ class ConvEncoder:
                                                    training)
         return ops.bn_relu_fwd(y, scale_shift), mean_rstd
 
+    # -- forward / backward, one ConvBlock at a time (the EINV2 CRNN cross-stitches between blocks) -------------------
+    def forward_block(self, i, x, B, T, F, dtype, training, buffers):
+        """ConvBlock i + its average pool (backbone.py:17-28 / :45-57). x: NHWC rows [B*T*F, cin_p]. Returns
+        (rows [B*T'*F', C_i], saved, T', F')."""
+        cout = self.widths[i]
+        cin_p = self.cin_p if i == 0 else self.widths[i - 1]
+        b = f'{self.prefix}conv_block{i + 1}.'
+        W1 = self._weight(b + 'conv1.weight', dtype, cin_p)
+        keep = training and self.keep_im2col
+        y1, A1 = self._conv_fwd(x, W1, B, T, F, keep)
+        z1, mr1 = self._bn(b, 1, y1, training, buffers)
+        W2 = self._weight(b + 'conv2.weight', dtype, cout)
+        y2, A2 = self._conv_fwd(z1, W2, B, T, F, keep)
+        z2, mr2 = self._bn(b, 2, y2, training, buffers)
+        pt, pf = self.pools[i]
+        s = dict(x=x, y1=y1, z1=z1, mr1=mr1, y2=y2, z2=z2, mr2=mr2, T=T, F=F, cin_p=cin_p, A1=A1, A2=A2)
+        return ops.avgpool_fwd(z2, B, T, F, pt, pf), s, T // pt, F // pf
+
+    def backward_block(self, i, dx, s, B, dtype):
+        a, cout = self.arena, self.widths[i]
+        b = f'{self.prefix}conv_block{i + 1}.'
+        pt, pf = self.pools[i]
+        dz2 = ops.avgpool_bwd(dx, B, s['T'], s['F'], pt, pf)
+        dy2 = ops.bn_relu_bwd(s['y2'], s['z2'], dz2, s['mr2'], a.p(b + 'bn2.weight'), a.g(b + 'bn2.weight'), a.g(b + 'bn2.bias'))
+        W2 = self._weight(b + 'conv2.weight', dtype, cout)
+        dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout, s['A2'], b + 'conv2.weight')
+        s['A2'] = None
+        dy1 = ops.bn_relu_bwd(s['y1'], s['z1'], dz1, s['mr1'], a.p(b + 'bn1.weight'), a.g(b + 'bn1.weight'), a.g(b + 'bn1.bias'))
+        W1 = self._weight(b + 'conv1.weight', dtype, s['cin_p'])
+        dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'], s['A1'], b + 'conv1.weight')
+        s['A1'] = None
+        return dx
+
+    def forward_tail(self, x, B, T, F):
+        """x.mean(dim=3) (accdoa.py:81): [B*T*F, C] -> [B*T, C]."""
+        return ops.avgpool_fwd(x, B, T, F, 1, F) if F > 1 else x
+
+    def backward_tail(self, dx, B, T, F):
+        return ops.avgpool_bwd(dx, B, T, F, 1, F) if F > 1 else dx
+
     # -- forward / backward over the whole stack ----------------------------------------------------------------
     def forward(self, x, B, T, F, dtype, training, buffers):
         """x: NHWC rows [B*T*F, cin_p] (already normalised). Returns ([B*T', C_last] after the frequency mean, saved)."""
         saved = []
-        cin, cin_p = self.in_chans, self.cin_p
-        for i, cout in enumerate(self.widths):
-            b = f'{self.prefix}conv_block{i + 1}.'
-            W1 = self._weight(b + 'conv1.weight', dtype, cin_p)
-            keep = training and self.keep_im2col
-            y1, A1 = self._conv_fwd(x, W1, B, T, F, keep)
-            z1, mr1 = self._bn(b, 1, y1, training, buffers)
-            W2 = self._weight(b + 'conv2.weight', dtype, cout)
-            y2, A2 = self._conv_fwd(z1, W2, B, T, F, keep)
-            z2, mr2 = self._bn(b, 2, y2, training, buffers)
-            pt, pf = self.pools[i]
-            saved.append(dict(x=x, y1=y1, z1=z1, mr1=mr1, y2=y2, z2=z2, mr2=mr2, T=T, F=F, cin=cin, cin_p=cin_p, A1=A1, A2=A2))
-            x = ops.avgpool_fwd(z2, B, T, F, pt, pf)
-            T, F, cin, cin_p = T // pt, F // pf, cout, cout
-        if F > 1:
-            x = ops.avgpool_fwd(x, B, T, F, 1, F)              # x.mean(dim=3), accdoa.py:81
-        return x, dict(blocks=saved, T_out=T, F_last=F)
+        for i in range(len(self.widths)):
+            x, s, T, F = self.forward_block(i, x, B, T, F, dtype, training, buffers)
+            saved.append(s)
+        return self.forward_tail(x, B, T, F), dict(blocks=saved, T_out=T, F_last=F)
 
     def backward(self, dx, saved, B, dtype):
-        a = self.arena
-        T, F = saved['T_out'], saved['F_last']
-        if F > 1:
-            dx = ops.avgpool_bwd(dx, B, T, F, 1, F)
+        dx = self.backward_tail(dx, B, saved['T_out'], saved['F_last'])
         for i in reversed(range(len(self.widths))):
-            s, cout = saved['blocks'][i], self.widths[i]
-            b = f'{self.prefix}conv_block{i + 1}.'
-            pt, pf = self.pools[i]
-            dz2 = ops.avgpool_bwd(dx, B, s['T'], s['F'], pt, pf)
-            dy2 = ops.bn_relu_bwd(s['y2'], s['z2'], dz2, s['mr2'], a.p(b + 'bn2.weight'), a.g(b + 'bn2.weight'), a.g(b + 'bn2.bias'))
-            W2 = self._weight(b + 'conv2.weight', dtype, cout)
-            dz1 = self._conv_bwd(dy2, s['z1'], W2, a.g(b + 'conv2.weight'), B, s['T'], s['F'], cout, s['A2'], b + 'conv2.weight')
-            s['A2'] = None
-            dy1 = ops.bn_relu_bwd(s['y1'], s['z1'], dz1, s['mr1'], a.p(b + 'bn1.weight'), a.g(b + 'bn1.weight'), a.g(b + 'bn1.bias'))
-            W1 = self._weight(b + 'conv1.weight', dtype, s['cin_p'])
-            dx = self._conv_bwd(dy1, s['x'], W1, a.g(b + 'conv1.weight'), B, s['T'], s['F'], s['cin_p'], s['A1'], b + 'conv1.weight')
-            s['A1'] = None
+            dx = self.backward_block(i, dx, saved['blocks'][i], B, dtype)
         return dx

@@ -80,14 +80,14 @@ class PasstEncoder:
         B, _, T, _ = feat.shape
         if ops.passt_grid_t(T) != self.Tg:
             raise ValueError(f"PaSST positional grid is built for {self.cfg['img_size'][1]} frames, got {T}")
-        A0 = ops.passt_patchify(feat, scale_shift, dtype)
+        A0 = ops.passt_patchify(feat, scale_shift, dtype, channels=self.in_chans)     # the first in_chans channels of feat
         W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 256)
         P0 = ops.linear_fwd(A0, W, a.p(p + 'patch_embed.proj.bias'))
         x = ops.passt_assemble_fwd(P0, a.p(p + 'time_new_pos_embed'), a.p(p + 'freq_new_pos_embed'), a.p(p + 'cls_token'),
                                    a.p(p + 'dist_token'), a.p(p + 'new_pos_embed'), B, self.Tg)
         return x, dict(A0=A0)
 
-    def backward_front(self, dx, saved, feat, mean_rstd, bn_dw, bn_db, B):
+    def backward_front(self, dx, saved, feat, mean_rstd, bn_dw, bn_db, B, accumulate_bn=False):
         a, p = self.arena, self.prefix
         dtype = dx.dtype
         dP0 = ops.passt_assemble_bwd(dx, a.g(p + 'time_new_pos_embed'), a.g(p + 'freq_new_pos_embed'), a.g(p + 'cls_token'),
@@ -96,7 +96,7 @@ class PasstEncoder:
                          dbias=a.g(p + 'patch_embed.proj.bias'))
         W = a.w(p + 'patch_embed.proj.weight', dtype).view(self.E, self.in_chans * 256)
         dA0 = ops.linear_dgrad(dP0, W)
-        ops.passt_bn_bwd(feat, mean_rstd, dA0, bn_dw, bn_db)
+        ops.passt_bn_bwd(feat, mean_rstd, dA0, bn_dw, bn_db, channels=self.in_chans, accumulate=accumulate_bn)
 
     def forward_block(self, i, x, B, drop_scale=None):
         """Block i (passt.py:97-101)."""

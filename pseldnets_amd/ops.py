@@ -442,25 +442,28 @@ def passt_grid_t(T):
     return _lib.lib().pseld_passt_grid_t(T)
 
 
-def passt_patchify(feat, scale_shift, dtype):
+def passt_patchify(feat, scale_shift, dtype, channels=None):
     _chk(feat, scale_shift)
-    B, C, T, F = feat.shape
+    B, Ctot, T, F = feat.shape
+    C = Ctot if channels is None else channels
     if F != 64:
         raise ValueError("passt_patchify is built for 64 mel bins")
     Tg = passt_grid_t(T)
     A = torch.empty((B * 6 * Tg, C * 256), dtype=dtype, device=feat.device)
-    rc = _lib.lib().pseld_passt_patchify(dtype_code(A), _lib.ptr(feat), _lib.ptr(scale_shift), _lib.ptr(A), B, C, T, _lib.stream_ptr())
+    rc = _lib.lib().pseld_passt_patchify(dtype_code(A), _lib.ptr(feat), _lib.ptr(scale_shift), _lib.ptr(A), B, C, Ctot, T,
+                                         _lib.stream_ptr())
     _lib.check(rc, "pseld_passt_patchify")
     return A
 
 
-def passt_bn_bwd(feat, mean_rstd, dA, dweight, dbias):
+def passt_bn_bwd(feat, mean_rstd, dA, dweight, dbias, channels=None, accumulate=False):
     _chk(feat, mean_rstd, dA, dweight, dbias)
-    B, C, T, _ = feat.shape
+    B, Ctot, T, _ = feat.shape
+    C = Ctot if channels is None else channels
     L = _lib.lib()
     ws = workspace(L.pseld_passt_bn_bwd_workspace(B, C, T), feat.device)
     rc = L.pseld_passt_bn_bwd(dtype_code(dA), _lib.ptr(feat), _lib.ptr(mean_rstd), _lib.ptr(dA), _lib.ptr(dweight), _lib.ptr(dbias),
-                              B, C, T, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+                              B, C, Ctot, T, int(accumulate), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_passt_bn_bwd")
 
 
@@ -516,6 +519,25 @@ def tanh_bwd(dy, y, ldz, dtype):
     dz = torch.empty((rows, ldz), dtype=dtype, device=y.device)
     _lib.check(_lib.lib().pseld_tanh_bwd(dtype_code(dz), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dz), ldz, rows, D, _lib.stream_ptr()),
                "pseld_tanh_bwd")
+    return dz
+
+
+def fc_out_fwd(z, y, D, act_tanh):
+    """y[rows, :D] (f32, row-strided view allowed) = (tanh if act_tanh else identity)(z[rows, :D]); z = padded Linear output."""
+    _chk(z)
+    assert y.dtype == torch.float32 and y.is_cuda and y.stride(1) == 1 and y.shape == (z.shape[0], D)
+    _lib.check(_lib.lib().pseld_fc_out_fwd(dtype_code(z), _lib.ptr(z), z.stride(0), _lib.ptr(y), y.stride(0), z.shape[0], D,
+                                           int(act_tanh), _lib.stream_ptr()), "pseld_fc_out_fwd")
+    return y
+
+
+def fc_out_bwd(dy, y, ldz, dtype, act_tanh):
+    """dz[rows, ldz] = dy * (1 - y^2 if act_tanh else 1), zeros in the padding columns; dy / y f32 row-strided views."""
+    rows, D = dy.shape
+    assert dy.dtype == torch.float32 and dy.is_cuda and dy.stride(1) == 1 and (y is None or y.stride() == dy.stride())
+    dz = torch.empty((rows, ldz), dtype=dtype, device=dy.device)
+    _lib.check(_lib.lib().pseld_fc_out_bwd(dtype_code(dz), _lib.ptr(dy), _lib.ptr(y) if act_tanh else None, dy.stride(0), _lib.ptr(dz),
+                                           ldz, rows, D, int(act_tanh), _lib.stream_ptr()), "pseld_fc_out_bwd")
     return dz
 
 

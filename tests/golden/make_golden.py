@@ -31,6 +31,7 @@ import utils.feature as ref_feature  # noqa: E402
 from oracle import htsat as oh  # noqa: E402
 from oracle import passt as op  # noqa: E402
 from oracle import crnn as oc  # noqa: E402
+from oracle import einv2 as oe  # noqa: E402
 from oracle import synth  # noqa: E402
 
 torch.set_num_threads(8)
@@ -762,8 +763,95 @@ def gen_transformer():
     save('transformer.npz', **out)
 
 
+def _einv2_cfg(decoder, n_layers=1):
+    return R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'),
+                      model=R.AttrDict(decoder=decoder, num_decoder_layers=n_layers, ps_gap=2), adapt=dict())
+
+
+def _einv2_common(make_net, sd, sd_dec, make_net_dec, B, C, out, skip_grad=('scalar.',)):
+    """eval outputs, float64 train outputs / tPIT loss / gradients for the decoder-less net; eval outputs with a decoder."""
+    x = oc.random_features(B, seed=1)
+    net = make_net()
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    net.eval()
+    with torch.no_grad():
+        p = net(x.clone())
+    out['eval_sed'], out['eval_doa'] = p['sed'].numpy(), p['doa'].numpy()
+    net64 = make_net().double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sd.items()})
+    net64.train()
+    pred = net64(x.double().clone())
+    sed_l, doa_l = synth.formula_einv2_label(B, 100, C)
+    ld = loss.einv2.Losses_pit({'sed': 'bce', 'doa': 'mse'}, 'loss_all', 'tPIT', 0.5)(
+        pred, {'sed_label': sed_l.double(), 'doa_label': doa_l.double()})
+    ld['loss_all'].backward()
+    out['train_sed'], out['train_doa'] = pred['sed'].detach().numpy(), pred['doa'].detach().numpy()
+    out['losses'] = np.array([ld['loss_all'].item(), ld['loss_sed'].item(), ld['loss_doa'].item()])
+    names, norms, heads = [], [], []
+    for n, prm in net64.named_parameters():
+        if n.startswith(skip_grad):
+            continue
+        names.append(n); norms.append(prm.grad.norm().item()); heads.append(prm.grad.reshape(-1)[:8].numpy().copy())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_heads'] = np.stack([np.pad(h, (0, 8 - len(h))) for h in heads])
+    sdn = net64.state_dict()
+    out['running_mean'] = torch.stack([sdn[f'scalar.{c}.running_mean'] for c in range(7)]).numpy()
+    out['running_var'] = torch.stack([sdn[f'scalar.{c}.running_var'] for c in range(7)]).numpy()
+    net = make_net_dec()
+    missing, unexpected = net.load_state_dict(sd_dec, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out['dec_state_keys'] = np.array(list(net.state_dict().keys()))
+    net.eval()
+    with torch.no_grad():
+        p = net(x.clone())
+    out['dec_eval_sed'], out['dec_eval_doa'] = p['sed'].numpy(), p['doa'].numpy()
+
+
+def gen_einv2_passt():
+    """einv2.PASST (einv2.py:446-575), ps_gap 2: tiny (E 128, depth 3 -> two stitches, the second in front of block 2)
+    without a decoder and with conformer decoders; configs/model/passt.yaml size, 13 classes, one chunk, eval."""
+    C = 3
+    tiny = dict(embed_dim=128, depth=3, num_heads=2)
+    out = {}
+    _einv2_common(lambda: einv2.PASST(_einv2_cfg(None), C, 7, pretrained_path=None, **passt_kwargs(tiny)),
+                  oe.passt_state(C, 7, tiny, 2, None, seed=0),
+                  oe.passt_state(C, 7, tiny, 2, 'conformer', 1, seed=0),
+                  lambda: einv2.PASST(_einv2_cfg('conformer'), C, 7, pretrained_path=None, **passt_kwargs(tiny)), 2, C, out)
+    net = einv2.PASST(_einv2_cfg(None), 13, 7, pretrained_path=None, **passt_kwargs(PASST_FULL))
+    net.load_state_dict(oe.passt_state(13, 7, PASST_FULL, 2, None, seed=2))
+    net.eval()
+    with torch.no_grad():
+        p = net(oc.random_features(1, seed=3))
+    out['full_sed'], out['full_doa'] = p['sed'].numpy(), p['doa'].numpy()
+    out['full_n_params'] = sum(q.numel() for q in net.parameters())
+    save('einv2_passt.npz', **out)
+
+
+def gen_einv2_crnn():
+    """einv2.CRNN (einv2.py:17-174): CNN8 with small widths without a decoder (eval, float64 train / loss / gradients) and
+    with GRU decoders (eval); configs/model/crnn.yaml widths (CNN12), 13 classes, no decoder, one chunk, eval."""
+    C = 3
+    nf = [8, 16, 32, 64]
+    out = {}
+    _einv2_common(lambda: einv2.CRNN(_einv2_cfg(None), C, 7, encoder='CNN8', pretrained_path=None, num_features=nf),
+                  oe.crnn_state(C, 7, 'CNN8', nf, None, seed=0),
+                  oe.crnn_state(C, 7, 'CNN8', nf, 'gru', 1, seed=0),
+                  lambda: einv2.CRNN(_einv2_cfg('gru'), C, 7, encoder='CNN8', pretrained_path=None, num_features=nf), 3, C, out)
+    net = einv2.CRNN(_einv2_cfg(None), 13, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_FULL)
+    net.load_state_dict(oe.crnn_state(13, 7, 'CNN12', CRNN_FULL, None, seed=2))
+    net.eval()
+    with torch.no_grad():
+        p = net(oc.random_features(1, seed=3))
+    out['full_sed'], out['full_doa'] = p['sed'].numpy(), p['doa'].numpy()
+    out['full_n_params'] = sum(q.numel() for q in net.parameters())
+    save('einv2_crnn.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -781,3 +869,5 @@ if __name__ == '__main__':
     if 'metrics' in which: gen_metrics()
     if 'gru' in which: gen_gru()
     if 'transformer' in which: gen_transformer()
+    if 'einv2_passt' in which: gen_einv2_passt()
+    if 'einv2_crnn' in which: gen_einv2_crnn()

@@ -99,7 +99,7 @@ def test_train_config_composition_and_module_wiring():
     loss = instantiate({'_target_': 'loss.multi_accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'})
     assert loss.loss_dict_keys == ['loss_all', 'loss_adpit', 'loss_other']
     with pytest.raises(NotImplementedError):
-        ModelMoodule['einv2'].CRNN(None, 3)
+        ModelMoodule['einv2'].ConvConformer(None, 3)     # cannot be constructed in the reference either (einv2.py:177-180)
 
 
 def test_pool_taps_equal_the_oracle_interpolate_mean_map():

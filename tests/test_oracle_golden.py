@@ -465,3 +465,69 @@ def test_transformer_decoder_golden():
     for n, norm, head in zip(g['grad_names'], g['grad_norms'], g['grad_heads']):
         gr = p[str(n)].grad
         assert abs(gr.norm().item() - norm) <= 1e-8 * max(norm, 1e-6) + 1e-14, n
+
+
+def _einv2_oracle_check(g, fwd, sd, sd_dec, dec_kw, B):
+    """Shared body: oracle forward (eval fp32, train float64), tPIT loss and every stored gradient against the reference's."""
+    from oracle import crnn as oc
+    x = oc.random_features(B, seed=1)
+    assert set(sd.keys()) == set(str(k) for k in g['state_keys'])
+    assert set(sd_dec.keys()) == set(str(k) for k in g['dec_state_keys'])
+    with torch.no_grad():
+        y = fwd(x.clone(), sd)
+        close(y['sed'], g['eval_sed'], 1e-4)
+        close(y['doa'], g['eval_doa'], 5e-5)
+        y = fwd(x.clone(), sd_dec, **dec_kw)
+        close(y['sed'], g['dec_eval_sed'], 1e-4)
+        close(y['doa'], g['dec_eval_doa'], 5e-5)
+    p = {k: (v.double().clone().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    upd = {}
+    pred = fwd(x.double(), p, training=True, bn_update=upd)
+    assert np.abs(pred['sed'].detach().numpy() - g['train_sed']).max() < 1e-9
+    assert np.abs(pred['doa'].detach().numpy() - g['train_doa']).max() < 1e-9
+    sl, dl = synth.formula_einv2_label(B, 100, 3)
+    ld = ol.tpit(pred, {'sed_label': sl.double(), 'doa_label': dl.double()})
+    assert np.abs(np.array([ld['loss_all'].item(), ld['loss_sed'].item(), ld['loss_doa'].item()]) - g['losses']).max() < 1e-10
+    ld['loss_all'].backward()
+    for n, norm in zip(g['grad_names'], g['grad_norms']):
+        gr = p[str(n)].grad
+        assert abs(gr.norm().item() - norm) <= 1e-7 * max(norm, 1e-6) + 1e-13, n
+    rm = torch.stack([upd[f'scalar.{c}.running_mean'] for c in range(7)]).numpy()
+    assert np.abs(rm - g['running_mean']).max() < 1e-9
+
+
+def test_einv2_passt_golden():
+    """oracle/einv2.py einv2_passt_forward against the reference's einv2.PASST (tiny: no decoder and conformer decoders;
+    configs/model/passt.yaml size, 13 classes)."""
+    from oracle import crnn as oc
+    from oracle import einv2 as oe
+    g = gold('einv2_passt.npz')
+    tiny = dict(embed_dim=128, depth=3, num_heads=2)
+    _einv2_oracle_check(g, lambda x, sd, **kw: oe.einv2_passt_forward(x, sd, tiny, 2, **kw),
+                        oe.passt_state(3, 7, tiny, 2, None, seed=0), oe.passt_state(3, 7, tiny, 2, 'conformer', 1, seed=0),
+                        dict(decoder='conformer', num_decoder_layers=1), 2)
+    full = dict(embed_dim=768, depth=7, num_heads=12)
+    sd = oe.passt_state(13, 7, full, 2, None, seed=2)
+    assert sum(v.numel() for k, v in sd.items() if 'running' not in k and 'num_batches' not in k) == int(g['full_n_params'])
+    with torch.no_grad():
+        y = oe.einv2_passt_forward(oc.random_features(1, seed=3), sd, full, 2)
+    close(y['sed'], g['full_sed'], 2e-4)
+    close(y['doa'], g['full_doa'], 1e-4)
+
+
+def test_einv2_crnn_golden():
+    """oracle/einv2.py einv2_crnn_forward against the reference's einv2.CRNN (CNN8 small widths: no decoder and GRU
+    decoders; configs/model/crnn.yaml widths on CNN12, 13 classes)."""
+    from oracle import crnn as oc
+    from oracle import einv2 as oe
+    g = gold('einv2_crnn.npz')
+    nf = [8, 16, 32, 64]
+    _einv2_oracle_check(g, lambda x, sd, **kw: oe.einv2_crnn_forward(x, sd, 'CNN8', **kw),
+                        oe.crnn_state(3, 7, 'CNN8', nf, None, seed=0), oe.crnn_state(3, 7, 'CNN8', nf, 'gru', 1, seed=0),
+                        dict(decoder='gru', num_decoder_layers=1), 3)
+    sd = oe.crnn_state(13, 7, 'CNN12', CRNN_FULL, None, seed=2)
+    assert sum(v.numel() for k, v in sd.items() if 'running' not in k and 'num_batches' not in k) == int(g['full_n_params'])
+    with torch.no_grad():
+        y = oe.einv2_crnn_forward(oc.random_features(1, seed=3), sd, 'CNN12')
+    close(y['sed'], g['full_sed'], 2e-4)
+    close(y['doa'], g['full_doa'], 1e-4)
