@@ -171,7 +171,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--clips', type=int, default=32, help='60 s clips per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2', 'crnn'],
+    ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2', 'crnn', 'passt_einv2', 'crnn_einv2'],
                     help='htsat = the headline workload (BASELINE.json configs[1]); htsat_einv2 = configs[2] (dual-branch, tPIT); '
                          'passt = the PaSST backbone, same data')
     ap.add_argument('--augment', default='none', choices=['none', 'augmix'],
@@ -224,6 +224,16 @@ def main():
     elif args.backbone == 'htsat_einv2':
         from pseldnets_amd.models import einv2
         net = einv2.HTSAT(cfg, CLASSES, 7, pretrained_path=None)             # einv2.py:189-327: SED + DOA encoders
+    elif args.backbone == 'passt_einv2':
+        from pseldnets_amd.models import einv2
+        cfg['model'] = AttrDict(decoder=None, num_decoder_layers=2, ps_gap=2)       # configs/model/passt.yaml:4-6
+        net = einv2.PASST(cfg, CLASSES, 7, pretrained_path=None)                    # einv2.py:446-575
+    elif args.backbone == 'crnn_einv2':
+        from pseldnets_amd.models import einv2
+        cfg['model'] = AttrDict(decoder=None if args.decoder == 'none' else args.decoder,
+                                num_decoder_layers=2 if args.decoder == 'gru' else 1)
+        net = einv2.CRNN(cfg, CLASSES, 7, encoder='CNN12', pretrained_path=None,
+                         num_features=[64, 128, 256, 512, 1024, 2048])              # einv2.py:17-174, configs/model/crnn.yaml kwargs
     elif args.backbone == 'crnn':
         cfg['model'] = AttrDict(decoder=None if args.decoder == 'none' else args.decoder,
                                 num_decoder_layers=2 if args.decoder == 'gru' else 1)   # configs/model/{crnn,default}.yaml:5-6
@@ -237,7 +247,7 @@ def main():
         import torch.distributed as dist
         for p in net.parameters():            # identical initial weights on every rank
             dist.broadcast(p.data, 0)
-    einv2_mode = args.backbone == 'htsat_einv2'
+    einv2_mode = args.backbone.endswith('_einv2')
     trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
                            process_group=group, sync_bn=False)
     wave, target = synthetic_batch(args.clips, device, 2024 + rank)
@@ -298,8 +308,12 @@ def main():
     clips_per_s = args.clips * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
-    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'crnn': {'conformer': 'CNN14-Conformer (CRNN: CNN12 + 1 Conformer block)', 'gru': 'CNN14-GRU (CRNN: CNN12 + 2-layer BiGRU)', 'none': 'CNN14 (CRNN: CNN12, Identity decoder)'}[args.decoder]}[args.backbone]
+    crnn_names = {'conformer': 'CNN12 x2 + 6 Conformer blocks', 'gru': 'CNN12 x2 + 6 two-layer BiGRUs', 'none': 'CNN12 x2, Identity decoders'}
+    name = {'htsat': 'HTS-AT', 'passt': 'PaSST', 'htsat_einv2': 'HTS-AT EINV2', 'passt_einv2': 'PaSST EINV2',
+            'crnn_einv2': f'CRNN EINV2 ({crnn_names[args.decoder]})', 'crnn': {'conformer': 'CNN14-Conformer (CRNN: CNN12 + 1 Conformer block)', 'gru': 'CNN14-GRU (CRNN: CNN12 + 2-layer BiGRU)', 'none': 'CNN14 (CRNN: CNN12, Identity decoder)'}[args.decoder]}[args.backbone]
     gflop_chunk = {'htsat': GFLOP_PER_CHUNK_TRAIN, 'passt': GFLOP_PER_CHUNK_TRAIN_PASST, 'htsat_einv2': GFLOP_PER_CHUNK_TRAIN_EINV2,
+                   'passt_einv2': 2 * GFLOP_PER_CHUNK_TRAIN_PASST - 0.583,       # two encoders, one feature extraction
+                   'crnn_einv2': 2 * GFLOP_PER_CHUNK_TRAIN_CRNN - 0.583,         # approximate: two conv stacks (decoders vary)
                    'crnn': GFLOP_PER_CHUNK_TRAIN_CRNN}[args.backbone]
     out = {
         "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA") + (" + AugMix" if args.augment == 'augmix' else "") + (" (adapter fine-tuning)" if args.adapt == 'adapter' else ""), "value": round(clips_per_s, 2), "unit": "clips/s",
@@ -307,7 +321,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
                                f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
-                               f"{'dropout 0.1' if args.backbone == 'crnn' else 'drop_path 0.0' if args.backbone == 'passt' else 'drop_path 0.1'}, BN train mode, {'AugMix augmentations (x3 chunks through the network)' if args.augment == 'augmix' else 'no augmentation'}",
+                               f"{'dropout 0.1' if args.backbone.startswith('crnn') else 'drop_path 0.0' if args.backbone.startswith('passt') else 'drop_path 0.1'}, BN train mode, {'AugMix augmentations (x3 chunks through the network)' if args.augment == 'augmix' else 'no augmentation'}",
                    "global_clips": args.clips * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
     }

@@ -43,6 +43,17 @@ ADAPT_GROUPS = {      # configs/adapt/{default,adapter,mono_adapter}.yaml
     'mono_adapter': {'method': 'mono_adapter', 'adapt_kwargs': {'position': ['MlpAdapter', 'SpatialAdapter'], 'type': 'adapter',
                                                                 'mlp_ratio': 0.5, 'act_layer': 'gelu', 'adapter_scalar': 0.1}},
 }
+MODEL_GROUPS = {      # configs/model/{htsat,passt,crnn}.yaml: backbone + kwargs (+ decoder keys); `model=<name>` replaces them
+    'htsat': {'backbone': 'HTSAT', 'kwargs': copy.deepcopy(DEFAULT_CFG['model']['kwargs'])},
+    'passt': {'backbone': 'PASST', 'decoder': None, 'num_decoder_layers': 2, 'ps_gap': 2,
+              'kwargs': {'u_patchout': 0, 's_patchout_t': 0, 's_patchout_f': 0, 'img_size': [64, 1001], 'patch_size': 16, 'stride': 10,
+                         'embed_dim': 768, 'depth': 7, 'num_heads': 12, 'mlp_ratio': 4, 'qkv_bias': True, 'representation_size': None,
+                         'distilled': True, 'drop_rate': 0., 'drop_path_rate': 0., 'norm_layer': None, 'act_layer': None,
+                         'audioset_pretrain': True, 'pretrained_path': None}},
+    'crnn': {'backbone': 'CRNN', 'decoder': 'conformer', 'num_decoder_layers': 1,
+             'kwargs': {'encoder': 'CNN12', 'num_features': [64, 128, 256, 512, 1024, 2048], 'audioset_pretrain': True,
+                        'pretrained_path': None}},
+}
 AUGMENT_GROUPS = {
     'default': {},
     'augmix': {'type': ['specaug', 'crop', 'freqshift', 'rotate', 'trackmix', 'wavmix'], 'AugMix': True},
@@ -50,6 +61,9 @@ AUGMENT_GROUPS = {
 EXPERIMENTS = {
     'synth_maccdoa': {},
     'synth_accdoa': {'model': {'method': 'accdoa', 'loss': {'_target_': 'loss.accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'}}},
+    # configs/experiment/synth_einv2.yaml over configs/loss/einv2_pit.yaml (its augment override is chosen with augment=augmix here)
+    'synth_einv2': {'model': {'method': 'einv2', 'loss': {'_target_': 'loss.einv2.Losses_pit', 'loss_fn': {'sed': 'bce', 'doa': 'mse'},
+                                                       'loss_type': 'loss_all', 'method': 'tPIT', 'loss_beta': 0.5}}},
 }
 
 
@@ -76,6 +90,13 @@ def compose(argv):
         key, _, val = arg.partition('=')
         if key == 'experiment':
             _merge(cfg, copy.deepcopy(EXPERIMENTS[val]))
+            continue
+        if key == 'model':
+            group = copy.deepcopy(MODEL_GROUPS[val])
+            cfg['model']['kwargs'] = {}
+            for k in ('decoder', 'num_decoder_layers', 'ps_gap'):
+                cfg['model'].pop(k, None)
+            _merge(cfg['model'], group)
             continue
         if key == 'augment':
             _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS[val]))
@@ -116,6 +137,14 @@ def synthetic_batch(cfg, method, device, gen):
         batch['ov'] = ['1'] * B                      # one source per synthetic chunk (TrackMix / WavMix pair these)
     elif method == 'accdoa':
         batch['accdoa_label'] = doa.reshape(B, 100, 3 * C)
+        batch['ov'] = ['1'] * B
+    elif method == 'einv2':                          # track-wise labels: the events on track 0 (one class per frame), tracks 1-2 silent
+        first = ((act.cumsum(-1) == 1) & (act > 0)).float()
+        sed = torch.zeros(B, 100, 3, C, device=device)
+        sed[:, :, 0] = first
+        dl = torch.zeros(B, 100, 3, 3, device=device)
+        dl[:, :, 0] = (doa * first.unsqueeze(2)).sum(-1)
+        batch['sed_label'], batch['doa_label'] = sed, dl
         batch['ov'] = ['1'] * B
     else:
         raise NotImplementedError(method)

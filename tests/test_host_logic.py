@@ -100,6 +100,16 @@ def test_train_config_composition_and_module_wiring():
     assert loss.loss_dict_keys == ['loss_all', 'loss_adpit', 'loss_other']
     with pytest.raises(NotImplementedError):
         ModelMoodule['einv2'].ConvConformer(None, 3)     # cannot be constructed in the reference either (einv2.py:177-180)
+    # model groups (configs/model/{passt,crnn}.yaml) and the EINV2 experiment (configs/experiment/synth_einv2.yaml + loss/einv2_pit.yaml)
+    cp = c = compose(['experiment=synth_einv2', 'model=passt', 'model.kwargs.depth=3', 'model.decoder=gru'])
+    assert (c.model.method, c.model.backbone, c.model.ps_gap, c.model.decoder) == ('einv2', 'PASST', 2, 'gru')
+    assert c.model.kwargs.depth == 3 and 'spec_size' not in c.model.kwargs and c.model.loss['method'] == 'tPIT'
+    c = compose(['model=crnn', 'model.decoder=gru', 'model.num_decoder_layers=2'])
+    assert (c.model.backbone, c.model.decoder, c.model.num_decoder_layers, c.model.kwargs.encoder) == ('CRNN', 'gru', 2, 'CNN12')
+    net = ModelMoodule['einv2'].PASST(cp, 3, 7, pretrained_path=None, embed_dim=128, depth=3, num_heads=2)
+    assert {'stitch1.0.weight', 'stitch1.1.weight', 'stitch2.2.weight', 'fc_sed.0.weight', 'fc_doa.2.bias',
+            'sed_decoder.0.decoder.weight_ih_l0', 'doa_encoder.blocks.2.mlp.fc2.bias'} <= set(net.state_dict().keys())
+    assert net.state_dict()['sed_encoder.patch_embed.proj.weight'].shape == (128, 4, 16, 16)
 
 
 def test_pool_taps_equal_the_oracle_interpolate_mean_map():
