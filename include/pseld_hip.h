@@ -311,6 +311,18 @@ int pseld_gru_seq_fwd(int dtype, const void* gi, const void* w_hh, const float* 
 int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, long ld_seq, const void* gates, const void* w_hh,
                       const void* w_hh_t, void* dgi, void* dgh, void* hprev_all, void* carry, void* direct, int B, int T, int H,
                       int reverse, void* stream);
+/* n independent recurrences of ONE geometry (B, T, H) advanced together, one launch per timestep for all of them: the two
+ * directions of a layer (model_utilities.py:250-252, bidirectional=True), or those of all six Decoder('gru') stacks of the
+ * EINV2 tail (einv2.py:52-57,472-476). Every pointer argument marked [n] is a HOST array of n device pointers with the
+ * meaning of the pseld_gru_seq_* argument of the same name; reverse [n] ints. Falls back to n sequential pseld_gru_seq_*
+ * calls for geometries the fused step kernels do not cover (fp32, B > 64). */
+int pseld_gru_multi_fwd(int dtype, int n, const void* const* gi, const void* const* w_hh, const float* const* b_hh,
+                        void* const* seq, long ld_seq, void* const* gates, void* const* gh, const int* reverse, int B, int T,
+                        int H, void* stream);
+int pseld_gru_multi_bwd(int dtype, int n, const void* const* dseq, const void* const* seq, long ld_seq,
+                        const void* const* gates, const void* const* w_hh, const void* const* w_hh_t, void* const* dgi,
+                        void* const* dgh, void* const* hprev_all, void* const* carry, void* const* direct, const int* reverse,
+                        int B, int T, int H, void* stream);
 int pseld_gru_gate_bwd(int dtype, const void* dh, long dh_stride, const void* carry, const void* gates, const void* hprev,
                        long hp_stride, void* dgi, long dgi_stride, void* dgh, void* dhprev, int B, int H, void* stream);
 

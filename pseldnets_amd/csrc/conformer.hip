@@ -945,7 +945,13 @@ __device__ __forceinline__ void skinny_accumulate(f32x16_ (&acc)[2], const bf16_
     }
 }
 
-__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs a) {
+// Up to GRU_MAX_SEQS independent recurrences of one geometry (the two directions of a layer, the six decoders of the EINV2 tail)
+// advance in the SAME launch: blockIdx.y picks the descriptor. The step count, not the work per step, sets the time.
+constexpr int GRU_MAX_SEQS = 12;
+struct GruMultiArgs { GruStepArgs s[GRU_MAX_SEQS]; };
+
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruMultiArgs m) {
+    const GruStepArgs& a = m.s[blockIdx.y];
     __shared__ float red[4][2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
     const int H = a.H, j0 = blockIdx.x * 8;
@@ -991,7 +997,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs a) {
     }
 }
 
-__global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruStepArgs a) {
+__global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruMultiArgs m) {
+    const GruStepArgs& a = m.s[blockIdx.y];
     __shared__ float red[8][2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
     const int H = a.H, j0 = blockIdx.x * 32;
@@ -1050,6 +1057,32 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 /* gi [B, T, 3H] (input projections incl. b_ih), w_hh [3H, H] in the compute dtype, b_hh f32 [3H]; seq = the layer's output
  * [B, T, ld_seq] with this direction's H columns starting at seq (caller offsets the pointer); gates [T, B, 4H]; gh scratch
  * [B, 3H]; reverse != 0 walks t = T-1 .. 0. */
+static void gru_fwd_step_args(GruStepArgs& a, const void* gi, const void* w_hh, const float* b_hh, void* seq, long ld_seq, void* gates, int B, int T,
+                              int H, int reverse, int k) {
+    const int t = reverse ? T - 1 - k : k;
+    const int prev = k > 0 ? (reverse ? T - k : k - 1) : -1;
+    memset(&a, 0, sizeof(a));
+    a.gi = (const bf16_t*)gi + (size_t)t * 3 * H; a.gi_stride = (long)T * 3 * H; a.w = (const bf16_t*)w_hh; a.b_hh = b_hh;
+    a.hprev = prev >= 0 ? (const bf16_t*)seq + (size_t)prev * ld_seq : nullptr; a.h = (bf16_t*)seq + (size_t)t * ld_seq; a.row = (long)T * ld_seq;
+    a.gates = (bf16_t*)gates + (size_t)t * B * 4 * H; a.B = B; a.H = H; a.first = prev < 0;
+}
+
+static void gru_bwd_step_args(GruStepArgs& a, const void* dseq, const void* seq, long ld_seq, const void* gates, const void* w_hh_t, void* dgi,
+                              void* dgh, void* hprev_all, void* carry, void* direct, int B, int T, int H, int reverse, int k) {
+    // step k consumes the dgh / direct of step k+1 (the time index processed just before in the loop) and ping-pongs `direct`
+    const int t = reverse ? T - 1 - k : k;
+    const int tp = k > 0 ? (reverse ? T - k : k - 1) : -1;
+    const int tn = k < T - 1 ? (reverse ? T - 2 - k : k + 1) : -1;
+    memset(&a, 0, sizeof(a));
+    a.w = (const bf16_t*)w_hh_t; a.first = tn < 0; a.B = B; a.H = H; a.row = (long)T * ld_seq; a.gi_stride = (long)T * 3 * H;
+    a.dgh_next = tn >= 0 ? (const bf16_t*)dgh + (size_t)tn * B * 3 * H : nullptr;
+    a.direct_in = (const bf16_t*)((k & 1) ? carry : direct); a.direct_out = (bf16_t*)((k & 1) ? direct : carry);
+    a.gates_in = (const bf16_t*)gates + (size_t)t * B * 4 * H; a.dseq = (const bf16_t*)dseq + (size_t)t * ld_seq;
+    a.hprev = tp >= 0 ? (const bf16_t*)seq + (size_t)tp * ld_seq : nullptr; a.dgi = (bf16_t*)dgi + (size_t)t * 3 * H;
+    a.dgh = (bf16_t*)dgh + (size_t)t * B * 3 * H;
+    a.hprev_out = tp >= 0 ? (bf16_t*)hprev_all + (size_t)t * B * H : nullptr;
+}
+
 extern "C" int pseld_gru_seq_fwd(int dtype, const void* gi, const void* w_hh, const float* b_hh, void* seq, long ld_seq, void* gates, void* gh,
                                  int B, int T, int H, int reverse, void* stream) {
     PSELD_CHECK_ARG(gi && w_hh && b_hh && seq && gates && gh && B > 0 && T > 0 && H > 0 && H % 8 == 0 && ld_seq % 8 == 0, "gru_seq_fwd: bad argument");
@@ -1063,11 +1096,9 @@ extern "C" int pseld_gru_seq_fwd(int dtype, const void* gi, const void* w_hh, co
         const char* hprev = prev >= 0 ? (const char*)seq + (size_t)prev * ld_seq * es : nullptr;
         int rc;
         if (fused) {
-            GruStepArgs a; memset(&a, 0, sizeof(a));
-            a.gi = (const bf16_t*)gi + (size_t)t * 3 * H; a.gi_stride = (long)T * 3 * H; a.w = (const bf16_t*)w_hh; a.b_hh = b_hh;
-            a.hprev = (const bf16_t*)hprev; a.h = (bf16_t*)seq + (size_t)t * ld_seq; a.row = row;
-            a.gates = (bf16_t*)gates + (size_t)t * B * 4 * H; a.B = B; a.H = H; a.first = hprev == nullptr;
-            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, a);
+            GruMultiArgs m;
+            gru_fwd_step_args(m.s[0], gi, w_hh, b_hh, seq, ld_seq, gates, B, T, H, reverse, k);
+            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / 8, 1), dim3(256), 0, (hipStream_t)stream, m);
             prev = t;
             continue;
         }
@@ -1107,16 +1138,9 @@ extern "C" int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, l
         const char* hprev = tp >= 0 ? (const char*)seq + (size_t)tp * ld_seq * es : nullptr;
         char* dgh_t = (char*)dgh + (size_t)t * B * 3 * H * es;
         if (fused) {
-            // step k consumes the dgh / direct of step k+1 (the time index processed just before in this loop) and ping-pongs `direct`
-            const int tn = k < T - 1 ? (reverse ? T - 2 - k : k + 1) : -1;
-            GruStepArgs a; memset(&a, 0, sizeof(a));
-            a.w = (const bf16_t*)w_hh_t; a.first = tn < 0; a.B = B; a.H = H; a.row = row; a.gi_stride = (long)T * 3 * H;
-            a.dgh_next = tn >= 0 ? (const bf16_t*)dgh + (size_t)tn * B * 3 * H : nullptr;
-            a.direct_in = (const bf16_t*)((k & 1) ? carry : direct); a.direct_out = (bf16_t*)((k & 1) ? direct : carry);
-            a.gates_in = (const bf16_t*)gates + (size_t)t * B * 4 * H; a.dseq = (const bf16_t*)dseq + (size_t)t * ld_seq;
-            a.hprev = (const bf16_t*)hprev; a.dgi = (bf16_t*)dgi + (size_t)t * 3 * H; a.dgh = (bf16_t*)dgh_t;
-            a.hprev_out = tp >= 0 ? (bf16_t*)hprev_all + (size_t)t * B * H : nullptr;
-            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / 32), dim3(512), 0, (hipStream_t)stream, a);
+            GruMultiArgs m;
+            gru_bwd_step_args(m.s[0], dseq, seq, ld_seq, gates, w_hh_t, dgi, dgh, hprev_all, carry, direct, B, T, H, reverse, k);
+            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / 32, 1), dim3(512), 0, (hipStream_t)stream, m);
             continue;
         }
         int rc = gru_gate_bwd_impl(dtype, (const char*)dseq + (size_t)t * ld_seq * es, row, have_carry ? carry : nullptr,
@@ -1158,4 +1182,62 @@ extern "C" int pseld_sdpa_small_bwd(int dtype, const void* q, const void* k, con
                                      scratch + (long)T * D + D, B, T, D, heads, workspace, workspace_bytes, stream);
     g_relattn_scale_override = 0.f;
     return rc;
+}
+
+// ---- n independent recurrences of one geometry advanced together (host arrays of n device pointers) --------------------------------------
+extern "C" int pseld_gru_multi_fwd(int dtype, int n, const void* const* gi, const void* const* w_hh, const float* const* b_hh, void* const* seq,
+                                   long ld_seq, void* const* gates, void* const* gh, const int* reverse, int B, int T, int H, void* stream) {
+    PSELD_CHECK_ARG(n > 0 && gi && w_hh && b_hh && seq && gates && gh && reverse, "gru_multi_fwd: bad argument");
+    const bool fused = dtype == PSELD_BF16 && B <= 64 && H % 16 == 0 && ld_seq % 8 == 0;
+    if (!fused) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = pseld_gru_seq_fwd(dtype, gi[i], w_hh[i], b_hh[i], seq[i], ld_seq, gates[i], gh[i], B, T, H, reverse[i], stream);
+            if (rc != PSELD_OK) return rc;
+        }
+        return PSELD_OK;
+    }
+    for (int i = 0; i < n; ++i) PSELD_CHECK_ARG(gi[i] && w_hh[i] && b_hh[i] && seq[i] && gates[i], "gru_multi_fwd: null pointer");
+    PSELD_CHECK_ARG(B > 0 && T > 0 && H > 0, "gru_multi_fwd: bad geometry");
+    for (int i0 = 0; i0 < n; i0 += GRU_MAX_SEQS) {
+        const int cnt = n - i0 < GRU_MAX_SEQS ? n - i0 : GRU_MAX_SEQS;
+        for (int k = 0; k < T; ++k) {
+            GruMultiArgs m;
+            for (int i = 0; i < cnt; ++i)
+                gru_fwd_step_args(m.s[i], gi[i0 + i], w_hh[i0 + i], b_hh[i0 + i], seq[i0 + i], ld_seq, gates[i0 + i], B, T, H, reverse[i0 + i], k);
+            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / 8, cnt), dim3(256), 0, (hipStream_t)stream, m);
+        }
+    }
+    PSELD_LAUNCH_CHECK("gru_multi_fwd");
+    return PSELD_OK;
+}
+
+extern "C" int pseld_gru_multi_bwd(int dtype, int n, const void* const* dseq, const void* const* seq, long ld_seq, const void* const* gates,
+                                   const void* const* w_hh, const void* const* w_hh_t, void* const* dgi, void* const* dgh, void* const* hprev_all,
+                                   void* const* carry, void* const* direct, const int* reverse, int B, int T, int H, void* stream) {
+    PSELD_CHECK_ARG(n > 0 && dseq && seq && gates && w_hh && dgi && dgh && hprev_all && carry && direct && reverse, "gru_multi_bwd: bad argument");
+    bool fused = dtype == PSELD_BF16 && B <= 64 && H % 32 == 0 && w_hh_t != nullptr;
+    for (int i = 0; fused && i < n; ++i) fused = w_hh_t[i] != nullptr;
+    if (!fused) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = pseld_gru_seq_bwd(dtype, dseq[i], seq[i], ld_seq, gates[i], w_hh[i], w_hh_t ? w_hh_t[i] : nullptr, dgi[i], dgh[i],
+                                             hprev_all[i], carry[i], direct[i], B, T, H, reverse[i], stream);
+            if (rc != PSELD_OK) return rc;
+        }
+        return PSELD_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        PSELD_CHECK_ARG(dseq[i] && seq[i] && gates[i] && dgi[i] && dgh[i] && hprev_all[i] && carry[i] && direct[i], "gru_multi_bwd: null pointer");
+    PSELD_CHECK_ARG(B > 0 && T > 0 && H > 0, "gru_multi_bwd: bad geometry");
+    for (int i0 = 0; i0 < n; i0 += GRU_MAX_SEQS) {
+        const int cnt = n - i0 < GRU_MAX_SEQS ? n - i0 : GRU_MAX_SEQS;
+        for (int k = T - 1; k >= 0; --k) {
+            GruMultiArgs m;
+            for (int i = 0; i < cnt; ++i)
+                gru_bwd_step_args(m.s[i], dseq[i0 + i], seq[i0 + i], ld_seq, gates[i0 + i], w_hh_t[i0 + i], dgi[i0 + i], dgh[i0 + i],
+                                  hprev_all[i0 + i], carry[i0 + i], direct[i0 + i], B, T, H, reverse[i0 + i], k);
+            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / 32, cnt), dim3(512), 0, (hipStream_t)stream, m);
+        }
+    }
+    PSELD_LAUNCH_CHECK("gru_multi_bwd");
+    return PSELD_OK;
 }

@@ -31,38 +31,66 @@ class GRUDecoder:
 
     def forward(self, x, B, T, training=None, buffers=None):
         """x [B*T, I] (row b*T + t) -> [B*T, 2H] (forward | reverse hidden states)."""
-        a, H, dt = self.arena, self.H, x.dtype
-        saved = []
-        for layer in range(self.L):
-            out = torch.empty((B * T, 2 * H), dtype=dt, device=x.device)
-            o3 = out.view(B, T, 2 * H)
-            per_dir = []
-            for d, sfx in enumerate(('', '_reverse')):
-                p = f'{self.prefix}%s_l{layer}{sfx}'
-                gi = ops.linear_fwd(x, a.w(p % 'weight_ih', dt), a.p(p % 'bias_ih')).view(B, T, 3 * H)
-                gates = torch.empty((T, B, 4 * H), dtype=dt, device=x.device)
-                ops.gru_seq_fwd(gi, a.w(p % 'weight_hh', dt), a.p(p % 'bias_hh'), o3[:, :, d * H:(d + 1) * H], gates, reverse=d == 1)
-                per_dir.append(gates)
-            saved.append(dict(x=x, out=out, gates=per_dir))
-            x = out
-        return x, dict(layers=saved, T=T)
+        outs, saved = self.forward_many([self], [x], B, T)
+        return outs[0], saved[0]
 
     def backward(self, dout, saved, B):
         """dout [B*T, 2H] -> dx [B*T, I]; parameter gradients land in the arena."""
-        a, H, T, dt = self.arena, self.H, saved['T'], dout.dtype
-        for layer in reversed(range(self.L)):
-            sv = saved['layers'][layer]
-            x, o3, d3 = sv['x'], sv['out'].view(B, T, 2 * H), dout.view(B, T, 2 * H)
-            dx = None
-            for d, sfx in enumerate(('', '_reverse')):
-                p = f'{self.prefix}%s_l{layer}{sfx}'
-                w_hh, w_hh_t = a.w(p % 'weight_hh', dt), a.wt(p % 'weight_hh', dt)
-                gates = sv['gates'][d]
-                dgi, dgh, hprev_all = ops.gru_seq_bwd(d3[:, :, d * H:(d + 1) * H], o3[:, :, d * H:(d + 1) * H], gates, w_hh, w_hh_t,
-                                                      reverse=d == 1)
-                dgi2 = dgi.view(B * T, 3 * H)
-                ops.linear_wgrad(dgh.view(T * B, 3 * H), hprev_all.view(T * B, H), a.g(p % 'weight_hh'), dbias=a.g(p % 'bias_hh'))
-                ops.linear_wgrad(dgi2, x, a.g(p % 'weight_ih'), dbias=a.g(p % 'bias_ih'))
-                dx = ops.linear_dgrad(dgi2, a.w(p % 'weight_ih', dt), wt=a.wt(p % 'weight_ih', dt), resid=dx)
-            dout = dx
-        return dout
+        return self.backward_many([self], [dout], [saved], B)[0]
+
+    @staticmethod
+    def forward_many(decs, xs, B, T):
+        """Several GRU stacks of one geometry (the six decoders of the EINV2 tail; a single stack is the two directions of each
+        layer) advanced together: per layer ONE launch per timestep covers every stack and direction."""
+        L, H = decs[0].L, decs[0].H
+        assert all(d.L == L and d.H == H for d in decs)
+        dt = xs[0].dtype
+        saved = [[] for _ in decs]
+        xs = list(xs)
+        for layer in range(L):
+            outs = [torch.empty((B * T, 2 * H), dtype=dt, device=xs[0].device) for _ in decs]
+            gis, whh, bhh, seqs, gates, rev = [], [], [], [], [], []
+            for dec, x, out in zip(decs, xs, outs):
+                a, o3 = dec.arena, out.view(B, T, 2 * H)
+                for d, sfx in enumerate(('', '_reverse')):
+                    p = f'{dec.prefix}%s_l{layer}{sfx}'
+                    gis.append(ops.linear_fwd(x, a.w(p % 'weight_ih', dt), a.p(p % 'bias_ih')).view(B, T, 3 * H))
+                    whh.append(a.w(p % 'weight_hh', dt)); bhh.append(a.p(p % 'bias_hh'))
+                    seqs.append(o3[:, :, d * H:(d + 1) * H])
+                    gates.append(torch.empty((T, B, 4 * H), dtype=dt, device=x.device))
+                    rev.append(d == 1)
+            ops.gru_multi_fwd(gis, whh, bhh, seqs, gates, rev)
+            for i, (x, out) in enumerate(zip(xs, outs)):
+                saved[i].append(dict(x=x, out=out, gates=gates[2 * i:2 * i + 2]))
+            xs = outs
+        return xs, [dict(layers=s, T=T) for s in saved]
+
+    @staticmethod
+    def backward_many(decs, douts, saveds, B):
+        L, H, T = decs[0].L, decs[0].H, saveds[0]['T']
+        dt = douts[0].dtype
+        douts = list(douts)
+        for layer in reversed(range(L)):
+            dseqs, seqs, gates, whh, whht, rev = [], [], [], [], [], []
+            for dec, dout, sv in zip(decs, douts, saveds):
+                a, s = dec.arena, sv['layers'][layer]
+                o3, d3 = s['out'].view(B, T, 2 * H), dout.view(B, T, 2 * H)
+                for d, sfx in enumerate(('', '_reverse')):
+                    p = f'{dec.prefix}%s_l{layer}{sfx}'
+                    dseqs.append(d3[:, :, d * H:(d + 1) * H]); seqs.append(o3[:, :, d * H:(d + 1) * H]); gates.append(s['gates'][d])
+                    whh.append(a.w(p % 'weight_hh', dt)); whht.append(a.wt(p % 'weight_hh', dt)); rev.append(d == 1)
+            dgis, dghs, hprevs = ops.gru_multi_bwd(dseqs, seqs, gates, whh, whht, rev)
+            new = []
+            for i, (dec, sv) in enumerate(zip(decs, saveds)):
+                a, x = dec.arena, sv['layers'][layer]['x']
+                dx = None
+                for d, sfx in enumerate(('', '_reverse')):
+                    p = f'{dec.prefix}%s_l{layer}{sfx}'
+                    dgi2 = dgis[2 * i + d].view(B * T, 3 * H)
+                    ops.linear_wgrad(dghs[2 * i + d].view(T * B, 3 * H), hprevs[2 * i + d].view(T * B, H), a.g(p % 'weight_hh'),
+                                     dbias=a.g(p % 'bias_hh'))
+                    ops.linear_wgrad(dgi2, x, a.g(p % 'weight_ih'), dbias=a.g(p % 'bias_ih'))
+                    dx = ops.linear_dgrad(dgi2, a.w(p % 'weight_ih', dt), wt=a.wt(p % 'weight_ih', dt), resid=dx)
+                new.append(dx)
+            douts = new
+        return douts

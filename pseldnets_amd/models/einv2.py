@@ -11,6 +11,7 @@ from .. import ops
 from . import accdoa
 from .accdoa import StaticBufferMixin, decoder_config, make_decoder
 from .components.crnn import ConvEncoder
+from .components.gru import GRUDecoder
 from .components.htsat import SwinEncoder, TscamHead
 from .components.passt import PasstEncoder
 from .components.seld_net import HTSATNetBase
@@ -57,9 +58,15 @@ class EinTracks:
         sed = torch.empty((rows, 3, self.C), dtype=torch.float32, device=xs.device)
         doa = torch.empty((rows, 3, 3), dtype=torch.float32, device=xs.device)
         saved = []
+        many = None
+        if isinstance(self.sed_dec[0], GRUDecoder):          # the six recurrences advance together, one launch per timestep
+            many = GRUDecoder.forward_many(self.sed_dec + self.doa_dec, [xs] * 3 + [xd] * 3, B, T)
         for t in range(3):
-            ps, s_s = self.sed_dec[t].forward(xs, B, T, training, buffers) if self.sed_dec[t] is not None else (xs, None)
-            pd, s_d = self.doa_dec[t].forward(xd, B, T, training, buffers) if self.doa_dec[t] is not None else (xd, None)
+            if many is not None:
+                (ps, pd), (s_s, s_d) = (many[0][t], many[0][3 + t]), (many[1][t], many[1][3 + t])
+            else:
+                ps, s_s = self.sed_dec[t].forward(xs, B, T, training, buffers) if self.sed_dec[t] is not None else (xs, None)
+                pd, s_d = self.doa_dec[t].forward(xd, B, T, training, buffers) if self.doa_dec[t] is not None else (xd, None)
             qs, qd = ops.cross_stitch_fwd(ps, pd, a.p(n['stitch'](t) + 'weight').view(-1, 4))
             if taps is not None:
                 qs, qd = ops.rows_pool_fwd(qs, taps, B), ops.rows_pool_fwd(qd, taps, B)
@@ -75,6 +82,8 @@ class EinTracks:
         ddoa = ddoa.contiguous().float().view(-1, 3, 3)
         doa, taps = saved['doa'], saved['taps']
         dxs = dxd = None
+        gru = isinstance(self.sed_dec[0], GRUDecoder)
+        pend_s, pend_d = [], []
         for t in range(3):
             s = saved['tracks'][t]
             dqs = self._fc_bwd(n['fc_sed'](t), dsed[:, t], None, s['qs'], self.Cp, False)
@@ -83,12 +92,20 @@ class EinTracks:
                 dqs, dqd = ops.rows_pool_bwd(dqs, taps, B), ops.rows_pool_bwd(dqd, taps, B)
             dps, dpd = ops.cross_stitch_bwd(s['ps'], s['pd'], a.p(n['stitch'](t) + 'weight').view(-1, 4), dqs, dqd,
                                             a.g(n['stitch'](t) + 'weight').view(-1, 4))
+            if gru:
+                pend_s.append(dps); pend_d.append(dpd)
+                continue
             if self.sed_dec[t] is not None:
                 dps = self.sed_dec[t].backward(dps, s['s_s'], B)
             if self.doa_dec[t] is not None:
                 dpd = self.doa_dec[t].backward(dpd, s['s_d'], B)
             dxs = dps if dxs is None else ops.add(dxs, dps)
             dxd = dpd if dxd is None else ops.add(dxd, dpd)
+        if gru:
+            tr = saved['tracks']
+            d = GRUDecoder.backward_many(self.sed_dec + self.doa_dec, pend_s + pend_d,
+                                         [tr[t]['s_s'] for t in range(3)] + [tr[t]['s_d'] for t in range(3)], B)
+            dxs, dxd = ops.add(ops.add(d[0], d[1]), d[2]), ops.add(ops.add(d[3], d[4]), d[5])
         return dxs, dxd
 
 

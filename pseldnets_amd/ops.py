@@ -982,6 +982,49 @@ def gru_seq_bwd(dseq_dir, seq_dir, gates, w_hh, w_hh_t, reverse):
     return dgi, dgh, hprev_all
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def gru_multi_fwd(gis, w_hhs, b_hhs, seq_dirs, gates, reverses):
+    """n independent recurrences of one geometry advanced together (one launch per timestep for all of them): lists of the
+    gru_seq_fwd arguments. seq_dirs: [B,T,H] column slices, all with the same strides."""
+    import ctypes
+    _chk(*gis, *w_hhs, *b_hhs, *gates)
+    n = len(gis)
+    B, T, H = seq_dirs[0].shape
+    st = seq_dirs[0].stride()
+    assert all(sd.shape == (B, T, H) and sd.stride() == st for sd in seq_dirs) and st[2] == 1
+    ghs = [torch.empty((B, 3 * H), dtype=gis[0].dtype, device=gis[0].device) for _ in range(n)]
+    rev = (ctypes.c_int * n)(*[int(r) for r in reverses])
+    _lib.check(_lib.lib().pseld_gru_multi_fwd(dtype_code(gis[0]), n, _ptr_array(gis), _ptr_array(w_hhs), _ptr_array(b_hhs), _ptr_array(seq_dirs),
+                                              st[1], _ptr_array(gates), _ptr_array(ghs), rev, B, T, H, _lib.stream_ptr()), "pseld_gru_multi_fwd")
+
+
+def gru_multi_bwd(dseq_dirs, seq_dirs, gates, w_hhs, w_hh_ts, reverses):
+    """BPTT of gru_multi_fwd: returns lists (dgi [B,T,3H], dgh [T,B,3H], hprev_all [T,B,H]) per recurrence."""
+    import ctypes
+    _chk(*gates, *w_hhs, *[w for w in w_hh_ts if w is not None])
+    n = len(gates)
+    B, T, H = seq_dirs[0].shape
+    st = seq_dirs[0].stride()
+    assert all(a.shape == (B, T, H) and a.stride() == st for a in list(seq_dirs) + list(dseq_dirs)) and st[2] == 1
+    dt, dev = gates[0].dtype, gates[0].device
+    dgi = [torch.empty((B, T, 3 * H), dtype=dt, device=dev) for _ in range(n)]
+    dgh = [torch.empty((T, B, 3 * H), dtype=dt, device=dev) for _ in range(n)]
+    hprev_all = [torch.zeros((T, B, H), dtype=dt, device=dev) for _ in range(n)]
+    carry = [torch.empty((B, H), dtype=dt, device=dev) for _ in range(n)]
+    direct = [torch.empty((B, H), dtype=dt, device=dev) for _ in range(n)]
+    rev = (ctypes.c_int * n)(*[int(r) for r in reverses])
+    have_t = all(w is not None for w in w_hh_ts)
+    _lib.check(_lib.lib().pseld_gru_multi_bwd(dtype_code(gates[0]), n, _ptr_array(dseq_dirs), _ptr_array(seq_dirs), st[1], _ptr_array(gates),
+                                              _ptr_array(w_hhs), _ptr_array(w_hh_ts) if have_t else None, _ptr_array(dgi), _ptr_array(dgh),
+                                              _ptr_array(hprev_all), _ptr_array(carry), _ptr_array(direct), rev, B, T, H, _lib.stream_ptr()),
+               "pseld_gru_multi_bwd")
+    return dgi, dgh, hprev_all
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Transformer decoder glue (csrc/conformer.hip)
 def relu_fwd(u):
