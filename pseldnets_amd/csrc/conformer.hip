@@ -955,6 +955,18 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruMultiArgs m) {
     __shared__ float red[4][2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
     const int H = a.H, j0 = blockIdx.x * 8;
+    // the cell operands of this thread's (unit, sample) pairs are fetched first: their latency hides behind the recurrent product
+    float pgi[2][3], pbh[2][3], php[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = threadIdx.x + 256 * it, u = idx & 7, b = idx >> 3, j = j0 + u;
+        if (idx < 8 * a.B) {
+            const bf16_t* gib = a.gi + b * a.gi_stride;
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) { pgi[it][gt] = (float)gib[gt * H + j]; pbh[it][gt] = a.b_hh[gt * H + j]; }
+            php[it] = a.first ? 0.f : (float)a.hprev[b * a.row + j];
+        }
+    }
     if (!a.first) {
         f32x16_ acc[2];
 #pragma unroll
@@ -973,12 +985,15 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruMultiArgs m) {
         __syncthreads();
     }
     // the cell update of the 8 units x B samples of this workgroup, spread over all 256 threads (unit fastest)
-    for (int idx = threadIdx.x; idx < 8 * a.B; idx += 256) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = threadIdx.x + 256 * it;
+        if (idx >= 8 * a.B) break;
         const int u = idx & 7, b = idx >> 3, j = j0 + u;
         float g3[3];
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) {
-            float v = a.b_hh[gt * H + j];
+            float v = pbh[it][gt];
             if (!a.first) {
                 const int t = b >> 5, e = 4 * gt + (u & 3), ln = (b & 31) + 32 * (u >> 2);          // tile row gt*8 + u
 #pragma unroll
@@ -986,29 +1001,46 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruMultiArgs m) {
             }
             g3[gt] = v;
         }
-        const bf16_t* gib = a.gi + b * a.gi_stride;
-        const float rr = sigmoidf_((float)gib[j] + g3[0]);
-        const float zz = sigmoidf_((float)gib[H + j] + g3[1]);
-        const float nn = tanhf((float)gib[2 * H + j] + rr * g3[2]);
-        const float hp = a.first ? 0.f : (float)a.hprev[b * a.row + j];
+        const float rr = sigmoidf_(pgi[it][0] + g3[0]);
+        const float zz = sigmoidf_(pgi[it][1] + g3[1]);
+        const float nn = tanhf(pgi[it][2] + rr * g3[2]);
+        const float hp = php[it];
         a.h[b * a.row + j] = (bf16_t)((1.f - zz) * nn + zz * hp);
         bf16_t* gs = a.gates + (long)b * 4 * H;
         gs[j] = (bf16_t)rr; gs[H + j] = (bf16_t)zz; gs[2 * H + j] = (bf16_t)nn; gs[3 * H + j] = (bf16_t)g3[2];
     }
 }
 
+// UB hidden units per workgroup: the 32-row MFMA tile is only partly used for UB < 32, but the launch is latency-bound and more,
+// shorter workgroups finish sooner (each reads UB rows of W_hh^T = UB x 3H weights)
+template <int UB>
 __global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruMultiArgs m) {
     const GruStepArgs& a = m.s[blockIdx.y];
     __shared__ float red[8][2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
-    const int H = a.H, j0 = blockIdx.x * 32;
+    const int H = a.H, j0 = blockIdx.x * UB;
+    // gate values, h_{t-1}, the output gradient and the direct carry term of this thread's (unit, sample) pairs: fetched first
+    constexpr int ITERS = UB / 8;                                               // UB * 64 samples / 512 threads
+    float pg[ITERS][4], php[ITERS], pds[ITERS], pdir[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = threadIdx.x + 512 * it, jl = idx % UB, b = idx / UB, j = j0 + jl;
+        if (idx < UB * a.B) {
+            const bf16_t* g = a.gates_in + (long)b * 4 * H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pg[it][q] = (float)g[q * H + j];
+            php[it] = a.hprev ? (float)a.hprev[b * a.row + j] : 0.f;
+            pds[it] = (float)a.dseq[b * a.row + j];
+            pdir[it] = a.first ? 0.f : (float)a.direct_in[(long)b * H + j];
+        }
+    }
     if (!a.first) {                                                             // carry = direct(t+1) + dgh(t+1) W_hh for units j0..j0+31
         f32x16_ acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-        const bf16_t* wrow = a.w + (long)min(j0 + r, H - 1) * 3 * H + 8 * h2;    // W_hh^T row j
+        const bf16_t* wrow = a.w + (long)(j0 + (r % UB)) * 3 * H + 8 * h2;       // W_hh^T row j (rows >= UB of the tile are unused)
         const bf16_t* a0 = a.dgh_next + (long)min(r, a.B - 1) * 3 * H + 8 * h2;
         const bf16_t* a1 = a.dgh_next + (long)min(32 + r, a.B - 1) * 3 * H + 8 * h2;
         skinny_accumulate(acc, wrow, a0, a1, a.B > 32, (3 * H) >> 4, wave, 8);
@@ -1019,21 +1051,22 @@ __global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruMultiArgs m) {
         __syncthreads();
     }
     // the gate backward of step t for the 32 units x B samples of this workgroup, spread over all 512 threads (unit fastest)
-    for (int idx = threadIdx.x; idx < 32 * a.B; idx += 512) {
-        const int jl = idx & 31, b = idx >> 5, j = j0 + jl;
-        if (j >= H) continue;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = threadIdx.x + 512 * it;
+        if (idx >= UB * a.B) break;
+        const int jl = idx % UB, b = idx / UB, j = j0 + jl;
         float carry = 0.f;
         if (!a.first) {
             const int t = b >> 5, e = (jl & 3) + 4 * (jl >> 3), ln = (b & 31) + 32 * ((jl >> 2) & 1);   // where the MFMA tile keeps (j, b)
-            carry = (float)a.direct_in[(long)b * H + j];
+            carry = pdir[it];
 #pragma unroll
             for (int w = 0; w < 8; ++w) carry += red[w][t][e][ln];
             carry = (float)(bf16_t)carry;                                      // the unfused path stores the carry in bf16
         }
-        const bf16_t* g = a.gates_in + (long)b * 4 * H;
-        const float rr = (float)g[j], zz = (float)g[H + j], nn = (float)g[2 * H + j], ghn = (float)g[3 * H + j];
-        const float hp = a.hprev ? (float)a.hprev[b * a.row + j] : 0.f;
-        const float d = (float)a.dseq[b * a.row + j] + carry;
+        const float rr = pg[it][0], zz = pg[it][1], nn = pg[it][2], ghn = pg[it][3];
+        const float hp = php[it];
+        const float d = pds[it] + carry;
         const float dn = d * (1.f - zz) * (1.f - nn * nn);
         const float dz = d * (hp - nn) * zz * (1.f - zz);
         const float dr = dn * ghn * rr * (1.f - rr);
@@ -1057,6 +1090,13 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 /* gi [B, T, 3H] (input projections incl. b_ih), w_hh [3H, H] in the compute dtype, b_hh f32 [3H]; seq = the layer's output
  * [B, T, ld_seq] with this direction's H columns starting at seq (caller offsets the pointer); gates [T, B, 4H]; gh scratch
  * [B, 3H]; reverse != 0 walks t = T-1 .. 0. */
+static void gru_bwd_launch(const GruMultiArgs& m, int H, int cnt, hipStream_t s) {
+    static const int ub = [] { const char* e = getenv("PSELD_GRU_BWD_UNITS"); return e ? atoi(e) : 8; }();
+    if (ub == 32) hipLaunchKernelGGL(gru_step_bwd_kernel<32>, dim3(H / 32, cnt), dim3(512), 0, s, m);
+    else if (ub == 16) hipLaunchKernelGGL(gru_step_bwd_kernel<16>, dim3(H / 16, cnt), dim3(512), 0, s, m);
+    else hipLaunchKernelGGL(gru_step_bwd_kernel<8>, dim3(H / 8, cnt), dim3(512), 0, s, m);
+}
+
 static void gru_fwd_step_args(GruStepArgs& a, const void* gi, const void* w_hh, const float* b_hh, void* seq, long ld_seq, void* gates, int B, int T,
                               int H, int reverse, int k) {
     const int t = reverse ? T - 1 - k : k;
@@ -1140,7 +1180,7 @@ extern "C" int pseld_gru_seq_bwd(int dtype, const void* dseq, const void* seq, l
         if (fused) {
             GruMultiArgs m;
             gru_bwd_step_args(m.s[0], dseq, seq, ld_seq, gates, w_hh_t, dgi, dgh, hprev_all, carry, direct, B, T, H, reverse, k);
-            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / 32, 1), dim3(512), 0, (hipStream_t)stream, m);
+            gru_bwd_launch(m, H, 1, (hipStream_t)stream);
             continue;
         }
         int rc = gru_gate_bwd_impl(dtype, (const char*)dseq + (size_t)t * ld_seq * es, row, have_carry ? carry : nullptr,
@@ -1235,7 +1275,7 @@ extern "C" int pseld_gru_multi_bwd(int dtype, int n, const void* const* dseq, co
             for (int i = 0; i < cnt; ++i)
                 gru_bwd_step_args(m.s[i], dseq[i0 + i], seq[i0 + i], ld_seq, gates[i0 + i], w_hh_t[i0 + i], dgi[i0 + i], dgh[i0 + i],
                                   hprev_all[i0 + i], carry[i0 + i], direct[i0 + i], B, T, H, reverse[i0 + i], k);
-            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / 32, cnt), dim3(512), 0, (hipStream_t)stream, m);
+            gru_bwd_launch(m, H, cnt, (hipStream_t)stream);
         }
     }
     PSELD_LAUNCH_CHECK("gru_multi_bwd");
