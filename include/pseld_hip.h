@@ -349,6 +349,15 @@ int pseld_mse_loss(const float* pred, const float* target, float* dpred, float* 
 int pseld_tpit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label, float* dsed,
                     float* ddoa, float* loss_out, long rows, int C, float beta, float* workspace, long workspace_bytes,
                     void* stream);
+/* loss/einv2.py:118-188 AGG loss (Losses_agg_pit; configs/loss/einv2_pit_agg.yaml): the EINV2 / SEDDOA outputs scored as
+ * multi-ACCDOA vectors pred[k,c,:] = sigmoid(sed[k,c]) * normalize(doa[k,:]) against sed_label[k,c] * doa_label[k,:]:
+ * agg = track-permutation-invariant mean error (:166-188), accdoa = mean error of the track sums (:148-153);
+ * loss_all = w_agg * agg + w_acc * accdoa ((1,0) = method mACCDOA_pit, (0,1) = ACCDOA, (alpha, 1-alpha) otherwise);
+ * l1 != 0 = loss_fn 'l1', else 'mse'. loss_out[0..2] = all, agg, accdoa; dsed / ddoa = gradients of loss_all. */
+long pseld_agg_pit_loss_workspace(long rows);
+int pseld_agg_pit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label, float* dsed,
+                       float* ddoa, float* loss_out, long rows, int C, float w_agg, float w_acc, int l1, float* workspace,
+                       long workspace_bytes, void* stream);
 
 /* ---- optimiser: clip_grad_norm_(max_norm) + AdamW over one flat fp32 arena --------------------------------------
  * models/components/model_module.py:128-146 (AdamW, torch defaults), configs/trainer/default.yaml:26 (clip 1.0). */

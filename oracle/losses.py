@@ -68,15 +68,16 @@ def tpit(pred, target, beta=0.5, max_ov=3):
     return {'loss_all': loss_all.mean(), 'loss_sed': loss_sed.mean(), 'loss_doa': loss_doa.mean(), 'loss_other': 0.}
 
 
-def agg_pit(pred, target, alpha=0.5, method='mACCDOA_pit'):
-    """einv2.py:140-188 (loss_fn mse)."""
+def agg_pit(pred, target, alpha=0.5, method='mACCDOA_pit', loss_fn='mse'):
+    """einv2.py:118-188 (loss_fn mse or l1, :121-126)."""
+    err = F.mse_loss if loss_fn == 'mse' else F.l1_loss
     sed_p = torch.sigmoid(pred['sed'])
     doa_p = F.normalize(pred['doa'], p=2, dim=-1)
     tgt = target['sed_label'][..., None] * target['doa_label'][:, :, :, None, :]
     prd = sed_p[..., None] * doa_p[:, :, :, None, :]
 
     def pit(p, t):
-        per = torch.stack([F.mse_loss(p, t[:, :, list(pm)], reduction='none').mean(dim=(2, 3, 4))
+        per = torch.stack([err(p, t[:, :, list(pm)], reduction='none').mean(dim=(2, 3, 4))
                            for pm in permutations(range(p.shape[2]))], 0)
         idx = torch.argmin(per, dim=0)
         return torch.gather(per, 0, idx.unsqueeze(0)).squeeze(0)
@@ -86,10 +87,10 @@ def agg_pit(pred, target, alpha=0.5, method='mACCDOA_pit'):
         loss_agg = pit(prd, tgt).mean()
         loss_all = loss_agg
     elif method == 'ACCDOA':
-        loss_acc = F.mse_loss(prd.sum(2), tgt.sum(2)).mean()
+        loss_acc = err(prd.sum(2), tgt.sum(2)).mean()
         loss_all = loss_acc
     else:
         loss_agg = pit(prd, tgt).mean()
-        loss_acc = F.mse_loss(prd.sum(2), tgt.sum(2)).mean()
+        loss_acc = err(prd.sum(2), tgt.sum(2)).mean()
         loss_all = alpha * loss_agg + (1 - alpha) * loss_acc
     return {'loss_all': loss_all, 'loss_agg': loss_agg, 'loss_accdoa': loss_acc, 'loss_other': 0.}

@@ -258,6 +258,116 @@ __global__ __launch_bounds__(256) void tpit_kernel(const float* __restrict__ sed
     if (threadIdx.x < 3) partial[(long)threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
+// ---- AGG loss (EINV2 / SEDDOA outputs scored as multi-ACCDOA vectors): one WAVE per (b, t), lanes over the classes -------------
+// pred[k,c,:] = sigmoid(sed[k,c]) * doa[k,:] / max(|doa[k]|, 1e-12); target[m,c,:] = sed_l[m,c] * doa_l[m,:].
+// agg  = min over the 6 track permutations of mean_{k,c,x} err(pred[k] - target[p(k)])   (err = square, or abs when l1)
+// acc  = mean_{c,x} err(sum_k pred[k] - sum_m target[m]);  loss_all = w_agg * agg + w_acc * acc (means over rows too).
+// partial: [3][gridDim.x] sums of (all, agg, acc) per block.
+__global__ __launch_bounds__(256) void agg_pit_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
+                                                      const float* __restrict__ sed_l, const float* __restrict__ doa_l,
+                                                      float* __restrict__ dsed, float* __restrict__ ddoa, float* __restrict__ partial,
+                                                      long rows, int C, float w_agg, float w_acc, int l1, float inv_rows) {
+    __shared__ float red[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    float l_all = 0.f, l_agg = 0.f, l_acc = 0.f;
+    if (row < rows) {
+        float n[3][3], dl[3][3], inv_norm[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v[3], ss = 0.f;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { v[x] = doa[(row * 3 + k) * 3 + x]; ss += v[x] * v[x]; dl[k][x] = doa_l[(row * 3 + k) * 3 + x]; }
+            inv_norm[k] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) n[k][x] = v[x] * inv_norm[k];
+        }
+        float D[3][3], acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) D[k][m] = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float sg[3], sl[3], P[3] = {0.f, 0.f, 0.f}, Tt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                sg[k] = 1.f / (1.f + __expf(-sed[(row * 3 + k) * C + c]));
+                sl[k] = sed_l[(row * 3 + k) * C + c];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { P[x] += sg[k] * n[k][x]; Tt[x] += sl[k] * dl[k][x]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        const float d = sg[k] * n[k][x] - sl[m] * dl[m][x];
+                        D[k][m] += l1 ? fabsf(d) : d * d;
+                    }
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { const float d = P[x] - Tt[x]; acc += l1 ? fabsf(d) : d * d; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) D[k][m] = wave_sum(D[k][m]);
+        acc = wave_sum(acc);
+        static const int PERM[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+        float best = 0.f;
+        int bi = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float tot = (D[0][PERM[q][0]] + D[1][PERM[q][1]] + D[2][PERM[q][2]]) / (9.f * C);
+            if (q == 0 || tot < best) { best = tot; bi = q; }
+        }
+        l_agg = best; l_acc = acc / (3.f * C); l_all = w_agg * l_agg + w_acc * l_acc;
+        const float ga = w_agg * inv_rows / (9.f * C), gb = w_acc * inv_rows / (3.f * C);
+        float dn[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) dn[k][x] = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float sg[3], sl[3], P[3] = {0.f, 0.f, 0.f}, Tt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                sg[k] = 1.f / (1.f + __expf(-sed[(row * 3 + k) * C + c]));
+                sl[k] = sed_l[(row * 3 + k) * C + c];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { P[x] += sg[k] * n[k][x]; Tt[x] += sl[k] * dl[k][x]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int m = PERM[bi][k];
+                float dsg = 0.f;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const float da = sg[k] * n[k][x] - sl[m] * dl[m][x], db = P[x] - Tt[x];
+                    const float gpa = l1 ? (da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f)) : 2.f * da;
+                    const float gpb = l1 ? (db > 0.f ? 1.f : (db < 0.f ? -1.f : 0.f)) : 2.f * db;
+                    const float gp = ga * gpa + gb * gpb;                          // d loss / d pred[k,c,x]
+                    dsg += gp * n[k][x];
+                    dn[k][x] += gp * sg[k];
+                }
+                dsed[(row * 3 + k) * C + c] = dsg * sg[k] * (1.f - sg[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float dot = 0.f;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { dn[k][x] = wave_sum(dn[k][x]); dot += dn[k][x] * n[k][x]; }
+            // F.normalize backward: (dn - n (n . dn)) / |doa|; below the eps clamp the map is linear, v / eps
+            const bool clamped = inv_norm[k] >= 1e12f;
+            if (lane < 3) ddoa[(row * 3 + k) * 3 + lane] = (dn[k][lane] - (clamped ? 0.f : n[k][lane] * dot)) * inv_norm[k];
+        }
+    }
+    if (lane == 0) { red[0][wave] = l_all; red[1][wave] = l_agg; red[2][wave] = l_acc; }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[(long)threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
 // ---- optimiser -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
     __shared__ float red[4];
@@ -385,6 +495,24 @@ extern "C" int pseld_tpit_loss(const float* sed, const float* doa, const float* 
     for (int k = 0; k < 3; ++k)
         hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, workspace + (long)k * nb, nb, inv, loss_out + k);
     PSELD_LAUNCH_CHECK("tpit_loss");
+    return PSELD_OK;
+}
+
+// loss_out[0..2] = (loss_all, loss_agg, loss_accdoa) means over rows = B*T. workspace >= 3*ceil(rows/4) floats.
+extern "C" long pseld_agg_pit_loss_workspace(long rows) { return (long)pseld_cdiv(rows, 4) * 12; }
+extern "C" int pseld_agg_pit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label, float* dsed, float* ddoa,
+                                  float* loss_out, long rows, int C, float w_agg, float w_acc, int l1, float* workspace,
+                                  long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(sed && doa && sed_label && doa_label && dsed && ddoa && loss_out && workspace && rows > 0 && C > 0, "agg_pit_loss: bad arguments");
+    const int nb = pseld_cdiv(rows, 4);
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_agg_pit_loss_workspace(rows), "agg_pit_loss: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const float inv = 1.f / (float)rows;
+    hipLaunchKernelGGL(agg_pit_kernel, dim3(nb), dim3(256), 0, s, sed, doa, sed_label, doa_label, dsed, ddoa, workspace, rows, C, w_agg, w_acc, l1,
+                       inv);
+    for (int k = 0; k < 3; ++k)
+        hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, workspace + (long)k * nb, nb, inv, loss_out + k);
+    PSELD_LAUNCH_CHECK("agg_pit_loss");
     return PSELD_OK;
 }
 

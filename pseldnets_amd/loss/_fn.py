@@ -46,3 +46,19 @@ class TpitFn(torch.autograd.Function):
     def backward(ctx, g_all, g_sed, g_doa):
         dsed, ddoa = ctx.saved_tensors
         return dsed * g_all, ddoa * g_all, None, None, None
+
+
+class AggPitFn(torch.autograd.Function):
+    """returns (loss_all, loss_agg, loss_accdoa); only loss_all carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, sed, doa, sed_label, doa_label, w_agg, w_acc, l1):
+        loss3, dsed, ddoa = ops.agg_pit_loss(sed.contiguous().float(), doa.contiguous().float(),
+                                             sed_label.contiguous().float(), doa_label.contiguous().float(), w_agg, w_acc, l1)
+        ctx.save_for_backward(dsed, ddoa)
+        return loss3[0], loss3[1].detach(), loss3[2].detach()
+
+    @staticmethod
+    def backward(ctx, g_all, g_agg, g_acc):
+        dsed, ddoa = ctx.saved_tensors
+        return dsed * g_all, ddoa * g_all, None, None, None, None, None

@@ -227,13 +227,16 @@ class SELDModelModule:
         if self._trainer is None:
             opt = dict(_get(self.cfg, 'model.optimizer.kwargs', {}))
             sch = dict(_get(self.cfg, 'model.lr_scheduler.kwargs', {}))
+            kind, agg = _LOSS_KIND[self.method], {}
+            if hasattr(self.loss, 'weights'):                       # loss.einv2.Losses_agg_pit (configs/loss/einv2_pit_agg.yaml)
+                kind, agg = 'agg_pit', dict(agg_weights=self.loss.weights(), agg_l1=self.loss.l1)
             self._trainer = FusedTrainer(
-                self.net, self.af_extractor, _LOSS_KIND[self.method], lr=opt.get('lr', 1e-4),
+                self.net, self.af_extractor, kind, lr=opt.get('lr', 1e-4),
                 max_norm=_get(self.cfg, 'trainer.gradient_clip_val', 1.0), weight_decay=opt.get('weight_decay', 0.01),
                 betas=tuple(opt.get('betas', (0.9, 0.999))), eps=opt.get('eps', 1e-8),
                 step_size=sch.get('step_size', 20), gamma=sch.get('gamma', 0.1), process_group=process_group,
                 sync_bn=bool(_get(self.cfg, 'trainer.sync_batchnorm', False)),
-                loss_beta=getattr(self.loss, 'beta', 0.5))
+                loss_beta=getattr(self.loss, 'beta', 0.5), **agg)
         return self._trainer
 
     def fused_training_step(self, batch_sample, process_group=None):

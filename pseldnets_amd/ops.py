@@ -355,6 +355,21 @@ def tpit_loss(sed, doa, sed_label, doa_label, beta):
     return loss, dsed, ddoa
 
 
+def agg_pit_loss(sed, doa, sed_label, doa_label, w_agg, w_acc, l1=False):
+    """AGG loss (loss/einv2.py:118-188): returns (loss f32[3] = all, agg, accdoa; dsed; ddoa)."""
+    _chk(sed, doa, sed_label, doa_label)
+    B, T, _, C = sed.shape
+    rows = B * T
+    L = _lib.lib()
+    ws = workspace(L.pseld_agg_pit_loss_workspace(rows), sed.device)
+    dsed, ddoa = torch.empty_like(sed), torch.empty_like(doa)
+    loss = torch.empty(3, dtype=torch.float32, device=sed.device)
+    rc = L.pseld_agg_pit_loss(_lib.ptr(sed), _lib.ptr(doa), _lib.ptr(sed_label), _lib.ptr(doa_label), _lib.ptr(dsed), _lib.ptr(ddoa),
+                              _lib.ptr(loss), rows, C, float(w_agg), float(w_acc), int(l1), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_agg_pit_loss")
+    return loss, dsed, ddoa
+
+
 def grad_norm(g, out=None):
     _chk(g)
     if out is None:

@@ -62,6 +62,13 @@ EXPERIMENTS = {
     'synth_maccdoa': {},
     'synth_accdoa': {'model': {'method': 'accdoa', 'loss': {'_target_': 'loss.accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'}}},
     # configs/experiment/synth_einv2.yaml over configs/loss/einv2_pit.yaml (its augment override is chosen with augment=augmix here)
+    # configs/experiment/synth_einv2_agg.yaml (einv2.HTSAT) / synth_seddoa_agg.yaml (model.backbone=HTSAT_SEDDOA) over
+    # configs/loss/einv2_pit_agg.yaml
+    'synth_einv2_agg': {'model': {'method': 'einv2', 'loss': {'_target_': 'loss.einv2.Losses_agg_pit', 'loss_fn': 'mse', 'loss_type': 'loss_all',
+                                                           'loss_alpha': 0., 'method': 'mACCDOA_pit'}}},
+    'synth_seddoa_agg': {'model': {'method': 'einv2', 'backbone': 'HTSAT_SEDDOA',
+                                   'loss': {'_target_': 'loss.einv2.Losses_agg_pit', 'loss_fn': 'mse', 'loss_type': 'loss_all',
+                                            'loss_alpha': 0., 'method': 'mACCDOA_pit'}}},
     'synth_einv2': {'model': {'method': 'einv2', 'loss': {'_target_': 'loss.einv2.Losses_pit', 'loss_fn': {'sed': 'bce', 'doa': 'mse'},
                                                        'loss_type': 'loss_all', 'method': 'tPIT', 'loss_beta': 0.5}}},
 }

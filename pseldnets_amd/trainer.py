@@ -14,13 +14,14 @@ from . import ops
 class FusedTrainer:
     def __init__(self, net, af_extractor, loss_kind='adpit', lr=1e-4, max_norm=1.0, weight_decay=0.01,
                  betas=(0.9, 0.999), eps=1e-8, step_size=20, gamma=0.1, process_group=None, sync_bn=False,
-                 loss_beta=0.5):
+                 loss_beta=0.5, agg_weights=(1.0, 0.0), agg_l1=False):
         self.net, self.af, self.loss_kind = net, af_extractor, loss_kind
         self.base_lr, self.max_norm, self.wd, self.betas, self.eps = lr, max_norm, weight_decay, betas, eps
         self.step_size, self.gamma, self.epoch = step_size, gamma, 0
         self.group = process_group
         self.world = 1
         self.loss_beta = loss_beta
+        self.agg_weights, self.agg_l1 = agg_weights, agg_l1      # loss_kind 'agg_pit' (loss/einv2.py:118-188)
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
@@ -54,6 +55,11 @@ class FusedTrainer:
             sed, doa = outs
             l3, dsed, ddoa = ops.tpit_loss(sed, doa, target['sed_label'], target['doa_label'], self.loss_beta)
             return l3[0:1], (dsed, ddoa), {'loss_all': l3[0:1], 'loss_sed': l3[1:2], 'loss_doa': l3[2:3]}
+        if self.loss_kind == 'agg_pit':
+            sed, doa = outs
+            l3, dsed, ddoa = ops.agg_pit_loss(sed, doa, target['sed_label'], target['doa_label'], self.agg_weights[0], self.agg_weights[1],
+                                              self.agg_l1)
+            return l3[0:1], (dsed, ddoa), {'loss_all': l3[0:1], 'loss_agg': l3[1:2], 'loss_accdoa': l3[2:3]}
         raise ValueError(self.loss_kind)
 
     def training_step(self, batch_x, batch_target, is_features=False):

@@ -209,6 +209,14 @@ def gen_losses():
     for method in ('mACCDOA_pit', 'ACCDOA', 'both'):
         ld = loss.einv2.Losses_agg_pit('mse', 'loss_all', 0.5, method)({'sed': sed2, 'doa': doa2}, {'sed_label': sl, 'doa_label': dl})
         out[f'agg_{method}'] = float(ld['loss_all'])
+        # AGG loss with gradients, both error functions (loss/einv2.py:121-126), alpha 0.3 for the mixed method
+        for fn in ('mse', 'l1'):
+            s3 = sed.detach().clone().requires_grad_(True); d3 = doa.detach().clone().requires_grad_(True)
+            ld = loss.einv2.Losses_agg_pit(fn, 'loss_all', 0.3, method)({'sed': s3, 'doa': d3}, {'sed_label': sl, 'doa_label': dl})
+            ld['loss_all'].backward()
+            out[f'agg_{fn}_{method}_losses'] = np.array([float(ld['loss_all']), float(ld['loss_agg']), float(ld['loss_accdoa'])])
+            out[f'agg_{fn}_{method}_grad_sed'] = s3.grad.numpy().copy()
+            out[f'agg_{fn}_{method}_grad_doa'] = d3.grad.numpy().copy()
     save('losses.npz', **out)
 
 

@@ -182,6 +182,10 @@ def test_full_size_forward_vs_golden(dev, kind, dtype, gate):
 @pytest.mark.parametrize("argv", [
     ['experiment=synth_einv2', 'model=passt', 'model.kwargs.embed_dim=128', 'model.kwargs.depth=3', 'model.kwargs.num_heads=2'],
     ['experiment=synth_einv2', 'model=crnn', 'model.decoder=gru', 'model.kwargs.encoder=CNN8', 'model.kwargs.num_features=[8,16,32,64]'],
+    # the AGG-loss experiments (configs/experiment/synth_seddoa_agg.yaml, synth_einv2_agg.yaml over loss/einv2_pit_agg.yaml)
+    ['experiment=synth_seddoa_agg', 'model.kwargs.embed_dim=48', 'model.kwargs.depths=[2,2,2,2]', 'model.kwargs.num_heads=[2,4,8,16]'],
+    ['experiment=synth_einv2_agg', 'model=passt', 'model.kwargs.embed_dim=128', 'model.kwargs.depth=2', 'model.kwargs.num_heads=2',
+     'model.loss.method=both', 'model.loss.loss_alpha=0.5'],
 ])
 def test_train_entry_point_runs_the_einv2_networks(dev, argv, capsys):
     """`python -m pseldnets_amd.train experiment=synth_einv2 model=...`: the module wiring (registry, tPIT loss, fused step)

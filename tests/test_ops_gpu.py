@@ -2,6 +2,7 @@
 Tolerances (max-abs error relative to the reference tensor's max-abs): f32 mode 2e-5 (exact-f32 MFMA, fp32
 reductions in a different order), bf16 mode 2e-2 (inputs are bf16-rounded identically on both sides; outputs are
 rounded to bf16)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -207,6 +208,40 @@ def test_adpit_and_mse_and_tpit_losses(dev):
     assert (loss3.cpu() - ref3).abs().max().item() < 2e-6
     check("tpit dsed", dsed, sr.grad, 1e-4)
     check("tpit ddoa", ddoa, dr.grad, 1e-4)
+
+
+@pytest.mark.parametrize("method", ['mACCDOA_pit', 'ACCDOA', 'both'])
+@pytest.mark.parametrize("fn", ['mse', 'l1'])
+def test_agg_pit_loss(dev, method, fn):
+    """AGG loss (loss/einv2.py:118-188): the three loss terms and both gradients against the reference-generated golden
+    (B 2, C 5) through the Losses_agg_pit mirror, and against the oracle's autograd at C = 170 with ragged rows."""
+    import os
+    from pseldnets_amd import ops
+    from pseldnets_amd.loss.einv2 import Losses_agg_pit
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'losses.npz'))
+    B, T, C = 2, 100, 5
+    sed = synth.formula_pred((B, T, 3, C), 0.5, 2.0).to(dev).requires_grad_(True)
+    doa = torch.tanh(synth.formula_pred((B, T, 3, 3), 0.8)).to(dev).requires_grad_(True)
+    sl, dl = synth.formula_einv2_label(B, T, C)
+    ld = Losses_agg_pit(fn, 'loss_all', 0.3, method)({'sed': sed, 'doa': doa}, {'sed_label': sl.to(dev), 'doa_label': dl.to(dev)})
+    got = np.array([float(torch.as_tensor(ld[k]).detach()) for k in ('loss_all', 'loss_agg', 'loss_accdoa')])
+    assert np.abs(got - g[f'agg_{fn}_{method}_losses']).max() < 2e-6
+    ld['loss_all'].backward()
+    check("agg dsed vs reference", sed.grad, torch.from_numpy(g[f'agg_{fn}_{method}_grad_sed']), 1e-4)
+    check("agg ddoa vs reference", doa.grad, torch.from_numpy(g[f'agg_{fn}_{method}_grad_doa']), 1e-4)
+    B, T, C = 3, 33, 170                                   # 99 rows: the last block of 4 waves is ragged; 170 classes
+    torch.manual_seed(5)
+    sed, doa = torch.randn(B, T, 3, C) * 2, torch.randn(B, T, 3, 3)
+    sl = (torch.rand(B, T, 3, C) < 0.05).float()
+    dl = torch.nn.functional.normalize(torch.randn(B, T, 3, 3), dim=-1) * (sl.sum(-1, keepdim=True) > 0)
+    w = {'mACCDOA_pit': (1.0, 0.0), 'ACCDOA': (0.0, 1.0), 'both': (0.3, 0.7)}[method]
+    loss3, dsed, ddoa = ops.agg_pit_loss(sed.to(dev), doa.to(dev), sl.to(dev), dl.to(dev), w[0], w[1], fn == 'l1')
+    sr, dr = sed.double().requires_grad_(True), doa.double().requires_grad_(True)
+    ref = ol.agg_pit({'sed': sr, 'doa': dr}, {'sed_label': sl.double(), 'doa_label': dl.double()}, 0.3, method, fn)
+    ref['loss_all'].backward()
+    assert abs(loss3[0].item() - ref['loss_all'].item()) < 2e-6 * max(1.0, abs(ref['loss_all'].item()))
+    check("agg dsed", dsed, sr.grad.float(), 2e-4)
+    check("agg ddoa", ddoa, dr.grad.float(), 2e-4)
 
 
 def test_clip_adamw_matches_oracle(dev):

@@ -151,6 +151,14 @@ def test_losses_golden():
     for method in ('mACCDOA_pit', 'ACCDOA', 'both'):
         v = ol.agg_pit({'sed': sed.detach(), 'doa': doa.detach()}, {'sed_label': sl, 'doa_label': dl}, 0.5, method)['loss_all']
         assert abs(float(v) - float(g[f'agg_{method}'])) < 1e-6, method
+        for fn in ('mse', 'l1'):
+            s3 = sed.detach().clone().requires_grad_(True); d3 = doa.detach().clone().requires_grad_(True)
+            ld = ol.agg_pit({'sed': s3, 'doa': d3}, {'sed_label': sl, 'doa_label': dl}, 0.3, method, fn)
+            got = np.array([float(torch.as_tensor(ld[k]).detach()) for k in ('loss_all', 'loss_agg', 'loss_accdoa')])
+            assert np.abs(got - g[f'agg_{fn}_{method}_losses']).max() < 1e-6, (method, fn)
+            ld['loss_all'].backward()
+            close(s3.grad, g[f'agg_{fn}_{method}_grad_sed'], 1e-8)
+            close(d3.grad, g[f'agg_{fn}_{method}_grad_doa'], 1e-8)
 
 
 def test_optimizer_golden():
