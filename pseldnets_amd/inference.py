@@ -104,6 +104,26 @@ def einv2_to_dcase(pred_sed, pred_doa, sed_threshold=0.5):
     return out
 
 
+def load_output_format_file(path):
+    """utils/data_utilities.py:67-88: DCASE CSV -> {frame: [[class, azimuth, elevation], ...]}; rows of 4 fields
+    (frame, class, azi, ele) or 5 / 6 / 7 fields (frame, class, track, azi, ele[, distance[, mids]])."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            item = [v for v in line.strip().split(',') if v != '']
+            if not item:
+                continue
+            frame = int(float(item[0]))
+            if len(item) == 4:
+                ev = [int(float(item[1])), float(item[2]), float(item[3])]
+            elif len(item) in (5, 6, 7):
+                ev = [int(float(item[1])), float(item[3]), float(item[4])]
+            else:
+                continue
+            out.setdefault(frame, []).append(ev)
+    return out
+
+
 def write_output_format_file(path, output_dict):
     """utils/data_utilities.py:91-104: DCASE CSV rows `frame,class,azimuth,elevation` (integers). Frames are written in
     ascending order (the reference writes them in its dictionary's insertion order)."""

@@ -7,6 +7,7 @@ The device part of the validation / test path (prediction incl. ACS, rank gather
 15-degree unification -> DCASE dictionaries) is mirrored too, and `update_metrics` accumulates the SELD scores
 (pseldnets_amd/utils/seld_scores.py, host numpy as in the reference)."""
 import importlib
+import math
 import random
 from itertools import combinations
 
@@ -73,6 +74,19 @@ class SELDModelModule:
             self.aug_TF_comb += combinations(aug_TF, n)
         self._trainer = None
         self.step_system_outputs = []
+        # components/model_module.py:41-53: predictions per test chunk, the per-recording padded frame count, the meta of the split
+        self.num_preds_per_chunk = int(round((_get(cfg, 'data.test_chunklen_sec', 10) or 10) / self.label_res))
+        self.valid_paths_dict = self.valid_gt_dcase_format = self.test_paths_dict = self.paths_dict = None
+        if valid_meta is not None:
+            self.valid_paths_dict, self.valid_gt_dcase_format = valid_meta
+            self.paths_dict = self.valid_paths_dict
+        if test_meta is not None:
+            self.test_paths_dict = test_meta
+            self.paths_dict = self.test_paths_dict
+        self.metrics = None
+
+    def get_num_frames(self, x):
+        return int(math.ceil(x / self.num_preds_per_chunk) * self.num_preds_per_chunk)
 
     def setup(self, stage='fit', device='cuda'):
         feature = _get(self.cfg, 'data.audio_feature')
@@ -215,6 +229,41 @@ class SELDModelModule:
             metrics = self.metrics
         metrics.update(pred_dcase_format, gt_dcase_format, num_frames)
         return metrics
+
+    def _per_recording(self, paths_dict, process_group):
+        """(path, label frames, DCASE dictionary) of every recording from the aggregated predictions (model_module.py:114-128,
+        165-176): recording i owns get_num_frames(frames_i) consecutive prediction frames, of which the first frames_i count."""
+        agg = self.pred_aggregation(process_group, paths_dict)
+        frame_ind = 0
+        for path, loc_frames in paths_dict.items():
+            if self.method == 'einv2':
+                frames = (agg['sed'][frame_ind:frame_ind + loc_frames], agg['doa'][frame_ind:frame_ind + loc_frames])
+            else:
+                frames = agg[self.method][frame_ind:frame_ind + loc_frames]
+            yield path, loc_frames, self.convert_to_dcase_format_polar(frames)
+            frame_ind += self.get_num_frames(loc_frames)
+
+    def on_validation_epoch_end(self, process_group=None):
+        """models/model_module.py:111-145: SELD scores of the validation split, {'macro': {...}, 'micro': {...}}."""
+        from ..utils.seld_scores import SeldScores
+        self.metrics = SeldScores(doa_threshold=_get(self.cfg, 'doa_threshold', 20), nb_classes=self.num_classes,
+                                  label_resolution=self.label_res)
+        for path, loc_frames, pred in self._per_recording(self.valid_paths_dict, process_group):
+            self.update_metrics(pred, self.valid_gt_dcase_format[path], loc_frames)
+        return {'macro': self.metrics.compute('macro'), 'micro': self.metrics.compute('micro')}
+
+    def on_test_epoch_end(self, submissions_dir, process_group=None):
+        """models/model_module.py:165-179: one DCASE CSV per recording (`<stem>.csv`) under submissions_dir."""
+        from pathlib import Path
+        from .. import inference
+        out = Path(submissions_dir)
+        out.mkdir(parents=True, exist_ok=True)
+        written = []
+        for path, _, pred in self._per_recording(self.test_paths_dict, process_group):
+            csv_path = out.joinpath(Path(path).stem + '.csv')
+            inference.write_output_format_file(csv_path, pred)
+            written.append(csv_path)
+        return written
 
     def configure_optimizers(self):
         opt_cfg, sch_cfg = _get(self.cfg, 'model.optimizer'), _get(self.cfg, 'model.lr_scheduler')

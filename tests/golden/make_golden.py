@@ -858,8 +858,61 @@ def gen_einv2_crnn():
     save('einv2_crnn.npz', **out)
 
 
+from tests.golden.epoch_inputs import C as EPOCH_C, epoch_inputs  # noqa: E402
+
+
+def gen_epoch_end():
+    """SELDModelModule.on_test_epoch_end / on_validation_epoch_end (models/model_module.py:111-145,165-179) with
+    BaseModelModule.pred_aggregation / convert_to_dcase_format_polar / update_metrics (components/model_module.py:177-262),
+    called unbound with a stand-in `self`: the CSV rows written per recording and the macro / micro SELD scores."""
+    import tempfile
+    import types
+    from pathlib import Path
+    from models.components.model_module import BaseModelModule
+    from models.model_module import SELDModelModule
+    from utils.SELD_metrics import SELDMetrics
+    out = {}
+    for method in ('multi_accdoa', 'accdoa', 'einv2'):
+        steps, paths, gts = epoch_inputs(method)
+        fake = type('S', (), {})()
+        fake.cfg = R.AttrDict(sed_threshold=0.5)
+        fake.method, fake.num_classes = method, EPOCH_C
+        fake.all_gather = lambda x: x
+        fake.trainer = R.AttrDict(world_size=1)
+        fake.get_num_frames = lambda x: int(np.ceil(x / 100) * 100)
+        fake.test_paths_dict = fake.valid_paths_dict = fake.paths_dict = paths
+        fake.valid_gt_dcase_format = gts
+        for name in ('pred_aggregation', 'convert_to_dcase_format_polar', 'update_metrics'):
+            setattr(fake, name, types.MethodType(getattr(BaseModelModule, name), fake))
+        logged = {}
+        fake.log_metrics = lambda d, set_type: logged.__setitem__(set_type, dict(d))
+        fake.log_losses = lambda *a, **k: None
+        fake.val_loss_dict = {}
+        fake.logging = types.SimpleNamespace(info=lambda *a, **k: None)
+        fake.metrics = SELDMetrics(nb_classes=EPOCH_C, doa_threshold=20)
+        with tempfile.TemporaryDirectory() as td:
+            fake.submissions_dir = Path(td)
+            fake.step_system_outputs = [{k: v.clone() for k, v in s_.items()} for s_ in steps]
+            SELDModelModule.on_test_epoch_end(fake)
+            for path in paths:
+                fn = Path(td) / (Path(path).stem + '.csv')
+                rows = [[float(v) for v in ln.split(',')] for ln in fn.read_text().splitlines() if ln]
+                out[f'{method}_csv_{Path(path).stem}'] = np.array(rows, np.float64).reshape(-1, 4)
+            cwd = os.getcwd()
+            os.chdir(td)                                   # on_validation_epoch_end opens 'metrics.csv' in the working directory
+            try:
+                fake.step_system_outputs = [{k: v.clone() for k, v in s_.items()} for s_ in steps]
+                SELDModelModule.on_validation_epoch_end(fake)
+            finally:
+                os.chdir(cwd)
+        for avg in ('macro', 'micro'):
+            d = logged[f'val/{avg}']
+            out[f'{method}_{avg}'] = np.array([d['ER'], d['F'], d['LE'], d['LR'], d['SELD_scr']], np.float64)
+    save('epoch_end.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -879,3 +932,4 @@ if __name__ == '__main__':
     if 'transformer' in which: gen_transformer()
     if 'einv2_passt' in which: gen_einv2_passt()
     if 'einv2_crnn' in which: gen_einv2_crnn()
+    if 'epoch_end' in which: gen_epoch_end()

@@ -88,3 +88,64 @@ def test_validation_hooks_of_the_model_module(dev):
     d = module.convert_to_dcase_format_polar(pred['multi_accdoa'][:100])
     assert isinstance(d, dict) and all(len(e) == 3 for v in d.values() for e in v)
     assert module.step_system_outputs == []
+
+
+@pytest.mark.parametrize("method", ['multi_accdoa', 'accdoa', 'einv2'])
+def test_epoch_end_hooks_vs_reference(dev, method, tmp_path):
+    """on_test_epoch_end / on_validation_epoch_end (models/model_module.py:111-145,165-179) against the reference's own hooks
+    run on the same step outputs (tests/golden/epoch_end.npz): the CSV rows of every recording and the macro / micro SELD scores."""
+    from pathlib import Path
+    from pseldnets_amd import inference as inf
+    from pseldnets_amd.models.model_module import SELDModelModule
+    from pseldnets_amd.train import SyntheticDataset, compose
+    from tests.golden.epoch_inputs import C, epoch_inputs
+    g = np.load(os.path.join(G, 'epoch_end.npz'))
+    steps, paths, gts = epoch_inputs(method)
+    exp = {'multi_accdoa': 'synth_maccdoa', 'accdoa': 'synth_accdoa', 'einv2': 'synth_einv2'}[method]
+    cfg = compose([f'experiment={exp}', f'data.num_classes={C}', 'data.test_chunklen_sec=10', 'data.test_hoplen_sec=10', 'sed_threshold=0.5'])
+    module = SELDModelModule(cfg, SyntheticDataset(cfg), valid_meta=(paths, gts), test_meta=paths)
+    assert module.get_num_frames(215) == 300 and module.num_preds_per_chunk == 100
+    module.step_system_outputs = [{k: v.to(dev) for k, v in s.items()} for s in steps]
+    written = module.on_test_epoch_end(tmp_path / 'submissions')
+    assert [p.name for p in written] == [Path(p).stem + '.csv' for p in paths]
+    for path, csv_path in zip(paths, written):
+        want = g[f'{method}_csv_{Path(path).stem}']
+        got = inf.load_output_format_file(csv_path)
+        rows = np.array([[f, e[0], e[1], e[2]] for f in sorted(got) for e in got[f]], np.float64).reshape(-1, 4)
+        assert rows.shape == want.shape, (path, rows.shape, want.shape)
+        key = lambda r: (r[0], r[1], r[2], r[3])
+        assert np.array_equal(np.array(sorted(rows.tolist(), key=key)), np.array(sorted(want.tolist(), key=key))), path
+    module.step_system_outputs = [{k: v.to(dev) for k, v in s.items()} for s in steps]
+    scores = module.on_validation_epoch_end()
+    for avg in ('macro', 'micro'):
+        got = np.array([scores[avg][k] for k in ('ER', 'F', 'LE', 'LR', 'SELD_scr')])
+        assert np.abs(got - g[f'{method}_{avg}']).max() < 1e-6, (avg, got, g[f'{method}_{avg}'])
+
+
+def _write_wav(path, pcm, sr=24000):
+    import wave
+    with wave.open(str(path), 'wb') as w:
+        w.setnchannels(pcm.shape[1]); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes(np.ascontiguousarray(pcm).tobytes())
+
+
+def test_infer_entry_point(dev, tmp_path, capsys):
+    """`python -m pseldnets_amd.infer`: WAV recordings -> HBM clip store -> test chunks -> eval predictions -> DCASE CSVs (mode=test),
+    and the SELD scores against metadata CSVs (mode=valid): scoring a run against its own written predictions is perfect."""
+    from pseldnets_amd import infer
+    from pseldnets_amd import inference as inf
+    rng = np.random.default_rng(3)
+    wav = tmp_path / 'foa'; wav.mkdir()
+    for i, sec in enumerate((12.3, 20.0, 5.0)):
+        _write_wav(wav / f'mix{i}.wav', (rng.standard_normal((int(sec * 24000), 4)) * 2000).astype(np.int16))
+    common = [f'wav_dir={wav}', 'data.num_classes=5', 'model.batch_size=3', 'model.kwargs.drop_path_rate=0.0', 'model.kwargs.embed_dim=48',
+              'model.kwargs.depths=[2,2,2,2]', 'model.kwargs.num_heads=[2,4,8,16]', 'sed_threshold=0.2', 'trainer.precision=32-true']
+    out = tmp_path / 'sub'
+    written = infer.main(common + ['mode=test', f'out_dir={out}'])
+    assert [p.name for p in written] == ['mix0.csv', 'mix1.csv', 'mix2.csv']
+    events = sum(len(v) for p in written for v in inf.load_output_format_file(p).values())
+    frames = [max(inf.load_output_format_file(p), default=-1) for p in written]
+    assert events > 0 and frames[0] < 123 and frames[1] < 200 and frames[2] < 50, (events, frames)
+    scores = infer.main(common + ['mode=valid', f'meta_dir={out}'])        # the same seed -> the same network -> the same predictions
+    assert abs(scores['micro']['F'] - 1.0) < 1e-6 and scores['micro']['ER'] < 1e-6 and scores['micro']['LE'] < 1.5   # the CSV holds whole degrees
+    assert 'val/macro' in capsys.readouterr().out
