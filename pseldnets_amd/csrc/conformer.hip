@@ -1091,7 +1091,10 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
  * [B, T, ld_seq] with this direction's H columns starting at seq (caller offsets the pointer); gates [T, B, 4H]; gh scratch
  * [B, 3H]; reverse != 0 walks t = T-1 .. 0. */
 static void gru_bwd_launch(const GruMultiArgs& m, int H, int cnt, hipStream_t s) {
-    static const int ub = [] { const char* e = getenv("PSELD_GRU_BWD_UNITS"); return e ? atoi(e) : 8; }();
+    // measured: 8 units per workgroup win while the launch is short of workgroups (one or two recurrences), 32 once many recurrences
+    // share it (every workgroup re-reads the [B, 3H] gate-gradient block: 12 x 128 workgroups of 8 units are slower than 12 x 32 of 32)
+    static const int forced = [] { const char* e = getenv("PSELD_GRU_BWD_UNITS"); return e ? atoi(e) : 0; }();
+    const int ub = forced ? forced : (cnt <= 2 ? 8 : 32);
     if (ub == 32) hipLaunchKernelGGL(gru_step_bwd_kernel<32>, dim3(H / 32, cnt), dim3(512), 0, s, m);
     else if (ub == 16) hipLaunchKernelGGL(gru_step_bwd_kernel<16>, dim3(H / 16, cnt), dim3(512), 0, s, m);
     else hipLaunchKernelGGL(gru_step_bwd_kernel<8>, dim3(H / 8, cnt), dim3(512), 0, s, m);
