@@ -195,35 +195,40 @@ __global__ void scalar_finish_kernel(const float* __restrict__ partial, int n, f
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
-// ---- track-wise PIT (EINV2): one thread per (b, t) ---------------------------------------------------------
-// sed logits [rows, 3, C], doa [rows, 3, 3], labels same shapes. out3 = mean over rows of (all, sed, doa).
+// ---- track-wise PIT (EINV2): one WAVE per (b, t), lanes over the classes (coalesced rows of sed / dsed) ---------------------
+// sed logits [rows, 3, C], doa [rows, 3, 3], labels same shapes. partial: [3][gridDim.x] sums of (all, sed, doa) per block.
 __global__ __launch_bounds__(256) void tpit_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
                                                    const float* __restrict__ sed_l, const float* __restrict__ doa_l,
                                                    float* __restrict__ dsed, float* __restrict__ ddoa,
                                                    float* __restrict__ partial, long rows, int C, float beta, float inv_rows) {
     __shared__ float red[3][4];
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
     float l_all = 0.f, l_sed = 0.f, l_doa = 0.f;
     if (row < rows) {
-        // pairwise costs: bce[i][j] = mean_c BCE(sed[i], label[j]); mse[i][j] = mean_xyz (doa[i]-label[j])^2
+        // pairwise costs: bce[i][j] = sum_c BCE(sed[i], label[j]); mse[i][j] = sum_xyz (doa[i]-label[j])^2
         float bce[3][3], mse[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { bce[i][j] = 0.f; mse[i][j] = 0.f; }
-        for (int c = 0; c < C; ++c) {
+            for (int j = 0; j < 3; ++j) bce[i][j] = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float lab[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) lab[j] = sed_l[(row * 3 + j) * C + c];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float x = sed[(row * 3 + i) * C + c];
                 const float sp = fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));   // softplus(x) = BCE(x, 0)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) bce[i][j] += sp - x * sed_l[(row * 3 + j) * C + c];
+                for (int j = 0; j < 3; ++j) bce[i][j] += sp - x * lab[j];
             }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
+                bce[i][j] = wave_sum(bce[i][j]);
                 float s = 0.f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { const float d = doa[(row * 3 + i) * 3 + a] - doa_l[(row * 3 + j) * 3 + a]; s += d * d; }
@@ -241,19 +246,18 @@ __global__ __launch_bounds__(256) void tpit_kernel(const float* __restrict__ sed
         }
         l_all = best; l_sed = bs; l_doa = bd;
         const float gs = beta * inv_rows / (3.f * C), gd = (1.f - beta) * inv_rows * 2.f / 9.f;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int j = PERM[bi][i];
-            for (int c = 0; c < C; ++c) {
+            for (int c = lane; c < C; c += 64) {
                 const float x = sed[(row * 3 + i) * C + c];
                 const float sg = 1.f / (1.f + __expf(-x));
                 dsed[(row * 3 + i) * C + c] = gs * (sg - sed_l[(row * 3 + j) * C + c]);
             }
-            for (int a = 0; a < 3; ++a)
-                ddoa[(row * 3 + i) * 3 + a] = gd * (doa[(row * 3 + i) * 3 + a] - doa_l[(row * 3 + j) * 3 + a]);
+            if (lane < 3) ddoa[(row * 3 + i) * 3 + lane] = gd * (doa[(row * 3 + i) * 3 + lane] - doa_l[(row * 3 + j) * 3 + lane]);
         }
     }
-    l_all = wave_sum(l_all); l_sed = wave_sum(l_sed); l_doa = wave_sum(l_doa);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l_all; red[1][threadIdx.x >> 6] = l_sed; red[2][threadIdx.x >> 6] = l_doa; }
+    if (lane == 0) { red[0][wave] = l_all; red[1][wave] = l_sed; red[2][wave] = l_doa; }
     __syncthreads();
     if (threadIdx.x < 3) partial[(long)threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
@@ -482,12 +486,12 @@ extern "C" int pseld_mse_loss(const float* pred, const float* target, float* dpr
     PSELD_LAUNCH_CHECK("mse_loss");
     return PSELD_OK;
 }
-// loss_out[0..2] = (loss_all, loss_sed, loss_doa) means over rows = B*T. workspace >= 3*ceil(rows/256) floats.
+// loss_out[0..2] = (loss_all, loss_sed, loss_doa) means over rows = B*T. workspace >= 3*ceil(rows/4) floats.
 extern "C" int pseld_tpit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label,
                                float* dsed, float* ddoa, float* loss_out, long rows, int C, float beta, float* workspace,
                                long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(sed && doa && sed_label && doa_label && dsed && ddoa && loss_out && workspace && rows > 0, "tpit_loss: bad arguments");
-    const int nb = pseld_cdiv(rows, 256);
+    const int nb = pseld_cdiv(rows, 4);
     PSELD_CHECK_ARG(workspace_bytes >= (long)nb * 12, "tpit_loss: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const float inv = 1.f / (float)rows;

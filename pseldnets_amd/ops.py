@@ -346,7 +346,7 @@ def tpit_loss(sed, doa, sed_label, doa_label, beta):
     _chk(sed, doa, sed_label, doa_label)
     B, T, _, C = sed.shape
     rows = B * T
-    ws = workspace(((rows + 255) // 256) * 12, sed.device)
+    ws = workspace(((rows + 3) // 4) * 12, sed.device)
     dsed, ddoa = torch.empty_like(sed), torch.empty_like(doa)
     loss = torch.empty(3, dtype=torch.float32, device=sed.device)
     rc = _lib.lib().pseld_tpit_loss(_lib.ptr(sed), _lib.ptr(doa), _lib.ptr(sed_label), _lib.ptr(doa_label), _lib.ptr(dsed),
