@@ -232,6 +232,14 @@ int pseld_relattn_bwd(int dtype, const void* q, const void* k, const void* v, co
                       void* dk, void* dv, float* dpos, float* du_bias, float* dv_bias, int B, int T, int D, int heads,
                       float* workspace, long workspace_bytes, void* stream);
 
+/* mono -> FOA spatialisation of the mono_adapter fine-tuning recipe (data/data.py:17-59 generate_spatial_samples; the
+ * host mirror draws (azimuth, elevation) per sample): foa [N,4,L] = (w, y*w, z*w, x*w) from mono rows at mono_stride, xyz
+ * f64 [N,3] = (x, y, z), products in double rounded once as numpy does. spatial_label: out[n,o,a,i] = coef[n][a] *
+ * lab[n,o,0,i] (a < 4; coef f64 [N,4]) — ADPIT [N,T*6,4,C] with (1,x,y,z), ACCDOA [N,T,4,C] with (0,x,y,z).
+ * spatial_doa_label: EINV2 doa label [N,T,3,3], track 0 = (activity summed over tracks and classes) * (x,y,z), rest 0. */
+int pseld_spatialize_mono(const float* mono, long mono_stride, const double* xyz, float* foa, int N, long L, void* stream);
+int pseld_spatial_label(const float* lab, float* out, const double* coef, int N, long outer, long inner, void* stream);
+int pseld_spatial_doa_label(const float* sed, const double* xyz, float* doa, int N, long T, int tracks, int C, void* stream);
 /* ---- on-device augmentations -----------------------------------------------------------------
  * src/augment/specaug.py:14-63, crop.py:10-32, freqshift.py:17-38, rotate.py:10-101, trackmix.py:15-75,
  * wavmix.py:16-116; called from models/model_module.py:47-68 and components/model_module.py:83-121. The host mirror

@@ -176,6 +176,41 @@ __global__ void mix_tracks_kernel(const float* __restrict__ sed, const float* __
     }
 }
 
+// ---- mono -> FOA spatialisation of the mono_adapter recipe (data/data.py:17-59) -----------------------------------------------------
+// foa[n] = (w, y*w, z*w, x*w) with the products formed in double and rounded once (numpy: float64 scalar * float32 array)
+__global__ void spatialize_mono_kernel(const float* __restrict__ mono, long mono_stride, const double* __restrict__ xyz, float* __restrict__ foa,
+                                       long L, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const long l = id % L, n = id / L;
+    const double w = (double)mono[n * mono_stride + l];
+    float* o = foa + n * 4 * L + l;
+    o[0] = (float)w; o[L] = (float)(xyz[n * 3 + 1] * w); o[2 * L] = (float)(xyz[n * 3 + 2] * w); o[3 * L] = (float)(xyz[n * 3] * w);
+}
+// out[n, o, a, i] = coef[n][a] * lab[n, o, 0, i] (A = 4): ADPIT labels [N, T*6, 4, C] with coef (1, x, y, z); ACCDOA labels
+// [N, T, 4, C] with coef (0, x, y, z) (the reference leaves the activity block of the rewritten ACCDOA label at zero)
+__global__ void spatial_label_kernel(const float* __restrict__ lab, float* __restrict__ out, const double* __restrict__ coef, long outer, long inner,
+                                     long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const long i = id % inner;
+    long rest = id / inner;
+    const int a = (int)(rest & 3);
+    rest >>= 2;
+    const long n = rest / outer;
+    out[id] = (float)(coef[n * 4 + a] * (double)lab[(rest * 4) * inner + i]);
+}
+// EINV2: doa_out[n,t,0,:] = (sum over tracks and classes of sed[n,t]) * (x, y, z), tracks 1-2 zero; one wave per (n, t)
+__global__ __launch_bounds__(256) void spatial_doa_label_kernel(const float* __restrict__ sed, const double* __restrict__ xyz, float* __restrict__ doa,
+                                                                long T, int K, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += sed[row * K + k];
+    s = wave_sum(s);
+    if (lane < 9) doa[row * 9 + lane] = lane < 3 ? (float)((double)s * xyz[(row / T) * 3 + lane]) : 0.f;
+}
 }  // namespace
 
 extern "C" int pseld_aug_rect_fill(float* x, const int* rects, int N, int C, int T, int F, int R, float value, void* stream) {
@@ -197,6 +232,27 @@ extern "C" int pseld_aug_freqshift(const float* x, float* y, const int* shift, i
     const long per = (long)C * T * F, total = per * N;
     hipLaunchKernelGGL(freqshift_kernel, dim3(pseld_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, shift, F, per, total);
     PSELD_LAUNCH_CHECK("aug_freqshift");
+    return PSELD_OK;
+}
+extern "C" int pseld_spatialize_mono(const float* mono, long mono_stride, const double* xyz, float* foa, int N, long L, void* stream) {
+    PSELD_CHECK_ARG(mono && xyz && foa && N > 0 && L > 0 && mono_stride >= L, "spatialize_mono: bad argument");
+    const long total = (long)N * L;
+    hipLaunchKernelGGL(spatialize_mono_kernel, dim3(pseld_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, mono, mono_stride, xyz, foa, L, total);
+    PSELD_LAUNCH_CHECK("spatialize_mono");
+    return PSELD_OK;
+}
+extern "C" int pseld_spatial_label(const float* lab, float* out, const double* coef, int N, long outer, long inner, void* stream) {
+    PSELD_CHECK_ARG(lab && out && coef && lab != out && N > 0 && outer > 0 && inner > 0, "spatial_label: bad argument");
+    const long total = (long)N * outer * 4 * inner;
+    hipLaunchKernelGGL(spatial_label_kernel, dim3(pseld_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, lab, out, coef, outer, inner, total);
+    PSELD_LAUNCH_CHECK("spatial_label");
+    return PSELD_OK;
+}
+extern "C" int pseld_spatial_doa_label(const float* sed, const double* xyz, float* doa, int N, long T, int tracks, int C, void* stream) {
+    PSELD_CHECK_ARG(sed && xyz && doa && N > 0 && T > 0 && tracks == 3 && C > 0, "spatial_doa_label: bad argument (3 tracks)");
+    const long rows = (long)N * T;
+    hipLaunchKernelGGL(spatial_doa_label_kernel, dim3(pseld_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, sed, xyz, doa, T, tracks * C, rows);
+    PSELD_LAUNCH_CHECK("spatial_doa_label");
     return PSELD_OK;
 }
 extern "C" int pseld_aug_rotate_wave(const float* x, float* y, const int* src, const float* sign, int N, long L, void* stream) {

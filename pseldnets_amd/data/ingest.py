@@ -122,3 +122,47 @@ def polar_labels(se, azi, ele):
     _lib.check(_lib.lib().pseld_polar_labels(_lib.ptr(se8), _lib.ptr(a16), _lib.ptr(e8), _lib.ptr(out), rows_tracks, C, _lib.stream_ptr()),
                "pseld_polar_labels")
     return out.view(*se.shape[:-1], 4, C) if se.ndim == 3 else out.view(se.shape[0], 4 * C)
+
+
+def generate_spatial_samples(audio, method, rng=None, **labels):
+    """Batch-wise device mirror of data/data.py:17-59 (the mono_adapter recipe, single-source targets only): every mono clip
+    becomes the FOA encoding of a source at a random direction and its label is rewritten to that direction.
+    audio f32 [N, L] or [N, ch, L] (channel 0 = the mono signal) on the device; labels: sed_label [N,T,3,C] + doa_label
+    (einv2), accdoa_label [N,T,4C] (accdoa), adpit_label [N,T,6,4,C] (multi_accdoa). `rng` (default numpy's global generator,
+    as the reference) is asked for randint(-180, 180) then randint(-90, 90) per sample, in batch order.
+    Returns (foa [N,4,L], label...) like the reference."""
+    rng = np.random if rng is None else rng
+    N = audio.shape[0]
+    mono = audio if audio.ndim == 2 else audio[:, 0]
+    if not mono.is_cuda or mono.dtype != torch.float32 or mono.stride(-1) != 1:
+        raise _lib.PseldError("generate_spatial_samples: audio must be fp32 on the MI355X with unit stride along time")
+    L = mono.shape[-1]
+    ang = np.array([[rng.randint(-180, 180), rng.randint(-90, 90)] for _ in range(N)], np.float64).reshape(N, 2)
+    azi, ele = np.deg2rad(ang[:, 0]), np.deg2rad(ang[:, 1])
+    xyz = np.stack((np.cos(azi) * np.cos(ele), np.sin(azi) * np.cos(ele), np.sin(ele)), 1)
+    xyz_d = torch.from_numpy(xyz).to(mono.device)
+    foa = torch.empty((N, 4, L), dtype=torch.float32, device=mono.device)
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    _lib.check(lib.pseld_spatialize_mono(_lib.ptr(mono), mono.stride(0), _lib.ptr(xyz_d), _lib.ptr(foa), N, L, st), "pseld_spatialize_mono")
+
+    def coef_label(lab, outer, inner, first):
+        lab = lab.contiguous().float()
+        coef = torch.from_numpy(np.concatenate((np.full((N, 1), first), xyz), 1)).to(mono.device)
+        out = torch.empty_like(lab)
+        _lib.check(lib.pseld_spatial_label(_lib.ptr(lab), _lib.ptr(out), _lib.ptr(coef), N, outer, inner, st), "pseld_spatial_label")
+        return out
+
+    if method == 'einv2':
+        sed = labels['sed_label'].contiguous().float()
+        doa = torch.empty(sed.shape[:3] + (3,), dtype=torch.float32, device=mono.device)
+        _lib.check(lib.pseld_spatial_doa_label(_lib.ptr(sed), _lib.ptr(xyz_d), _lib.ptr(doa), N, sed.shape[1], sed.shape[2], sed.shape[3], st),
+                   "pseld_spatial_doa_label")
+        return foa, labels['sed_label'], doa
+    if method == 'accdoa':
+        lab = labels['accdoa_label']
+        C = lab.shape[-1] // 4
+        return foa, coef_label(lab, lab.shape[1], C, 0.0)
+    if method == 'multi_accdoa':
+        lab = labels['adpit_label']
+        return foa, coef_label(lab, lab.shape[1] * lab.shape[2], lab.shape[4], 1.0)
+    raise NotImplementedError(method)

@@ -911,8 +911,57 @@ def gen_epoch_end():
     save('epoch_end.npz', **out)
 
 
+def spatial_inputs(method, N=3, T=20, C=4, L=480):
+    """Seeded single-source inputs for generate_spatial_samples (shared with the tests through the stored arrays)."""
+    g = np.random.default_rng(21)
+    audio = g.standard_normal((N, 1, L)).astype(np.float32)
+    active = g.random((N, T)) < 0.5
+    cls = g.integers(0, C, (N, T))
+    if method == 'einv2':
+        sed = np.zeros((N, T, 3, C), np.float32)
+        for n in range(N):
+            for t in range(T):
+                if active[n, t]:
+                    sed[n, t, 0, cls[n, t]] = 1
+        return audio, dict(sed_label=sed, doa_label=g.standard_normal((N, T, 3, 3)).astype(np.float32))
+    if method == 'accdoa':
+        lab = g.standard_normal((N, T, 4 * C)).astype(np.float32)
+        lab[..., :C] = 0
+        for n in range(N):
+            for t in range(T):
+                if active[n, t]:
+                    lab[n, t, cls[n, t]] = 1
+        return audio, dict(accdoa_label=lab)
+    lab = np.zeros((N, T, 6, 4, C), np.float32)
+    for n in range(N):
+        for t in range(T):
+            if active[n, t]:
+                lab[n, t, 0, 0, cls[n, t]] = 1
+                lab[n, t, 0, 1:, cls[n, t]] = g.standard_normal(3)
+    return audio, dict(adpit_label=lab)
+
+
+def gen_spatial():
+    """data/data.py:17-59 generate_spatial_samples (h5py / soundfile stubbed: the function does not touch them), per sample
+    with numpy's global generator seeded once per method."""
+    R._mod('h5py'); R._mod('soundfile')
+    import data.data as dd
+    out = {}
+    for method in ('einv2', 'accdoa', 'multi_accdoa'):
+        audio, labels = spatial_inputs(method)
+        out[f'{method}_audio'] = audio
+        for k, v in labels.items():
+            out[f'{method}_in_{k}'] = v
+        np.random.seed(77)
+        res = [dd.generate_spatial_samples(audio[n], method, **{k: v[n] for k, v in labels.items()}) for n in range(audio.shape[0])]
+        out[f'{method}_foa'] = np.stack([r[0] for r in res]).astype(np.float32)
+        for j in range(1, len(res[0])):
+            out[f'{method}_out{j}'] = np.stack([r[j] for r in res]).astype(np.float32)
+    save('spatial.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -933,3 +982,4 @@ if __name__ == '__main__':
     if 'einv2_passt' in which: gen_einv2_passt()
     if 'einv2_crnn' in which: gen_einv2_crnn()
     if 'epoch_end' in which: gen_epoch_end()
+    if 'spatial' in which: gen_spatial()

@@ -1,6 +1,7 @@
 """Device-side ingest (pseldnets_amd/data/ingest.py, csrc/ingest.hip): HBM-resident PCM16 clips cut / padded / converted by
 one launch, and the (se, azimuth, elevation) -> ADPIT / ACCDOA label synthesis, against the numpy restatement of the
 reference's dataset code (oracle/data.py)."""
+import os
 import wave
 
 import numpy as np
@@ -55,3 +56,21 @@ def test_label_synthesis(dev):
     got = polar_labels(torch.as_tensor(se[:, 0]).to(dev), torch.as_tensor(azi[:, 0]).to(dev), torch.as_tensor(ele[:, 0]).to(dev))
     want = od.accdoa_label(se[:, 0], azi[:, 0], ele[:, 0])
     assert got.shape == (T, 4 * C) and np.abs(got.cpu().numpy() - want).max() < 1e-6
+
+
+@pytest.mark.parametrize("method", ['einv2', 'accdoa', 'multi_accdoa'])
+def test_generate_spatial_samples_vs_reference(dev, method):
+    """The mono_adapter recipe (data/data.py:17-59) batch-wise on the device against the reference's per-sample function run
+    on the same inputs with numpy's generator seeded identically (tests/golden/spatial.npz): bit-exact audio and labels."""
+    from pseldnets_amd.data.ingest import generate_spatial_samples
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'spatial.npz'))
+    audio = torch.from_numpy(g[f'{method}_audio']).to(dev)
+    labels = {k[len(method) + 4:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith(f'{method}_in_')}
+    res = generate_spatial_samples(audio, method, rng=np.random.RandomState(77), **labels)
+    assert torch.equal(res[0].cpu(), torch.from_numpy(g[f'{method}_foa']))
+    for j in range(1, len(res)):
+        want = torch.from_numpy(g[f'{method}_out{j}'])
+        assert res[j].shape == want.shape and torch.equal(res[j].float().cpu(), want), (method, j)
+    mono2d = audio[:, 0].contiguous()
+    res2 = generate_spatial_samples(mono2d, method, rng=np.random.RandomState(77), **labels)
+    assert torch.equal(res2[0], res[0])

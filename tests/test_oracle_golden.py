@@ -539,3 +539,17 @@ def test_einv2_crnn_golden():
         y = oe.einv2_crnn_forward(oc.random_features(1, seed=3), sd, 'CNN12')
     close(y['sed'], g['full_sed'], 2e-4)
     close(y['doa'], g['full_doa'], 1e-4)
+
+
+@pytest.mark.parametrize("method", ['einv2', 'accdoa', 'multi_accdoa'])
+def test_generate_spatial_samples_golden(method):
+    """oracle/data.py generate_spatial_samples against the reference's (data/data.py:17-59), same numpy generator state."""
+    from oracle import data as od
+    g = gold('spatial.npz')
+    audio = g[f'{method}_audio']
+    labels = {k[len(method) + 4:]: g[k] for k in g.files if k.startswith(f'{method}_in_')}
+    rng = np.random.RandomState(77)
+    res = [od.generate_spatial_samples(audio[n], method, rng, **{k: v[n] for k, v in labels.items()}) for n in range(audio.shape[0])]
+    assert np.array_equal(np.stack([r[0] for r in res]).astype(np.float32), g[f'{method}_foa'])
+    for j in range(1, len(res[0])):
+        assert np.array_equal(np.stack([r[j] for r in res]).astype(np.float32), g[f'{method}_out{j}'])
