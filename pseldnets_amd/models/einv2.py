@@ -109,6 +109,35 @@ class EinTracks:
         return dxs, dxd
 
 
+def _load_htsat_ckpt(net, pretrained_path, audioset_pretrain, encoders):
+    ck = torch.load(pretrained_path, map_location='cpu')['state_dict']
+    own = net.state_dict()
+    if audioset_pretrain:
+        ck = {k.replace('sed_model.', ''): v for k, v in ck.items()}
+        for prefix, cin in encoders:
+            for key in own:
+                if not key.startswith(prefix):
+                    continue
+                src = key[len(prefix):]
+                if src == 'patch_embed.proj.weight':
+                    own[key].copy_(ck[src].repeat(1, cin, 1, 1) / cin)
+                else:
+                    own[key].copy_(ck[src])
+        for c in range(net.in_channels):
+            for leaf in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                own[f'scalar.{c}.{leaf}'].copy_(ck[f'bn0.{leaf}'])
+    else:
+        ck = {k.replace('net.', '').replace('_orig_mod.', ''): v for k, v in ck.items()}
+        for key, value in ck.items():
+            if key.startswith(('sed_tscam_conv.', 'head', 'af_extractor')):
+                continue
+            if key in own:
+                own[key].copy_(value)
+            elif 'relative_position_index' not in key and 'attn_mask' not in key:       # index buffers this path does not keep
+                raise KeyError(f'{pretrained_path}: unexpected entry {key}')
+    net.shadow_trusted = False
+
+
 class HTSAT(HTSATNetBase):
     def __init__(self, cfg, num_classes, in_channels=7, audioset_pretrain=True,
                  pretrained_path='ckpts/HTSAT-fullset-imagenet-768d-32000hz.ckpt', **kwargs):
@@ -125,8 +154,13 @@ class HTSAT(HTSATNetBase):
         self.doa_head = TscamHead(self.arena, 'doa_tscam_conv.', self.doa_enc.num_features, 9, True)
         self._finish_init()
         if pretrained_path:
-            raise NotImplementedError("checkpoint adaptation for EINV2 (einv2.py:239-272) is not mirrored yet: "
-                                      "pass pretrained_path=None and load a state dict")
+            self.load_ckpts(pretrained_path, audioset_pretrain)
+
+    def load_ckpts(self, pretrained_path, audioset_pretrain=True):
+        """einv2.py:239-272: AudioSet HTS-AT checkpoints into both encoders (one-channel patch embedding replicated /
+        in_channels, bn0 copied into every scalar) or PSELDNets checkpoints (sed_tscam_conv / head / af_extractor skipped)."""
+        _load_htsat_ckpt(self, pretrained_path, audioset_pretrain,
+                         (('sed_encoder.', self.sed_in_channels), ('doa_encoder.', self.doa_in_channels)))
 
     def _forward_impl(self, x, training):
         B, dt = x.shape[0], self.compute_dtype
@@ -183,7 +217,11 @@ class HTSAT_SEDDOA(HTSATNetBase):
         self.doa_head = TscamHead(self.arena, 'doa_tscam_conv.', self.enc.num_features, 9, True)
         self._finish_init()
         if pretrained_path:
-            raise NotImplementedError("pass pretrained_path=None and load a state dict")
+            self.load_ckpts(pretrained_path, audioset_pretrain)
+
+    def load_ckpts(self, pretrained_path, audioset_pretrain=True):
+        """einv2.py:369-396: as einv2.HTSAT.load_ckpts with the single encoder."""
+        _load_htsat_ckpt(self, pretrained_path, audioset_pretrain, (('encoder.', self.in_channels),))
 
     def _forward_impl(self, x, training):
         B, dt = x.shape[0], self.compute_dtype

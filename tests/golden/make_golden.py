@@ -960,8 +960,67 @@ def gen_spatial():
     save('spatial.npz', **out)
 
 
+from tests.golden import ckpt_inputs as CK  # noqa: E402
+
+
+def ckpt_cases():
+    """(name, builder of the reference network given pretrained_path / audioset_pretrain, encoder prefixes, checkpoint kind)."""
+    cfgd = _einv2_cfg(None)
+    pk, hk = passt_kwargs(PASST_TINY), ref_kwargs(TINY)
+    nf = [8, 16, 16, 32, 32, 64]
+    return [
+        ('accdoa_htsat', lambda **k: accdoa.HTSAT(CFG, 3, 7, **k, **hk), ['encoder.'], 'htsat'),
+        ('einv2_htsat', lambda **k: einv2.HTSAT(CFG, 3, 7, **k, **hk), ['sed_encoder.', 'doa_encoder.'], 'htsat'),
+        ('einv2_seddoa', lambda **k: einv2.HTSAT_SEDDOA(CFG, 3, 7, **k, **hk), ['encoder.'], 'htsat'),
+        ('accdoa_passt', lambda **k: accdoa.PASST(CFG, 3, 7, **k, **pk), ['encoder.'], 'passt'),
+        ('einv2_passt', lambda **k: einv2.PASST(cfgd, 3, 7, **k, **pk), ['sed_encoder.', 'doa_encoder.'], 'passt'),
+        ('accdoa_crnn', lambda **k: accdoa.CRNN(cfgd, 3, 7, encoder='CNN12', num_features=nf, **k), ['convs.'], 'cnn14'),
+        ('einv2_crnn', lambda **k: einv2.CRNN(cfgd, 3, 7, encoder='CNN12', num_features=nf, **k), ['sed_convs.', 'doa_convs.'], 'cnn14'),
+    ]
+
+
+def gen_ckpt():
+    """Every load_ckpts of the registry (AudioSet-style and PSELDNets-style checkpoints) on synthetic checkpoint files
+    (tests/golden/ckpt_inputs.py): per-key checksums of the resulting state dict."""
+    import tempfile
+    out = {}
+    for name, make, prefixes, kind in ckpt_cases():
+        plain = make(pretrained_path=None)
+        sd0 = plain.state_dict()
+        enc = CK.shapes(sd0, prefixes[-1])                       # the widest encoder (all input channels)
+        audioset = {'htsat': CK.htsat_audioset, 'passt': CK.passt_audioset, 'cnn14': CK.cnn14_audioset}[kind](enc)
+        inner = audioset.get('state_dict', audioset.get('model', audioset))
+        for k, v in sd0.items():                                 # reference-only entries (index buffers, unused heads): keep its values
+            if k.startswith(prefixes[-1]):
+                src = ('sed_model.' if kind == 'htsat' else '') + k[len(prefixes[-1]):]
+                if not v.is_floating_point() and 'num_batches_tracked' not in k:
+                    inner[src] = v.clone()
+        keys = [k for k, v in sd0.items() if v.is_floating_point() or 'num_batches_tracked' in k]
+        keys = [k for k in keys if 'attn_mask' not in k]
+        out[f'{name}_keys'] = np.array(keys)
+        def load_and_diff(path, audioset_flag):
+            net = make(pretrained_path=None)
+            before = {k: v.clone() for k, v in net.state_dict().items()}
+            net.load_ckpts(path, audioset_pretrain=audioset_flag)
+            after = net.state_dict()
+            changed = np.array([not torch.equal(before[k], after[k]) for k in keys])
+            return np.array(CK.checksums(after, keys)), changed
+
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, 'audioset.ckpt')
+            torch.save(audioset, path)
+            out[f'{name}_audioset'], out[f'{name}_audioset_changed'] = load_and_diff(path, True)
+            path2 = os.path.join(td, 'pseld.ckpt')
+            compiled = name == 'einv2_htsat'
+            ck2 = CK.keep_index_buffers(CK.pseld(CK.shapes(sd0), compiled=compiled), sd0, '', kind,
+                                        pseld_prefix='net._orig_mod.' if compiled else 'net.')
+            torch.save(ck2, path2)
+            out[f'{name}_pseld'], out[f'{name}_pseld_changed'] = load_and_diff(path2, False)
+    save('ckpt.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -983,3 +1042,4 @@ if __name__ == '__main__':
     if 'einv2_crnn' in which: gen_einv2_crnn()
     if 'epoch_end' in which: gen_epoch_end()
     if 'spatial' in which: gen_spatial()
+    if 'ckpt' in which: gen_ckpt()

@@ -158,3 +158,68 @@ def test_seld_scores_match_the_reference_class():
     m.reset()
     e = m.compute('macro')
     assert np.allclose([e['ER'], e['F'], e['LE'], e['LR'], e['SELD_scr']], g['empty_macro'])
+
+
+def _ckpt_cases():
+    from pseldnets_amd.models import accdoa, einv2
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    cfg = A(data=A(n_mels=64, sample_rate=24000, hoplen=240), model=A(decoder=None, num_decoder_layers=1, ps_gap=2), adapt=A())
+    hk = dict(embed_dim=48, depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16], drop_path_rate=0.0)
+    pk = dict(embed_dim=128, depth=2, num_heads=2)
+    nf = [8, 16, 16, 32, 32, 64]
+    return [
+        ('accdoa_htsat', lambda **k: accdoa.HTSAT(cfg, 3, 7, **k, **hk), ['encoder.'], 'htsat'),
+        ('einv2_htsat', lambda **k: einv2.HTSAT(cfg, 3, 7, **k, **hk), ['sed_encoder.', 'doa_encoder.'], 'htsat'),
+        ('einv2_seddoa', lambda **k: einv2.HTSAT_SEDDOA(cfg, 3, 7, **k, **hk), ['encoder.'], 'htsat'),
+        ('accdoa_passt', lambda **k: accdoa.PASST(cfg, 3, 7, **k, **pk), ['encoder.'], 'passt'),
+        ('einv2_passt', lambda **k: einv2.PASST(cfg, 3, 7, **k, **pk), ['sed_encoder.', 'doa_encoder.'], 'passt'),
+        ('accdoa_crnn', lambda **k: accdoa.CRNN(cfg, 3, 7, encoder='CNN12', num_features=nf, **k), ['convs.'], 'cnn14'),
+        ('einv2_crnn', lambda **k: einv2.CRNN(cfg, 3, 7, encoder='CNN12', num_features=nf, **k), ['sed_convs.', 'doa_convs.'], 'cnn14'),
+    ]
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_checkpoint_loaders_match_the_reference(case, tmp_path):
+    """Every load_ckpts of the registry on synthetic AudioSet-style (HTS-AT / PaSST / PANNs CNN14) and PSELDNets-style checkpoint
+    files: the resulting state dict equals the one the reference's loader produces from the same file (tests/golden/ckpt.npz:
+    per-key sum, abs-sum, first and last element). Runs on the CPU: loading happens before the arena is materialised."""
+    import os
+    import numpy as np
+    from tests.golden import ckpt_inputs as CK
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ckpt.npz'))
+    name, make, prefixes, kind = _ckpt_cases()[case]
+    sd0 = make(pretrained_path=None).state_dict()
+    gkeys = [str(k) for k in g[f'{name}_keys']]
+    keys = CK.checked_keys(sd0)
+    assert set(keys) <= set(gkeys), sorted(set(keys) - set(gkeys))[:5]
+    rows = [gkeys.index(k) for k in keys]
+    audioset = {'htsat': CK.htsat_audioset, 'passt': CK.passt_audioset, 'cnn14': CK.cnn14_audioset}[kind](CK.shapes(sd0, prefixes[-1]))
+    CK.keep_index_buffers(audioset, sd0, prefixes[-1], kind)
+    def load_and_check(path, audioset_flag, tag):
+        net = make(pretrained_path=None)
+        before = {k: v.clone() for k, v in net.state_dict().items()}
+        net.load_ckpts(path, audioset_pretrain=audioset_flag)
+        after = net.state_dict()
+        changed = np.array([not torch.equal(before[k], after[k]) for k in keys])
+        want_changed = g[f'{name}_{tag}_changed'][rows]
+        assert np.array_equal(changed, want_changed), [k for k, a, b in zip(keys, changed, want_changed) if a != b][:5]
+        got, want = np.array(CK.checksums(after, keys))[changed], g[f'{name}_{tag}'][rows][changed]
+        assert changed.sum() > 10 and np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), \
+            [k for k, a, b in zip(np.array(keys)[changed], got, want) if np.abs(a - b).max() > 1e-6][:5]
+
+    path = str(tmp_path / 'audioset.ckpt')
+    torch.save(audioset, path)
+    load_and_check(path, True, 'audioset')
+    path2 = str(tmp_path / 'pseld.ckpt')
+    compiled = name == 'einv2_htsat'
+    torch.save(CK.keep_index_buffers(CK.pseld(CK.shapes(sd0), compiled=compiled), sd0, '', kind,
+                                     pseld_prefix='net._orig_mod.' if compiled else 'net.'), path2)
+    load_and_check(path2, False, 'pseld')
+    # the constructor path (pretrained_path given) runs the same loader
+    net = make(pretrained_path=path) if name == 'accdoa_passt' else make(pretrained_path=path, audioset_pretrain=True)
+    ref = make(pretrained_path=None)
+    ref.load_ckpts(path, audioset_pretrain=True)
+    probe = [k for k in keys if k.endswith('norm.weight') or k.endswith('bn2.weight')][-1]
+    assert torch.equal(net.state_dict()[probe], ref.state_dict()[probe]) and not torch.equal(net.state_dict()[probe], sd0[probe])
