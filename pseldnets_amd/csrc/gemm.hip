@@ -644,7 +644,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
 template <int WM, int WN, int STAGES = 2>
-__global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 1) void gemm_dma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 2) void gemm_dma_kernel(GemmArgs g) {
     constexpr int THREADS = WM * WN * 64, WAVES = WM * WN, BM = WM * 64, BN = WN * 96;
     constexpr int BKD = 32;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
@@ -969,7 +969,12 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
         if (!(e && e[0] == '0')) {
             const bool narrow = g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288);
             if (narrow && K < 384) return launch_gemm_dma<4, 1>(g, s);     // 256x96 with a long K loop: gemm_kernel is faster
-            if (!narrow) return launch_gemm_dma<2, 2>(g, s);
+            if (!narrow) {
+                // PSELD_GEMM_RING3=<K>: 3-stage ring at two workgroups per CU (4 slices in flight per CU instead of 3) for K >= <K>
+                static const int ring_k = [] { const char* e = getenv("PSELD_GEMM_RING3"); return e ? atoi(e) : 0; }();
+                if (ring_k > 0 && K >= ring_k) return launch_gemm_dma<2, 2, 3>(g, s);
+                return launch_gemm_dma<2, 2>(g, s);
+            }
         }
     }
     if (dtype == PSELD_BF16) {
