@@ -50,7 +50,17 @@ def _worker(rank, world, port, q):
     tr._reduce_range(0, hi)
     for w in tr._works:
         w.wait()
-    q.put((rank, batches, arena.grad.clone().numpy()))
+    # validation / test epoch end: every rank's step outputs gathered back into the sampler's order (components/model_module.py:178-184:
+    # all_gather, then value.transpose(0, 1).reshape(-1, ...) per step — rank r holds samples r, r + world, ... of each global batch)
+    from pseldnets_amd.models.model_module import SELDModelModule
+    from pseldnets_amd.train import compose
+    mod = SELDModelModule.__new__(SELDModelModule)
+    mod.cfg, mod.method, mod.label_res = compose(['experiment=synth_accdoa']), 'accdoa', 0.1
+    steps, B, D = 3, 4, 6
+    glob = torch.arange(steps * B * world * 100 * D, dtype=torch.float32).reshape(steps, B * world, 100, D)
+    mod.step_system_outputs = [{'accdoa': glob[st, rank::world].clone()} for st in range(steps)]
+    agg = mod.pred_aggregation(dist.group.WORLD)['accdoa']
+    q.put((rank, batches, arena.grad.clone().numpy(), torch.equal(agg, glob.reshape(-1, D)) and mod.step_system_outputs == []))
     dist.destroy_process_group()
 
 
@@ -65,7 +75,8 @@ def test_two_process_gloo_sampler_and_gradient_buckets():
     for p in procs:
         p.join(60)
     g = np.load(os.path.join(G, 'sampler.npz'))
-    for rank, batches, grad in res:
+    for rank, batches, grad, gathered_in_order in res:
+        assert gathered_in_order
         assert np.array_equal(batches, g[f'n100_b8_w2_s2024_r{rank}'])
         n = grad.shape[0]
         assert np.array_equal(grad, np.arange(n, dtype=np.float32) * 3.0)   # (1 + 2) * arange: every element reduced once
