@@ -1019,8 +1019,48 @@ def gen_ckpt():
     save('ckpt.npz', **out)
 
 
+from tests.golden.meta_inputs import meta_rows, write_meta  # noqa: E402
+
+
+def gen_labels():
+    """preproc/preprocess.py extract_accdoa_label / extract_adpit_label / extract_track_label run unbound on seeded metadata CSV
+    files with a stand-in `self` and an in-memory stand-in for h5py.File (h5py is absent): the datasets they would store."""
+    import tempfile
+    import types
+    from pathlib import Path
+    store = {}
+
+    class FakeFile:
+        def __init__(self, path, mode):
+            pass
+
+        def create_dataset(self, name, data, dtype):
+            store[name] = np.asarray(data).astype(dtype)
+
+        def close(self):
+            pass
+    R._mod('h5py', File=FakeFile); R._mod('soundfile')
+    for name in [m for m in list(sys.modules) if m.startswith('preproc')]:
+        del sys.modules[name]
+    from preproc.preprocess import Preprocess
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        meta_dir = Path(td) / 'meta'; meta_dir.mkdir()
+        for i, seed in enumerate((31, 32)):
+            write_meta(meta_dir / f'mix{i}.csv', meta_rows(seed))
+        fake = types.SimpleNamespace(num_classes=5, meta_dir=meta_dir, cfg=R.AttrDict(dataset='synth'),
+                                     meta_accdoa_path=Path(td) / 'h5' / 'accdoa.h5', meta_adpit_path=Path(td) / 'h5' / 'adpit.h5',
+                                     meta_track_path=Path(td) / 'h5' / 'track.h5')
+        Preprocess.extract_accdoa_label(fake)
+        Preprocess.extract_adpit_label(fake)
+        Preprocess.extract_track_label(fake)
+    for k, v in store.items():
+        out[k.replace('/', '__')] = v
+    save('labels.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt', 'labels']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -1043,3 +1083,4 @@ if __name__ == '__main__':
     if 'epoch_end' in which: gen_epoch_end()
     if 'spatial' in which: gen_spatial()
     if 'ckpt' in which: gen_ckpt()
+    if 'labels' in which: gen_labels()

@@ -234,3 +234,29 @@ def test_checkpoint_loaders_match_the_reference(case, tmp_path):
     ref.load_ckpts(path, audioset_pretrain=True)
     probe = [k for k in keys if k.endswith('norm.weight') or k.endswith('bn2.weight')][-1]
     assert torch.equal(net.state_dict()[probe], ref.state_dict()[probe]) and not torch.equal(net.state_dict()[probe], sd0[probe])
+
+
+def test_label_extraction_matches_the_reference_preprocessing(tmp_path):
+    """data/labels.py (ACCDOA, ADPIT and track-wise labels from DCASE metadata) against the arrays the reference's
+    preproc/preprocess.py stores for the same seeded metadata files (tests/golden/labels.npz), bit for bit."""
+    import numpy as np
+    from pseldnets_amd import inference as inf
+    from pseldnets_amd.data import labels as L
+    from tests.golden.meta_inputs import meta_rows, write_meta
+    g = np.load(os.path.join(G, 'labels.npz'))
+    for i, seed in enumerate((31, 32)):
+        path = tmp_path / f'mix{i}.csv'
+        write_meta(path, meta_rows(seed))
+        rows = L.read_meta_rows(path)
+        num_frames = int(rows[-1, 0]) + 1
+        se, azi, ele = L.accdoa_labels(inf.load_output_format_file(path), num_frames, 5)
+        for name, got in (('se', se), ('azi', azi), ('ele', ele)):
+            want = g[f'mix{i}__accdoa__{name}']
+            assert got.dtype == want.dtype and np.array_equal(got, want), ('accdoa', name)
+        se, azi, ele = L.adpit_labels(inf.load_output_format_file(path), 5)
+        for name, got in (('se', se), ('azi', azi), ('ele', ele)):
+            want = g[f'mix{i}__adpit__{name}']
+            assert got.dtype == want.dtype and np.array_equal(got, want), ('adpit', name)
+        assert se[:, 3:].any() and se[:, 1:3].any()            # the fixtures exercise the B and C slots
+        sed, doa = L.track_labels(rows, 5)
+        assert np.array_equal(sed, g[f'mix{i}__sed_label']) and np.array_equal(doa, g[f'mix{i}__doa_label'])
