@@ -166,3 +166,70 @@ def generate_spatial_samples(audio, method, rng=None, **labels):
         lab = labels['adpit_label']
         return foa, coef_label(lab, lab.shape[1] * lab.shape[2], lab.shape[4], 1.0)
     raise NotImplementedError(method)
+
+
+class DeviceSELDDataset:
+    """The training split as the reference's datasets see it (data/components/data.py:12-116 + data/data.py:62-252), resident in
+    HBM: recordings as 16-bit PCM (`DeviceClipStore`), labels as the compact (se, azimuth, elevation) arrays of the label
+    files (or, for EINV2, the track-wise arrays), the index rows of `extract_index`. `batch(indices)` returns what the
+    reference's DataLoader would collate for those rows — {'filename', 'data' f32 [B,4,L], '<method> label' [B,100,...], 'ov'} —
+    with ONE chunk-cutting launch and one label-synthesis launch for the whole batch.
+    method: 'multi_accdoa' | 'accdoa' | 'einv2'; metas: {recording name: path of its DCASE metadata CSV}."""
+
+    def __init__(self, store, metas, method, num_classes, sample_rate=24000, chunklen_sec=10, hoplen_sec=10, label_res=0.1, max_ov=3):
+        from .. import inference
+        from . import labels as L
+        self.store, self.method, self.C = store.finalize(), method, num_classes
+        self.chunk_len = int(chunklen_sec * sample_rate)
+        self.ppp = int(sample_rate * label_res)                       # points_per_predictions
+        self.frames = int(chunklen_sec / label_res)
+        self.max_ov = max_ov
+        self.rows = store.index_rows(self.chunk_len, int(hoplen_sec * sample_rate))
+        dev = store.device
+        self.labels = {}
+        for name in store.names:
+            if method == 'einv2':
+                sed, doa = L.track_labels(L.read_meta_rows(metas[name]), num_classes, max_ov)
+                self.labels[name] = (torch.from_numpy(sed).to(dev), torch.from_numpy(doa).to(dev))
+            else:
+                meta = inference.load_output_format_file(metas[name])
+                if method == 'multi_accdoa':
+                    arrs = L.adpit_labels(meta, num_classes)
+                else:
+                    arrs = L.accdoa_labels(meta, int(L.read_meta_rows(metas[name])[-1, 0]) + 1, num_classes)
+                self.labels[name] = tuple(torch.from_numpy(a).to(dev) for a in arrs)
+
+    def __len__(self):
+        return len(self.rows)
+
+    def _label_slices(self, rows, k):
+        """Label frames [begin / ppp, end / ppp) of array k for every row, zero-padded to the chunk's frame count (data.py:197-222)."""
+        out = []
+        for r in rows:
+            a = self.labels[r[0]][k]
+            sl = a[int(r[1] / self.ppp):int(r[2] / self.ppp)]
+            if sl.shape[0] < self.frames:
+                sl = torch.cat((sl, torch.zeros((self.frames - sl.shape[0],) + tuple(sl.shape[1:]), dtype=sl.dtype, device=sl.device)), 0)
+            out.append(sl[:self.frames])
+        return torch.stack(out, 0)
+
+    def batch(self, indices):
+        rows = [self.rows[int(i)] for i in indices]
+        sample = {'filename': [r[0] for r in rows], 'data': self.store.chunks(rows, self.chunk_len)}
+        B = len(rows)
+        if self.method == 'einv2':
+            sed = self._label_slices(rows, 0)[:, :, :self.max_ov].float()
+            sample['sed_label'], sample['doa_label'] = sed, self._label_slices(rows, 1)[:, :, :self.max_ov].float()
+            act = sed.sum(dim=(2, 3))
+        else:
+            se, azi, ele = (self._label_slices(rows, k) for k in range(3))
+            lab = polar_labels(se.reshape(B * self.frames, *se.shape[2:]), azi.reshape(B * self.frames, *azi.shape[2:]),
+                               ele.reshape(B * self.frames, *ele.shape[2:]))
+            if self.method == 'multi_accdoa':
+                sample['adpit_label'] = lab.view(B, self.frames, 6, 4, self.C)
+                act = se.float().sum(dim=(2, 3))
+            else:
+                sample['accdoa_label'] = lab.view(B, self.frames, 4 * self.C)[:, :, self.C:]      # data.py:95: the xyz blocks
+                act = se.float().sum(dim=2)
+        sample['ov'] = [str(max(int(v), 1)) for v in act.max(dim=1).values.tolist()]             # data.py:229: one host sync per batch
+        return sample

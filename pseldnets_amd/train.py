@@ -178,14 +178,31 @@ def main(argv=None):
             dist.broadcast(p.data, 0)
     gen = torch.Generator(device=device).manual_seed(cfg.seed + rank)
     trainer = module.fused_trainer(group)
+    batches, n_batches = None, cfg.trainer.limit_train_batches
+    if cfg.data.get('wav_dir'):
+        # recordings + DCASE metadata on disk -> HBM-resident split, batches drawn by the reference's rank-strided sampler
+        # (data/components/sampler.py) and assembled on the device (data/ingest.py:DeviceSELDDataset)
+        from pathlib import Path
+        from .data.components.sampler import UserDistributedBatchSampler
+        from .data.ingest import DeviceClipStore, DeviceSELDDataset
+        store = DeviceClipStore(device, 4)
+        wavs = sorted(Path(cfg.data.wav_dir).glob('*.wav'))
+        for w in wavs:
+            store.add_wav(w)
+        metas = {str(w): Path(cfg.data.get('meta_dir') or cfg.data.wav_dir) / (w.stem + '.csv') for w in wavs}
+        ds = DeviceSELDDataset(store, metas, cfg.model.method, cfg.data.num_classes, cfg.data.sample_rate, cfg.data.train_chunklen_sec,
+                               cfg.data.get('train_hoplen_sec', cfg.data.train_chunklen_sec))
+        sampler = UserDistributedBatchSampler(len(ds), cfg.model.batch_size, seed=cfg.seed)
+        batches, n_batches = iter(sampler), min(n_batches, len(sampler)) if n_batches else len(sampler)
     for epoch in range(cfg.trainer.max_epochs):
         t0 = time.perf_counter()
-        for it in range(cfg.trainer.limit_train_batches):
-            loss = module.fused_training_step(synthetic_batch(cfg, cfg.model.method, device, gen), group)
+        for it in range(n_batches):
+            batch = ds.batch(next(batches)) if batches is not None else synthetic_batch(cfg, cfg.model.method, device, gen)
+            loss = module.fused_training_step(batch, group)
         torch.cuda.synchronize()
         if rank == 0:
             print(f"epoch {epoch}: loss_all {loss['loss_all'].item():.5f}  lr {trainer.lr:.2e}  "
-                  f"{cfg.trainer.limit_train_batches * cfg.model.batch_size * world / (time.perf_counter() - t0):.1f} chunks/s")
+                  f"{n_batches * cfg.model.batch_size * world / (time.perf_counter() - t0):.1f} chunks/s")
         trainer.end_epoch()
     if world > 1:
         import torch.distributed as dist
