@@ -357,6 +357,10 @@ int pseld_mse_loss(const float* pred, const float* target, float* dpred, float* 
 int pseld_tpit_loss(const float* sed, const float* doa, const float* sed_label, const float* doa_label, float* dsed,
                     float* ddoa, float* loss_out, long rows, int C, float beta, float* workspace, long workspace_bytes,
                     void* stream);
+/* model_utilities_adapt.py:19-20,40 (adapter_scalar: learnable_scalar): out[0] (+)= <a, b> / div[0] — the gradient of the
+ * learnable scale s of an Adapter from its already s-scaled fc2 gradients: <dW2, W2> / s + <db2, b2> / s. workspace >= 1 KiB. */
+int pseld_dot_div(const float* a, const float* b, long n, const float* div, float* out, int accumulate, float* workspace,
+                  long workspace_bytes, void* stream);
 /* loss/einv2.py:118-188 AGG loss (Losses_agg_pit; configs/loss/einv2_pit_agg.yaml): the EINV2 / SEDDOA outputs scored as
  * multi-ACCDOA vectors pred[k,c,:] = sigmoid(sed[k,c]) * normalize(doa[k,:]) against sed_label[k,c] * doa_label[k,:]:
  * agg = track-permutation-invariant mean error (:166-188), accdoa = mean error of the track sums (:148-153);

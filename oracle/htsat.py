@@ -108,6 +108,7 @@ def attention_core(qkv, table, heads, mask, rel_index):
 
 def adapter(x, sd, pre, scale):
     """model_utilities_adapt.py:7-44 Adapter: fc2(gelu(fc1(x))) * scale (present when the state holds `pre`fc1.weight)."""
+    scale = sd.get(pre + 'scale', scale)                    # adapter_scalar: learnable_scalar (model_utilities_adapt.py:19-20)
     return F.linear(F.gelu(F.linear(x, sd[pre + 'fc1.weight'], sd[pre + 'fc1.bias'])), sd[pre + 'fc2.weight'], sd[pre + 'fc2.bias']) * scale
 
 

@@ -382,6 +382,25 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void dot_finish_kernel(const float* __restrict__ partial, int n, const float* __restrict__ div, float* out, int accumulate) {
+    __shared__ float red[256];
+    red[threadIdx.x] = threadIdx.x < n ? partial[threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0] / div[0];
+}
 __global__ void norm_finish_kernel(const float* __restrict__ partial, int n, float* out) {
     __shared__ float red[256];
     float s = 0.f;
@@ -517,6 +536,19 @@ extern "C" int pseld_agg_pit_loss(const float* sed, const float* doa, const floa
     for (int k = 0; k < 3; ++k)
         hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, workspace + (long)k * nb, nb, inv, loss_out + k);
     PSELD_LAUNCH_CHECK("agg_pit_loss");
+    return PSELD_OK;
+}
+
+// out[0] (+)= (sum_i a[i] * b[i]) / div[0] — the gradient of a learnable adapter scale from the already scaled fc2 gradients
+// (model_utilities_adapt.py:19-20,40): d/ds sum(dy * s * z) = <dW2, W2> / s + <db2, b2> / s. workspace >= 256 floats.
+extern "C" int pseld_dot_div(const float* a, const float* b, long n, const float* div, float* out, int accumulate, float* workspace,
+                             long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(a && b && div && out && workspace && n > 0 && workspace_bytes >= 256 * 4, "dot_div: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)(pseld_cdiv(n, 256 * 8) < 256 ? pseld_cdiv(n, 256 * 8) : 256);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, n, workspace);
+    hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(256), 0, s, workspace, nb, div, out, accumulate);
+    PSELD_LAUNCH_CHECK("dot_div");
     return PSELD_OK;
 }
 

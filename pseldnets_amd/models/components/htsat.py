@@ -74,8 +74,9 @@ class SwinEncoder:
         if self.attn_adapter or self.mlp_adapter:
             if akw.get('type', 'adapter') != 'adapter' or akw.get('act_layer', 'gelu') != 'gelu' or akw.get('new_adapter'):
                 raise NotImplementedError("adapters: only type=adapter, act_layer=gelu, no new_adapter (configs/adapt/adapter.yaml)")
-            if isinstance(self.adapter_scale, str):
-                raise NotImplementedError("adapter_scalar=learnable_scalar is not built; use the numeric scalar of adapter.yaml")
+            if isinstance(self.adapter_scale, str) and self.adapter_scale != 'learnable_scalar':
+                raise NotImplementedError(f"adapter_scalar={self.adapter_scale}: a number or 'learnable_scalar' (model_utilities_adapt.py:19-22)")
+        self.learn_scale = self.adapter_scale == 'learnable_scalar'
         a, p, E = arena, prefix, self.E
 
         def lora_entries(base, out_f, in_f):
@@ -100,12 +101,16 @@ class SwinEncoder:
                 a.add(b + 'attn.proj.weight', (C, C)); a.add(b + 'attn.proj.bias', (C,)); lora_entries(b + 'attn.proj.', C, C)
                 ah = int(C * self.adapter_ratio)
                 if self.attn_adapter:
+                    if self.learn_scale:
+                        a.add(b + 'attn.adapter.scale', (1,))
                     a.add(b + 'attn.adapter.fc1.weight', (ah, C)); a.add(b + 'attn.adapter.fc1.bias', (ah,))
                     a.add(b + 'attn.adapter.fc2.weight', (C, ah)); a.add(b + 'attn.adapter.fc2.bias', (C,))
                 a.add(b + 'norm2.weight', (C,)); a.add(b + 'norm2.bias', (C,))
                 a.add(b + 'mlp.fc1.weight', (hid, C)); a.add(b + 'mlp.fc1.bias', (hid,)); lora_entries(b + 'mlp.fc1.', hid, C)
                 a.add(b + 'mlp.fc2.weight', (C, hid)); a.add(b + 'mlp.fc2.bias', (C,)); lora_entries(b + 'mlp.fc2.', C, hid)
                 if self.mlp_adapter:
+                    if self.learn_scale:
+                        a.add(b + 'mlp.adapter.scale', (1,))
                     a.add(b + 'mlp.adapter.fc1.weight', (ah, C)); a.add(b + 'mlp.adapter.fc1.bias', (ah,))
                     a.add(b + 'mlp.adapter.fc2.weight', (C, ah)); a.add(b + 'mlp.adapter.fc2.bias', (C,))
             if li < self.nl - 1:
@@ -228,7 +233,9 @@ class SwinEncoder:
             ops.colsum(dy if rowscale is None else ops.rowscale(dy, rowscale, per_scale_elems), a.g(bname))
 
     # -- Adapter (model_utilities_adapt.py:7-44): fc2(gelu(fc1(x))) * scale (+ resid) --------------------------------------
-    def _scale_vec(self, device):
+    def _scale_vec(self, device, pre=None):
+        if self.learn_scale:
+            return self.arena.p(pre + 'scale')                 # nn.Parameter(torch.ones(1)) of this adapter
         if self._ad_scale is None or self._ad_scale.device != device:
             self._ad_scale = torch.full((1,), float(self.adapter_scale), dtype=torch.float32, device=device)
         return self._ad_scale
@@ -236,15 +243,19 @@ class SwinEncoder:
     def _adapter_fwd(self, x, pre, resid=None):
         a, dtype, M = self.arena, x.dtype, x.shape[0]
         h, g = ops.linear_fwd(x, a.w(pre + 'fc1.weight', dtype), a.p(pre + 'fc1.bias'), gelu_dual=True)
-        y = ops.linear_fwd(h, a.w(pre + 'fc2.weight', dtype), a.p(pre + 'fc2.bias'), resid=resid, rowscale=self._scale_vec(x.device),
+        y = ops.linear_fwd(h, a.w(pre + 'fc2.weight', dtype), a.p(pre + 'fc2.bias'), resid=resid, rowscale=self._scale_vec(x.device, pre),
                            rows_per_scale=M)
         return y, dict(h=h, g=g)
 
     def _adapter_bwd(self, dy, x, sv, pre, dresid=None):
         """dy = gradient of the adapter output; returns the gradient wrt its input (+ dresid for the 'adapter(x) + x' form)."""
         a, dtype, M = self.arena, dy.dtype, dy.shape[0]
-        sc = self._scale_vec(dy.device)
+        sc = self._scale_vec(dy.device, pre)
         ops.linear_wgrad(dy, sv['h'], a.g(pre + 'fc2.weight'), dbias=a.g(pre + 'fc2.bias'), rowscale=sc, rows_per_scale=M)
+        if self.learn_scale:
+            # d/ds of (fc2(h) * s): <dy, fc2(h)> = (<dW2, W2> + <db2, b2>) / s with the s-scaled gradients just written
+            ops.dot_div(a.g(pre + 'fc2.weight'), a.p(pre + 'fc2.weight'), sc, a.g(pre + 'scale'))
+            ops.dot_div(a.g(pre + 'fc2.bias'), a.p(pre + 'fc2.bias'), sc, a.g(pre + 'scale'), accumulate=True)
         dh = ops.linear_dgrad(dy, a.w(pre + 'fc2.weight', dtype), wt=a.wt(pre + 'fc2.weight', dtype), mul=sv['g'], rowscale=sc, rows_per_scale=M)
         ops.linear_wgrad(dh, x, a.g(pre + 'fc1.weight'), dbias=a.g(pre + 'fc1.bias'))
         return ops.linear_dgrad(dh, a.w(pre + 'fc1.weight', dtype), wt=a.wt(pre + 'fc1.weight', dtype), resid=dresid)
@@ -411,6 +422,8 @@ def default_init(name, shape):
         t.zero_()
     elif 'lora_A' in name:
         torch.nn.init.kaiming_uniform_(t.view(shape[0], -1), a=math.sqrt(5))
+    elif name.endswith('.adapter.scale'):                               # model_utilities_adapt.py:20: nn.Parameter(torch.ones(1))
+        t.fill_(1.0)
     elif '.adapter.fc2.' in name:                                       # model_utilities_adapt.py:26-30: the adapter starts as identity
         t.zero_()
     elif name.startswith('stitch'):

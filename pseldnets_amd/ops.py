@@ -370,6 +370,15 @@ def agg_pit_loss(sed, doa, sed_label, doa_label, w_agg, w_acc, l1=False):
     return loss, dsed, ddoa
 
 
+def dot_div(a, b, div, out, accumulate=False):
+    """out[0] (+)= <a, b> / div[0] (all fp32 device tensors; a, b contiguous of equal size)."""
+    _chk(a, b, div, out)
+    ws = workspace(1024, a.device)
+    _lib.check(_lib.lib().pseld_dot_div(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(div), _lib.ptr(out), int(accumulate), _lib.ptr(ws),
+                                        ws.numel() * 4, _lib.stream_ptr()), "pseld_dot_div")
+    return out
+
+
 def grad_norm(g, out=None):
     _chk(g)
     if out is None:

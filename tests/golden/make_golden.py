@@ -569,6 +569,13 @@ ADAPT_CFG = dict(method='adapter', adapt_kwargs=dict(position=['MlpAdapter', 'Sp
                                                      adapter_scalar=0.1, act_layer='gelu'))
 
 
+def learnable_scales(sd, names):
+    """Distinct seeded values for the learnable adapter scales (shared rule with the tests: 0.05 + 0.03 * (index % 7))."""
+    for i, k in enumerate(names):
+        sd[k] = torch.tensor([0.05 + 0.03 * (i % 7)])
+    return sd
+
+
 def gen_adapter():
     """multi_accdoa.HTSAT with configs/adapt/adapter.yaml (MlpAdapter + SpatialAdapter, AdapterBit freezing): eval output,
     the trainable-parameter set, train-step loss and the gradients of every trainable parameter. The adapters get seeded
@@ -611,6 +618,29 @@ def gen_adapter():
     pick = ['encoder.layers.2.blocks.1.mlp.adapter.fc2.weight', 'encoder.layers.0.blocks.0.attn.qkv.bias', 'tscam_conv.weight']
     out['after_names'] = np.array(pick)
     out['after_heads'] = np.stack([dict(net.named_parameters())[n].detach().reshape(-1)[:8].numpy() for n in pick])
+    # adapter_scalar: learnable_scalar (model_utilities_adapt.py:19-20): one trainable scale per adapter, seeded to distinct values
+    cfgl = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'),
+                      adapt=dict(ADAPT_CFG, adapt_kwargs=dict(ADAPT_CFG['adapt_kwargs'], adapter_scalar='learnable_scalar')))
+    net = multi_accdoa.HTSAT(cfgl, C, 7, pretrained_path=None, audioset_pretrain=False, **ref_kwargs(TINY))
+    sdl = learnable_scales(dict(sd), [k for k in net.state_dict() if k.endswith('.adapter.scale')])
+    missing, unexpected = net.load_state_dict(sdl, strict=False)
+    assert not unexpected and all(('relative_position_index' in k) or ('attn_mask' in k) for k in missing), (missing, unexpected)
+    out['ls_scale_names'] = np.array([k for k in net.state_dict() if k.endswith('.adapter.scale')])
+    out['ls_trainable'] = np.array([n for n, p in net.named_parameters() if p.requires_grad])
+    net.eval()
+    with torch.no_grad():
+        out['ls_eval'] = net(x.clone())['multi_accdoa'].numpy()
+    net.train()
+    pred = net(x.clone())
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab})
+    ld['loss_all'].backward()
+    out['ls_loss'] = ld['loss_all'].item()
+    names, grads = [], []
+    for n, p in net.named_parameters():
+        if p.requires_grad and not n.startswith('scalar.'):
+            names.append(n); grads.append(p.grad.norm().item())
+    out['ls_grad_names'], out['ls_grad_norms'] = np.array(names), np.array(grads)
+    out['ls_scale_grads'] = np.array([dict(net.named_parameters())[str(k)].grad.item() for k in out['ls_scale_names']])
     save('adapter.npz', **out)
 
 

@@ -373,3 +373,43 @@ def test_bench_size_batch_independence(dev, dtype):
             small = net(x[b0:b0 + 7].clone())['multi_accdoa']
             assert torch.equal(big[b0:b0 + 7], small), (dtype, b0, (big[b0:b0 + 7] - small).abs().max().item())
     assert big.shape == (B, 100, 9 * 170) and torch.isfinite(big).all()
+
+
+def test_adapter_learnable_scalar_vs_reference(dev):
+    """adapter_scalar: learnable_scalar (model_utilities_adapt.py:19-20): one trainable scale per adapter — state-dict keys,
+    trainable set, eval output, loss, the gradient of every scale (a dot product of the scaled fc2 gradients with fc2) and the
+    gradient norms of the whole trainable set against the reference (tests/golden/adapter.npz); one fused step moves the scales."""
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'adapter.npz'))
+    C = 3
+    cfg = A(data=CFG.data, adapt=A(method='adapter', adapt_kwargs=A(ADAPT.adapt_kwargs, adapter_scalar='learnable_scalar')))
+    net = multi_accdoa.HTSAT(cfg, C, 7, pretrained_path=None, **kw(TINY))
+    names = [str(k) for k in g['ls_scale_names']]
+    assert [k for k in net.state_dict() if k.endswith('.adapter.scale')] == names
+    assert all(net.state_dict()[k].item() == 1.0 for k in names)                 # nn.Parameter(torch.ones(1))
+    sd = oh.add_adapters(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+    for i, k in enumerate(names):
+        sd[k] = torch.tensor([0.05 + 0.03 * (i % 7)])
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all('relative_position_index' in k or 'attn_mask' in k for k in missing)
+    assert set(n for n, p in net.named_parameters() if p.requires_grad) == set(str(n) for n in g['ls_trainable'])
+    net.to(dev)
+    x = oh.formula_features(2).to(dev)
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(x.clone())['multi_accdoa'], g['ls_eval']) < 1e-3
+    net.train()
+    ld = Losses('mse', 'loss_all')(net(x.clone()), {'adpit_label': synth.formula_adpit_label(2, 100, C).to(dev)})
+    assert abs(ld['loss_all'].item() - float(g['ls_loss'])) < 1e-4 * abs(float(g['ls_loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    got = np.array([params[n].grad.item() for n in names])
+    err = np.abs(got - g['ls_scale_grads']).max() / np.abs(g['ls_scale_grads']).max()
+    print('learnable adapter scales: worst gradient rel err', err)
+    assert err < 5e-3
+    for n, norm in zip(g['ls_grad_names'], g['ls_grad_norms']):
+        assert abs(params[str(n)].grad.norm().item() - norm) <= 5e-3 * max(norm, 1e-12), n
+    before = {n: params[n].detach().clone() for n in names}
+    net.fused_adamw_step(1e-3, max_norm=1.0)
+    assert all(not torch.equal(dict(net.named_parameters())[n].detach(), before[n]) for n in names)

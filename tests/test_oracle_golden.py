@@ -553,3 +553,33 @@ def test_generate_spatial_samples_golden(method):
     assert np.array_equal(np.stack([r[0] for r in res]).astype(np.float32), g[f'{method}_foa'])
     for j in range(1, len(res[0])):
         assert np.array_equal(np.stack([r[j] for r in res]).astype(np.float32), g[f'{method}_out{j}'])
+
+
+def _learnable_scales(sd, names):
+    for i, k in enumerate(names):
+        sd[k] = torch.tensor([0.05 + 0.03 * (i % 7)])
+    return sd
+
+
+def test_adapter_learnable_scalar_golden():
+    """adapter_scalar: learnable_scalar (model_utilities_adapt.py:19-20): the oracle with per-adapter scale entries against the
+    reference (eval output, loss, the gradient of every scale and the gradient norms of the trainable set)."""
+    g = gold('adapter.npz')
+    C = 3
+    x = oh.formula_features(2)
+    names = [str(k) for k in g['ls_scale_names']]
+    assert len(names) == 16 and all(n.endswith('.adapter.scale') for n in names)
+    sd = _learnable_scales(oh.add_adapters(oh.formula_state('multi_accdoa', C, 7, TINY), TINY), names)
+    with torch.no_grad():
+        close(oh.accdoa_htsat_forward(x.clone(), sd, TINY, key='multi_accdoa')['multi_accdoa'], g['ls_eval'], 2e-5)
+    trainable = set(str(n) for n in g['ls_trainable'])
+    assert set(names) <= trainable
+    p = {k: (v.clone().requires_grad_(k in trainable) if v.is_floating_point() else v) for k, v in sd.items()}
+    pred = oh.accdoa_htsat_forward(x.clone(), p, TINY, training=True, key='multi_accdoa')
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, C)})
+    assert abs(ld['loss_all'].item() - float(g['ls_loss'])) < 1e-6
+    ld['loss_all'].backward()
+    got = np.array([p[n].grad.item() for n in names])
+    assert np.abs(got - g['ls_scale_grads']).max() <= 2e-3 * np.abs(g['ls_scale_grads']).max()
+    for n, norm in zip(g['ls_grad_names'], g['ls_grad_norms']):
+        assert abs(p[str(n)].grad.norm().item() - norm) <= 2e-3 * max(norm, 1e-6), n
