@@ -176,8 +176,10 @@ class DeviceSELDDataset:
     with ONE chunk-cutting launch and one label-synthesis launch for the whole batch.
     method: 'multi_accdoa' | 'accdoa' | 'einv2'; metas: {recording name: path of its DCASE metadata CSV}."""
 
-    def __init__(self, store, metas, method, num_classes, sample_rate=24000, chunklen_sec=10, hoplen_sec=10, label_res=0.1, max_ov=3):
+    def __init__(self, store, metas, method, num_classes, sample_rate=24000, chunklen_sec=10, hoplen_sec=10, label_res=0.1, max_ov=3,
+                 mono_adapter=False, rng=None):
         from .. import inference
+        self.mono_adapter, self.rng = mono_adapter, rng          # cfg.adapt.method == 'mono_adapter' (data.py:109-111,169-171,223-225)
         from . import labels as L
         self.store, self.method, self.C = store.finalize(), method, num_classes
         self.chunk_len = int(chunklen_sec * sample_rate)
@@ -231,5 +233,15 @@ class DeviceSELDDataset:
             else:
                 sample['accdoa_label'] = lab.view(B, self.frames, 4 * self.C)[:, :, self.C:]      # data.py:95: the xyz blocks
                 act = se.float().sum(dim=2)
+        if self.mono_adapter:      # every chunk becomes the FOA encoding of its first channel at a random direction, labels rewritten
+            keys = [k for k in sample if k.endswith('_label')]
+            if self.method == 'accdoa':                           # the recipe works on the full (se | x | y | z) label, then drops se again
+                full = generate_spatial_samples(sample['data'], 'accdoa', self.rng, accdoa_label=lab.view(B, self.frames, 4 * self.C))
+                sample['data'], sample['accdoa_label'] = full[0], full[1][:, :, self.C:]
+            else:
+                res = generate_spatial_samples(sample['data'], self.method, self.rng, **{k: sample[k] for k in keys})
+                sample['data'] = res[0]
+                for k, v in zip(keys, res[1:]):
+                    sample[k] = v
         sample['ov'] = [str(max(int(v), 1)) for v in act.max(dim=1).values.tolist()]             # data.py:229: one host sync per batch
         return sample

@@ -191,7 +191,8 @@ def main(argv=None):
             store.add_wav(w)
         metas = {str(w): Path(cfg.data.get('meta_dir') or cfg.data.wav_dir) / (w.stem + '.csv') for w in wavs}
         ds = DeviceSELDDataset(store, metas, cfg.model.method, cfg.data.num_classes, cfg.data.sample_rate, cfg.data.train_chunklen_sec,
-                               cfg.data.get('train_hoplen_sec', cfg.data.train_chunklen_sec))
+                               cfg.data.get('train_hoplen_sec', cfg.data.train_chunklen_sec),
+                               mono_adapter=(cfg.adapt or {}).get('method') == 'mono_adapter')
         sampler = UserDistributedBatchSampler(len(ds), cfg.model.batch_size, seed=cfg.seed)
         batches, n_batches = iter(sampler), min(n_batches, len(sampler)) if n_batches else len(sampler)
     for epoch in range(cfg.trainer.max_epochs):

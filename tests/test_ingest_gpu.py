@@ -145,3 +145,31 @@ def test_train_entry_point_on_recordings(dev, tmp_path, capsys):
     lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('epoch')]
     losses = [float(ln.split('loss_all')[1].split()[0]) for ln in lines]
     assert len(losses) == 2 and all(np.isfinite(losses)) and all(0.0 < v < 5.0 for v in losses), lines
+
+
+@pytest.mark.parametrize("method", ['multi_accdoa', 'accdoa', 'einv2'])
+def test_device_dataset_mono_adapter(dev, tmp_path, method):
+    """cfg.adapt.method == 'mono_adapter': the batch equals the plain batch pushed through generate_spatial_samples (pinned to the
+    reference) with the same generator; the SE part of the labels is untouched and 'ov' with it."""
+    from pseldnets_amd.data.ingest import DeviceSELDDataset, generate_spatial_samples
+    from tests.golden.meta_inputs import write_meta
+    store, metas, _ = _make_split(tmp_path, dev, seeds=(31,))
+    rows = [[f, 2, 0, 10 * f - 170, f - 40] for f in range(0, 60, 2)]          # single-source metadata (the recipe's precondition)
+    write_meta(metas[list(metas)[0]], rows)
+    plain = DeviceSELDDataset(store, metas, method, 5).batch([0])
+    mono = DeviceSELDDataset(store, metas, method, 5, mono_adapter=True, rng=np.random.RandomState(3)).batch([0])
+    rng = np.random.RandomState(3)
+    if method == 'einv2':
+        want = generate_spatial_samples(plain['data'], 'einv2', rng, sed_label=plain['sed_label'], doa_label=plain['doa_label'])
+        assert torch.equal(mono['sed_label'], want[1]) and torch.equal(mono['doa_label'], want[2])
+    elif method == 'multi_accdoa':
+        want = generate_spatial_samples(plain['data'], 'multi_accdoa', rng, adpit_label=plain['adpit_label'])
+        assert torch.equal(mono['adpit_label'], want[1]) and torch.equal(mono['adpit_label'][:, :, :, 0], plain['adpit_label'][:, :, :, 0])
+    else:
+        full = torch.cat(((plain['accdoa_label'][:, :, :5] != 0).float() * 0, plain['accdoa_label']), dim=2)   # placeholder se block
+        se = (plain['accdoa_label'].view(1, 100, 3, 5).abs().sum(2) > 0).float()
+        full[:, :, :5] = se
+        want = generate_spatial_samples(plain['data'], 'accdoa', rng, accdoa_label=full)
+        assert torch.allclose(mono['accdoa_label'], want[1][:, :, 5:])
+    assert torch.equal(mono['data'], want[0]) and mono['ov'] == plain['ov'] == ['1']
+    assert not torch.equal(mono['data'][:, 1], plain['data'][:, 1]) and torch.equal(mono['data'][:, 0], plain['data'][:, 0])
