@@ -145,6 +145,10 @@ long pseld_passt_assemble_bwd_workspace(int E, int Tg);
 int pseld_passt_assemble_bwd(int dtype, const void* dX, void* dP, float* dtpos, float* dfpos, float* dcls,
                              float* ddist, float* dnpos, int B, int E, int Tg, float* workspace, long workspace_bytes,
                              void* stream);
+/* Structured patch-out (passt.py:250-258,333-338: training-time removal of frequency rows of the patch grid):
+ * Y[b, j, :] = X[b, map[j], :] for j < n_dst (zeros where map[j] < 0); X [B, n_src, E], Y [B, n_dst, E], map int32 [n_dst] on the
+ * device. With map = kept token rows it drops tokens; with the inverse map (-1 for dropped rows) it is the adjoint. */
+int pseld_rows_select(int dtype, const void* X, const int* map, void* Y, int B, int n_src, int n_dst, int E, void* stream);
 int pseld_passt_pool_fwd(int dtype, const void* X, void* Y, int B, int E, int Tg, void* stream);
 int pseld_passt_pool_bwd(int dtype, const void* dY, void* dX, int B, int E, int Tg, void* stream);
 int pseld_tanh_fwd(int dtype, const void* z, int ldz, float* y, long rows, int D, void* stream);

@@ -26,7 +26,7 @@ def grid_size(cfg):
     return tuple((s + 2 * pad - c['patch_size']) // c['stride'] + 1 for s in c['img_size'])
 
 
-def encoder_before(x, sd, pre, cfg):
+def encoder_before(x, sd, pre, cfg, training=False):
     """passt.py:314-357 (forward_before; = :216-247 of forward_features) with no patch-out: x [B, C, T, F] (already
     normalised) -> ([B, 2 + Fg*Tg, E] tokens, (Fg, Tg))."""
     c = _cfg(cfg)
@@ -35,6 +35,11 @@ def encoder_before(x, sd, pre, cfg):
                  stride=c['stride'], padding=pad)                                   # [B, E, Fg, Tg]
     B, _, Fg, Tg = x.shape
     x = x + sd[pre + 'time_new_pos_embed'][:, :, :, :Tg] + sd[pre + 'freq_new_pos_embed']
+    s_f = c.get('s_patchout_f', 0)
+    if training and s_f:             # structured frequency patch-out (passt.py:224,254-256 / :321,336-338): same generator calls
+        torch.randint(1, (1,))
+        x = x[:, :, torch.randperm(Fg)[:Fg - s_f].sort().values, :]
+        Fg = Fg - s_f
     x = x.flatten(2).transpose(1, 2)                                                # [B, Fg*Tg, E]
     cls = sd[pre + 'cls_token'].expand(B, -1, -1) + sd[pre + 'new_pos_embed'][:, :1]
     dist = sd[pre + 'dist_token'].expand(B, -1, -1) + sd[pre + 'new_pos_embed'][:, 1:]
@@ -69,10 +74,10 @@ def encoder_after(x, sd, pre, cfg, grid):
     return fmap, features
 
 
-def encoder_forward(x, sd, pre, cfg):
+def encoder_forward(x, sd, pre, cfg, training=False):
     """passt.py:214-312 with distilled=True: x [B, C, T, F] (already normalised) -> (feature_map [B, T', E] after the
     head LayerNorm, features [B, E])."""
-    x, grid = encoder_before(x, sd, pre, cfg)
+    x, grid = encoder_before(x, sd, pre, cfg, training)
     for i in range(_cfg(cfg)['depth']):
         x = encoder_block(x, sd, f'{pre}blocks.{i}.', cfg)
     return encoder_after(x, sd, pre, cfg, grid)
@@ -81,7 +86,7 @@ def encoder_forward(x, sd, pre, cfg):
 def accdoa_passt_forward(x, sd, cfg=None, training=False, bn_update=None, key='accdoa'):
     """models/accdoa.py:312-329 / multi_accdoa.py:46-54. x [B, C, 1001, 64] -> {key: [B, 100, D]}."""
     x = scalar_batchnorm(x, sd, training, update=bn_update)
-    fmap, _ = encoder_forward(x, sd, 'encoder.', cfg)
+    fmap, _ = encoder_forward(x, sd, 'encoder.', cfg, training)
     return {key: torch.tanh(F.linear(fmap, sd['fc.weight'], sd['fc.bias']))}
 
 

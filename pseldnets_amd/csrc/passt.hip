@@ -169,6 +169,27 @@ __global__ void passt_pos_grads_kernel(const float* __restrict__ S, float* __res
     for (int f = 0; f < FG; ++f) dfpos[e * FG + f] = ft[f];
 }
 
+// Structured patch-out (passt.py:250-258,333-338): Y[b, j] = X[b, src[j]] keeps a subset of the token rows; its adjoint writes
+// dX[b, i] = dY[b, inv[i]] (zeros where inv[i] < 0). One thread = 8 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_select_kernel(const T* __restrict__ X, const int* __restrict__ map, T* __restrict__ Y, int n_src,
+                                                          int n_dst, int E, long chunks) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= chunks) return;
+    const int cpr = E / 8;
+    const long row = id / cpr;
+    const int e0 = (int)(id - row * cpr) * 8;
+    const long b = row / n_dst;
+    const int j = (int)(row - b * n_dst), i = map[j];
+    float v[8];
+    if (i >= 0) load8<T>(X + (b * n_src + i) * E + e0, v);
+    else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
+    store8<T>(Y + id * 8, v);
+}
+
 // Y[b, tg] = mean_fg X[b, 2 + fg*Tg + tg]      (passt.py:296-300)
 template <typename T>
 __global__ __launch_bounds__(256) void passt_pool_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, int E, int Tg, long chunks) {
@@ -313,6 +334,14 @@ extern "C" int pseld_passt_assemble_bwd(int dtype, const void* dX, void* dP, flo
     hipLaunchKernelGGL(passt_pos_grads_kernel, dim3(pseld_cdiv(E, 128)), dim3(128), 0, s, workspace, dtpos, dfpos, dcls, ddist, dnpos, E, Tg);
     PSELD_LAUNCH_CHECK("passt_assemble_bwd");
     return PSELD_OK;
+}
+
+extern "C" int pseld_rows_select(int dtype, const void* X, const int* map, void* Y, int B, int n_src, int n_dst, int E, void* stream) {
+    PSELD_CHECK_ARG(X && map && Y && X != Y && B > 0 && n_src > 0 && n_dst > 0 && E % 8 == 0, "rows_select: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long chunks = (long)B * n_dst * (E / 8);
+    PASST_DISPATCH("rows_select", hipLaunchKernelGGL(rows_select_kernel<T>, dim3(pseld_cdiv(chunks, 256)), dim3(256), 0, s, (const T*)X, map,
+                                                      (T*)Y, n_src, n_dst, E, chunks));
 }
 
 extern "C" int pseld_passt_pool_fwd(int dtype, const void* X, void* Y, int B, int E, int Tg, void* stream) {

@@ -181,12 +181,12 @@ class PASST(HTSATNetBase):
         B, dt = x.shape[0], self.compute_dtype
         mean_rstd, scale_shift = self._bn_front(x, training)
         drop = self._drop_scales(B, self.enc, x.device, training)
-        tok, s_front = self.enc.forward_front(x, scale_shift, dt)
+        tok, s_front = self.enc.forward_front(x, scale_shift, dt, training)
         s_blocks = []
         for i in range(self.enc.depth):
             tok, s = self.enc.forward_block(i, tok, B, drop)
             s_blocks.append(s)
-        fmap, s_back = self.enc.forward_back(tok, B)
+        fmap, s_back = self.enc.forward_back(tok, B, s_front['maps'])
         y, s_head = self.head.forward(fmap, B)
         return y, dict(feat=x, mean_rstd=mean_rstd, front=s_front, blocks=s_blocks, back=s_back, head=s_head, B=B)
 

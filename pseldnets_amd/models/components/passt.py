@@ -9,7 +9,10 @@ no patch-out). No tensor arithmetic happens in this file: every step is one call
   * fc1's GEMM epilogue emits gelu(u) and gelu'(u) like the Swin path; DropPath factors ride in the GEMM epilogues;
   * the training-time random time offset of the positional embedding (passt.py:223-227) is randint(1) == 0 for the
     100-column grid, so the embedding is added whole;
-  * structured / unstructured patch-out (passt.py:250-269) are 0 in every shipped config; non-zero values raise.
+  * structured frequency patch-out (s_patchout_f, passt.py:254-256 / :336-338; training only) keeps randperm(6)[:6 - s] rows,
+    drawn from torch's CPU generator like the reference: the tokens of the dropped rows are removed after the positional
+    embeddings are added (`rows_select`) and the frequency mean runs over the kept rows; s_patchout_t / u_patchout cannot run
+    in the reference's SELD nets (its feature-map reshape uses the un-reduced T) and raise.
 """
 import torch
 
@@ -33,8 +36,11 @@ class PasstEncoder:
                 or cfg['norm_layer'] is not None or cfg['act_layer'] is not None:
             raise NotImplementedError("the MI355X path is built for the reference's PaSST geometry: 64 mel bins, patch 16 / "
                                       "stride 10, distilled, LayerNorm(1e-6) + GELU blocks, no dropout")
-        if cfg['u_patchout'] or cfg['s_patchout_t'] or cfg['s_patchout_f']:
-            raise NotImplementedError("patch-out (passt.py:250-269) is 0 in the shipped configs and is not built")
+        if cfg['u_patchout'] or cfg['s_patchout_t']:
+            raise NotImplementedError("u_patchout / s_patchout_t break the reference's own feature-map reshape (passt.py:279-281,368-370 use "
+                                      "the un-reduced T_dim); only s_patchout_f (frequency rows, training) can run there and is built")
+        if not 0 <= cfg['s_patchout_f'] < 6:
+            raise ValueError("s_patchout_f must leave at least one of the 6 frequency rows")
         self.cfg, self.arena, self.prefix, self.in_chans = cfg, arena, prefix, in_chans
         self.E, self.depth, self.heads = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
         if self.E != 64 * self.heads:
@@ -71,10 +77,28 @@ class PasstEncoder:
 
     @property
     def seq(self):
-        return self.Fg * self.Tg + 2
+        return self._rows_kept * self.Tg + 2
+
+    _rows_kept = 6
+
+    def patchout_maps(self, device, training):
+        """Structured frequency patch-out (passt.py:254-256 / :336-338, training only): torch.randperm(F)[:F - s].sort() rows are
+        kept — drawn from torch's CPU generator exactly like the reference. Returns (kept-token map, inverse map) or None."""
+        s_f = self.cfg['s_patchout_f']
+        if not training or not s_f:
+            self._rows_kept = self.Fg
+            return None
+        torch.randint(1, (1,))             # the reference draws its (always zero) time offset first (passt.py:224 / :321)
+        rows = torch.randperm(self.Fg)[:self.Fg - s_f].sort().values
+        self._rows_kept = rows.numel()
+        tg = torch.arange(self.Tg)
+        keep = torch.cat((torch.arange(2), (2 + rows[:, None] * self.Tg + tg[None, :]).reshape(-1))).to(torch.int32)
+        inv = torch.full((self.Fg * self.Tg + 2,), -1, dtype=torch.int32)
+        inv[keep.long()] = torch.arange(keep.numel(), dtype=torch.int32)
+        return keep.to(device), inv.to(device)
 
     # -- forward -------------------------------------------------------------------------------------------
-    def forward_front(self, feat, scale_shift, dtype):
+    def forward_front(self, feat, scale_shift, dtype, training=False):
         """passt.py:214-247: BN'd image -> patches -> + positional embeddings -> [cls, dist, patches]."""
         a, p = self.arena, self.prefix
         B, _, T, _ = feat.shape
@@ -85,11 +109,16 @@ class PasstEncoder:
         P0 = ops.linear_fwd(A0, W, a.p(p + 'patch_embed.proj.bias'))
         x = ops.passt_assemble_fwd(P0, a.p(p + 'time_new_pos_embed'), a.p(p + 'freq_new_pos_embed'), a.p(p + 'cls_token'),
                                    a.p(p + 'dist_token'), a.p(p + 'new_pos_embed'), B, self.Tg)
-        return x, dict(A0=A0)
+        maps = self.patchout_maps(x.device, training)
+        if maps is not None:                                  # the positional embeddings are added first, as in the reference
+            x = ops.rows_select(x, maps[0], B, self.Fg * self.Tg + 2)
+        return x, dict(A0=A0, maps=maps)
 
     def backward_front(self, dx, saved, feat, mean_rstd, bn_dw, bn_db, B, accumulate_bn=False):
         a, p = self.arena, self.prefix
         dtype = dx.dtype
+        if saved.get('maps') is not None:
+            dx = ops.rows_select(dx, saved['maps'][1], B, saved['maps'][0].numel())
         dP0 = ops.passt_assemble_bwd(dx, a.g(p + 'time_new_pos_embed'), a.g(p + 'freq_new_pos_embed'), a.g(p + 'cls_token'),
                                      a.g(p + 'dist_token'), a.g(p + 'new_pos_embed'), B, self.Tg)
         ops.linear_wgrad(dP0, saved['A0'], a.g(p + 'patch_embed.proj.weight').view(self.E, self.in_chans * 256),
@@ -133,19 +162,28 @@ class PasstEncoder:
         return ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'), a.g(b + 'norm1.bias'),
                                  dres=dx_mid, eps=1e-6)
 
-    def forward_back(self, x, B):
+    def forward_back(self, x, B, maps=None):
         """passt.py:292-311: final LayerNorm(1e-6), drop cls/dist, mean over frequency rows, head LayerNorm(1e-5)."""
         a, p = self.arena, self.prefix
         xn = ops.layernorm_fwd(x, a.p(p + 'norm.weight'), a.p(p + 'norm.bias'), eps=1e-6)
-        pooled = ops.passt_pool_fwd(xn, B, self.Tg)
+        if maps is not None:       # mean over the kept rows = (sum over all 6 with zeros in the dropped ones) / 6 * 6 / kept
+            xn = ops.rows_select(xn, maps[1], B, maps[0].numel())
+            pooled = ops.passt_pool_fwd(xn, B, self.Tg)
+            pooled = ops.axpby(pooled, pooled, self.Fg / self._rows_kept, 0.0)
+        else:
+            pooled = ops.passt_pool_fwd(xn, B, self.Tg)
         fmap = ops.layernorm_fwd(pooled, a.p(p + 'head.0.weight'), a.p(p + 'head.0.bias'), eps=1e-5)
-        return fmap, dict(x_last=x, pooled=pooled)
+        return fmap, dict(x_last=x, pooled=pooled, maps=maps, kept=self._rows_kept)
 
     def backward_back(self, dfmap, saved, B):
         a, p = self.arena, self.prefix
         dpooled = ops.layernorm_bwd(dfmap, saved['pooled'], a.p(p + 'head.0.weight'), a.g(p + 'head.0.weight'),
                                     a.g(p + 'head.0.bias'), eps=1e-5)
-        dxn = ops.passt_pool_bwd(dpooled, B, self.Tg)
+        if saved.get('maps') is not None:
+            dpooled = ops.axpby(dpooled, dpooled, self.Fg / saved['kept'], 0.0)
+            dxn = ops.rows_select(ops.passt_pool_bwd(dpooled, B, self.Tg), saved['maps'][0], B, self.Fg * self.Tg + 2)
+        else:
+            dxn = ops.passt_pool_bwd(dpooled, B, self.Tg)
         return ops.layernorm_bwd(dxn, saved['x_last'], a.p(p + 'norm.weight'), a.g(p + 'norm.weight'), a.g(p + 'norm.bias'),
                                  eps=1e-6)
 

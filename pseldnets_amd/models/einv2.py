@@ -425,8 +425,8 @@ class PASST(StaticBufferMixin, HTSATNetBase):
         mean_rstd, scale_shift = self._bn_front(x, training)
         drop_s = self._drop_scales(B, self.sed_enc, x.device, training)
         drop_d = self._drop_scales(B, self.doa_enc, x.device, training)
-        xs, fs = self.sed_enc.forward_front(x, scale_shift, dt)
-        xd, fd = self.doa_enc.forward_front(x, scale_shift, dt)
+        xs, fs = self.sed_enc.forward_front(x, scale_shift, dt, training)
+        xd, fd = self.doa_enc.forward_front(x, scale_shift, dt, training)
         blocks = []
         for i in range(self.sed_enc.depth):
             s = {}
@@ -436,8 +436,8 @@ class PASST(StaticBufferMixin, HTSATNetBase):
             xs, s['sed'] = self.sed_enc.forward_block(i, xs, B, drop_s)
             xd, s['doa'] = self.doa_enc.forward_block(i, xd, B, drop_d)
             blocks.append(s)
-        ms, bs = self.sed_enc.forward_back(xs, B)
-        md, bd = self.doa_enc.forward_back(xd, B)
+        ms, bs = self.sed_enc.forward_back(xs, B, fs['maps'])
+        md, bd = self.doa_enc.forward_back(xd, B, fd['maps'])
         sed, doa, s_tr = self.tracks.forward(ms, md, B, self.sed_enc.Tg, training, self._bn_bufs)
         return (sed, doa), dict(feat=x, mean_rstd=mean_rstd, fs=fs, fd=fd, blocks=blocks, bs=bs, bd=bd, tracks=s_tr, B=B)
 

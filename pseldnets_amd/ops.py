@@ -491,6 +491,16 @@ def passt_bn_bwd(feat, mean_rstd, dA, dweight, dbias, channels=None, accumulate=
     _lib.check(rc, "pseld_passt_bn_bwd")
 
 
+def rows_select(X, row_map, B, n_src):
+    """Y[b, j] = X[b, row_map[j]] (zeros where row_map[j] < 0): X [B*n_src, E] -> [B*len(row_map), E]; row_map int32 on the device."""
+    _chk(X, row_map)
+    n_dst, E = row_map.numel(), X.shape[1]
+    Y = torch.empty((B * n_dst, E), dtype=X.dtype, device=X.device)
+    _lib.check(_lib.lib().pseld_rows_select(dtype_code(X), _lib.ptr(X), _lib.ptr(row_map), _lib.ptr(Y), B, n_src, n_dst, E, _lib.stream_ptr()),
+               "pseld_rows_select")
+    return Y
+
+
 def passt_assemble_fwd(P, tpos, fpos, cls, dist, npos, B, Tg):
     _chk(P, tpos, fpos, cls, dist, npos)
     E = P.shape[1]

@@ -329,6 +329,25 @@ def gen_passt():
         y = net(oh.formula_features(1))['multi_accdoa']
     out['full_eval'] = y.numpy()
     out['full_n_params'] = sum(p.numel() for p in net.parameters())
+    # structured frequency patch-out (s_patchout_f = 2, training only): float64 train run under torch.manual_seed(123)
+    po = dict(PASST_TINY, s_patchout_f=2)
+    kw = passt_kwargs(PASST_TINY); kw['s_patchout_f'] = 2
+    net64 = multi_accdoa.PASST(CFG, C, 7, pretrained_path=None, **kw).double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in op.formula_state('multi_accdoa', C, 7, PASST_TINY).items()})
+    net64.eval()
+    with torch.no_grad():
+        out['po_eval'] = net64(x.double().clone())['multi_accdoa'].numpy()
+    net64.train()
+    torch.manual_seed(123)
+    pred = net64(x.double().clone())
+    ld = loss.multi_accdoa.Losses('mse', 'loss_all')(pred, {'adpit_label': lab.double()})
+    ld['loss_all'].backward()
+    out['po_train'], out['po_loss'] = pred['multi_accdoa'].detach().numpy(), ld['loss_all'].item()
+    names, norms = [], []
+    for n, p in net64.named_parameters():
+        if not n.startswith('scalar.'):
+            names.append(n); norms.append(p.grad.norm().item())
+    out['po_grad_names'], out['po_grad_norms'] = np.array(names), np.array(norms)
     save('passt.npz', **out)
 
 

@@ -583,3 +583,24 @@ def test_adapter_learnable_scalar_golden():
     assert np.abs(got - g['ls_scale_grads']).max() <= 2e-3 * np.abs(g['ls_scale_grads']).max()
     for n, norm in zip(g['ls_grad_names'], g['ls_grad_norms']):
         assert abs(p[str(n)].grad.norm().item() - norm) <= 2e-3 * max(norm, 1e-6), n
+
+
+def test_passt_frequency_patchout_golden():
+    """oracle/passt.py with s_patchout_f = 2 against the reference's float64 train run under torch.manual_seed(123): the same
+    generator calls keep the same frequency rows; eval ignores patch-out."""
+    from oracle import passt as op
+    g = gold('passt.npz')
+    cfg = dict(embed_dim=128, depth=2, num_heads=2, s_patchout_f=2)
+    x = oh.formula_features(2).double()
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in op.formula_state('multi_accdoa', 3, 7, cfg).items()}
+    with torch.no_grad():
+        assert np.abs(op.accdoa_passt_forward(x.clone(), sd, cfg, key='multi_accdoa')['multi_accdoa'].numpy() - g['po_eval']).max() < 1e-10
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v) for k, v in sd.items()}
+    torch.manual_seed(123)
+    pred = op.accdoa_passt_forward(x.clone(), p, cfg, training=True, key='multi_accdoa')
+    assert np.abs(pred['multi_accdoa'].detach().numpy() - g['po_train']).max() < 1e-10
+    ld = ol.adpit(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3).double()})
+    assert abs(ld['loss_all'].item() - float(g['po_loss'])) < 1e-10
+    ld['loss_all'].backward()
+    for n, norm in zip(g['po_grad_names'], g['po_grad_norms']):
+        assert abs(p[str(n)].grad.norm().item() - norm) <= 1e-8 * max(norm, 1e-9) + 1e-14, n

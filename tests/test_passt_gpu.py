@@ -215,3 +215,37 @@ def test_all_gradients_vs_oracle(dev, dtype, gate):
             worst = (n, e)
     print(f'PaSST worst parameter-gradient rel-L2 ({dtype}):', worst)
     assert worst[1] < gate, worst
+
+
+def test_frequency_patchout_train_step_vs_golden(dev):
+    """s_patchout_f = 2 (passt.py:254-256,336-338): under torch.manual_seed(123) the HIP path keeps the frequency rows the
+    reference keeps (same CPU generator calls); train output, loss and every gradient norm against the reference's float64
+    run; eval ignores patch-out."""
+    from pseldnets_amd.loss.multi_accdoa import Losses
+    from pseldnets_amd.models import multi_accdoa
+    g = np.load(os.path.join(G, 'passt.npz'))
+    cfg = dict(TINY, s_patchout_f=2)
+    net = multi_accdoa.PASST(CFG, 3, 7, pretrained_path=None, **cfg)
+    net.load_state_dict(op.formula_state('multi_accdoa', 3, 7, TINY), strict=True)
+    net.to(dev)
+    x = oh.formula_features(2).to(dev)
+    net.eval()
+    with torch.no_grad():
+        y = net(x.clone())['multi_accdoa']
+    assert y.shape == (2, 100, 27) and rel(y, g['po_eval']) < 1e-3
+    net.train()
+    torch.manual_seed(123)
+    pred = net(x.clone())
+    assert net.enc.seq == 2 + 4 * 100 and rel(pred['multi_accdoa'], g['po_train']) < 1e-3
+    ld = Losses('mse', 'loss_all')(pred, {'adpit_label': synth.formula_adpit_label(2, 100, 3).to(dev)})
+    assert abs(ld['loss_all'].item() - float(g['po_loss'])) < 1e-3 * abs(float(g['po_loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for n, norm in zip(g['po_grad_names'], g['po_grad_norms']):
+        e = abs(params[str(n)].grad.norm().item() - norm) / max(norm, 1e-6)
+        worst = max(worst, (str(n), e), key=lambda t: t[1])
+    print('PaSST frequency patch-out: worst grad-norm rel err', worst)
+    assert worst[1] < 2e-3, worst
+    with pytest.raises(NotImplementedError):
+        multi_accdoa.PASST(CFG, 3, 7, pretrained_path=None, **dict(TINY, s_patchout_t=10))
