@@ -364,9 +364,12 @@ class CRNN(StaticBufferMixin, HTSATNetBase):
 
 
 class _NotBuilt:
+    """Registry entries the reference itself cannot construct (einv2.ConvConformer: its super().__init__ call passes the arguments of
+    an older signature and fails on `cfg.data`, einv2.py:177-180)."""
+
     def __init__(self, *a, **k):
-        raise NotImplementedError("this backbone of the reference registry is not built on the MI355X path yet "
-                                  "(SURVEY.md §8 rows a16/a17); use backbone=HTSAT")
+        raise NotImplementedError("einv2.ConvConformer cannot be constructed in the reference either (einv2.py:177-180); "
+                                  "use einv2.CRNN with model.decoder=conformer")
 
 
 class ConvConformer(CRNN):
