@@ -413,3 +413,43 @@ def test_adapter_learnable_scalar_vs_reference(dev):
     before = {n: params[n].detach().clone() for n in names}
     net.fused_adamw_step(1e-3, max_norm=1.0)
     assert all(not torch.equal(dict(net.named_parameters())[n].detach(), before[n]) for n in names)
+
+
+def test_fused_step_through_a_single_rank_rccl_group(dev):
+    """The data-parallel code path on the one GPU of the test box: a world-size-1 RCCL ('nccl') process group makes the trainer
+    issue its bucketed asynchronous all-reduces over the gradient arena (back to front, overlapped with the backward) and wait
+    for them before clip + AdamW; the result must match the step without a group (an all-reduce over one rank is the identity)."""
+    import torch.distributed as dist
+    from pseldnets_amd.models import multi_accdoa
+    from pseldnets_amd.trainer import FusedTrainer
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29871', rank=0, world_size=1, device_id=dev)
+    except Exception as e:           # no RCCL on this box
+        pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        x = oh.formula_features(2).to(dev)
+        lab = {'adpit_label': synth.formula_adpit_label(2, 100, 3).to(dev)}
+        results = []
+        for group in (None, dist.group.WORLD):
+            net, _ = build_net(multi_accdoa.HTSAT, 'multi_accdoa', 3, TINY, dev)
+            ranges = []
+            tr = FusedTrainer(net, None, 'adpit', lr=1e-3, process_group=group)
+            if group is not None:
+                orig = tr._reduce_range
+                tr._reduce_range = lambda a, b: (ranges.append((a, b)), orig(a, b))[1]
+            ld = tr.training_step(x.clone(), lab, is_features=True)
+            torch.cuda.synchronize()
+            results.append((ld['loss_all'].item(), net.arena.grad.clone(), net.arena.flat.clone()))
+            if group is not None:
+                # three buckets, back to front, together covering the arena exactly once
+                assert len(ranges) == 3 and ranges[0][1] == net.arena.size and ranges[-1][0] == 0
+                assert all(ranges[i][0] == ranges[i + 1][1] for i in range(2)) and all(a < b for a, b in ranges)
+        # equal up to the run-to-run noise of the fp32 atomics in the bias-table gradients
+        # (the updated parameters are compared loosely: AdamW normalises gradients, so noise in a near-zero gradient moves a weight by up to lr)
+        assert abs(results[0][0] - results[1][0]) < 1e-5 * abs(results[0][0])
+        assert (results[0][1] - results[1][1]).norm().item() < 1e-5 * results[0][1].norm().item()
+        assert (results[0][2] - results[1][2]).abs().max().item() <= 2.5e-3
+    finally:
+        dist.destroy_process_group()
