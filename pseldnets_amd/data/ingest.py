@@ -77,8 +77,11 @@ class DeviceClipStore:
         self._total += pcm.shape[0]
         self.pcm = None
 
-    def add_wav(self, path):
-        pcm, _ = read_wav_pcm16(path)
+    def add_wav(self, path, sample_rate=None):
+        """sample_rate: cfg.data.sample_rate — a recording at another rate would be chunked and labelled on the wrong time base."""
+        pcm, rate = read_wav_pcm16(path)
+        if sample_rate is not None and int(rate) != int(sample_rate):
+            raise ValueError(f'{path}: sample rate {rate} Hz, expected cfg.data.sample_rate = {sample_rate} Hz (no resampler on this path)')
         self.add_clip(str(path), pcm)
 
     def finalize(self):

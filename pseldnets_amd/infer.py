@@ -41,7 +41,7 @@ def build_split(cfg, device):
     store = DeviceClipStore(device, 4)
     if cfg.wav_dir:
         for p in sorted(Path(cfg.wav_dir).glob('*.wav')):
-            store.add_wav(p)
+            store.add_wav(p, sample_rate=sr)
     else:
         g = torch.Generator().manual_seed(cfg.seed)
         for i in range(cfg.n_clips):

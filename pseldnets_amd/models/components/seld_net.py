@@ -96,6 +96,7 @@ class HTSATNetBase(nn.Module):
     # -- device placement ------------------------------------------------------------------------------------
     def _materialize(self, device):
         if self._materialized_on == device:
+            self._check_master_version()
             return
         _lib.require_gpu()
         init = {n: _get(self, n).detach().to(device=device, dtype=torch.float32) for n in self.arena.entries}
@@ -114,6 +115,25 @@ class HTSATNetBase(nn.Module):
             node._buffers['num_batches_tracked'] = self._nbt[c]
         self._materialized_on = device
         self.shadow_trusted = False
+        self._params = [_get(self, n) for n in self.arena.entries]
+        self._master_sig = None
+        self._check_master_version()
+
+    def _master_signature(self):
+        # every in-place write torch knows about bumps a version counter: the arena's own (ops on arena.flat) or a
+        # parameter's (load_state_dict, torch optimizers, EMA, user edits). The fused AdamW kernel writes master and bf16
+        # shadow together through raw pointers and bumps neither.
+        return self.arena.flat._version + sum(p._version for p in self._params)
+
+    def _check_master_version(self):
+        """The bf16 shadow (and its transposed copies) are valid only for the fp32 master values they were cast from:
+        any in-place change since then invalidates them, whoever made it (a sticky 'trusted' flag kept serving
+        stale weights after load_state_dict / a torch optimizer step that followed a fused step)."""
+        sig = self._master_signature()
+        if sig != self._master_sig:
+            self.arena.shadow_valid = False
+            self.arena.shadow_t_valid = False
+            self._master_sig = sig
 
     def _apply(self, fn, *a, **k):
         # .to()/.cuda() re-create tensors: drop the arena binding, it is rebuilt on the next forward
@@ -173,9 +193,7 @@ class HTSATNetBase(nn.Module):
 
     def _run(self, x):
         self._check_input(x)
-        self._materialize(x.device)
-        if not self.shadow_trusted:
-            self.arena.shadow_valid = False
+        self._materialize(x.device)           # (re-checks the master version: the shadow follows any in-place weight change)
         x = x.contiguous().float()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             params = [_get(self, n) for n in self.arena.entries]
@@ -212,6 +230,7 @@ class HTSATNetBase(nn.Module):
         if frozen is not None:                 # undo the weight decay on the frozen entries: p = p * mask + p_frozen * (1 - mask)
             a.flat.copy_(ops.axpby(ops.mul(a.flat, frozen['mask']), frozen['keep'], 1.0, 1.0))
             a.shadow_valid = False
+        self._master_sig = self._master_signature()
         return grad_norm
 
     def _frozen_state(self):

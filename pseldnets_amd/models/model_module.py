@@ -159,9 +159,21 @@ class SELDModelModule:
         batch_x, batch_y = self.augment_step(batch_x, batch_y)
         return self.forward(batch_x), batch_y
 
+    def train(self, mode=True):
+        """Lightning toggles the module's `training` flag and the network's together around every fit / validation / test
+        loop; without Lightning the hooks below do it themselves (a validation epoch used to leave `training`
+        False and silently switch every augmentation off for the rest of the run)."""
+        self.training = bool(mode)
+        if self.net is not None:
+            self.net.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
     def training_step(self, batch_sample, batch_idx=0):
         """Reference semantics: returns the scalar to back-propagate (loss_dict[loss.loss_type])."""
-        self.net.train()
+        self.train()
         batch_target = {k: v for k, v in batch_sample.items() if 'data' not in k}
         pred, target = self.common_step(batch_sample['data'], batch_target)
         loss_dict = self.loss(pred, target)
@@ -171,12 +183,15 @@ class SELDModelModule:
     def predict(self, batch_data):
         """Eval-mode prediction of one batch; cfg.post_processing == 'ACS' runs the 16-pass test-time augmentation."""
         from .. import inference
-        self.net.eval()
-        self.training = False
-        with torch.no_grad():
-            if _get(self.cfg, 'post_processing') == 'ACS':
-                return inference.acs_predict(batch_data, self.standardize, self.forward, output_format=self.method)
-            return self.common_step(batch_data)[0]
+        was_training = self.training
+        self.eval()
+        try:
+            with torch.no_grad():
+                if _get(self.cfg, 'post_processing') == 'ACS':
+                    return inference.acs_predict(batch_data, self.standardize, self.forward, output_format=self.method)
+                return self.common_step(batch_data)[0]
+        finally:
+            self.training = was_training          # the next training step sets the network's own flag itself
 
     def validation_step(self, batch_sample, batch_idx=0):
         batch_target = {k: v for k, v in batch_sample.items() if 'label' in k}
@@ -274,7 +289,14 @@ class SELDModelModule:
     # -- fused path -----------------------------------------------------------------------------------------------
     def fused_trainer(self, process_group=None):
         if self._trainer is None:
+            # the fused step is clip + AdamW + StepLR (configs/model/*.yaml as shipped); anything else the config asks for
+            # must not train silently with different dynamics
+            om, sm = _get(self.cfg, 'model.optimizer.method', 'AdamW'), _get(self.cfg, 'model.lr_scheduler.method', 'StepLR')
             opt = dict(_get(self.cfg, 'model.optimizer.kwargs', {}))
+            if om != 'AdamW' or sm != 'StepLR' or opt.get('amsgrad', False) or _get(self.cfg, 'model.optimizer.multi_opt', False):
+                raise NotImplementedError(f"fused training step: optimizer {om} (amsgrad={opt.get('amsgrad', False)}, multi_opt="
+                                          f"{_get(self.cfg, 'model.optimizer.multi_opt', False)}) / scheduler {sm} is not built on the MI355X "
+                                          "path; use training_step + configure_optimizers (torch optimisers) for it")
             sch = dict(_get(self.cfg, 'model.lr_scheduler.kwargs', {}))
             kind, agg = _LOSS_KIND[self.method], {}
             if hasattr(self.loss, 'weights'):                       # loss.einv2.Losses_agg_pit (configs/loss/einv2_pit_agg.yaml)
@@ -290,8 +312,8 @@ class SELDModelModule:
 
     def fused_training_step(self, batch_sample, process_group=None):
         batch_target = {k: v for k, v in batch_sample.items() if 'data' not in k}
+        self.train()
         if self.data_aug['type'] or self.data_aug['AugMix']:
-            self.training = True
             feats, batch_target = self.augment_step(batch_sample['data'], batch_target)
             return self.fused_trainer(process_group).training_step(feats, batch_target, is_features=True)
         return self.fused_trainer(process_group).training_step(batch_sample['data'], batch_target)

@@ -188,7 +188,7 @@ def main(argv=None):
         store = DeviceClipStore(device, 4)
         wavs = sorted(Path(cfg.data.wav_dir).glob('*.wav'))
         for w in wavs:
-            store.add_wav(w)
+            store.add_wav(w, sample_rate=cfg.data.sample_rate)
         metas = {str(w): Path(cfg.data.get('meta_dir') or cfg.data.wav_dir) / (w.stem + '.csv') for w in wavs}
         ds = DeviceSELDDataset(store, metas, cfg.model.method, cfg.data.num_classes, cfg.data.sample_rate, cfg.data.train_chunklen_sec,
                                cfg.data.get('train_hoplen_sec', cfg.data.train_chunklen_sec),

@@ -26,6 +26,12 @@ class FusedTrainer:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
             if sync_bn:
+                # configs/trainer/gpu.yaml:9 converts EVERY BatchNorm. The scalar front of all networks is synchronised here
+                # (seld_net._bn_front); the conv-stack BatchNorm2d / Conformer BatchNorm1d kernels use rank-local statistics, so
+                # a CRNN run would diverge per rank without a word — refuse instead.
+                if any(hasattr(net, a) for a in ('conv_enc', 'sed_enc')) and hasattr(getattr(net, 'conv_enc', getattr(net, 'sed_enc', None)), '_bn'):
+                    raise NotImplementedError("sync_batchnorm over the CRNN conv-stack BatchNorms is not built on the MI355X path; "
+                                              "run CRNN backbones with trainer.sync_batchnorm=false")
                 net.sync_bn_group = process_group
         self._works = []
 

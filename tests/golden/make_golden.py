@@ -491,6 +491,52 @@ def gen_conformer():
     save('conformer.npz', **out)
 
 
+def gen_conformer_full():
+    """BASELINE config 1 at its shipped width (configs/model/crnn.yaml: CNN12 [64..2048] + 1 Conformer block, d_model 2048,
+    8 heads = head_dim 256; conformer/attention.py:28-115): ACCDOA, 170 classes, four 10 s chunks -> [4, 100, 510] (eval), and a
+    FLOAT64 train run (dropout p forced to 0, B = 2) for the loss and every non-scalar gradient norm."""
+    C = 170
+    cfgc = R.AttrDict(data=dict(n_mels=64, sample_rate=24000, hoplen=240, nfft=1024, window='hann'),
+                      model=R.AttrDict(decoder='conformer', num_decoder_layers=1), adapt=dict())
+    out = {}
+    sd = oc.add_conformer(oc.random_state('accdoa', C, 7, 'CNN12', CRNN_FULL, seed=0), CRNN_FULL[-1], 1, seed=3)
+    x = oc.random_features(4, seed=1)
+    net = accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_FULL)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out['n_params'] = sum(p.numel() for p in net.parameters())
+    net.eval()
+    with torch.no_grad():
+        y = net(x.clone())['accdoa']
+    assert tuple(y.shape) == (4, 100, 510)
+    idx = torch.linspace(0, y.numel() - 1, 8192).long()
+    out['eval_index'] = idx.numpy()
+    out['eval_sample'] = y.reshape(-1)[idx].numpy()
+    out['eval_norm'] = y.norm().item()
+    out['eval_absmax'] = y.abs().max().item()
+    net64 = accdoa.CRNN(cfgc, C, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_FULL).double()
+    net64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sd.items()})
+    for m in net64.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net64.train()
+    pred = net64(x[:2].double().clone())
+    lab = synth.formula_accdoa_label(2, 100, C)
+    ld = loss.accdoa.Losses('mse', 'loss_all')(pred, {'accdoa_label': lab.double()})
+    ld['loss_all'].backward()
+    out['train_loss'] = ld['loss_all'].item()
+    ty = pred['accdoa'].detach().float()
+    out['train_sample'] = ty.reshape(-1)[torch.linspace(0, ty.numel() - 1, 4096).long()].numpy()
+    names, norms = [], []
+    for n, p in net64.named_parameters():
+        if n.startswith('scalar.'):
+            continue
+        names.append(n); norms.append(p.grad.norm().item())
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    save('conformer_full.npz', **out)
+
+
 from tests.golden.aug_inputs import aug_inputs  # noqa: E402
 
 
@@ -1109,7 +1155,7 @@ def gen_labels():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt', 'labels']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'conformer_full', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt', 'labels']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -1119,6 +1165,7 @@ if __name__ == '__main__':
     if 'passt' in which: gen_passt()
     if 'crnn' in which: gen_crnn()
     if 'conformer' in which: gen_conformer()
+    if 'conformer_full' in which: gen_conformer_full()
     if 'augment' in which: gen_augment()
     if 'decode' in which: gen_decode()
     if 'adapter' in which: gen_adapter()

@@ -453,3 +453,166 @@ def test_fused_step_through_a_single_rank_rccl_group(dev):
         assert (results[0][2] - results[1][2]).abs().max().item() <= 2.5e-3
     finally:
         dist.destroy_process_group()
+
+
+# ---- parity at the sizes the bench times (round-2: full-size backward, bench-batch backward, bf16 drift) -----------------------
+
+def test_full_size_f32_train_step_vs_oracle(dev):
+    """Full-size HTS-AT mACCDOA (embed 96, depths 2-2-6-2, 170 classes), f32 parity mode, TRAIN step on B = 2 chunks against
+    the oracle's autograd: loss at 1e-3, every parameter's gradient (relative L2 of the whole tensor AND its norm) at 2e-3, the
+    relative-position bias-table gradients element-wise. This is the backward at the production widths (C = 96 ... 768,
+    head N = 1536): split-K weight gradients, slab reducers, attention-backward and bias-table atomics at their real shapes."""
+    from pseldnets_amd import ops
+    from pseldnets_amd.models import multi_accdoa
+    cfg = dict(FULL, drop_path_rate=0.0)
+    B, C = 2, 170
+    net, sd = build(multi_accdoa, 'multi_accdoa', C, cfg, dev)
+    net.train()
+    x = oh.formula_features(B)
+    lab = synth.formula_adpit_label(B, 100, C)
+    net._materialize(dev)
+    y, saved = net._forward_impl(x.to(dev), True)
+    loss, dpred = ops.adpit_loss(y, lab.to(dev))
+    net.zero_grad_arena()
+    net._backward_impl(saved, (dpred,))
+    names = [n for n, _ in net.named_parameters()]
+    pr = {k: (t.clone().requires_grad_(True) if (t.is_floating_point() and k in names) else t.clone()) for k, t in sd.items()}
+    out = oh.accdoa_htsat_forward(x.clone(), pr, cfg, training=True, bn_update={}, key='multi_accdoa')
+    assert rel(y, out['multi_accdoa']) < 1e-3
+    lo = ol.adpit(out, {'adpit_label': lab})['loss_all']
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-3 * abs(lo.item()), (loss.item(), lo.item())
+    worst_l2, worst_norm = ('', 0.0), ('', 0.0)
+    for n in names:
+        got, want = net.arena.g(n).cpu(), pr[n].grad
+        wn = want.norm().item()
+        e_l2 = (got - want).norm().item() / max(wn, 1e-8)
+        e_n = abs(got.norm().item() - wn) / max(wn, 1e-8)
+        worst_l2 = max(worst_l2, (n, e_l2), key=lambda t: t[1])
+        worst_norm = max(worst_norm, (n, e_n), key=lambda t: t[1])
+        if 'relative_position_bias_table' in n:
+            assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-9, n
+    print('full-size f32 train step: loss', loss.item(), 'oracle', lo.item(), '; worst gradient rel-L2', worst_l2, '; worst norm err', worst_norm)
+    assert worst_norm[1] < 2e-3, worst_norm
+    assert worst_l2[1] < 2e-3, worst_l2
+
+
+def test_bench_size_backward_additivity(dev):
+    """Size-independent property of the BACKWARD at the BASELINE workload (full HTS-AT, bf16, 192 chunks = M 786 432 at stage 0):
+    with per-sample-independent forward arithmetic (BatchNorm on its running statistics, drop_path 0) the parameter gradient of
+    the 192-chunk launch must equal the sum of the gradients of sub-batches of 7 fed the SAME per-sample output gradients —
+    identical bf16 values per sample, so only the fp32 summation order (split-K plan, slab reducers, bias-table atomics, the
+    resident-round attention-backward grid) differs between the two sides."""
+    from pseldnets_amd import ops
+    from pseldnets_amd.models import multi_accdoa
+    torch.manual_seed(11)
+    cfg = dict(FULL, drop_path_rate=0.0)
+    net = multi_accdoa.HTSAT(CFG, 170, 7, pretrained_path=None, **kw(cfg))
+    net.compute_dtype = torch.bfloat16
+    net.to(dev)
+    Bt = 192
+    gcpu = torch.Generator().manual_seed(5)
+    x = torch.randn(Bt, 7, 1001, 64, generator=gcpu).to(dev)
+    act = (torch.rand(Bt, 100, 170, generator=gcpu) < 0.02).float()
+    lab = torch.zeros(Bt, 100, 6, 4, 170)
+    lab[:, :, 0, 0] = act
+    lab[:, :, 0, 1:] = torch.nn.functional.normalize(torch.randn(Bt, 100, 3, 170, generator=gcpu), dim=2) * act.unsqueeze(2)
+    lab = lab.to(dev)
+    net._materialize(dev)
+    y, saved = net._forward_impl(x, False)
+    _, dpred = ops.adpit_loss(y, lab)
+    net.zero_grad_arena()
+    net._backward_impl(saved, (dpred,))
+    big = net.arena.grad.clone()
+    del saved
+    acc = torch.zeros_like(big)
+    for b0 in range(0, Bt, 7):
+        b1 = min(Bt, b0 + 7)
+        ys, ss = net._forward_impl(x[b0:b1].contiguous(), False)
+        assert torch.equal(ys, y[b0:b1])
+        net.zero_grad_arena()
+        net._backward_impl(ss, (dpred[b0:b1].contiguous(),))
+        acc += net.arena.grad
+    assert torch.isfinite(big).all() and big.norm().item() > 0
+    worst = ('', 0.0)
+    for n in net.arena.entries:
+        a, b = net.arena.view(big, n), net.arena.view(acc, n)
+        e = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+    tot = (big - acc).norm().item() / acc.norm().item()
+    print(f'192-chunk backward vs sum of 7-chunk backwards: arena rel-L2 {tot:.3e}; worst parameter', worst)
+    assert tot < 2e-5 and worst[1] < 2e-4, (tot, worst)
+
+
+def _default_init_net(dev, dtype, seed=21):
+    from pseldnets_amd.models import multi_accdoa
+    torch.manual_seed(seed)
+    net = multi_accdoa.HTSAT(CFG, 170, 7, pretrained_path=None, **kw(dict(FULL, drop_path_rate=0.0)))
+    net.compute_dtype = dtype
+    return net.to(dev)
+
+
+def test_bf16_drift_on_default_initialised_weights(dev):
+    """bf16 (throughput) mode against f32 (parity) mode on REALISTIC weights — the reference constructors' defaults (kaiming-
+    uniform Linear / Conv, trunc_normal(0.02) bias tables, unit norms; components/htsat.py:default_init), not the adversarial
+    closed-form state of the goldens: full-size eval forward error, and a 200-step training curve (same batch, clip 1.0, AdamW
+    lr 1e-4) whose bf16 losses must track the f32 ones."""
+    from pseldnets_amd.trainer import FusedTrainer
+    gcpu = torch.Generator().manual_seed(9)
+    B = 4
+    x = torch.randn(B, 7, 1001, 64, generator=gcpu).to(dev)
+    act = (torch.rand(B, 100, 170, generator=gcpu) < 0.02).float()
+    lab = torch.zeros(B, 100, 6, 4, 170)
+    lab[:, :, 0, 0] = act
+    lab[:, :, 0, 1:] = torch.nn.functional.normalize(torch.randn(B, 100, 3, 170, generator=gcpu), dim=2) * act.unsqueeze(2)
+    target = {'adpit_label': lab.to(dev)}
+    outs, curves = {}, {}
+    for dtype in (torch.float32, torch.bfloat16):
+        net = _default_init_net(dev, dtype)
+        net.eval()
+        with torch.no_grad():
+            outs[dtype] = net(x.clone())['multi_accdoa'].float().cpu()
+        tr = FusedTrainer(net, None, 'adpit', lr=1e-4, max_norm=1.0)
+        ls = []
+        for _ in range(200):
+            ls.append(tr.training_step(x, target, is_features=True)['loss_all'])
+        curves[dtype] = torch.cat(ls).cpu()
+    ref, got = outs[torch.float32], outs[torch.bfloat16]
+    fwd_rel = ((got - ref).abs().max() / ref.abs().max()).item()
+    fwd_l2 = ((got - ref).norm() / ref.norm()).item()
+    cf, cb = curves[torch.float32], curves[torch.bfloat16]
+    dev_curve = ((cb - cf).abs() / cf.abs()).max().item()
+    print(f'bf16 vs f32, default init: eval forward max-abs rel {fwd_rel:.3e}, rel-L2 {fwd_l2:.3e}; 200-step loss curve '
+          f'f32 {cf[0].item():.6f} -> {cf[-1].item():.6f}, bf16 {cb[0].item():.6f} -> {cb[-1].item():.6f}, max rel deviation {dev_curve:.3e}')
+    assert torch.isfinite(cb).all() and cf[-1] < cf[0] and cb[-1] < cb[0]
+    assert fwd_rel < 5e-2 and fwd_l2 < 2e-2, (fwd_rel, fwd_l2)
+    assert dev_curve < 2e-2, dev_curve
+
+
+def test_weights_changed_behind_the_arena_are_seen(dev):
+    """after a fused step the bf16 shadow must follow ANY in-place change of the fp32 master (load_state_dict to
+    restore a checkpoint, a torch optimizer, EMA) — the forward of the updated net must equal a fresh net with those weights."""
+    from pseldnets_amd.models import multi_accdoa
+    from pseldnets_amd.trainer import FusedTrainer
+    x = oh.formula_features(2).to(dev)
+    lab = {'adpit_label': synth.formula_adpit_label(2, 100, 3).to(dev)}
+    net, sd = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev, torch.bfloat16)
+    tr = FusedTrainer(net, None, 'adpit', lr=1e-2)
+    tr.training_step(x.clone(), lab, is_features=True)           # shadow now comes from the fused AdamW kernel
+    net.load_state_dict(sd, strict=False)                        # restore the initial weights behind the arena's back
+    net.eval()
+    with torch.no_grad():
+        y_restored = net(x.clone())['multi_accdoa']
+    fresh, _ = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev, torch.bfloat16)
+    fresh.eval()
+    with torch.no_grad():
+        y_fresh = fresh(x.clone())['multi_accdoa']
+    assert torch.equal(y_restored, y_fresh)
+    # the training path (FusedTrainer -> _forward_impl directly) must see an in-place edit too
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.0)
+        dict(net.named_parameters())['tscam_conv.bias'].add_(0.25)
+    net.train()
+    y_train, _ = net._forward_impl(x.clone(), False)
+    assert not torch.equal(y_train, y_fresh)
