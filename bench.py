@@ -4,8 +4,11 @@
 One step = one pass of the hot path over one batch of synthetic input already resident in HBM:
   32 clips/GPU = 192 ten-second chunks -> fused STFT/log-mel/IV -> scalar BN -> HTS-AT (Swin) -> mACCDOA head ->
   ADPIT loss -> hand-written backward -> (bucketed RCCL all-reduce) -> clip(1.0) -> AdamW.
-Contract: python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run, one rank per GPU).
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions).
+Contract: python bench.py --gpus N --steps K --warmup W. N > 1: either under torch.distributed.run (one rank per GPU, the
+driver's launch line) or plain `python bench.py --gpus N`, which then starts the N ranks itself (child processes, spawned
+before this process has touched a GPU; never an exec). Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the
+roofline / cpu_baseline definitions). `--chunks 32` times the reference-native chunk batch (configs/experiment/
+synth_maccdoa.yaml:8) instead of 32 whole clips.
 """
 import argparse
 import json
@@ -37,13 +40,17 @@ def make_cfg():
                                   audio_feature='logmelIV'), adapt=AttrDict())
 
 
-def synthetic_batch(clips, device, seed):
+def synthetic_batch(clips, device, seed, chunks=None):
     """wave = 0.1*N(0,1) f32[clips, 4, 1 440 000] chunked as segment_index(chunklen=hoplen=10 s)
-    would (6 full chunks per clip); adpit_label: track A0 only, act ~ Bernoulli(0.02), unit DOA."""
+    would (6 full chunks per clip); adpit_label: track A0 only, act ~ Bernoulli(0.02), unit DOA. chunks: the
+    reference-native chunk batch instead (f32[chunks, 4, 240 000], configs/experiment/synth_maccdoa.yaml:8)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    chunks = clips * CHUNKS_PER_CLIP
-    wave = 0.1 * torch.randn(clips, 4, CHUNKS_PER_CLIP, 10 * FS, generator=g, device=device)
-    wave = wave.permute(0, 2, 1, 3).reshape(chunks, 4, 10 * FS).contiguous()
+    if chunks is not None:
+        wave = 0.1 * torch.randn(chunks, 4, 10 * FS, generator=g, device=device)
+    else:
+        chunks = clips * CHUNKS_PER_CLIP
+        wave = 0.1 * torch.randn(clips, 4, CHUNKS_PER_CLIP, 10 * FS, generator=g, device=device)
+        wave = wave.permute(0, 2, 1, 3).reshape(chunks, 4, 10 * FS).contiguous()
     act = (torch.rand(chunks, 100, CLASSES, generator=g, device=device) < 0.02).float()
     doa = torch.randn(chunks, 100, 3, CLASSES, generator=g, device=device)
     doa = doa / doa.norm(dim=2, keepdim=True).clamp_min(1e-6)
@@ -126,18 +133,21 @@ def pmc_traffic(args):
     this process: the figure is the one measured with rocprofv3 on this same command (two separate --pmc passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/."""
     path = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic_pmc.json')
-    if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or not os.path.exists(path):
+    if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks or not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
     return round(d['traffic_bytes_per_launch'], 1), 'profiles/r01_gemm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 
 
-def cpu_baseline(chunks=4, steps=2):
+def cpu_baseline(chunks=4, steps=3, threads=None):
     """The CPU oracle (a port: the reference's Python cannot travel) timed on this host: features + HTS-AT mACCDOA
-    fwd + ADPIT + backward + clip + AdamW on `chunks` 10 s chunks, fp32, all host threads."""
+    fwd + ADPIT + backward + clip + AdamW on `chunks` 10 s chunks, fp32; `threads` = torch intra-op threads (None: all)."""
     from oracle import feature as of, htsat as oh, losses as ol, optim as oo
     torch.manual_seed(0)
+    all_threads = torch.get_num_threads()
+    if threads is not None:
+        torch.set_num_threads(threads)
     cfg = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.0)
     sd = oh.formula_state('multi_accdoa', CLASSES, 7, cfg)
     names = [k for k, v in sd.items() if v.is_floating_point() and 'running' not in k]
@@ -158,10 +168,43 @@ def cpu_baseline(chunks=4, steps=2):
             plist = [sd[n] for n in names]
             oo.adamw_step(plist, [p[n].grad for n in names], m, v, it + 1, 1e-4)
         times.append(time.perf_counter() - t0)
-    t = min(times[1:])
-    return {"value": round(chunks / CHUNKS_PER_CLIP / t, 4), "unit": "clips/s", "cores": torch.get_num_threads(),
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    used = torch.get_num_threads()
+    torch.set_num_threads(all_threads)
+    return {"value": round(chunks / CHUNKS_PER_CLIP / t, 4), "unit": "clips/s", "cores": used,
             "kind": "port", "sample": f"{steps} timed train steps of {chunks} ten-second chunks (fp32 oracle, "
-            f"features+fwd+bwd+clip+AdamW), best step {t:.2f} s"}
+            f"features+fwd+bwd+clip+AdamW) after 1 warm-up, median step {t:.2f} s"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (which has not
+    touched a GPU: torch is imported, no HIP call has been made), one per GPU, rendezvous on 127.0.0.1. Rank 0's stdout (the
+    JSON line) is relayed to ours; any failing rank fails the run and the others are stopped by their exact PIDs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PSELD_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for pr in procs[1:]:
+        try:
+            codes.append(pr.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            codes.append(pr.wait())
+    sys.stdout.write(out0.decode() if out0 else '')
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
 
 
 def main():
@@ -170,6 +213,12 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--clips', type=int, default=32, help='60 s clips per GPU per step')
+    ap.add_argument('--chunks', type=int, default=0,
+                    help='N > 0: time the reference-native chunk batch (N ten-second chunks per GPU per step, '
+                         'configs/experiment/synth_maccdoa.yaml:8 batch_size 32) instead of --clips whole clips; clips/s = (N/6)*world/step')
+    ap.add_argument('--sync-bn', default='auto', choices=['auto', 'on', 'off'],
+                    help="all-reduce the scalar-BatchNorm statistics over the ranks (configs/trainer/gpu.yaml:9 sync_batchnorm: True). "
+                         "auto = on when N > 1 (the reference's DDP recipe)")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2', 'crnn', 'passt_einv2', 'crnn_einv2'],
                     help='htsat = the headline workload (BASELINE.json configs[1]); htsat_einv2 = configs[2] (dual-branch, tPIT); '
@@ -187,9 +236,14 @@ def main():
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)                 # nothing in this process has touched a GPU yet
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the two must agree "
+                         "(a one-rank run must not be reported as an N-GPU number)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # PSELD_BENCH_BACKEND=gloo: control-flow check of the multi-rank path on a box with fewer GPUs than ranks (ranks
@@ -248,9 +302,12 @@ def main():
         for p in net.parameters():            # identical initial weights on every rank
             dist.broadcast(p.data, 0)
     einv2_mode = args.backbone.endswith('_einv2')
+    sync_bn = world > 1 and (args.sync_bn == 'on' or (args.sync_bn == 'auto' and not args.backbone.startswith('crnn')))
     trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
-                           process_group=group, sync_bn=False)
-    wave, target = synthetic_batch(args.clips, device, 2024 + rank)
+                           process_group=group, sync_bn=sync_bn)
+    wave, target = synthetic_batch(args.clips, device, 2024 + rank, chunks=args.chunks or None)
+    n_chunks = wave.shape[0]
+    clips_per_step = n_chunks / CHUNKS_PER_CLIP
     if einv2_mode:     # track-wise labels: track 0 carries the ADPIT A0 events, tracks 1-2 silent
         lab = target['adpit_label']
         act = lab[:, :, 0, 0]                                        # [chunks, 100, C]
@@ -294,18 +351,24 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
+    # HIP events at the step boundaries on the launch stream: per-step durations (median) beside the whole-region clock
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = 1e3 * elapsed / args.steps
-    clips_per_s = args.clips * world / (elapsed / args.steps)
+    clips_per_s = clips_per_step * world / (elapsed / args.steps)
     loss_val = float(loss['loss_all'].item())
 
     crnn_names = {'conformer': 'CNN12 x2 + 6 Conformer blocks', 'gru': 'CNN12 x2 + 6 two-layer BiGRUs', 'none': 'CNN12 x2, Identity decoders'}
@@ -319,11 +382,18 @@ def main():
         "metric": f"train clips/sec (60 s 4-ch FOA) {name}" + ("" if einv2_mode else " mACCDOA") + (" + AugMix" if args.augment == 'augmix' else "") + (" (adapter fine-tuning)" if args.adapt == 'adapter' else ""), "value": round(clips_per_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, {args.clips} clips x 60 s FOA @ 24 kHz per GPU = "
-                               f"{args.clips * CHUNKS_PER_CLIP} ten-second chunks/step, 170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
+        "config": {"workload": f"{name}{' dual-branch (tPIT)' if einv2_mode else ' mACCDOA'} {args.dtype}, "
+                               + (f"reference-native chunk batch: {n_chunks} ten-second chunks (= {clips_per_step:.2f} clips of 60 s) per GPU per step, "
+                                  if args.chunks else f"{args.clips} clips x 60 s FOA @ 24 kHz per GPU = {n_chunks} ten-second chunks/step, ")
+                               + f"170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
                                f"{'dropout 0.1' if args.backbone.startswith('crnn') else 'drop_path 0.0' if args.backbone.startswith('passt') else 'drop_path 0.1'}, BN train mode, {'AugMix augmentations (x3 chunks through the network)' if args.augment == 'augmix' else 'no augmentation'}",
-                   "global_clips": args.clips * world, "parallelism": f"dp{world}"},
+                   "global_clips": round(clips_per_step * world, 3), "global_chunks": n_chunks * world, "parallelism": f"dp{world}",
+                   "sync_batchnorm": bool(sync_bn)},
         "loss": round(loss_val, 6),
+        # per-step HIP-event durations on rank 0's launch stream (median over >= 100 steps when --steps >= 100)
+        "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(step_ms[0], 3), "ms_per_step_p90": round(step_ms[int(0.9 * (len(step_ms) - 1))], 3),
+        "value_at_median_step": round(clips_per_step * world / (median_ms * 1e-3), 2),
+        "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1), "comm_backend": backend if world > 1 else None,
     }
     if args.augment == 'augmix':
         gflop_chunk = 3 * gflop_chunk                     # every original chunk goes through the network three times
@@ -374,7 +444,9 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline()                       # every host core
+                # BASELINE.md section 3's comparability line: the survey's probe of the REFERENCE ran on 8 threads (0.45 clips/s)
+                out["cpu_baseline"]["at_8_threads"] = cpu_baseline(threads=8)
             except Exception as e:  # the checker must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -84,7 +84,8 @@ def test_glue_kernels(dev, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("B,T,D,heads,masked", [(2, 125, 64, 8, True), (3, 37, 256, 8, False), (1, 128, 96, 4, True)])
+@pytest.mark.parametrize("B,T,D,heads,masked", [(2, 125, 64, 8, True), (3, 37, 256, 8, False), (1, 128, 96, 4, True),
+                                                (2, 125, 2048, 8, True)])      # configs/model/crnn.yaml: d_model 2048 / 8 heads = head_dim 256
 def test_relative_attention(dev, dtype, tol, B, T, D, heads, masked):
     """attention.py:75-112 (content + relatively-shifted positional score, / sqrt(d_model), softmax, dropout, @ v) and all
     of its gradients against torch autograd of the oracle's formulation."""
@@ -312,3 +313,64 @@ def test_transformer_network_vs_reference_goldens(dev, tag):
     netb.to(dev).eval()
     with torch.no_grad():
         assert rel(netb(x.to(dev))['multi_accdoa'], g['eval']) < 1.5e-1
+
+
+
+FULL = [64, 128, 256, 512, 1024, 2048]
+
+
+def test_config1_full_width_crnn_conformer_vs_reference(dev):
+    """BASELINE configs[0] at its shipped width (configs/model/crnn.yaml:4-11: CNN12 [64..2048] + one Conformer block, d_model
+    2048, 8 heads -> head_dim 256; conformer/attention.py:28-115): ACCDOA, 170 classes, four 10 s chunks -> [4, 100, 510] against
+    the reference's eval output, then a train step (dropout 0, B = 2): prediction, MSE loss and every decoder / fc / conv
+    gradient norm against the reference's float64 run (tests/golden/make_golden.py:gen_conformer_full)."""
+    from pseldnets_amd.loss.accdoa import Losses
+    from pseldnets_amd.models import accdoa
+    g = np.load(os.path.join(G, 'conformer_full.npz'))
+    C, D = 170, FULL[-1]
+    sd = oc.add_conformer(oc.random_state('accdoa', C, 7, 'CNN12', FULL, seed=0), D, 1, seed=3)
+    net = accdoa.CRNN(CFG, C, 7, encoder='CNN12', pretrained_path=None, num_features=FULL)
+    net.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in net.parameters()) == int(g['n_params'])
+    net.to(dev).eval()
+    x = oc.random_features(4, seed=1)
+    with torch.no_grad():
+        y = net(x.to(dev))['accdoa']
+    assert y.shape == (4, 100, 510)
+    got = y.reshape(-1)[torch.from_numpy(g['eval_index']).to(dev)]
+    r = rel(got, g['eval_sample'])
+    print(f'config 1 (CNN12 + Conformer D=2048) eval rel err {r:.3e}; |y| {y.norm().item():.4f} vs {float(g["eval_norm"]):.4f}')
+    assert r < 1e-3 and abs(y.norm().item() - float(g['eval_norm'])) < 1e-3 * float(g['eval_norm'])
+    net.train()
+    net.dec_blocks.p = 0.0
+    pred = net(x[:2].to(dev))
+    ty = pred['accdoa'].reshape(-1)
+    assert rel(ty[torch.linspace(0, ty.numel() - 1, 4096).long().to(dev)], g['train_sample']) < 1e-3
+    ld = Losses('mse', 'loss_all')(pred, {'accdoa_label': synth.formula_accdoa_label(2, 100, C).to(dev)})
+    assert abs(ld['loss_all'].item() - float(g['train_loss'])) < 1e-3 * abs(float(g['train_loss']))
+    ld['loss_all'].backward()
+    params = dict(net.named_parameters())
+    worst_dec, worst_conv = ('', 0.0), ('', 0.0)
+    for n, norm in zip(g['grad_names'], g['grad_norms']):
+        n = str(n)
+        gr = params[n].grad
+        if norm < 1e-10:
+            assert gr.norm().item() < 1e-5, n
+            continue
+        e = abs(gr.norm().item() - norm) / norm
+        if n.startswith(('decoder.', 'fc.')):
+            worst_dec = max(worst_dec, (n, e), key=lambda t: t[1])
+        else:
+            worst_conv = max(worst_conv, (n, e), key=lambda t: t[1])
+    print('config 1 train step: worst decoder/fc grad-norm rel err', worst_dec, '; worst conv-stack', worst_conv)
+    assert worst_dec[1] < 5e-3, worst_dec
+    assert worst_conv[1] < 3e-2, worst_conv           # the bar test_crnn_gpu.py holds the conv stack to (fp32 vs float64 BatchNorm residuals)
+    netb = accdoa.CRNN(CFG, C, 7, encoder='CNN12', pretrained_path=None, num_features=FULL)
+    netb.load_state_dict(sd, strict=True)
+    netb.compute_dtype = torch.bfloat16
+    netb.to(dev).eval()
+    with torch.no_grad():
+        yb = netb(x.to(dev))['accdoa']
+    rb = rel(yb.reshape(-1)[torch.from_numpy(g['eval_index']).to(dev)], g['eval_sample'])
+    print(f'config 1 eval bf16 rel err {rb:.3e}')
+    assert rb < 1.5e-1

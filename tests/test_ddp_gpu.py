@@ -92,3 +92,29 @@ def test_bench_two_ranks_terminates_and_reports(dev):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and 'roofline' in out
     assert out['config']['global_clips'] == 2 and 'cpu_baseline' not in out
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(dev):
+    """`python bench.py --gpus 2` with no torchrun around it: the parent (which never touches a GPU) starts two child ranks,
+    relays rank 0's single JSON line and exits 0; the line reports 2 ranks, sync-BN on (the reference's DDP recipe,
+    configs/trainer/gpu.yaml:9) and the reference-native chunk batch when asked for."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(PSELD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--chunks', '4']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['config']['sync_batchnorm'] is True
+    assert out['config']['global_chunks'] == 8 and abs(out['config']['global_clips'] - 8 / 6) < 1e-3
+    assert out['value'] > 0 and out['ms_per_step_median'] > 0
+    # a launcher / flag disagreement must fail loudly instead of reporting a one-rank number as N GPUs
+    env1 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env1,
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and 'must agree' in (r.stderr + r.stdout)

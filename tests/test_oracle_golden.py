@@ -279,6 +279,18 @@ def test_crnn_full_size_golden():
     close(y, g['full_eval'], 5e-5)
 
 
+def test_config1_full_width_conformer_golden():
+    """oracle/crnn.py at BASELINE configs[0]'s shipped width (CNN12 [64..2048] + one Conformer block, d_model 2048 / 8 heads)
+    against the reference: ACCDOA, 170 classes, four 10 s chunks -> [4, 100, 510] (tests/golden/conformer_full.npz)."""
+    from oracle import crnn as oc
+    g = gold('conformer_full.npz')
+    sd = oc.add_conformer(oc.random_state('accdoa', 170, 7, 'CNN12', CRNN_FULL, seed=0), CRNN_FULL[-1], 1, seed=3)
+    with torch.no_grad():
+        y = oc.accdoa_crnn_forward(oc.random_features(4, seed=1), sd, 'CNN12', key='accdoa', decoder='conformer', num_decoder_layers=1)['accdoa']
+    assert tuple(y.shape) == (4, 100, 510)
+    close(y.reshape(-1)[torch.from_numpy(g['eval_index'])], g['eval_sample'], 5e-5)
+
+
 def _conformer_case(g, tag, dropout_p, masks, tol=1e-8):
     from oracle import crnn as oc
     D = CRNN_TINY[-1]
