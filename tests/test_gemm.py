@@ -76,7 +76,9 @@ def test_linear_dgrad_gelu_grad(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(4096, 96, 96), (8192, 288, 96), (4096, 384, 1536), (2048, 1536, 4608), (1024, 48, 112)])
+@pytest.mark.parametrize("M,N,K", [(4096, 96, 96), (8192, 288, 96), (4096, 384, 1536), (2048, 1536, 4608), (1024, 48, 112),
+                                   # the LDS-DMA ring kernel's shapes (bf16): whole 384 x 192 tiles, ragged columns / rows, the 256-row tile
+                                   (6144, 1152, 384), (2080, 768, 360), (1536, 600, 384), (3200, 512, 768)])
 def test_linear_wgrad(dev, dtype, M, N, K):
     from pseldnets_amd import ops
     dy, x = _mk((M, N), dtype, 8, 0.1), _mk((M, K), dtype, 9)
@@ -120,6 +122,26 @@ def test_fc1_dual_gelu_epilogue_and_mul_dgrad(dev, dtype):
     dy, w2 = _mk((M, 96), dtype, 5), _mk((96, N), dtype, 6, 0.1)
     du = ops.linear_dgrad(dy.to(dev), w2.to(dev), mul=g)
     _check("dU = (dY W2) * g", du, (dy.double() @ w2.double()) * g.double().cpu(), dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows_per_scale,N,K", [(64, 384, 384), (256, 1536, 384), (96, 768, 192)])
+def test_droppath_factor_in_the_large_weight_gradients(dev, dtype, rows_per_scale, N, K):
+    """The same at the sizes the LDS-DMA ring weight-gradient kernel takes (bf16): slices of dropped samples are skipped, kept
+    samples' dY fragments are scaled; the fused bias gradient sees the scaled rows; accumulate adds onto the old dW."""
+    from pseldnets_amd import ops
+    nsamp = 24
+    M = nsamp * rows_per_scale
+    dy, h = _mk((M, N), dtype, 1, 0.2), _mk((M, K), dtype, 2)
+    s = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25, 1.25, 0.0] * 3)
+    srow = s.repeat_interleave(rows_per_scale).double()[:, None]
+    dwb = torch.ones(N * K + N, device=dev)
+    dw, db = dwb[:N * K].view(N, K), dwb[N * K:]
+    ops.linear_wgrad(dy.to(dev), h.to(dev), dw, dbias=db, rowscale=s.to(dev), rows_per_scale=rows_per_scale, accumulate=True)
+    sdy = dy.double() * srow
+    denom = (dy.double().abs().t() @ h.double().abs()).max().item()
+    _check("dW += (s dY)^T H", dw, 1.0 + sdy.t() @ h.double(), dtype, denom)
+    _check("db += sum s dY", db, 1.0 + sdy.sum(0), dtype, dy.double().abs().sum(0).max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
