@@ -69,7 +69,7 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
-            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_passt_grid_t'):
+            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_passt_grid_t'):
                 continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn

@@ -107,13 +107,18 @@ int pseld_cross_stitch_bwd(int dtype, const void* x, const void* y, const float*
 /* ---- (shifted-)window attention ----------------------------------------------------------------------------------
  * htsat.py:23-50 (partition/reverse), :239-260 (roll), :118-138 (WindowAttention core), :203-222 (mask).
  * qkv [B, res*res, 3C] -> out [B, res*res, C], both in natural token order; 8x8 windows, head_dim 8..32.
- * bias_table f32[225, heads]. Backward adds d(bias_table) (deterministic up to fp32 atomic order). */
-int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, int B, int res, int C,
+ * bias_table f32[225, heads]. The forward also writes lse f32[B*res*res, heads] (log-sum-exp of the masked, biased scores of
+ * every query and head; may be NULL for inference). The backward takes the saved forward output and lse — P = exp(S - lse),
+ * dS = P (dP - rowsum(dO o out)), so no softmax reduction is repeated — and adds d(bias_table) (deterministic up to fp32
+ * atomic order). */
+int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, float* lse, int B, int res, int C,
                           int heads, int shift, void* stream);
 long pseld_window_attn_bwd_workspace(int heads);
-int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* dout, void* dqkv,
-                          float* dbias_table, int B, int res, int C, int heads, int shift, int accumulate,
-                          float* workspace, long workspace_bytes, void* stream);
+/* Diagnostic only: 64 x 8 x 8 u64 s_memtime stamps (phases of the first windows of the first workgroups of the backward). */
+void pseld_attn_set_debug_buffer(void* device_u64_buffer);
+int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* out, const float* lse,
+                          const void* dout, void* dqkv, float* dbias_table, int B, int res, int C, int heads, int shift,
+                          int accumulate, float* workspace, long workspace_bytes, void* stream);
 
 /* ---- global multi-head self-attention of the PaSST blocks -----------------------------------------------------------
  * passt.py:62-82 (Attention.forward: qkv split, q k^T * head_dim^-0.5, softmax, @ v, head merge), head_dim 64.

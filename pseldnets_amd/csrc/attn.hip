@@ -12,15 +12,19 @@
 //   S^T = K Q^T (lane = query, so the softmax reduction is in-register + one cross-half shuffle),
 //   O   = P V with the S^T accumulators re-used directly as the A operand (no LDS round trip) and V read
 //         through ds_read_b64_tr_b16.
-// Backward recomputes P in both orientations (S^T for dQ and the bias gradient, S for dV/dK) so that no
-// accumulator tile ever needs a transpose; d(bias table) is summed in registers across all windows a workgroup
-// walks and flushed with one fp32 atomic tile per head per workgroup.
+// The forward also writes the per-(token, head) log-sum-exp of the scores. The backward uses it, flash-attention style:
+// P = exp(S - lse) and dS = P (dP - delta) with delta = rowsum(dO o O) taken from the saved forward output, so every
+// 32 x 32 score tile is independent (no row maximum / sum / delta passes, no 64-key register footprint): the kernel needs
+// ~200 registers instead of > 256 and runs two waves per SIMD instead of one. Each tile's P and dS are dropped into LDS as
+// [query][key] images and read back k-major (ds_read_b64_tr_b16) for the products that contract over queries (dV, dK);
+// d(bias table) is summed in registers across all windows a workgroup walks and flushed with one fp32 atomic tile per head.
 // T = bf16 (v_mfma_f32_32x32x16_bf16) or f32 (v_mfma_f32_32x32x2_f32, parity mode) share every loader.
 //
 // Roofline: HBM-bound (reads 3C, writes C per token; ~100 flop/B at head_dim 24).
 #include "common.h"
 #include "mma_frag.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -40,6 +44,9 @@ struct AttnArgs {
     void* dqkv;        // bwd: [B, L, 3C]
     const float* bias_table;  // [225, heads]
     float* dbias_acc;         // bwd: [heads, 64(key), 64(query)] fp32, atomically accumulated
+    float* lse;               // fwd (out, optional) / bwd (in): [B*L, heads] log-sum-exp of the masked, biased scores
+    const void* osaved;       // bwd: the forward output [B, L, C] (delta = rowsum(dO o O))
+    unsigned long long* dbg;  // diagnostic: s_memtime stamps of workgroup 0's first windows
     int B, res, C, heads, hd, shift;
     int n_win_total;          // B * (res/8)^2
     float scale;
@@ -85,6 +92,58 @@ __device__ __forceinline__ void window_copy(char* tile, int strideB, T* gbase, i
         } else {
             if (sizeof(T) == 2) *(f32x4*)g = *(const f32x4*)l;
             else { ((f32x4*)g)[0] = ((const f32x4*)l)[0]; ((f32x4*)g)[1] = ((const f32x4*)l)[1]; }
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr_a;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr_a;
+
+// LDS row geometry of a window tile with NSEG column segments of seg_elems elements per token: rows are rowbytes + 16 (or
+// + 32) bytes apart so that (stride / 16) is odd: 16 consecutive rows then start in 16 different 16-byte bank slots.
+__device__ __forceinline__ int window_stride_bytes(int nseg, int seg_elems, int esize) {
+    const int rb = nseg * seg_elems * esize + 16;
+    return ((rb >> 4) & 1) ? rb : rb + 16;
+}
+
+// The 64 token rows of a window, NSEG segments each, straight from HBM into the LDS tile by LDS-DMA (no staging registers,
+// every load of the window in flight at once: the chunk-by-chunk copy loop exposed one memory latency per chunk - 12.7k of a
+// 31k-cycle window, tools/attn_stamps.py). One wave-instruction fills floor(64 / lanes_per_row) whole rows: lane -> (row slot,
+// 16-byte chunk); the destination is lane-linear and a row slot is exactly one stride wide, so the row padding falls on idle
+// lanes. seg_src(seg) returns the global base pointer and leading dimension of a segment, gcol its first column.
+template <typename T, int NSEG, typename SrcFn>
+__device__ __forceinline__ void window_dma_load(char* tile, int strideB, int seg_elems, int live_elems, const long* toks, int nwaves, SrcFn seg_src) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nl = strideB >> 4;                          // lanes per row slot
+    const int cps = seg_elems / EPC;                      // chunks per segment in the tile layout
+    const int cpl = live_elems / EPC;                     // ... of which the first cpl exist in memory (last head group of an odd head count)
+    if (nl <= 64) {
+        const int rpi = 64 / nl;                          // rows per instruction
+        const int slot = lane / nl, c = lane - slot * nl;
+        const int seg = c / cps, k = c - seg * cps;
+        const bool lane_ok = slot < rpi && seg < NSEG && k < cpl;
+        for (int i = wave; i * rpi < 64; i += nwaves) {
+            const int row = i * rpi + slot;
+            if (lane_ok && row < 64) {
+                const T* base; int ld, gcol;
+                seg_src(seg, base, ld, gcol);
+                const T* src = base + toks[row] * ld + gcol + k * EPC;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr_a)src, (lds_void_ptr_a)(tile + i * rpi * strideB), 16, 0, 0);
+            }
+        }
+    } else {                                              // rows longer than one instruction (1 KB): several instructions per row
+        const int parts = (NSEG * cps + 63) >> 6;
+        for (int j = wave; j < 64 * parts; j += nwaves) {
+            const int row = j / parts, part = j - row * parts;
+            const int c = part * 64 + lane;
+            const int seg = c / cps, k = c - seg * cps;
+            if (seg < NSEG && k < cpl) {
+                const T* base; int ld, gcol;
+                seg_src(seg, base, ld, gcol);
+                const T* src = base + toks[row] * ld + gcol + k * EPC;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr_a)src, (lds_void_ptr_a)(tile + row * strideB + part * 1024), 16, 0, 0);
+            }
         }
     }
 }
@@ -271,6 +330,7 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
                 }
             l += __shfl_xor(l, 32, 64);
             inv_l[qt] = 1.f / l;
+            if (a.lse && h2 == 0) a.lse[toks[qi] * a.heads + head] = m + __logf(l);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -284,27 +344,51 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     window_copy<T, false>(tile, strideB, (T*)a.out, a.C, hg * GW, 0, heads_here * hd, toks);
 }
 
-// row stride of the per-head [32 queries][64 keys] score images: 64 (mod 128) bytes for the transposed bf16 reads
-template <typename T> struct ImgStride { static constexpr int value = sizeof(T) == 2 ? 192 : 272; };
+// one 32 x 32 tile: acc = A[ta*32 + row][dims] . B[tb*32 + col][dims]^T (rows in registers, cols = lanes)
+template <typename T>
+__device__ __forceinline__ void qk_tile(f32x16& acc, const char* tile, int strideB, int ca, int ta, int cb, int tb, int hd, int lane) {
+    using M = AMma<T>;
+    const int r = lane & 31, h2 = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int d0 = 16 * kk + 8 * h2;
+        const bool live = d0 < hd;          // dims >= hd belong to the neighbouring head (or the row pad): read, then zero
+        if (16 * kk < hd) {
+            const typename M::Frag fa = M::keep_if(M::ld_row(tile + (ta * 32 + r) * strideB + (ca + d0) * (int)sizeof(T)), live);
+            const typename M::Frag fb = M::keep_if(M::ld_row(tile + (tb * 32 + r) * strideB + (cb + d0) * (int)sizeof(T)), live);
+            M::mma(fa, fb, acc);
+        }
+    }
+}
 
+// row stride of the per-wave [32 queries][32 keys] P / dS images: 64 (mod 128) bytes for the transposed bf16 reads
+template <typename T> struct ImgStride { static constexpr int value = sizeof(T) == 2 ? 64 : 144; };
+
+// Backward: one workgroup = one window x HG heads, TWO waves per head: wave (head, kt) owns key tile kt (32 keys) of its head —
+// dK / dV of those keys are complete in the wave (they sum over queries, which the wave walks), dQ is a partial sum over
+// its keys and meets the partner's partial through LDS. Per wave: 2 score tiles [32 keys x 32 queries] per window.
 template <typename T, int HG>
-__global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
-    constexpr int NTHR = HG * 64;
+__global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_kernel(AttnArgs a) {
+    constexpr int NTHR = HG * 128;
     constexpr int IMG = ImgStride<T>::value;
     using M = AMma<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
     const int GW = HG * hd;
-    const int strideB = 4 * GW * (int)sizeof(T) + 16;    // q | k | v | dO
+    const int strideB = window_stride_bytes(5, GW, (int)sizeof(T));    // q | k | v | dO | O
     char* tile = smem;
     float* btab = (float*)(smem + 64 * strideB);          // [HG][225]
-    long* toks = (long*)(btab + HG * 225);
-    int* labels = (int*)(toks + 64);
-    char* imgs = smem + (((char*)(labels + 64) - smem + 15) & ~15);   // [HG][2][32][IMG]: P and dS of the current query tile
+    float* lse_s = btab + HG * 225;                       // [64][HG]
+    long* toks = (long*)(lse_s + 64 * HG + (HG & 1));     // (8-byte aligned)
+    int* labels = (int*)(toks + 64);                      // [64] + [1]: "this window mixes mask regions"
+    char* imgs = smem + (((char*)(labels + 65) - smem + 15) & ~15);   // [2*HG waves][4 KB]: P and dS images of the current tile; then the dQ partial
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane0 = threadIdx.x & 63, lane = lane0, wave = threadIdx.x >> 6;
+    const int hl = wave >> 1, kt = wave & 1;              // head inside the group, key tile of this wave
     const int hg = blockIdx.y;
-    const int head = hg * HG + wave;
+    const int head = hg * HG + hl;
     const int heads_here = min(HG, a.heads - hg * HG);
     const int r = lane & 31, h2 = lane >> 5;
     const bool active = head < a.heads;
@@ -313,207 +397,175 @@ __global__ __launch_bounds__(HG * 64) void attn_bwd_kernel(AttnArgs a) {
         const int hh = i / 225, idx = i - hh * 225;
         btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh];
     }
-    f32x16 dsum[2][2];  // sum over windows of dS^T [key tile][query tile]
+    f32x16 dsum[2];  // sum over windows of dS^T [this key tile][query tile]
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int y = 0; y < 2; ++y)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dsum[x][y][e] = 0.f;
+        for (int e = 0; e < 16; ++e) dsum[y][e] = 0.f;
 
     const T* qkv = (const T*)a.qkv;
     const T* dout = (const T*)a.dout;
-    const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd, cdo = 3 * GW + wave * hd;
-    const float* bt = btab + wave * 225;
-    char* pimg = imgs + wave * 2 * 32 * IMG;
+    const T* osv = (const T*)a.osaved;
+    const int cq = hl * hd, ck = GW + hl * hd, cv = 2 * GW + hl * hd, cdo = 3 * GW + hl * hd, co = 4 * GW + hl * hd;
+    const float* bt = btab + hl * 225;
+    constexpr int IMGB = sizeof(T) == 2 ? 4096 : 2 * 32 * IMG;        // bytes per wave: two images, or 64 lanes x 16 floats of a dQ partial
+    char* pimg = imgs + wave * IMGB;
     char* simg = pimg + 32 * IMG;
+    float* dq_mine = (float*)pimg;                                    // published after the tile loop
+    const float* dq_partner = (const float*)(imgs + (wave ^ 1) * IMGB);
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float scale2 = a.scale * LOG2E;
 
-    // bf16: the NEXT window's q|k|v|dO rows are requested from HBM (16-byte chunks held in registers) while the
-    // current window is being computed — with one workgroup per CU nothing else would hide that latency (measured:
-    // 400 of 905 us at stage 0 were exposed loads). Token lists are double-buffered in LDS for that.
-    constexpr bool PREFETCH_T = sizeof(T) == 2;
-    constexpr int MAXCH = PREFETCH_T ? 12 : 1;             // 12 chunks per thread cover head_dim <= 24 (every HTS-AT stage)
-    f32x4 pre[MAXCH];
-    const int cps = (heads_here * hd) >> 3;                 // 16-byte chunks per token per segment
-    const int nchunks = 4 * 64 * cps;
-    const bool PREFETCH = PREFETCH_T && nchunks <= MAXCH * NTHR;
-    auto issue_loads = [&](const long* tk) {
-#pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
-            const int c = threadIdx.x + j * NTHR;
-            if (c < nchunks) {
-                const int seg = c / (64 * cps), rem = c - seg * 64 * cps, t = rem / cps, k = rem - t * cps;
-                const T* src = seg < 3 ? qkv + tk[t] * (3 * a.C) + seg * a.C + hg * GW + k * 8
-                                       : dout + tk[t] * a.C + hg * GW + k * 8;
-                pre[j] = *(const f32x4*)src;
-            }
-        }
-    };
-    auto stage_loads = [&]() {
-#pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
-            const int c = threadIdx.x + j * NTHR;
-            if (c < nchunks) {
-                const int seg = c / (64 * cps), rem = c - seg * 64 * cps, t = rem / cps, k = rem - t * cps;
-                *(f32x4*)(tile + t * strideB + (seg * GW + k * 8) * (int)sizeof(T)) = pre[j];
-            }
-        }
-    };
-    long* toks2 = (long*)(imgs + HG * 2 * 32 * IMG);          // second token / label list (PREFETCH)
-    int* labels2 = (int*)(toks2 + 64);
-    int par = 0;
-    if (PREFETCH && blockIdx.x < a.n_win_total) {
+    int it = 0;
+    const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 64;
+    for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x, ++it) {
+        __syncthreads();  // previous iteration's stores out of the tile are done
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 0] = __builtin_amdgcn_s_memtime();
         if (threadIdx.x < 64) {
             long tk; int lb;
-            window_token(a, blockIdx.x, threadIdx.x, tk, lb);
+            window_token(a, wi, threadIdx.x, tk, lb);
             toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
+            // wave 0 holds all 64 labels: does the window straddle mask regions at all? (only the last row / column of
+            // windows of a shifted block does; everywhere else the mask is identically zero)
+            const int l0 = __builtin_amdgcn_readfirstlane(lb);
+            const unsigned long long diff = __ballot(lb != l0);
+            if (threadIdx.x == 0) labels[64] = diff != 0ull;
         }
         __syncthreads();
-        issue_loads(toks);
-    }
-    for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x) {
-        long* tcur = par ? toks2 : toks;
-        int* lcur = par ? labels2 : labels;
-        long* tnext = par ? toks : toks2;
-        int* lnext = par ? labels : labels2;
-        __syncthreads();  // previous iteration's stores out of the tile are done
-        if (PREFETCH) {
-            stage_loads();
-            const int wn = wi + gridDim.x;
-            if (wn < a.n_win_total && threadIdx.x < 64) {
-                long tk; int lb;
-                window_token(a, wn, threadIdx.x, tk, lb);
-                tnext[threadIdx.x] = tk; lnext[threadIdx.x] = lb;
+        {
+            const int C = a.C, col0 = hg * GW;
+            window_dma_load<T, 5>(tile, strideB, GW, heads_here * hd, toks, 2 * HG, [&](int seg, const T*& base, int& ld, int& gcol) {
+                base = seg < 3 ? qkv : (seg == 3 ? dout : osv);
+                ld = seg < 3 ? 3 * C : C;
+                gcol = (seg < 3 ? seg * C : 0) + col0;
+            });
+            for (int i = threadIdx.x; i < 64 * heads_here; i += NTHR) {
+                const int t = i / heads_here, h = i - t * heads_here;
+                lse_s[t * HG + h] = a.lse[toks[t] * a.heads + hg * HG + h];
             }
-            __syncthreads();
-            if (wn < a.n_win_total) issue_loads(tnext);
-        } else {
-            if (threadIdx.x < 64) {
-                long tk; int lb;
-                window_token(a, wi, threadIdx.x, tk, lb);
-                tcur[threadIdx.x] = tk; lcur[threadIdx.x] = lb;
-            }
-            __syncthreads();
-            for (int sel = 0; sel < 3; ++sel)
-                window_copy<const T, true>(tile, strideB, qkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, tcur);
-            window_copy<const T, true>(tile, strideB, dout, a.C, hg * GW, 3 * GW, heads_here * hd, tcur);
-            __syncthreads();
         }
-        par ^= PREFETCH ? 1 : 0;
-        const int* labels_w = lcur;
-        const long* toks_w = tcur;
+        __syncthreads();   // (hipcc drains the DMA with vmcnt(0) in front of this barrier)
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 1] = __builtin_amdgcn_s_memtime();
 
-        if (active) {
-            // Scores are formed once, transposed (rows = keys, lane = query), one 32-query tile at a time. Each
-            // tile's P and dS are also dropped into LDS as natural [query][key] images so that the products that
-            // contract over QUERIES (dV = P^T dO, dK = dS^T Q) read them back as k-major MFMA operands
-            // (ds_read_b64_tr_b16) — no second softmax, no accumulator transposes.
-            f32x16 dv[2], dk[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { dv[kt][e] = 0.f; dk[kt][e] = 0.f; }
+        // (kt is made a compile-time constant by running one of two instances of the body: indexing the register arrays
+        //  dq[] / dsum[] with the runtime wave parity costs a 31-deep select chain per element)
+        f32x16 dq_keep;          // this wave's partial of the query tile it finishes after the exchange (qt == kt)
+        auto compute = [&](auto KTc) {
+            constexpr int kt = decltype(KTc)::value;
+            f32x16 dq[2];
+            const bool mixed = labels[64] != 0;
+            // per-lane row constants of its two queries (qt = 0, 1): -lse * log2(e) and delta = sum_d dO[q][d] O[q][d]
+            float nlse[2], delta[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                f32x16 pt[2], dpt[2];
-                qk_half<T>(pt, tile, strideB, ck, cq, qt, hd, lane);      // S^T[:, qt] = K Q_qt^T
-                qk_half<T>(dpt, tile, strideB, cv, cdo, qt, hd, lane);    // dP^T[:, qt] = V dO_qt^T
                 const int qi = qt * 32 + r;
-                const int ql = labels_w[qi];
-                const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
-                const int* labh = labels_w + 4 * h2;
-                float m = -1e30f;
+                nlse[qt] = -lse_s[qi * HG + hl] * LOG2E;
+                float dsum_q = 0.f;
+                for (int c = h2; c * 8 < hd; c += 2) {          // the two lane halves split the 8-element chunks of the row
+                    float od[8], dd[8];
+                    load8<T>((const T*)(tile + qi * strideB + (co + c * 8) * (int)sizeof(T)), od);
+                    load8<T>((const T*)(tile + qi * strideB + (cdo + c * 8) * (int)sizeof(T)), dd);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                    for (int j = 0; j < 8; ++j) dsum_q = fmaf(od[j], dd[j], dsum_q);
+                }
+                delta[qt] = dsum_q + __shfl_xor(dsum_q, 32, 64);
+            }
+            f32x16 dv, dk;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float sv = pt[kt][e] * a.scale + btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))];
-                        sv -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;
-                        pt[kt][e] = sv;
-                        m = fmaxf(m, sv);
-                    }
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                float l = 0.f;
+            for (int e = 0; e < 16; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+            for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float pv = __expf(pt[kt][e] - m);
-                        pt[kt][e] = pv;
-                        l += pv;
-                    }
-                l += __shfl_xor(l, 32, 64);
-                const float il = 1.f / l;
-                float delta = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        pt[kt][e] *= il;
-                        delta += pt[kt][e] * dpt[kt][e];
-                    }
-                delta += __shfl_xor(delta, 32, 64);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int e = 0; e < 16; ++e) dq[qt][e] = 0.f;
+                // the lane id is laundered per tile: otherwise hipcc hoists every fragment address of both tiles out of the
+                // persistent window loop and keeps ~60 address registers alive across it (spills at two waves per SIMD)
+                int lane = lane0;
+                asm volatile("" : "+v"(lane));
+                const int r = lane & 31, h2 = lane >> 5;
+                f32x16 pt, dpt;
+                qk_tile<T>(pt, tile, strideB, ck, kt, cq, qt, hd, lane);      // S^T[kt, qt] = K_kt Q_qt^T   (rows = keys, lane = query)
+                qk_tile<T>(dpt, tile, strideB, cv, kt, cdo, qt, hd, lane);    // dP^T[kt, qt] = V_kt dO_qt^T
+                const int qi = qt * 32 + r;
+                // key = kt*32 + (e&3) + 8*(e>>2) + 4*h2: (y, x) = (kt*4 + (e>>2), (e&3) + 4*h2) -> table index = per-lane base - constant
+                const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2 - kt * 60;
+                if (mixed) {
+                    const int ql = labels[qi];
+                    const int* labh = labels + 4 * h2 + kt * 32;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const float ds = pt[kt][e] * (dpt[kt][e] - delta);
-                        dpt[kt][e] = ds;               // dS^T
-                        dsum[kt][qt][e] += ds;
+                        float b = btq[-((e >> 2) * 15 + (e & 3))];
+                        b -= (labh[(e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;
+                        pt[e] = __builtin_amdgcn_exp2f(fmaf(pt[e], scale2, fmaf(b, LOG2E, nlse[qt])));
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float b = btq[-((e >> 2) * 15 + (e & 3))];
+                        pt[e] = __builtin_amdgcn_exp2f(fmaf(pt[e], scale2, fmaf(b, LOG2E, nlse[qt])));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float ds = pt[e] * (dpt[e] - delta[qt]);
+                    dpt[e] = ds;                   // dS^T
+                    dsum[qt][e] += ds;
+                }
                 // images: row = query r of this tile, 4 consecutive keys per register group
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int key0 = 8 * g4 + 4 * h2;
+                    store4<T>(pimg + r * IMG + key0 * (int)sizeof(T), pt[4 * g4], pt[4 * g4 + 1], pt[4 * g4 + 2], pt[4 * g4 + 3]);
+                    store4<T>(simg + r * IMG + key0 * (int)sizeof(T), dpt[4 * g4], dpt[4 * g4 + 1], dpt[4 * g4 + 2], dpt[4 * g4 + 3]);
+                }
+                // dQ[qt][d] (partial over this wave's keys) = sum_key dS^T[key][query] K[key][d]  (accumulators re-used as A operands)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int key0 = kt * 32 + 8 * g4 + 4 * h2;
-                        store4<T>(pimg + r * IMG + key0 * (int)sizeof(T), pt[kt][4 * g4], pt[kt][4 * g4 + 1], pt[kt][4 * g4 + 2], pt[kt][4 * g4 + 3]);
-                        store4<T>(simg + r * IMG + key0 * (int)sizeof(T), dpt[kt][4 * g4], dpt[kt][4 * g4 + 1], dpt[kt][4 * g4 + 2], dpt[kt][4 * g4 + 3]);
-                    }
-                // dQ[query tile qt][d] = sum_key dS^T[key][query] K[key][d]  (accumulators re-used as A operands)
-                f32x16 dq;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int sx = 0; sx < 2; ++sx)
-                        M::mma(M::from_acc(dpt[kt], sx), M::ld_cols(tile, strideB, kt * 32 + 16 * sx, ck, lane), dq);
-                // dV[key][d] += sum_{query in tile} P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Q[query][d]
+                for (int sx = 0; sx < 2; ++sx)
+                    M::mma(M::from_acc(dpt, sx), M::ld_cols(tile, strideB, kt * 32 + 16 * sx, ck, lane), dq[qt]);
+                // dV[kt][d] += sum_{query in qt} P[query][key] dO[query][d];  dK[kt][d] += dS[query][key] Q[query][d]
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx) {
                     const typename M::Frag fdo = M::ld_cols_std(tile, strideB, qt * 32 + 16 * sx, cdo, lane);
                     const typename M::Frag fq = M::ld_cols_std(tile, strideB, qt * 32 + 16 * sx, cq, lane);
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        M::mma(M::ld_cols_std(pimg, IMG, 16 * sx, kt * 32, lane), fdo, dv[kt]);
-                        M::mma(M::ld_cols_std(simg, IMG, 16 * sx, kt * 32, lane), fq, dk[kt]);
-                    }
+                    M::mma(M::ld_cols_std(pimg, IMG, 16 * sx, 0, lane), fdo, dv);
+                    M::mma(M::ld_cols_std(simg, IMG, 16 * sx, 0, lane), fq, dk);
                 }
-                // every read of this head's q rows of tile qt is complete: overwrite them with dQ
-                store_tile<T>(tile, strideB, cq, qt, dq, a.scale, hd, lane);
-                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);     // the next tile's image writes stay behind this tile's image reads
             }
+            // nobody reads this head's k / v rows of key tile kt again (the partner wave owns the other 32 keys)
+            store_tile<T>(tile, strideB, cv, kt, dv, 1.f, hd, lane);
+            store_tile<T>(tile, strideB, ck, kt, dk, a.scale, hd, lane);
+            // publish the dQ partial of the query tile the PARTNER finishes (qt = 1 - kt): [16 registers][64 lanes] floats
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                store_tile<T>(tile, strideB, cv, kt, dv[kt], 1.f, hd, lane);
-                store_tile<T>(tile, strideB, ck, kt, dk[kt], a.scale, hd, lane);
-            }
+            for (int e = 0; e < 16; ++e) dq_mine[e * 64 + lane] = dq[1 - kt][e];
+            dq_keep = dq[kt];
+        };
+        if (active) {
+            if (kt == 0) compute(std::integral_constant<int, 0>{});
+            else compute(std::integral_constant<int, 1>{});
+        }
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 2] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 3] = __builtin_amdgcn_s_memtime();
+        if (active) {
+            f32x16 z = dq_keep;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] += dq_partner[e * 64 + lane];
+            store_tile<T>(tile, strideB, cq, kt, z, a.scale, hd, lane);     // every read of the q rows is behind the barrier above
         }
         __syncthreads();
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 4] = __builtin_amdgcn_s_memtime();
         for (int sel = 0; sel < 3; ++sel)
-            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks_w);
+            window_copy<T, false>(tile, strideB, (T*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 5] = __builtin_amdgcn_s_memtime();
     }
     // flush d(bias) partial sums: dbias_acc[head][key][query] += dsum (lane = query: 128-byte contiguous atomics)
     if (active) {
         float* dst = a.dbias_acc + (long)head * 4096;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    atomicAdd(dst + (kt * 32 + acc_row(e, h2)) * 64 + qt * 32 + r, dsum[kt][qt][e]);
+            for (int e = 0; e < 16; ++e)
+                atomicAdd(dst + (kt * 32 + acc_row(e, h2)) * 64 + qt * 32 + r, dsum[qt][e]);
     }
 }
 
@@ -537,7 +589,7 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
 }
 
 template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
-template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (4 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 2 * (64 * 8 + 64 * 4) + 16 + (size_t)HG * 2 * 32 * (sizeof(T) == 2 ? 192 : 272); }
+template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (5 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 64 * HG * 4 + 8 + 64 * 8 + 65 * 4 + 16 + (size_t)2 * HG * (sizeof(T) == 2 ? 4096 : 2 * 32 * ImgStride<T>::value); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
     PSELD_CHECK_ARG(B > 0 && res >= 8 && res % 8 == 0, "%s: grid side must be a multiple of 8 (got %d)", who, res);
@@ -550,13 +602,16 @@ int check_args(const char* who, int B, int res, int C, int heads, int shift) {
 
 }  // namespace
 
-extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, int B, int res,
+static unsigned long long* g_attn_dbg = nullptr;
+extern "C" void pseld_attn_set_debug_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; }
+
+extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, float* lse, int B, int res,
                                      int C, int heads, int shift, void* stream) {
     PSELD_CHECK_ARG(qkv && bias_table && out, "window_attn_fwd: null pointer");
     int rc = check_args("window_attn_fwd", B, res, C, heads, shift);
     if (rc) return rc;
     AttnArgs a; memset(&a, 0, sizeof(a));
-    a.qkv = qkv; a.out = out; a.bias_table = bias_table; a.B = B; a.res = res; a.C = C; a.heads = heads;
+    a.qkv = qkv; a.out = out; a.lse = lse; a.bias_table = bias_table; a.B = B; a.res = res; a.C = C; a.heads = heads;
     a.hd = C / heads; a.shift = shift; a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
@@ -576,16 +631,18 @@ extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bi
 
 extern "C" long pseld_window_attn_bwd_workspace(int heads) { return (long)heads * 4096 * (long)sizeof(float); }
 
-// dqkv [B,L,3C] from dout [B,L,C]; dbias_table f32[225, heads] (+)=. workspace: pseld_window_attn_bwd_workspace bytes.
-extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* dout, void* dqkv,
-                                     float* dbias_table, int B, int res, int C, int heads, int shift, int accumulate,
-                                     float* workspace, long workspace_bytes, void* stream) {
-    PSELD_CHECK_ARG(qkv && bias_table && dout && dqkv && dbias_table && workspace, "window_attn_bwd: null pointer");
+// dqkv [B,L,3C] from dout [B,L,C], the saved forward output out [B,L,C] and lse [B*L, heads]; dbias_table f32[225, heads] (+)=.
+// workspace: pseld_window_attn_bwd_workspace bytes.
+extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* out, const float* lse,
+                                     const void* dout, void* dqkv, float* dbias_table, int B, int res, int C, int heads, int shift,
+                                     int accumulate, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(qkv && bias_table && out && lse && dout && dqkv && dbias_table && workspace, "window_attn_bwd: null pointer");
     int rc = check_args("window_attn_bwd", B, res, C, heads, shift);
     if (rc) return rc;
     PSELD_CHECK_ARG(workspace_bytes >= pseld_window_attn_bwd_workspace(heads), "window_attn_bwd: workspace too small");
     AttnArgs a; memset(&a, 0, sizeof(a));
     a.qkv = qkv; a.dout = dout; a.dqkv = dqkv; a.bias_table = bias_table; a.dbias_acc = workspace;
+    a.osaved = out; a.lse = const_cast<float*>(lse); a.dbg = g_attn_dbg;
     a.B = B; a.res = res; a.C = C; a.heads = heads; a.hd = C / heads; a.shift = shift;
     a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)a.hd);
@@ -593,25 +650,25 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     if (hipMemsetAsync(workspace, 0, (size_t)heads * 4096 * sizeof(float), s) != hipSuccess) {
         pseld_set_error("window_attn_bwd: memset failed"); return PSELD_ERR_HIP;
     }
-    // ~512-1024 workgroups in total, each walking several windows, so the d(bias) flush (one atomic tile per head
-    // per workgroup) stays a small fraction of the traffic
-    // backward: 2 heads per workgroup (50 KB LDS, 3 workgroups per CU) wins from 8 heads up, 4 at stage 0 (tools/attn_bench.py)
+    // Persistent workgroups, one resident round: two waves per head and two waves per SIMD (<= 256 registers), i.e. one
+    // 4-head (8-wave) or two 2-head (4-wave) workgroups per CU; each walks several windows, so the d(bias) flush (one atomic
+    // tile per wave per workgroup) stays a small fraction of the traffic. PSELD_ATTN_HG / PSELD_ATTN_BWD_WGS: experiment knobs (tools/attn_bench.py).
     const int hgv = (dtype == PSELD_BF16 && !getenv("PSELD_ATTN_HG")) ? (heads >= 8 ? 2 : 4) : attn_hg(dtype);
     const int nhg = pseld_cdiv(heads, hgv);
     const char* es = getenv("PSELD_ATTN_BWD_WGS");                  // experiment knob: total workgroups of the persistent loop
-    // one resident round: the kernel needs > 256 registers, so a CU holds 4 waves = one 4-head or two 2-head workgroups
-    // (tools/attn_bench.py WGS sweep: 256 / 512 total are the fastest, 768 — not a multiple of the capacity — the slowest)
     int slots = (es ? atoi(es) : (hgv == 4 ? 256 : 512)) / nhg;
     if (slots > a.n_win_total) slots = a.n_win_total;
     if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);
     if (dtype == PSELD_BF16) {
-        if (hgv == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(256), bwd_lds<bf16_t>(a.hd, 4), s, a);
-        else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), bwd_lds<bf16_t>(a.hd, 2), s, a);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        if (hgv == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(512), bwd_lds<bf16_t>(a.hd, 4), s, a);
+        else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(256), bwd_lds<bf16_t>(a.hd, 2), s, a);
     } else if (dtype == PSELD_F32) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), grid, dim3(128), bwd_lds<float>(a.hd, 2), s, a);
+        hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), grid, dim3(256), bwd_lds<float>(a.hd, 2), s, a);
     } else { pseld_set_error("window_attn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_bwd");
     hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);

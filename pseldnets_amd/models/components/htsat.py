@@ -275,7 +275,7 @@ class SwinEncoder:
                 s1, s2 = drop_scale[gi, 0], drop_scale[gi, 1]
             xh1 = ops.layernorm_fwd(x, a.p(b + 'norm1.weight'), a.p(b + 'norm1.bias'))
             qkv = ops.linear_fwd(xh1, self._w(b + 'attn.qkv.weight', dtype), a.p(b + 'attn.qkv.bias'))
-            ao = ops.window_attn_fwd(qkv, a.p(b + 'attn.relative_position_bias_table'), B, res, heads, shift)
+            ao, lse = ops.window_attn_fwd(qkv, a.p(b + 'attn.relative_position_bias_table'), B, res, heads, shift)
             ad = {}
             if self.attn_adapter:
                 # x = adapter(proj(attn)) + proj(attn) (htsat.py:141-143), then the block's DropPath + residual
@@ -296,7 +296,7 @@ class SwinEncoder:
                                        rowscale=s2, rows_per_scale=L)
                 if self.mlp_adapter:
                     x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
-                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1,
+                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1,
                                          s2=s2, shift=shift, ad=ad))
             else:
                 u = ops.linear_fwd(xh2, self._w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'))
@@ -304,7 +304,7 @@ class SwinEncoder:
                                        rowscale=s2, rows_per_scale=L, gelu_in=True)
                 if self.mlp_adapter:
                     x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
-                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, x_mid=x_mid, xh2=xh2, u=u, s1=s1, s2=s2,
+                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, xh2=xh2, u=u, s1=s1, s2=s2,
                                          shift=shift, ad=ad))
             x = x_out
         saved = dict(blocks=saved_blocks)
@@ -352,7 +352,7 @@ class SwinEncoder:
             else:
                 self._wgrad(dx_mid, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias', rowscale=s['s1'], rows_per_scale=L, per_scale_elems=L * C)
                 dao = ops.linear_dgrad(dx_mid, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
-            dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), dao,
+            dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), s['ao'], s['lse'], dao,
                                        a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
             self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
             dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=self._wt(b + 'attn.qkv.weight', dtype))

@@ -216,24 +216,26 @@ def rowscale(x, scale, elems_per_scale):
 
 # ---------------------------------------------------------------------------------------------------------
 # window attention
-def window_attn_fwd(qkv, bias_table, B, res, heads, shift):
+def window_attn_fwd(qkv, bias_table, B, res, heads, shift, need_lse=True):
+    """Returns (out [B*L, C], lse f32[B*L, heads] or None): the backward needs both."""
     _chk(qkv, bias_table)
     C = qkv.shape[1] // 3
     out = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
-    rc = _lib.lib().pseld_window_attn_fwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(out), B, res, C,
+    lse = torch.empty((qkv.shape[0], heads), dtype=torch.float32, device=qkv.device) if need_lse else None
+    rc = _lib.lib().pseld_window_attn_fwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(out), _lib.ptr(lse), B, res, C,
                                           heads, shift, _lib.stream_ptr())
     _lib.check(rc, "pseld_window_attn_fwd")
-    return out
+    return out, lse
 
 
-def window_attn_bwd(qkv, bias_table, dout, dbias_table, B, res, heads, shift, accumulate=False):
-    _chk(qkv, bias_table, dout, dbias_table)
+def window_attn_bwd(qkv, bias_table, out, lse, dout, dbias_table, B, res, heads, shift, accumulate=False):
+    _chk(qkv, bias_table, out, lse, dout, dbias_table)
     C = qkv.shape[1] // 3
     L = _lib.lib()
     ws = workspace(L.pseld_window_attn_bwd_workspace(heads), qkv.device)
     dqkv = torch.empty_like(qkv)
-    rc = L.pseld_window_attn_bwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(dout), _lib.ptr(dqkv),
-                                 _lib.ptr(dbias_table), B, res, C, heads, shift, int(accumulate), _lib.ptr(ws),
+    rc = L.pseld_window_attn_bwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(dout),
+                                 _lib.ptr(dqkv), _lib.ptr(dbias_table), B, res, C, heads, shift, int(accumulate), _lib.ptr(ws),
                                  ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_window_attn_bwd")
     return dqkv

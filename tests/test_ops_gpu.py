@@ -132,7 +132,7 @@ def test_window_attention(dev, dtype, B, res, C, heads, shift):
     qkv = rnd((B * L, 3 * C), 1, dtype)
     table = 0.5 * rnd((225, heads), 2)
     dout = rnd((B * L, C), 3, dtype)
-    out = ops.window_attn_fwd(qkv.to(dev), table.to(dev), B, res, heads, shift)
+    out, lse = ops.window_attn_fwd(qkv.to(dev), table.to(dev), B, res, heads, shift)
     q = qkv.double().requires_grad_(True)
     tb = table.double().requires_grad_(True)
     mask = oh.shifted_window_mask(res, res, 8, shift).double() if shift else None
@@ -142,7 +142,7 @@ def test_window_attention(dev, dtype, B, res, C, heads, shift):
     check(f"attn fwd res{res} C{C} h{heads} s{shift}", out, ref, tol(dtype))
     ref.backward(dout.double())
     dtab = torch.zeros(225, heads, device=dev)
-    dqkv = ops.window_attn_bwd(qkv.to(dev), table.to(dev), dout.to(dev), dtab, B, res, heads, shift)
+    dqkv = ops.window_attn_bwd(qkv.to(dev), table.to(dev), out, lse, dout.to(dev), dtab, B, res, heads, shift)
     check("attn dqkv", dqkv, q.grad, tol(dtype) * (1 if dtype == torch.float32 else 2))
     check("attn dbias_table", dtab, tb.grad, 1e-4 if dtype == torch.float32 else 2e-2)
 

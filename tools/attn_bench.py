@@ -27,15 +27,16 @@ for li, (C, heads) in enumerate(((96, 4), (192, 8), (384, 16), (768, 32))):
     dbt = torch.zeros(225, heads, device=dev)
     shift = 4 if res > 8 else 0
     tf = timeit(lambda: ops.window_attn_fwd(qkv, bt, B, res, heads, shift))
+    ao, lse = ops.window_attn_fwd(qkv, bt, B, res, heads, shift)
     u = qkv.numel() * 2 / 3 / 5.4e12 * 1e6
     out = [f"s{li} fwd {tf:6.1f} us (floor {4 * u:5.1f})"]
     for m in masks:
         os.environ['PSELD_ATTN_SKIP'] = str(m)
-        tb = timeit(lambda: ops.window_attn_bwd(qkv, bt, dout, dbt, B, res, heads, shift))
+        tb = timeit(lambda: ops.window_attn_bwd(qkv, bt, ao, lse, dout, dbt, B, res, heads, shift))
         out.append(f"bwd[skip={m}] {tb:6.1f}")
     os.environ['PSELD_ATTN_SKIP'] = '0'
     for w in wgs:
         os.environ['PSELD_ATTN_BWD_WGS'] = w
-        out.append(f"bwd[wgs={w}] {timeit(lambda: ops.window_attn_bwd(qkv, bt, dout, dbt, B, res, heads, shift)):6.1f}")
+        out.append(f"bwd[wgs={w}] {timeit(lambda: ops.window_attn_bwd(qkv, bt, ao, lse, dout, dbt, B, res, heads, shift)):6.1f}")
     os.environ.pop('PSELD_ATTN_BWD_WGS', None)
     print('  '.join(out) + f"  (bwd floor {7 * u:5.1f})")
