@@ -267,10 +267,10 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
     const int GW = HG * hd;                              // columns per q/k/v segment in the tile
-    const int strideB = 3 * GW * (int)sizeof(T) + 16;
+    const int strideB = window_stride_bytes(3, GW, (int)sizeof(T));
     char* tile = smem;
     float* btab = (float*)(smem + 64 * strideB);          // [HG][225]
-    long* toks = (long*)(btab + HG * 225);                // [64]
+    long* toks = (long*)(btab + HG * 225 + (HG & 1));     // [64] (8-byte aligned)
     int* labels = (int*)(toks + 64);                      // [64]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -290,9 +290,13 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     }
     __syncthreads();
     const T* qkv = (const T*)a.qkv;
-    for (int sel = 0; sel < 3; ++sel)
-        window_copy<const T, true>(tile, strideB, qkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, heads_here * hd, toks);
-    __syncthreads();
+    {
+        const int C = a.C, col0 = hg * GW;
+        window_dma_load<T, 3>(tile, strideB, GW, heads_here * hd, toks, HG, [&](int seg, const T*& base, int& ld, int& gcol) {
+            base = qkv; ld = 3 * C; gcol = seg * C + col0;
+        });
+    }
+    __syncthreads();   // (hipcc drains the DMA with vmcnt(0) in front of this barrier)
 
     if (head < a.heads) {
         const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd;
@@ -588,7 +592,7 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
     dtable[i] = accumulate ? dtable[i] + s : s;
 }
 
-template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 16) + HG * 225 * 4 + 64 * 8 + 64 * 4; }
+template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 8 + 64 * 8 + 64 * 4; }
 template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (5 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 64 * HG * 4 + 8 + 64 * 8 + 65 * 4 + 16 + (size_t)2 * HG * (sizeof(T) == 2 ? 4096 : 2 * 32 * ImgStride<T>::value); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
