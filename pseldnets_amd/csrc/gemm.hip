@@ -676,9 +676,25 @@ __global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 2) void gemm_dma_ke
                 const int row = ii * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
                 const bf16_t* src = isA ? Ag + (long)min(m0 + row, g.M - 1) * g.lda + k0 + chunk * 8
                                         : Bg + (long)min(n0 + row, g.N - 1) * g.ldb + k0 + chunk * 8;
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(st + i * 1024), 16, 0, 0);
+                if constexpr (STAGES > 2) {
+                    // ring: inline asm, so that hipcc does not drain the slices in flight with vmcnt(0) before the next ds_read
+                    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_ptr)(st + i * 1024));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                } else {
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(st + i * 1024), 16, 0, 0);
+                }
             } else {
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(Ag + lane * 8), (lds_void_ptr)dummy, 16, 0, 0);
+                if constexpr (STAGES > 2) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_ptr)dummy);
+                    unsigned keep;
+                    const bf16_t* src = Ag + lane * 8;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                } else {
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)(Ag + lane * 8), (lds_void_ptr)dummy, 16, 0, 0);
+                }
             }
         }
     };
@@ -752,6 +768,190 @@ static int gemm_xcd_mode(bool wgrad) {
     const int v = e ? atoi(e) : 3;
     return wgrad ? (v >> 1) & 1 : v & 1;
 }
+
+// ---- weight gradient fed by a deep LDS-DMA ring (bf16, large matrices) ---------------------------------------------------
+// dW[N_out, K_in] (one fp32 slab per token split) = dY^T X with BOTH operands token-major, i.e. k-major LDS images: a slice is
+// 32 token rows of dY (BM columns) and of X (BN columns), written lane-linear by the DMA and read back as MFMA operands with
+// ds_read_b64_tr_b16. Why a second weight-gradient kernel: s_memtime stamps on the register-staged one (tools/gemm_stamps.py,
+// stage-2 fc1: 4.0k cycles per 64-token slice against 1.5k of MFMA time) show a loop that waits for memory with ONE slice in
+// flight per CU, and the A/B of tools/gemm_ab.py shows what bounds an LDS-fed loop on this chip once latency is covered: the
+// CU's vector-memory path moves about 28 B/clk into LDS wherever the DMA instructions are placed, so the tile must be large
+// enough in flop per operand byte. Here: ONE workgroup of 8 waves per CU, a 384 x 192 tile (wave tile 96 x 96 = 3 x 3 MFMA
+// tiles, 128 flop per LDS-DMA byte), 32-token slices of 36 KB in a 4-stage ring (three slices = 108 KB in flight per CU,
+// counted vmcnt, one raw s_barrier per slice), no staging registers and no ds_write.
+// The 16-byte chunk a lane fetches is ROTATED inside its row by 4 * (k & 3) chunks so that the four token rows one transposed
+// read touches fall in four different 64-byte bank groups (row lengths 768 and 384 bytes are multiples of 128).
+// DropPath (PRO_ROWSCALE_A): a slice never straddles samples (rows_per_scale % 32 == 0), its factor is wave-uniform: slices of
+// dropped samples (factor 0) are skipped by the MFMAs, other factors scale the dY fragments.
+template <int MT, int NT>
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_ring_kernel(GemmArgs g) {
+    constexpr int WM = 4, WN = 2, WAVES = 8, BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int BKD = 32, STAGES = 4;
+    constexpr int RA = BM * 2, RB = BN * 2, CA = BM / 8, CB = BN / 8;        // row bytes / 16-byte chunks per row
+    constexpr int ROTA = ((RA / 64) & 1) ? 0 : 4, ROTB = ((RB / 64) & 1) ? 0 : 4;
+    constexpr int A_BYTES = BKD * RA, B_BYTES = BKD * RB, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024, TOTAL = STAGE / 1024;
+    constexpr int LPW_HI = (TOTAL + WAVES - 1) / WAVES, LPW_LO = TOTAL / WAVES;   // DMA instructions per slice: waves < NHI issue LPW_HI
+    constexpr int NHI = TOTAL - LPW_LO * WAVES;                                   // (0: every wave issues LPW_LO)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    int bx, by, bz;
+    if (!tile_coords(g, bx, by, bz)) return;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nslices = (kend - kbeg) / BKD;
+    const bf16_t* Ag = (const bf16_t*)g.A;
+    const bf16_t* Bg = (const bf16_t*)g.B;
+    const bool hi = NHI > 0 && wave < NHI;
+
+    // per-lane source offsets of this wave's DMA instructions (slice-independent part), computed once
+    long srcoff[LPW_HI];
+    bool srcA[LPW_HI];
+#pragma unroll
+    for (int j = 0; j < LPW_HI; ++j) {
+        const int i = wave + WAVES * j;
+        const bool isA = i < A_INSTR;
+        const int off = (isA ? i : i - A_INSTR) * 1024 + lane * 16;
+        const int R = isA ? RA : RB, C = isA ? CA : CB, ROT = isA ? ROTA : ROTB;
+        const int krow = off / R, pc = (off - krow * R) >> 4;
+        int c = pc - ROT * (krow & 3);
+        c += c < 0 ? C : 0;
+        srcA[j] = isA;
+        srcoff[j] = isA ? (long)krow * g.lda + min(m0 + c * 8, g.M - 8) : (long)krow * g.ldb + min(n0 + c * 8, g.N - 8);
+    }
+    auto issue = [&](int s) {                 // slices past the end are issued too (into their ring slot, from slice 0's rows):
+        char* st = smem + (s % STAGES) * STAGE;   // the vmcnt distance stays constant in the tail and nobody reads them
+        const long k0 = kbeg + (long)(s < nslices ? s : 0) * BKD;
+#pragma unroll
+        for (int j = 0; j < LPW_HI; ++j) {
+            const int i = wave + WAVES * j;
+            if (j < LPW_LO || hi) {
+                const bf16_t* src = srcA[j] ? Ag + k0 * g.lda + srcoff[j] : Bg + k0 * g.ldb + srcoff[j];
+                // inline asm, not __builtin_amdgcn_global_load_lds: hipcc cannot prove that the ring slot being filled and the
+                // slot the next ds_read touches differ, and drains the ring with s_waitcnt vmcnt(0) before every slice's reads
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_ptr)(st + i * 1024));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        }
+    };
+    // MFMA operand for image columns col0 + (lane&31), k-step kk: two transposed 8-byte reads (k rows q and q + 4)
+    auto frag_t = [&](const char* img, int R, int C, int ROT, int col0, int kk) -> bf16x8 {
+        const int i = lane & 15, q = i >> 2, p = i & 3, gsel = (lane >> 4) & 1;
+        const int col = col0 + 16 * gsel + 4 * p;
+        const int krow = kk * 16 + 8 * h + q;
+        int pc = (col >> 3) + ROT * (krow & 3);
+        pc -= pc >= C ? C : 0;
+        const char* addr = img + krow * R + pc * 16 + (col & 7) * 2;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr));
+        const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 4 * R));
+        typedef __attribute__((ext_vector_type(8))) short short8v;
+        short8v v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    float colacc[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) colacc[mi] = 0.f;
+    const bool do_colsum = g.colsum && bx == 0 && wn == 0;
+    const bool scaled = (g.pro & PRO_ROWSCALE_A) != 0;
+
+    const long dbgi = (((long)bz * g.ny + by) * g.nx + bx) * 6;
+    if (g.dbg && tid == 0) g.dbg[dbgi + 0] = __builtin_amdgcn_s_memtime();
+    // One phase per slice: retire the oldest slice (counted vmcnt: the two younger ones stay in flight), barrier, refill the
+    // slot everybody has just finished reading, then fragments + MFMAs. (A two-group ping-pong version of this loop - one wave
+    // of each SIMD computing while its partner loads - measured slower: tools/experiments/gemm_round2_experiments.hip.txt.)
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p) issue(p);
+    for (int s = 0; s < nslices; ++s) {
+        if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPW_HI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPW_LO) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g.dbg && tid == 0 && (s == 0 || s == 8)) g.dbg[dbgi + (s == 0 ? 1 : 4)] = __builtin_amdgcn_s_memtime();
+        issue(s + STAGES - 1);
+        const char* As = smem + (s % STAGES) * STAGE;
+        const char* Bs = As + A_BYTES;
+        // DropPath factor of this slice's sample through the SCALAR cache (inline asm: hipcc would fetch it with a VMEM load -
+        // the pointer is not provably read-only - and then drain the whole DMA ring with vmcnt(0) before the first use)
+        float sc = 1.f;
+        if (scaled) {
+            const float* sp = g.rowscale + __builtin_amdgcn_readfirstlane((kbeg + s * BKD) / g.rows_per_scale);
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc) : "s"(sp) : "memory");
+        }
+        if (sc == 0.f) continue;        // uniform: a dropped sample contributes nothing
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                fa[mi] = frag_t(As, RA, CA, ROTA, (wm * MT + mi) * 32, kk);
+                if (scaled && sc != 1.f) fa[mi] = __builtin_bit_cast(bf16x8, scale_chunk<bf16_t>(__builtin_bit_cast(f32x4, fa[mi]), sc));
+                if (do_colsum) colacc[mi] += frag_sum<bf16_t>(fa[mi]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fb[ni] = frag_t(Bs, RB, CB, ROTB, (wn * NT + ni) * 32, kk);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail's surplus DMAs must not outlive the workgroup's LDS
+    if (g.dbg && tid == 0) g.dbg[dbgi + 2] = __builtin_amdgcn_s_memtime();
+    if (do_colsum) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const float cs = colacc[mi] + __shfl_xor(colacc[mi], 32, 64);
+            const int m = m0 + (wm * MT + mi) * 32 + r;
+            if (h == 0 && m < g.M) g.colsum[(long)bz * g.colsum_stride + m] = cs;
+        }
+    }
+    float* Cg = (float*)g.C + (long)bz * g.slab_stride;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + (wn * NT + ni) * 32 + r;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M) Cg[(long)m * g.ldc + n] = acc[mi][ni][e];
+            }
+    }
+    if (g.dbg) {
+        const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { g.dbg[dbgi + 5] = t5; g.dbg[dbgi + 3] = __builtin_amdgcn_s_memtime(); }
+    }
+}
+
+template <int MT, int NT>
+int launch_wgrad_ring(const GemmArgs& g, int splits, hipStream_t stream) {
+    constexpr int BM = 4 * MT * 32, BN = 2 * NT * 32;
+    constexpr int LDS = 4 * 32 * (BM + BN) * 2;
+    GemmArgs ga = g;
+    ga.nx = pseld_cdiv(g.N, BN); ga.ny = pseld_cdiv(g.M, BM); ga.nz = splits;
+    ga.xcd_swizzle = gemm_xcd_mode(true) && (splits == 1 || splits % 8 == 0);
+    const long nblocks = !ga.xcd_swizzle ? (long)ga.nx * ga.ny * splits
+                         : splits == 1 ? (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx : (long)8 * pseld_cdiv(splits, 8) * ga.nx * ga.ny;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_wgrad_ring_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL((gemm_wgrad_ring_kernel<MT, NT>), dim3((unsigned)nblocks), dim3(512), LDS, stream, ga);
+    PSELD_LAUNCH_CHECK("gemm_wgrad_ring");
+    return PSELD_OK;
+}
+
 
 template <typename T, typename OutT, int WM, int WN, bool TA, bool TB, bool CONV = false>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
@@ -971,7 +1171,7 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
             if (narrow && K < 384) return launch_gemm_dma<4, 1>(g, s);     // 256x96 with a long K loop: gemm_kernel is faster
             if (!narrow) {
                 // PSELD_GEMM_RING3=<K>: 3-stage ring at two workgroups per CU (4 slices in flight per CU instead of 3) for K >= <K>
-                static const int ring_k = [] { const char* e = getenv("PSELD_GEMM_RING3"); return e ? atoi(e) : 0; }();
+                const int ring_k = [] { const char* e = getenv("PSELD_GEMM_RING3"); return e ? atoi(e) : 0; }();
                 if (ring_k > 0 && K >= ring_k) return launch_gemm_dma<2, 2, 3>(g, s);
                 return launch_gemm_dma<2, 2>(g, s);
             }
@@ -1023,9 +1223,43 @@ static int wgrad_splits_for(int dtype, int Mtok, int N, int K) {
     if (splits < 1) splits = 1;
     return splits;
 }
+// The ring kernel (gemm_wgrad_ring_kernel) takes the large bf16 weight gradients: returns its M-tile count in 32-row units
+// (3: 384 x 192 tile, 2: 256 x 192) and the split count, or 0 when the register-staged kernel keeps the shape.
+static int wgrad_ring_plan(int dtype, int Mtok, int N, int K, int gelu_on_x, int rows_per_scale, bool has_rowscale, int* splits_out) {
+    const int enabled = [] { const char* e = getenv("PSELD_WGRAD_RING"); return e ? atoi(e) : 1; }();   // (read per call: in-process A/B)
+    if (!enabled || dtype != PSELD_BF16 || gelu_on_x || Mtok % 32 != 0 || N % 8 != 0 || K % 8 != 0) return 0;
+    if (has_rowscale && rows_per_scale % 32 != 0) return 0;
+    if (N < 256 || K < 192 || (long)N * K < 384L * 384) return 0;          // small matrices: the 256x96 / 128x192 tiles waste less
+    auto tiles_of = [&](int bm) { return (long)pseld_cdiv(N, bm) * pseld_cdiv(K, 192); };
+    const long pad3 = tiles_of(384) * 384 * 192, pad2 = tiles_of(256) * 256 * 192;
+    const int mt = pad3 <= pad2 ? 3 : 2;
+    if ((double)(mt == 3 ? pad3 : pad2) > 1.34 * (double)N * K) return 0;   // more than a third of the tile area would be padding
+    const int tiles = (int)tiles_of(mt == 3 ? 384 : 256);
+    int splits = 256 / tiles;                                               // one workgroup per CU, one resident round
+    if (splits >= 8 && gemm_xcd_mode(true) && (splits / 8 * 8) * 10 >= splits * 9) splits = splits / 8 * 8;   // XCD-local splits if that keeps >= 90 % of the CUs busy
+    const int max_splits = Mtok / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int kchunk = pseld_cdiv(pseld_cdiv(Mtok, splits), 32) * 32;
+    // short token ranges per workgroup (< 32 slices) leave the ring's prologue and the 384 x 192 fp32 slab store un-amortised:
+    // tools/wgrad_ab.py, 12288 x 768 x 768 and 49152 x 384 x 384 (512 tokens per split) are 5-7 % slower than the 256 x 192 kernel
+    if (kchunk < 1024 && enabled != 2) return 0;      // (PSELD_WGRAD_RING=2: take every eligible shape - the parity tests)
+    *splits_out = pseld_cdiv(Mtok, kchunk);
+    return mt;
+}
 extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
     const int sa = wgrad_splits_for(PSELD_BF16, Mtok, N, K), sb = wgrad_splits_for(PSELD_F32, Mtok, N, K);
-    const int splits = (sa > sb ? sa : sb) + 1;        // +1: rounding kchunk to the slice size can add one split
+    int sr = 0;
+    {   // the ring kernel's plan (always counted, whatever PSELD_WGRAD_RING says now: workspaces are sized once)
+        const long t3 = (long)pseld_cdiv(N, 384) * pseld_cdiv(K, 192), t2 = (long)pseld_cdiv(N, 256) * pseld_cdiv(K, 192);
+        const long tiles = t3 < t2 ? t3 : t2;
+        sr = (int)(256 / (tiles > 0 ? tiles : 1));
+        if (sr > Mtok / 512) sr = Mtok / 512;
+        if (sr < 1) sr = 1;
+    }
+    int splits = (sa > sb ? sa : sb);
+    if (sr > splits) splits = sr;
+    splits += 1;                                       // +1: rounding kchunk to the slice size can add one split
     if (splits_out) *splits_out = splits;
     return (long)splits * ((long)N * K + N) * (long)sizeof(float);   // dW slabs + bias-gradient slabs
 }
@@ -1042,13 +1276,16 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr);
     PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
     int splits = wgrad_splits_for(dtype, Mtok, N, K);
+    int ring_splits = 0;
+    const int ring_mt = wgrad_ring_plan(dtype, Mtok, N, K, gelu_on_x, rows_per_scale > 0 ? rows_per_scale : 1, rowscale != nullptr, &ring_splits);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = X; g.C = workspace;
     g.M = N; g.N = K; g.K = Mtok; g.lda = lddy; g.ldb = ldx; g.ldc = K;
     g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     g.rowscale = rowscale;
-    const int bk = (dtype == PSELD_BF16) ? 64 : 32;
+    const int bk = ring_mt ? 32 : (dtype == PSELD_BF16) ? 64 : 32;
+    if (ring_mt) splits = ring_splits;
     int kchunk = pseld_cdiv(Mtok, splits);
     kchunk = pseld_cdiv(kchunk, bk) * bk;
     splits = pseld_cdiv(Mtok, kchunk);
@@ -1061,7 +1298,9 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     else { g.colsum = dbias ? workspace + (long)splits * N * K : nullptr; g.colsum_stride = N; }
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true>(g, splits, s);
+    if (ring_mt == 3) rc = launch_wgrad_ring<3, 3>(g, splits, s);
+    else if (ring_mt == 2) rc = launch_wgrad_ring<2, 3>(g, splits, s);
+    else if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true>(g, splits, s);
     else if (dtype == PSELD_F32) rc = dispatch_tile<float, float, true, true>(g, splits, s);
     else { pseld_set_error("gemm_wgrad: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
     if (rc != PSELD_OK) return rc;

@@ -73,6 +73,8 @@ for M, N, K, epi in [(49152, 1536, 384, 'bias'), (49152, 384, 1536, ''), (49152,
         L.pseld_gemm_set_debug_buffer(None)
         d = dbg.view(-1, 6).cpu()
         d = d[d[:, 0] > 0].double()
+        if d.shape[0] == 0:
+            print(f'stamps M={M} N={N} K={K} {name}: this build carries no stamps in that kernel'); continue
         first = (d[:, 1] - d[:, 0]).median().item(); loop = (d[:, 2] - d[:, 1]).median().item(); epil = (d[:, 3] - d[:, 2]).median().item()
         span = (d[:, 3].max() - d[:, 0].min()).item()
         print(f"stamps M={M} N={N} K={K} {name:7s}: workgroups {d.shape[0]}; median ticks: first slice {first:.0f}, rest of loop {loop:.0f} "
