@@ -762,6 +762,119 @@ int launch_gemm_dma(const GemmArgs& g, hipStream_t stream) {
     return PSELD_OK;
 }
 
+
+// ---- forward / input-gradient GEMM with a long contraction: 256 x 192 tile, 8 waves, 4-stage LDS-DMA ring -----------------------
+// Same images, fragment maps and staged epilogue as gemm_dma_kernel, but ONE workgroup of 8 waves per CU on a 256 x 192 tile
+// (110 flop per LDS-DMA byte instead of 77: the loop of the 128 x 192 kernel is bound by the ~28 B/clk a CU's vector-memory
+// path moves into LDS, tools/gemm_ab.py) with three 28 KB slices in flight (inline-asm DMA + counted vmcnt: with the builtin
+// hipcc drains the ring before every slice's ds_reads). The epilogue of a tile is not overlapped with anything (one workgroup
+// per CU): measured against the 128 x 192 kernel (tools/gemm_ab.py, in-process) it wins 9-10 % at K >= 3072 and loses 8-15 % at
+// K <= 1536, so it only takes K >= 3072 (dispatch in pseld_gemm; PSELD_GEMM_FWD_RING=<K threshold>).
+__global__ __launch_bounds__(512, 2) void gemm_fwd_ring_kernel(GemmArgs g) {
+    constexpr int WM = 4, WN = 2, WAVES = 8, BM = 256, BN = 192;
+    constexpr int BKD = 32, STAGES = 4;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024, TOTAL = STAGE / 1024;              // 16 + 12 DMA instructions per slice
+    constexpr int LPW_HI = (TOTAL + WAVES - 1) / WAVES, LPW_LO = TOTAL / WAVES, NHI = TOTAL - LPW_LO * WAVES;   // 4, 3, waves 0-3
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    int bx, by, bz;
+    if (!tile_coords(g, bx, by, bz)) return;
+    const int m0 = by * BM, n0 = bx * BN;
+    if (tid < BN) bias_s[tid] = ((g.epi & EPI_BIAS) && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+    const bf16_t* Ag = (const bf16_t*)g.A;
+    const bf16_t* Bg = (const bf16_t*)g.B;
+    const int nslices = g.K / BKD;
+    const bool hi = wave < NHI;
+
+    const bf16_t* srcp[LPW_HI];                   // this wave's DMA rows (slice 0), computed once
+#pragma unroll
+    for (int j = 0; j < LPW_HI; ++j) {
+        const int i = min(wave + WAVES * j, TOTAL - 1);
+        const bool isA = i < A_INSTR;
+        const int ii = isA ? i : i - A_INSTR;
+        const int row = ii * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
+        srcp[j] = isA ? Ag + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8 : Bg + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
+    }
+    auto issue = [&](int s) {                     // slices past the end re-read slice 0 into a slot nobody reads: constant vmcnt distance
+        char* st = smem + (s % STAGES) * STAGE;
+        const int k0 = (s < nslices ? s : 0) * BKD;
+#pragma unroll
+        for (int j = 0; j < LPW_HI; ++j) {
+            if (j < LPW_LO || hi) {
+                const int i = wave + WAVES * j;
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_ptr)(st + i * 1024));
+                const bf16_t* src = srcp[j] + k0;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        }
+    };
+    auto frag = [&](const char* img, int row, int kk) -> bf16x8 {
+        return *(const bf16x8*)(img + row * 64 + (((2 * kk + h) ^ ((row >> 2) & 3)) << 4));
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p) issue(p);
+    for (int s = 0; s < nslices; ++s) {
+        if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPW_HI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPW_LO) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(s + STAGES - 1);
+        const char* As = smem + (s % STAGES) * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[3];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[mi] = frag(As, wm * 64 + mi * 32 + r, kk);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) fb[ni] = frag(Bs, wn * 96 + ni * 32 + r, kk);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail's surplus DMAs land before the C tile is staged over the ring
+    unsigned long long t4 = 0;
+    bf16_t* Cb = (bf16_t*)g.C;
+    const int e = g.epi & ~EPI_BIAS;
+    if (e == 0 && !g.rowscale) staged_epilogue<EM_PLAIN, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_RESID && !g.rowscale) staged_epilogue<EM_RESID, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_RESID && g.rows_per_scale >= 64) staged_epilogue<EM_RESID_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_GELU_DUAL && !g.rowscale) staged_epilogue<EM_GELU_DUAL, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_MULAUX && !g.rowscale) staged_epilogue<EM_MULAUX, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == EPI_MULAUX && g.rows_per_scale >= 64) staged_epilogue<EM_MULAUX_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else if (e == 0 && g.rows_per_scale >= 64) staged_epilogue<EM_SCALE, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+    else staged_epilogue<EM_GENERIC, WM, WN>(g, smem, bias_s, acc, m0, n0, Cb, t4);
+}
+
+static int launch_gemm_fwd_ring(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = 256, BN = 192;
+    constexpr int LDS = 4 * (BM + BN) * 64;               // 112 KB ring; the 256 x (192 * 2 + 16) C staging (100 KB) re-uses it
+    GemmArgs ga = g;
+    ga.nx = pseld_cdiv(g.N, BN); ga.ny = pseld_cdiv(g.M, BM); ga.nz = 1;
+    ga.xcd_swizzle = 1;
+    const long nblocks = (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_fwd_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL(gemm_fwd_ring_kernel, dim3((unsigned)nblocks), dim3(512), LDS, stream, ga);
+    PSELD_LAUNCH_CHECK("gemm_fwd_ring");
+    return PSELD_OK;
+}
+
 // PSELD_GEMM_XCD: bit 0 = swizzle forward / input-gradient launches, bit 1 = swizzle weight-gradient launches
 static int gemm_xcd_mode(bool wgrad) {
     const char* e = getenv("PSELD_GEMM_XCD");
@@ -1170,6 +1283,9 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
             const bool narrow = g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288);
             if (narrow && K < 384) return launch_gemm_dma<4, 1>(g, s);     // 256x96 with a long K loop: gemm_kernel is faster
             if (!narrow) {
+                // long contractions: the 256 x 192 ring kernel (PSELD_GEMM_FWD_RING=<K threshold>, 0 = never; read per call for in-process A/B)
+                { const char* er = getenv("PSELD_GEMM_FWD_RING"); const int kth = er ? atoi(er) : 3072;
+                  if (kth > 0 && K >= kth && M >= 2048) return launch_gemm_fwd_ring(g, s); }
                 // PSELD_GEMM_RING3=<K>: 3-stage ring at two workgroups per CU (4 slices in flight per CU instead of 3) for K >= <K>
                 const int ring_k = [] { const char* e = getenv("PSELD_GEMM_RING3"); return e ? atoi(e) : 0; }();
                 if (ring_k > 0 && K >= ring_k) return launch_gemm_dma<2, 2, 3>(g, s);

@@ -58,47 +58,51 @@ __global__ void head_col2im_kernel(const T* __restrict__ dA, T* __restrict__ dto
 }
 
 // ---- pooled output: y[b][f][d] = act( sum_j w[f][j] * z[b][i0[f] + j][d] ) -------------------------------------
-template <typename T>
-__global__ void head_pool_fwd_kernel(const T* __restrict__ z, float* __restrict__ y, const int* __restrict__ i0,
-                                     const float* __restrict__ w, int B, int D, int ldz, int n_out, int n_in, int act) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, f, d)
-    const long total = (long)B * n_out * D;
-    if (i >= total) return;
-    const int d = (int)(i % D);
-    const int f = (int)((i / D) % n_out);
-    const long b = i / ((long)D * n_out);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int tt = i0[f] + j;
-        if (tt < n_in) s += w[f * 3 + j] * to_f32<T>(z[(b * n_in + tt) * ldz + d]);
-    }
-    y[i] = act ? tanhf(s) : s;
+// tanh through one v_exp_f32 and one v_rcp_f32 (|error| < 2e-7 absolute: below fp32 round-off of the pooled sums it follows)
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(-2.f * fabsf(x));
+    return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
 }
-// dz[b][tt][d] = sum over taps (f, wgt) of column tt: wgt * dy[b][f][d] * act'(y[b][f][d]); pad columns zeroed
+// one workgroup row = one (b, f): the tap list of the row is wave-uniform, threads run along d (coalesced), no integer divisions
 template <typename T>
-__global__ void head_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* __restrict__ dz,
-                                     const int* __restrict__ t_cnt, const int* __restrict__ t_f,
-                                     const float* __restrict__ t_w, int B, int D, int ldz, int n_out, int n_in, int act,
-                                     int max_taps) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, tt, dcol < ldz)
-    const long total = (long)B * n_in * ldz;
-    if (i >= total) return;
-    const int d = (int)(i % ldz);
-    const int tt = (int)((i / ldz) % n_in);
-    const long b = i / ((long)ldz * n_in);
-    float s = 0.f;
-    if (d < D) {
-        const int cnt = t_cnt[tt];
-        for (int k = 0; k < cnt; ++k) {
-            const int f = t_f[tt * max_taps + k];
-            const long o = (b * n_out + f) * D + d;
-            float g = dy[o];
-            if (act) { const float yv = y[o]; g *= (1.f - yv * yv); }
-            s += t_w[tt * max_taps + k] * g;
-        }
+__global__ __launch_bounds__(256) void head_pool_fwd_kernel(const T* __restrict__ z, float* __restrict__ y, const int* __restrict__ i0,
+                                                            const float* __restrict__ w, int B, int D, int ldz, int n_out, int n_in, int act) {
+    const int row = blockIdx.y;                              // b * n_out + f
+    const int b = row / n_out, f = row - b * n_out;
+    const int t0 = i0[f];
+    const float w0 = w[f * 3], w1 = w[f * 3 + 1], w2 = w[f * 3 + 2];
+    const T* z0 = z + ((long)b * n_in + t0) * ldz;
+    const bool h1 = t0 + 1 < n_in, h2 = t0 + 2 < n_in;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) {
+        float s = w0 * to_f32<T>(z0[d]);
+        if (h1) s += w1 * to_f32<T>(z0[ldz + d]);
+        if (h2) s += w2 * to_f32<T>(z0[2 * ldz + d]);
+        y[(long)row * D + d] = act ? tanh_fast(s) : s;
     }
-    dz[i] = from_f32<T>(s);
+}
+// dz[b][tt][d] = sum over taps (f, wgt) of column tt: wgt * dy[b][f][d] * act'(y[b][f][d]); pad columns zeroed.
+// one workgroup row = one (b, tt)
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* __restrict__ dz,
+                                                            const int* __restrict__ t_cnt, const int* __restrict__ t_f,
+                                                            const float* __restrict__ t_w, int B, int D, int ldz, int n_out, int n_in, int act,
+                                                            int max_taps) {
+    const int row = blockIdx.y;                              // b * n_in + tt
+    const int b = row / n_in, tt = row - b * n_in;
+    const int cnt = t_cnt[tt];
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < ldz; d += gridDim.x * 256) {
+        float s = 0.f;
+        if (d < D) {
+            for (int k = 0; k < cnt; ++k) {
+                const int f = t_f[tt * max_taps + k];
+                const long o = ((long)b * n_out + f) * D + d;
+                float g = dy[o];
+                if (act) { const float yv = y[o]; g *= (1.f - yv * yv); }
+                s += t_w[tt * max_taps + k] * g;
+            }
+        }
+        dz[(long)row * ldz + d] = from_f32<T>(s);
+    }
 }
 
 // ---- ADPIT loss (forward value + gradient in one pass) --------------------------------------------------------
@@ -461,9 +465,9 @@ extern "C" int pseld_head_pool_fwd(int dtype, const void* z, float* y, const int
                                    int n_out, int n_in, int act_tanh, void* stream) {
     PSELD_CHECK_ARG(z && y && i0 && w && B > 0 && D > 0 && ldz >= D, "head_pool_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * n_out * D;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_fwd_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh),
-               hipLaunchKernelGGL(head_pool_fwd_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const float*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh), "head_pool_fwd");
+    const dim3 grid(pseld_cdiv(D, 256) > 4 ? 4 : pseld_cdiv(D, 256), B * n_out);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh),
+               hipLaunchKernelGGL(head_pool_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh), "head_pool_fwd");
     PSELD_LAUNCH_CHECK("head_pool_fwd");
     return PSELD_OK;
 }
@@ -472,9 +476,9 @@ extern "C" int pseld_head_pool_bwd(int dtype, const float* dy, const float* y, v
                                    void* stream) {
     PSELD_CHECK_ARG(dy && y && dz && t_cnt && t_f && t_w && ldz >= D, "head_pool_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * n_in * ldz;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, dy, y, (bf16_t*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps),
-               hipLaunchKernelGGL(head_pool_bwd_kernel<float>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, dy, y, (float*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps), "head_pool_bwd");
+    const dim3 grid(pseld_cdiv(ldz, 256) > 4 ? 4 : pseld_cdiv(ldz, 256), B * n_in);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dy, y, (bf16_t*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps),
+               hipLaunchKernelGGL(head_pool_bwd_kernel<float>, grid, dim3(256), 0, s, dy, y, (float*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps), "head_pool_bwd");
     PSELD_LAUNCH_CHECK("head_pool_bwd");
     return PSELD_OK;
 }

@@ -1,17 +1,17 @@
-"""In-process A/B of forward / input-gradient GEMM feeder variants on the HTS-AT shapes (192 chunks, bf16), interleaved rounds
-(cdna_hip_programming.md rule 24): baseline (128x192, 2 stages, 3 workgroups/CU), PSELD_GEMM_RING3 (3-stage ring, 2/CU),
-PSELD_GEMM_TOUCH=n (software L2 prefetch of the first n 128-byte columns of the A panel). Then s_memtime phase stamps.
+"""In-process A/B of forward / input-gradient GEMM kernels on the HTS-AT shapes (192 chunks, bf16), interleaved rounds
+(cdna_hip_programming.md rule 24): base (128x192, 2 stages, 3 workgroups/CU), fring (256x192, 8 waves, 4-stage ring, 1/CU:
+PSELD_GEMM_FWD_RING=<K threshold>), ring3 (128x192, 3-stage ring, 2/CU). Then s_memtime phase stamps where the build has them.
+(The round-2 experiments with a software L2 prefetch and spread DMA issue: tools/experiments/gemm_round2_experiments.hip.txt.)
 python tools/gemm_ab.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pseldnets_amd import ops, _lib
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-VARIANTS = [('base', {}), ('ring3', {'PSELD_GEMM_RING3': '96'}), ('touch6', {'PSELD_GEMM_TOUCH': '6'}), ('spread1', {'PSELD_GEMM_SPREAD': '1'}),
-            ('spread2', {'PSELD_GEMM_SPREAD': '2'})]
+VARIANTS = [('base', {'PSELD_GEMM_FWD_RING': '0'}), ('fring', {'PSELD_GEMM_FWD_RING': '96'}), ('ring3', {'PSELD_GEMM_FWD_RING': '0', 'PSELD_GEMM_RING3': '96'})]
 if os.environ.get('AB_VARIANTS'):
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ['AB_VARIANTS'].split(',')]
-KNOBS = ('PSELD_GEMM_RING3', 'PSELD_GEMM_TOUCH', 'PSELD_GEMM_SPREAD')
+KNOBS = ('PSELD_GEMM_RING3', 'PSELD_GEMM_FWD_RING')
 SHAPES = [(49152, 1536, 384, 'gelu'), (49152, 1536, 384, 'mul'), (49152, 384, 1536, 'resid'), (49152, 384, 1536, ''), (49152, 1152, 384, 'bias'),
           (49152, 384, 1152, ''), (49152, 384, 384, 'resid'), (49152, 384, 384, ''), (196608, 768, 192, 'gelu'), (196608, 192, 768, 'resid'),
           (12288, 3072, 768, 'gelu'), (12288, 768, 3072, 'resid'), (12288, 2304, 768, 'bias'), (6144, 1536, 4608, 'bias')]
