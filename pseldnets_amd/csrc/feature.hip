@@ -11,7 +11,11 @@
 // features is written: the complex STFT, the power spectrogram and the three 513-bin intensity maps of the unfused
 // reference never exist in memory.
 //
-// Roofline: HBM-bound by design (5.634 MB algorithmic bytes per 10 s chunk: 3.84 MB in + 1.794 MB out).
+// Roofline: the HBM floor (5.634 MB algorithmic bytes per 10 s chunk: 3.84 MB in + 1.794 MB out -> 0.2 ms per 192 chunks) is NOT
+// what binds this kernel: it is VALU-issue-bound. rocprofv3 --pmc (profiles/r02_pmc_feature.json): 3 590 vector instructions per
+// frame (two 1024-point register FFTs in packed fp32, inter-stage twiddles, spectrum split, compact mel) = 690 M wave-instructions
+// per 192 chunks, SQ_ACTIVE_INST_VALU = 81 % of the kernel's wave-cycles (2 waves per SIMD, 4 cycles per wave64 instruction),
+// 1.2x the algorithmic bytes fetched. Getting closer to the HBM floor means fewer instructions per frame, not better memory access.
 #include "common.h"
 
 namespace {
@@ -51,7 +55,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 constexpr int EX_LD = 33;                  // transpose row stride (elements): lane k1' reads row k1' conflict-free
 constexpr int FFT_LDS = 32 * EX_LD;        // elements per FFT region (also holds the 1024-point spectrum afterwards)
 constexpr int WAVES2 = 8;                  // waves (= frames in flight) per workgroup
-constexpr int FPB2 = 16;                   // frames per workgroup
+constexpr int FPB2 = 32;                   // frames per workgroup (the 14 KB of tables are re-read per workgroup: amortised over 4 frames per wave)
 constexpr int V2_WAVE_BYTES = 2 * FFT_LDS * 8 + 64;
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
