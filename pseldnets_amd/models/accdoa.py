@@ -88,8 +88,9 @@ class HTSAT(HTSATNetBase):
     def _forward_impl(self, x, training):
         B = x.shape[0]
         dt = self.compute_dtype
-        mean_rstd, scale_shift = self._bn_front(x, training)
-        drop = self._drop_scales(B, self.enc, x.device, training)
+        box = []
+        mean_rstd, scale_shift = self._bn_front(x, training, overlap=lambda: box.append(self._drop_scales(B, self.enc, x.device, training)))
+        drop = box[0]
         tok, s_patch = self.enc.forward_patch(x, scale_shift, dt)
         s_layers = []
         for li in range(self.enc.nl):
@@ -179,8 +180,9 @@ class PASST(HTSATNetBase):
 
     def _forward_impl(self, x, training):
         B, dt = x.shape[0], self.compute_dtype
-        mean_rstd, scale_shift = self._bn_front(x, training)
-        drop = self._drop_scales(B, self.enc, x.device, training)
+        box = []
+        mean_rstd, scale_shift = self._bn_front(x, training, overlap=lambda: box.append(self._drop_scales(B, self.enc, x.device, training)))
+        drop = box[0]
         tok, s_front = self.enc.forward_front(x, scale_shift, dt, training)
         s_blocks = []
         for i in range(self.enc.depth):

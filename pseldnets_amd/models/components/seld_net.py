@@ -141,22 +141,30 @@ class HTSATNetBase(nn.Module):
         return super()._apply(fn, *a, **k)
 
     # -- the BN front shared by every HTS-AT variant -----------------------------------------------------------
-    def _bn_front(self, feat, training):
+    def _bn_front(self, feat, training, overlap=None):
+        """Scalar-BatchNorm statistics -> (mean, rstd) and the folded (scale, shift). With a sync-BN group the 2 x 7 x 64 sums are
+        all-reduced ASYNCHRONOUSLY (RCCL runs on its own stream) right behind the statistics kernel; `overlap()` - host work and
+        launches that do not need the statistics, e.g. drawing the DropPath factors - runs while the collective is on the wire,
+        and the compute stream only waits for it in front of the finalize kernel (configs/trainer/gpu.yaml:9)."""
         a, C = self.arena, self.in_channels
         n = C * self.mel_bins
         w = a.flat[a.offsets['scalar.0.weight'][0]: a.offsets['scalar.0.weight'][0] + n]
         b = a.flat[a.offsets['scalar.0.bias'][0]: a.offsets['scalar.0.bias'][0] + n]
         B, _, T, _ = feat.shape
         count = float(B * T)
-        sums, centered = None, False
+        sums, centered, work = None, False, None
         if training:
             group = self.sync_bn_group
             centered = group is None
             sums = ops.bn_scalar_stats(feat, centered=centered)
             if group is not None:
                 import torch.distributed as dist
-                dist.all_reduce(sums[:2 * n], group=group)
+                work = dist.all_reduce(sums[:2 * n], group=group, async_op=True)
                 count *= dist.get_world_size(group)
+        if overlap is not None:
+            overlap()
+        if work is not None:
+            work.wait()
         mean_rstd, scale_shift = ops.bn_scalar_finalize(sums, count, centered, w, b, self._rm.view(-1), self._rv.view(-1),
                                                        self._nbt, training, self.bn_momentum, self.bn_eps)
         return mean_rstd, scale_shift
@@ -214,6 +222,7 @@ class HTSATNetBase(nn.Module):
         frozen = self._frozen_state()
         if frozen is not None:                 # adapter fine-tuning: frozen parameters take no part in the clip norm or the update
             a.grad.copy_(ops.mul(a.grad, frozen['mask']))
+            grad_norm = None                   # a norm taken before the masking would count the frozen entries
         if max_norm and grad_norm is None:
             grad_norm = ops.grad_norm(a.grad)
         shadow = None

@@ -165,9 +165,9 @@ class HTSAT(HTSATNetBase):
     def _forward_impl(self, x, training):
         B, dt = x.shape[0], self.compute_dtype
         a = self.arena
-        mean_rstd, scale_shift = self._bn_front(x, training)
-        drop_s = self._drop_scales(B, self.sed_enc, x.device, training)
-        drop_d = self._drop_scales(B, self.doa_enc, x.device, training)
+        box = []
+        mean_rstd, scale_shift = self._bn_front(x, training, overlap=lambda: box.extend((self._drop_scales(B, self.sed_enc, x.device, training), self._drop_scales(B, self.doa_enc, x.device, training))))
+        drop_s, drop_d = box
         xs, sp_s = self.sed_enc.forward_patch(x, scale_shift, dt, 0)
         xd, sp_d = self.doa_enc.forward_patch(x, scale_shift, dt, 0)
         layers = []
@@ -225,8 +225,9 @@ class HTSAT_SEDDOA(HTSATNetBase):
 
     def _forward_impl(self, x, training):
         B, dt = x.shape[0], self.compute_dtype
-        mean_rstd, scale_shift = self._bn_front(x, training)
-        drop = self._drop_scales(B, self.enc, x.device, training)
+        box = []
+        mean_rstd, scale_shift = self._bn_front(x, training, overlap=lambda: box.append(self._drop_scales(B, self.enc, x.device, training)))
+        drop = box[0]
         tok, sp = self.enc.forward_patch(x, scale_shift, dt)
         layers = []
         for li in range(self.enc.nl):
@@ -422,9 +423,9 @@ class PASST(StaticBufferMixin, HTSATNetBase):
 
     def _forward_impl(self, x, training):
         B, dt, a = x.shape[0], self.compute_dtype, self.arena
-        mean_rstd, scale_shift = self._bn_front(x, training)
-        drop_s = self._drop_scales(B, self.sed_enc, x.device, training)
-        drop_d = self._drop_scales(B, self.doa_enc, x.device, training)
+        box = []
+        mean_rstd, scale_shift = self._bn_front(x, training, overlap=lambda: box.extend((self._drop_scales(B, self.sed_enc, x.device, training), self._drop_scales(B, self.doa_enc, x.device, training))))
+        drop_s, drop_d = box
         xs, fs = self.sed_enc.forward_front(x, scale_shift, dt, training)
         xd, fd = self.doa_enc.forward_front(x, scale_shift, dt, training)
         blocks = []

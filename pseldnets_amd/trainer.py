@@ -33,7 +33,8 @@ class FusedTrainer:
                     raise NotImplementedError("sync_batchnorm over the CRNN conv-stack BatchNorms is not built on the MI355X path; "
                                               "run CRNN backbones with trainer.sync_batchnorm=false")
                 net.sync_bn_group = process_group
-        self._works = []
+        self._works, self._ranges = [], []
+        self._train_idx = None       # adapter / LoRA fine-tuning: arena indices of the trainable elements (the only ones all-reduced)
 
     @property
     def lr(self):
@@ -49,6 +50,16 @@ class FusedTrainer:
             return
         import torch.distributed as dist
         self._works.append(dist.all_reduce(self.net.arena.grad[a:b], group=self.group, async_op=True))
+        self._ranges.append((a, b))
+
+    def _trainable_index(self):
+        """Arena indices of the trainable elements when part of the network is frozen (configs/adapt/*.yaml), else None."""
+        st = self.net._frozen_state()
+        if st is None:
+            return None
+        if self._train_idx is None or self._train_idx[0] is not st['mask']:
+            self._train_idx = (st['mask'], torch.nonzero(st['mask'], as_tuple=False).view(-1))
+        return self._train_idx[1]
 
     def _loss(self, outs, target):
         if self.loss_kind == 'adpit':
@@ -80,10 +91,30 @@ class FusedTrainer:
         outs, saved = net._forward_impl(x.contiguous().float(), True)
         loss, douts, loss_dict = self._loss(outs, batch_target)
         net.zero_grad_arena()
-        self._works = []
-        net._backward_impl(saved, douts, on_range_done=self._reduce_range if self.group is not None else None)
-        for w in self._works:
-            w.wait()
+        self._works, self._ranges = [], []
+        grad_norm = None
+        if self.group is None:
+            net._backward_impl(saved, douts)
+        elif self._trainable_index() is not None:
+            # fine-tuning: << 1 % of the arena trains. Only those elements travel: gathered into one contiguous buffer,
+            # all-reduced once, scattered back (the frozen slots hold nothing the optimiser reads)
+            import torch.distributed as dist
+            net._backward_impl(saved, douts)
+            idx = self._trainable_index()
+            buf = net.arena.grad.index_select(0, idx)
+            dist.all_reduce(buf, group=self.group)
+            net.arena.grad.index_copy_(0, idx, buf)
+        else:
+            # buckets are issued back to front while earlier layers are still in backward (RCCL's own stream); each is waited for
+            # in issue order and its share of the clipping norm is taken at once, while the later buckets are still on the wire
+            net._backward_impl(saved, douts, on_range_done=self._reduce_range)
+            parts = []
+            for (a, b), w in zip(self._ranges, self._works):
+                w.wait()
+                if self.max_norm:
+                    parts.append(ops.grad_norm(net.arena.grad[a:b]))
+            if parts:
+                grad_norm = torch.linalg.vector_norm(torch.cat(parts)).view(1)
         net.fused_adamw_step(self.lr, max_norm=self.max_norm, betas=self.betas, eps=self.eps, weight_decay=self.wd,
-                             grad_scale=1.0 / self.world)
+                             grad_scale=1.0 / self.world, grad_norm=grad_norm)
         return loss_dict

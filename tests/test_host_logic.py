@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
         pass
     net = FakeNet(); net.arena = arena
     tr = FusedTrainer.__new__(FusedTrainer)
-    tr.net, tr.group, tr._works = net, dist.group.WORLD, []
+    tr.net, tr.group, tr._works, tr._ranges = net, dist.group.WORLD, [], []
     hi = arena.size
     for name in ('p2', 'p1'):
         lo = arena.offsets[name][0]

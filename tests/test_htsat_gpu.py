@@ -616,3 +616,55 @@ def test_weights_changed_behind_the_arena_are_seen(dev):
     net.train()
     y_train, _ = net._forward_impl(x.clone(), False)
     assert not torch.equal(y_train, y_fresh)
+
+
+def test_fine_tuning_all_reduces_only_the_trainable_elements(dev):
+    """Adapter fine-tuning through a world-size-1 RCCL group with sync-BN on: the data-parallel step gathers the trainable
+    gradient elements (biases, adapters, head: a few per cent of the arena) into one buffer, all-reduces that buffer alone, and
+    must land on the same parameters as the step without a group; the scalar-BN statistics go through the asynchronous
+    all-reduce in front of the finalize kernel."""
+    import torch.distributed as dist
+    from pseldnets_amd.models import multi_accdoa
+    from pseldnets_amd.trainer import FusedTrainer
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29873', rank=0, world_size=1, device_id=dev)
+    except Exception as e:           # no RCCL on this box
+        pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        C = 3
+        cfg = A(data=CFG.data, adapt=ADAPT)
+        x = oh.formula_features(2).to(dev)
+        lab = {'adpit_label': synth.formula_adpit_label(2, 100, C).to(dev)}
+        sd = oh.add_adapters(oh.formula_state('multi_accdoa', C, 7, TINY), TINY)
+        res = []
+        for group in (None, dist.group.WORLD):
+            net = multi_accdoa.HTSAT(cfg, C, 7, pretrained_path=None, **kw(TINY))
+            net.load_state_dict(sd, strict=False)
+            net.to(dev)
+            tr = FusedTrainer(net, None, 'adpit', lr=1e-3, process_group=group, sync_bn=group is not None)
+            reduced = []
+            if group is not None:
+                orig = dist.all_reduce
+                def spy(t, *a, **k):
+                    reduced.append(t.numel())
+                    return orig(t, *a, **k)
+                dist.all_reduce = spy
+            try:
+                ld = tr.training_step(x.clone(), lab, is_features=True)
+            finally:
+                if group is not None:
+                    dist.all_reduce = orig
+            torch.cuda.synchronize()
+            res.append((ld['loss_all'].item(), net.arena.flat.clone(), net._rm.clone()))
+            if group is not None:
+                n_train = int(net._frozen_state()['mask'].sum().item())
+                assert 0 < n_train < 0.2 * net.arena.size
+                # one all-reduce of the BN sums (2 x 7 x 64) and one of exactly the trainable elements; never the arena
+                assert sorted(reduced) == sorted([2 * 7 * 64, n_train]), (reduced, n_train, net.arena.size)
+        assert abs(res[0][0] - res[1][0]) < 1e-5 * abs(res[0][0])
+        assert (res[0][1] - res[1][1]).abs().max().item() <= 2.5e-3
+        assert (res[0][2] - res[1][2]).abs().max().item() < 1e-5
+    finally:
+        dist.destroy_process_group()
