@@ -69,7 +69,7 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
-            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_passt_grid_t'):
+            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel'):
                 continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn
@@ -81,13 +81,14 @@ class KernelTimer:
                 s.record()
                 rc = _fn(*a)
                 e.record()
-                self.records.append((_n, a, s, e))
+                sym = self.lib.pseld_gemm_last_kernel().decode() if _n in ('pseld_gemm', 'pseld_gemm_wgrad') else None
+                self.records.append((_n, a, s, e, sym))
                 return rc
             setattr(self.lib, n, wrapped)
 
     def detail(self):
         rows = {}
-        for n, a, s, e in self.records:
+        for n, a, s, e, _sym in self.records:
             if n == 'pseld_gemm':
                 key = ('gemm', a[1], a[2], a[6], a[7], a[8], a[19], a[20])      # ta, tb, M, N, K, epi, pro
             elif n == 'pseld_gemm_wgrad':
@@ -102,10 +103,26 @@ class KernelTimer:
             print(f"{kind:5s} ta{ta} tb{tb} M={M:7d} N={N:5d} K={K:5d} epi={epi:2d} pro={pro}: {c // 2:3d} launches/step, "
                   f"{t / c * 1e3:7.1f} us each, {fl / (t / c * 1e-3) / 1e12:6.0f} TF/s, {t / 2:7.3f} ms/step", file=sys.stderr)
 
+    def by_symbol(self):
+        """{kernel symbol: [ms, launches, flops, algorithmic bytes]} over the forward / input-gradient launches of pseld_gemm
+        (the weight-gradient entry point launches a GEMM and a slab reduction: its time is not a single kernel's)."""
+        torch.cuda.synchronize()
+        out = {}
+        for n, a, s, e, sym in self.records:
+            if n != 'pseld_gemm' or not sym:
+                continue
+            M, N, K, epi = a[6], a[7], a[8], a[19]
+            extra = M * N * ((1 if epi & 2 else 0) + (1 if epi & (4 | 32) else 0) + (1 if epi & 16 else 0))   # resid / aux rows read, second GELU output written
+            d = out.setdefault(sym, [0.0, 0, 0.0, 0.0, 0.0])
+            d[0] += s.elapsed_time(e); d[1] += 1; d[2] += 2.0 * M * N * K
+            d[3] += ESIZE * (M * K + N * K + M * N)                    # operands + result once (SURVEY 8d / DESIGN 4 definition)
+            d[4] += ESIZE * (M * K + N * K + M * N + extra)            # + the fused epilogue operands the launch must also move
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for n, a, s, e in self.records:
+        for n, a, s, e, _sym in self.records:
             key = n
             flops = 0.0
             nbytes = 0.0
@@ -132,12 +149,11 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel family from the PMC counters. Counters cannot be read from inside
     this process: the figure is the one measured with rocprofv3 on this same command (two separate --pmc passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/."""
-    path = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_dominant_kernel_pmc.json')
     if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks or not os.path.exists(path):
-        return None, None
+        return None
     with open(path) as f:
-        d = json.load(f)
-    return round(d['traffic_bytes_per_launch'], 1), 'profiles/r01_gemm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+        return json.load(f)
 
 
 def cpu_baseline(chunks=4, steps=3, threads=None):
@@ -254,6 +270,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None
+    if world == 1 and os.environ.get('PSELD_BENCH_FORCE_GROUP'):
+        # stream-placement check on one GPU: a world-size-1 RCCL group makes the trainer issue its bucketed all-reduces
+        # (identity collectives on RCCL's own stream) so that a kernel trace shows them beside the backward kernels
+        import torch.distributed as dist
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29877', rank=0, world_size=1, device_id=device)
+        group = dist.group.WORLD
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -302,7 +324,7 @@ def main():
         for p in net.parameters():            # identical initial weights on every rank
             dist.broadcast(p.data, 0)
     einv2_mode = args.backbone.endswith('_einv2')
-    sync_bn = world > 1 and (args.sync_bn == 'on' or (args.sync_bn == 'auto' and not args.backbone.startswith('crnn')))
+    sync_bn = group is not None and (args.sync_bn == 'on' or (args.sync_bn == 'auto' and not args.backbone.startswith('crnn')))
     trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
                            process_group=group, sync_bn=sync_bn)
     wave, target = synthetic_batch(args.clips, device, 2024 + rank, chunks=args.chunks or None)
@@ -416,26 +438,39 @@ def main():
         total = sum(v[0] for v in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1][0])
         gem = [v for k, v in agg.items() if k.startswith('gemm_kernel(fwd')]
+        syms = timer.by_symbol()
+        if syms:
+            # the single dominant kernel of the step: the symbol with the largest launch-time total (HIP events on the launch stream)
+            sym, (tms, n, fl, nb, nb_moved) = max(syms.items(), key=lambda kv: kv[1][0])
+            ach_tf = fl / (tms * 1e-3) / 1e12
+            gbs = nb / (tms * 1e-3) / 1e9
+            # which ceiling binds this symbol's launches: their aggregate arithmetic intensity against the ridge (peak flops / peak bytes)
+            hbm = (fl / nb) < (PEAK_FLOPS * 1e12) / (PEAK_HBM_GBS * 1e9)
+            pmc = pmc_traffic(args) or {}
+            same = pmc.get('kernel') == sym
+            out["roofline"] = {"bound": "hbm" if hbm else "mfma", "kernel": sym,
+                               "achieved": round(gbs if hbm else ach_tf, 2), "peak": PEAK_HBM_GBS if hbm else PEAK_FLOPS,
+                               "unit": "GB/s" if hbm else "TFLOP/s",
+                               "frac": round((gbs / PEAK_HBM_GBS) if hbm else (ach_tf / PEAK_FLOPS), 4),
+                               "launches_per_step": n // 2, "avg_launch_ms": round(tms / n, 4),
+                               "algorithmic_bytes_per_launch": round(nb / n, 1), "flops_per_launch": round(fl / n, 1),
+                               "bytes_incl_fused_epilogue_operands_per_launch": round(nb_moved / n, 1),
+                               "achieved_tflops": round(ach_tf, 2), "achieved_gbs": round(gbs, 1),
+                               "achieved_gbs_incl_fused_operands": round(nb_moved / (tms * 1e-3) / 1e9, 1),
+                               # counters cannot be read from inside this process: rocprofv3 --pmc passes of this same command,
+                               # reduced per launch of this kernel symbol by tools/pmc_kernel.py and committed (static figures)
+                               "traffic": round(pmc['traffic_bytes_per_launch'], 1) if same else None,
+                               "mfma_busy": pmc.get('mfma_busy') if same else None,
+                               "rocprof_avg_launch_ms": pmc.get('rocprof_avg_launch_ms') if same else None,
+                               "pmc_source": ("profiles/r02_dominant_kernel_pmc.json (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
+                                              "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes over this command)") if same else None}
         if gem:
             tms, n, fl, nb, roof_ms, mfma_bound_ms = gem[0]
-            ach = fl / (tms * 1e-3) / 1e12
-            gbs = nb / (tms * 1e-3) / 1e9
-            # The family mixes shapes on both sides of the ridge (peak flops / peak bytes): "bound" names the ceiling
-            # that binds most of its measured time; frac/achieved/peak are quoted against that ceiling, and
-            # frac_shape_aware = sum(per-launch roofline time) / sum(measured time) uses each launch's own ceiling.
-            hbm = mfma_bound_ms < 0.5 * tms
-            traffic, traffic_src = pmc_traffic(args)
-            out["roofline"] = {"bound": "hbm" if hbm else "mfma",
-                               "achieved": round(gbs if hbm else ach, 2), "peak": PEAK_HBM_GBS if hbm else PEAK_FLOPS,
-                               "unit": "GB/s" if hbm else "TFLOP/s",
-                               "frac": round((gbs / PEAK_HBM_GBS) if hbm else (ach / PEAK_FLOPS), 4),
-                               "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "pseld_gemm forward + input-gradient launches (gemm_dma_kernel<WM,WN> for bf16 NT products, gemm_kernel<T,..,TA=0,TB> otherwise)",
-                               "launches": n // 2, "avg_launch_ms": round(tms / n, 4),
-                               "flops_per_launch_avg": round(fl / n, 1), "bytes_per_launch_avg": round(nb / n, 1),
-                               "achieved_tflops": round(ach, 2), "achieved_gbs": round(gbs, 1),
-                               "frac_shape_aware": round(roof_ms / tms, 4),
-                               "time_share_mfma_bound_shapes": round(mfma_bound_ms / tms, 4)}
+            out["roofline_family"] = {"kernel": "every pseld_gemm forward + input-gradient launch (all tile variants)",
+                                      "launches_per_step": n // 2, "avg_launch_ms": round(tms / n, 4),
+                                      "achieved_tflops": round(fl / (tms * 1e-3) / 1e12, 2), "achieved_gbs": round(nb / (tms * 1e-3) / 1e9, 1),
+                                      "frac_shape_aware": round(roof_ms / tms, 4),
+                                      "time_share_mfma_bound_shapes": round(mfma_bound_ms / tms, 4)}
         out["kernel_time_share"] = {k: {"ms_per_step": round(v[0] / 2, 3), "launches": v[1] // 2,
                                         "share": round(v[0] / total, 4)} for k, v in top[:(40 if args.gemm_detail else 10)]}
         for k, v in agg.items():
@@ -450,7 +485,7 @@ def main():
             except Exception as e:  # the checker must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -57,6 +57,8 @@ int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float*
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */
 void pseld_gemm_set_debug_buffer(void* device_buffer);
+/* Measurement aid: symbol of the kernel the last pseld_gemm / pseld_gemm_wgrad call of this process launched. */
+const char* pseld_gemm_last_kernel(void);
 
 /* Bias gradient: out f32[N] (+)= sum_m X[m,n]. */
 long pseld_colsum_workspace(int M, int N);

@@ -35,6 +35,11 @@
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
                         hipStream_t stream);
 
+// name of the kernel the last pseld_gemm / pseld_gemm_wgrad call launched (measurement aid: bench.py attributes its HIP-event
+// launch times to kernel symbols with it)
+static const char* g_last_gemm_kernel = "";
+extern "C" const char* pseld_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+
 namespace {
 
 constexpr int ROWB = 144;  // bytes per non-transposed LDS row: 128 B of K + 16 B pad
@@ -757,6 +762,7 @@ int launch_gemm_dma(const GemmArgs& g, hipStream_t stream) {
     const long nblocks = (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    g_last_gemm_kernel = (WM == 2 && STAGES == 2) ? "gemm_dma_kernel<2, 2, 2>" : (WM == 4 ? "gemm_dma_kernel<4, 1, 2>" : "gemm_dma_kernel<2, 2, 3>");
     hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, STAGES>), dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm_dma");
     return PSELD_OK;
@@ -870,6 +876,7 @@ static int launch_gemm_fwd_ring(const GemmArgs& g, hipStream_t stream) {
     const long nblocks = (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_fwd_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    g_last_gemm_kernel = "gemm_fwd_ring_kernel";
     hipLaunchKernelGGL(gemm_fwd_ring_kernel, dim3((unsigned)nblocks), dim3(512), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm_fwd_ring");
     return PSELD_OK;
@@ -1060,6 +1067,7 @@ int launch_wgrad_ring(const GemmArgs& g, int splits, hipStream_t stream) {
                          : splits == 1 ? (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx : (long)8 * pseld_cdiv(splits, 8) * ga.nx * ga.ny;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_wgrad_ring_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    g_last_gemm_kernel = MT == 3 ? "gemm_wgrad_ring_kernel<3, 3>" : "gemm_wgrad_ring_kernel<2, 3>";
     hipLaunchKernelGGL((gemm_wgrad_ring_kernel<MT, NT>), dim3((unsigned)nblocks), dim3(512), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm_wgrad_ring");
     return PSELD_OK;
@@ -1086,6 +1094,8 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, OutT, WM, WN, TA, TB, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     }
+    g_last_gemm_kernel = TA ? (WM == 4 && WN == 2 ? "gemm_kernel<.., 4, 2, TA>" : (WM == 4 ? "gemm_kernel<.., 4, 1, TA>" : "gemm_kernel<.., 2, 2, TA>"))
+                            : (WM == 4 ? "gemm_kernel<.., 4, 1>" : "gemm_kernel<.., 2, 2>");
     hipLaunchKernelGGL((gemm_kernel<T, OutT, WM, WN, TA, TB, CONV>), grid, dim3(WM * WN * 64), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm");
     return PSELD_OK;
@@ -1274,6 +1284,7 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
         (epi & ~(EPI_BIAS | EPI_RESID)) == 0) {
         if (K >= 2048) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(pseld_cdiv(N, 32)), dim3(512), 0, s, g);   // long K, few column tiles
         else hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(pseld_cdiv(N, 32)), dim3(256), 0, s, g);
+        g_last_gemm_kernel = "gemm_skinny_kernel";
         PSELD_LAUNCH_CHECK("gemm_skinny");
         return PSELD_OK;
     }
