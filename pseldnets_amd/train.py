@@ -91,12 +91,53 @@ def _merge(dst, src):
             dst[k] = v
 
 
+def _fill_missing(dst, src):
+    for k, v in src.items():
+        if k not in dst:
+            dst[k] = copy.deepcopy(v)
+        elif isinstance(v, dict) and isinstance(dst[k], dict):
+            _fill_missing(dst[k], v)
+
+
 def compose(argv):
+    """`[--config-dir DIR [--config-name NAME]] key=value ...`. With --config-dir (or PSELD_CONFIG_DIR) the configuration is composed
+    from that Hydra-style tree (utils/hydra_lite.py: defaults lists, `# @package _global_`, `override /group:`, interpolations,
+    key=value / +key=value / ~key overrides) - point it at the reference's own `configs/` and `experiment=synth_maccdoa` resolves
+    exactly as `python src/train.py experiment=synth_maccdoa` does; the keys the synthetic loop of this entry needs and that tree
+    does not define (data.num_classes, trainer.limit_train_batches) are filled from the built-in defaults. Without it the
+    built-in tables below (the same groups, transcribed) are used."""
+    argv = list(argv)
+    config_dir, config_name = os.environ.get('PSELD_CONFIG_DIR'), 'train'
+    rest = []
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a in ('--config-dir', '--config-name') and i + 1 < len(argv):
+            if a == '--config-dir':
+                config_dir = argv[i + 1]
+            else:
+                config_name = argv[i + 1]
+            i += 2
+            continue
+        if a.startswith('--config-dir='):
+            config_dir = a.partition('=')[2]
+        elif a.startswith('--config-name='):
+            config_name = a.partition('=')[2]
+        else:
+            rest.append(a)
+        i += 1
+    if config_dir:
+        from .utils.hydra_lite import compose as compose_tree
+        cfg = dict(compose_tree(config_dir, config_name, rest))
+        _fill_missing(cfg, {'data': {'num_classes': DEFAULT_CFG['data']['num_classes']},
+                            'trainer': {'limit_train_batches': DEFAULT_CFG['trainer']['limit_train_batches']}, 'adapt': {}})
+        return AttrDict(cfg)
     cfg = copy.deepcopy(DEFAULT_CFG)
-    for arg in argv:
+    for arg in rest:
         key, _, val = arg.partition('=')
         if key == 'experiment':
             _merge(cfg, copy.deepcopy(EXPERIMENTS[val]))
+            _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS['augmix']))      # every synth_* experiment: `override /augment: augmix.yaml`
             continue
         if key == 'model':
             group = copy.deepcopy(MODEL_GROUPS[val])
@@ -106,6 +147,8 @@ def compose(argv):
             _merge(cfg['model'], group)
             continue
         if key == 'augment':
+            if val == 'default':
+                cfg['augment'].update(type=[], AugMix=False)
             _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS[val]))
             continue
         if key == 'adapt':
