@@ -69,7 +69,7 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
-            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel'):
+            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections'):
                 continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn
@@ -247,6 +247,8 @@ def main():
                     help="--backbone crnn only: configs/model/crnn.yaml's conformer (1 block), configs/model/default.yaml's gru (2 layers) or Identity")
     ap.add_argument('--adapt', default='none', choices=['none', 'adapter'],
                     help="adapter = configs/adapt/adapter.yaml fine-tuning (HTS-AT only): adapters + biases + head train. Not the headline.")
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the training step as one hipGraph (trainer.py use_graph). auto = off: measured, the replay is no faster than the eager launches at 32 or at 192 chunks (the step is GPU-bound at both)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
@@ -325,10 +327,12 @@ def main():
             dist.broadcast(p.data, 0)
     einv2_mode = args.backbone.endswith('_einv2')
     sync_bn = group is not None and (args.sync_bn == 'on' or (args.sync_bn == 'auto' and not args.backbone.startswith('crnn')))
-    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
-                           process_group=group, sync_bn=sync_bn)
     wave, target = synthetic_batch(args.clips, device, 2024 + rank, chunks=args.chunks or None)
     n_chunks = wave.shape[0]
+    use_graph = group is None and args.adapt == 'none' and args.warmup >= 2 and \
+        args.graph == 'on'
+    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
+                           process_group=group, sync_bn=sync_bn, use_graph=use_graph, graph_warmup=min(3, args.warmup - 1))
     clips_per_step = n_chunks / CHUNKS_PER_CLIP
     if einv2_mode:     # track-wise labels: track 0 carries the ADPIT A0 events, tracks 1-2 silent
         lab = target['adpit_label']
@@ -416,6 +420,7 @@ def main():
         "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(step_ms[0], 3), "ms_per_step_p90": round(step_ms[int(0.9 * (len(step_ms) - 1))], 3),
         "value_at_median_step": round(clips_per_step * world / (median_ms * 1e-3), 2),
         "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1), "comm_backend": backend if world > 1 else None,
+        "hip_graph": bool(use_graph and trainer._graph is not None),      # the timed steps were replays of one captured hipGraph
     }
     if args.augment == 'augmix':
         gflop_chunk = 3 * gflop_chunk                     # every original chunk goes through the network three times
@@ -427,6 +432,7 @@ def main():
         # rank runs them: a training step contains the gradient all-reduce, so rank 0 cannot step alone.
         if timer is not None:
             timer.on = True
+        trainer.use_graph = False                             # the instrumented steps launch kernel by kernel
         for _ in range(2):
             step()
         barrier()

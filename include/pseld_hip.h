@@ -388,6 +388,13 @@ int pseld_grad_norm(const float* g, long n, float* norm_out, float* workspace, l
 int pseld_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* grad_norm,
                      float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, void* stream);
+/* The same step for a training step captured into a hipGraph: lr and the two bias corrections come from device memory,
+ * hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} (refreshed by the host in front of each replay), so that StepLR
+ * (model_module.py:143-146) and the step count do not force a re-capture. */
+void pseld_adamw_bias_corrections(float beta1, float beta2, int step, float* out2 /* host */);
+int pseld_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* grad_norm,
+                         float max_norm, float grad_scale, const float* hyper, float beta1, float beta2, float eps,
+                         float weight_decay, void* stream);
 int pseld_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 /* Transposed bf16 copies of the arena's 2-D weights, for the input-gradient GEMMs (dX = dY W as a k-contiguous product):
  * desc = n_desc x {element offset, rows, cols, first 32x32 tile} (device longs), dst[off + c*rows + r] = src[off + r*cols + c]. */

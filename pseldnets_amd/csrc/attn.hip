@@ -573,6 +573,11 @@ __global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_ker
     }
 }
 
+__global__ void zero_f4_kernel(float4* __restrict__ p, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // dtable[idx][h] (+)= sum over (q,k) with rel_index(q,k) == idx of acc[h][q][k]
 __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __restrict__ dtable, int heads, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,9 +656,10 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, (size_t)heads * 4096 * sizeof(float), s) != hipSuccess) {
-        pseld_set_error("window_attn_bwd: memset failed"); return PSELD_ERR_HIP;
-    }
+    // zeroed by a kernel, not hipMemsetAsync: inside a captured hipGraph (trainer.py use_graph) the memset NODE of this image's
+    // runtime left stale sums in the accumulator after a few replays (tools/graph_debug.py: inf in d(bias_table) at the 4th replay)
+    hipLaunchKernelGGL(zero_f4_kernel, dim3(heads * 4), dim3(256), 0, s, (float4*)workspace, (long)heads * 1024);
+    PSELD_LAUNCH_CHECK("window_attn_bwd(zero)");
     // Persistent workgroups, one resident round: two waves per head and two waves per SIMD (<= 256 registers), i.e. one
     // 4-head (8-wave) or two 2-head (4-wave) workgroups per CU; each walks several windows, so the d(bias) flush (one atomic
     // tile per wave per workgroup) stays a small fraction of the traffic. PSELD_ATTN_HG / PSELD_ATTN_BWD_WGS: experiment knobs (tools/attn_bench.py).

@@ -418,9 +418,11 @@ __global__ void norm_finish_kernel(const float* __restrict__ partial, int n, flo
 // global L2 norm, possibly all-reduced); clip coefficient = min(1, max_norm / (norm + 1e-6)) as clip_grad_norm_.
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              bf16_t* __restrict__ shadow, long n, const float* __restrict__ grad_norm, float max_norm,
-                             float grad_scale, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                             float grad_scale, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                             const float* __restrict__ hyper) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // step-dependent scalars of a captured (hipGraph) step
     float coef = grad_scale;
     if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (grad_norm[0] * grad_scale + 1e-6f));
     const float gi = g[i] * coef;
@@ -576,8 +578,27 @@ extern "C" int pseld_adamw_step(float* p, const float* g, float* m, float* v, vo
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n,
-                       grad_norm, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                       grad_norm, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (const float*)nullptr);
     PSELD_LAUNCH_CHECK("adamw_step");
+    return PSELD_OK;
+}
+// Host helper: the two bias corrections exactly as pseld_adamw_step computes them (same float arithmetic), for callers that fill
+// the device scalars of pseld_adamw_step_dev. out2 = {1 - beta1^step, sqrt(1 - beta2^step)}.
+extern "C" void pseld_adamw_bias_corrections(float beta1, float beta2, int step, float* out2) {
+    out2[0] = 1.f - powf(beta1, (float)step);
+    out2[1] = sqrtf(1.f - powf(beta2, (float)step));
+}
+// The same step with its step-dependent scalars read from DEVICE memory: hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step)}.
+// A training step captured into a hipGraph replays with fixed kernel arguments; the host refreshes these three floats (one small
+// asynchronous copy in front of the replay) instead of re-capturing when StepLR or the bias correction moves.
+extern "C" int pseld_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n,
+                                    const float* grad_norm, float max_norm, float grad_scale, const float* hyper, float beta1,
+                                    float beta2, float eps, float weight_decay, void* stream) {
+    PSELD_CHECK_ARG(p && g && m && v && hyper && n > 0, "adamw_step_dev: bad arguments");
+    PSELD_CHECK_ARG(max_norm <= 0.f || grad_norm, "adamw_step_dev: clipping needs the device grad norm");
+    hipLaunchKernelGGL(adamw_kernel, dim3(pseld_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n,
+                       grad_norm, max_norm, grad_scale, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, hyper);
+    PSELD_LAUNCH_CHECK("adamw_step_dev");
     return PSELD_OK;
 }
 // Batched transpose of the 2-D bf16 weights of a parameter arena: tensor t = [rows, cols] at element offset off (same

@@ -214,11 +214,13 @@ class HTSATNetBase(nn.Module):
         self.arena.grad.zero_()
 
     def fused_adamw_step(self, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0,
-                         grad_norm=None):
-        """clip_grad_norm_(max_norm) + AdamW over the whole arena in two kernels; refreshes the bf16 shadow."""
+                         grad_norm=None, hyper=None):
+        """clip_grad_norm_(max_norm) + AdamW over the whole arena in two kernels; refreshes the bf16 shadow.
+        hyper: device tensor {lr, bias corrections} of a hipGraph-captured step (trainer.py); the caller then owns arena.step."""
         a = self.arena
         a.ensure_opt_state()
-        a.step += 1
+        if hyper is None:
+            a.step += 1
         frozen = self._frozen_state()
         if frozen is not None:                 # adapter fine-tuning: frozen parameters take no part in the clip norm or the update
             a.grad.copy_(ops.mul(a.grad, frozen['mask']))
@@ -231,7 +233,7 @@ class HTSATNetBase(nn.Module):
                 a.shadow = torch.empty(a.size, dtype=torch.bfloat16, device=a.flat.device)
             shadow = a.shadow
         ops.adamw_step(a.flat, a.grad, a.m, a.v, a.step, lr, grad_norm_t=grad_norm, max_norm=max_norm or 0.0,
-                       grad_scale=grad_scale, betas=betas, eps=eps, weight_decay=weight_decay, shadow=shadow)
+                       grad_scale=grad_scale, betas=betas, eps=eps, weight_decay=weight_decay, shadow=shadow, hyper=hyper)
         if shadow is not None:
             a.shadow_valid = True
             a.shadow_t_valid = False       # the transposed copies follow lazily (arena.wt)

@@ -391,8 +391,16 @@ def grad_norm(g, out=None):
 
 
 def adamw_step(p, g, m, v, step, lr, grad_norm_t=None, max_norm=0.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay=0.01, shadow=None):
-    _chk(p, g, m, v, grad_norm_t, shadow)
+               weight_decay=0.01, shadow=None, hyper=None):
+    """hyper: optional device tensor {lr, 1 - beta1^step, sqrt(1 - beta2^step)} read by the kernel instead of (lr, step) — the
+    form a hipGraph-captured step uses."""
+    _chk(p, g, m, v, grad_norm_t, shadow, hyper)
+    if hyper is not None:
+        rc = _lib.lib().pseld_adamw_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(shadow), p.numel(),
+                                             _lib.ptr(grad_norm_t), max_norm, grad_scale, _lib.ptr(hyper), betas[0], betas[1], eps,
+                                             weight_decay, _lib.stream_ptr())
+        _lib.check(rc, "pseld_adamw_step_dev")
+        return
     rc = _lib.lib().pseld_adamw_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(shadow), p.numel(),
                                      _lib.ptr(grad_norm_t), max_norm, grad_scale, lr, betas[0], betas[1], eps, weight_decay,
                                      step, _lib.stream_ptr())

@@ -5,6 +5,13 @@ training_step: features -> net -> loss), src/models/components/model_module.py:1
 configs/trainer/default.yaml:26 (gradient_clip_val 1.0), configs/trainer/gpu.yaml:4-10 (DDP, sync_batchnorm).
 One process per GPU; gradients live in one flat arena that is all-reduced over RCCL in a few large buckets,
 issued back-to-front while earlier layers are still in backward (xGMI is point-to-point: few, large messages).
+
+hipGraph mode (use_graph=True): at the reference's native batch (32 ten-second chunks per GPU,
+configs/experiment/synth_maccdoa.yaml:8) a step is ~210 launches of a few microseconds each and the host, not the GPU, sets
+the pace. The step is then captured once (after `graph_warmup` ordinary steps) into a hipGraph and replayed: batches are copied
+into static input tensors, and the three step-dependent scalars of AdamW (lr of StepLR, the two bias corrections) are refreshed in a
+small device tensor in front of every replay instead of being kernel arguments. Nothing in the reference corresponds to this (its
+torch.compile flag, model_module.py:35-36, is the nearest thing).
 """
 import torch
 
@@ -14,7 +21,7 @@ from . import ops
 class FusedTrainer:
     def __init__(self, net, af_extractor, loss_kind='adpit', lr=1e-4, max_norm=1.0, weight_decay=0.01,
                  betas=(0.9, 0.999), eps=1e-8, step_size=20, gamma=0.1, process_group=None, sync_bn=False,
-                 loss_beta=0.5, agg_weights=(1.0, 0.0), agg_l1=False):
+                 loss_beta=0.5, agg_weights=(1.0, 0.0), agg_l1=False, use_graph=False, graph_warmup=3):
         self.net, self.af, self.loss_kind = net, af_extractor, loss_kind
         self.base_lr, self.max_norm, self.wd, self.betas, self.eps = lr, max_norm, weight_decay, betas, eps
         self.step_size, self.gamma, self.epoch = step_size, gamma, 0
@@ -35,6 +42,13 @@ class FusedTrainer:
                 net.sync_bn_group = process_group
         self._works, self._ranges = [], []
         self._train_idx = None       # adapter / LoRA fine-tuning: arena indices of the trainable elements (the only ones all-reduced)
+        # hipGraph capture of the whole step (single process only: collectives stay outside graphs here)
+        self.use_graph = bool(use_graph)
+        if self.use_graph and process_group is not None:
+            raise NotImplementedError("use_graph with a process group: the captured step holds no collectives; run data-parallel ranks eagerly")
+        self.graph_warmup = graph_warmup
+        self._graph = None           # {'graph', 'x', 'target', 'out', 'hyper', 'hyper_host', 'sig'}
+        self._eager_steps = 0
 
     @property
     def lr(self):
@@ -79,10 +93,71 @@ class FusedTrainer:
             return l3[0:1], (dsed, ddoa), {'loss_all': l3[0:1], 'loss_agg': l3[1:2], 'loss_accdoa': l3[2:3]}
         raise ValueError(self.loss_kind)
 
+    # -- hipGraph replay ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _batch_signature(batch_x, batch_target, is_features):
+        return (tuple(batch_x.shape), batch_x.dtype, bool(is_features),
+                tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch_target.items()) if torch.is_tensor(v)))
+
+    def _refresh_hyper(self, g):
+        """lr (StepLR) and AdamW's bias corrections of the step about to run -> the device tensor the captured kernel reads."""
+        import ctypes
+        from . import _lib
+        a = self.net.arena
+        a.step += 1
+        # a small ring of pinned staging slots, each guarded by the event of its last copy: the host may run several replays
+        # ahead of the GPU, and must not overwrite a slot whose copy has not been executed yet
+        slot = a.step % len(g['hyper_host'])
+        h, ev = g['hyper_host'][slot], g['hyper_events'][slot]
+        if ev is not None:
+            ev.synchronize()
+        bc = (ctypes.c_float * 2)()
+        _lib.lib().pseld_adamw_bias_corrections(self.betas[0], self.betas[1], a.step, bc)      # the arithmetic of pseld_adamw_step
+        h[0] = self.lr; h[1] = bc[0]; h[2] = bc[1]
+        g['hyper'].copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        g['hyper_events'][slot] = ev
+
+    def _capture(self, batch_x, batch_target, is_features):
+        dev = batch_x.device
+        g = {'sig': self._batch_signature(batch_x, batch_target, is_features),
+             'x': batch_x.clone(), 'target': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch_target.items()},
+             'hyper': torch.zeros(3, device=dev), 'hyper_host': [torch.zeros(3).pin_memory() for _ in range(4)],
+             'hyper_events': [None] * 4}
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g['out'] = self._step(g['x'], g['target'], is_features, hyper=g['hyper'])
+        g['graph'] = graph
+        return g
+
     def training_step(self, batch_x, batch_target, is_features=False):
         """features -> net -> loss -> backward -> (bucketed all-reduce) -> clip -> AdamW. Returns the loss dict
         (device tensors; nothing here synchronises with the host). is_features: batch_x already is the feature tensor
-        (the augmentation path extracts features itself, models/model_module.py:47-65)."""
+        (the augmentation path extracts features itself, models/model_module.py:47-65).
+        use_graph: the first graph_warmup steps run eagerly (they size every workspace and settle the arena's lazily built
+        copies), the next one is captured, and every later step of the same batch geometry is a copy-in + replay; the
+        returned loss tensors are then the graph's static outputs (overwritten by the next replay)."""
+        if not self.use_graph or self.net._frozen_state() is not None:
+            return self._step(batch_x, batch_target, is_features)
+        if self._graph is None:
+            if self._eager_steps < self.graph_warmup:
+                self._eager_steps += 1
+                return self._step(batch_x, batch_target, is_features)
+            self._graph = self._capture(batch_x, batch_target, is_features)      # capture launches nothing: fall through to the replay
+        g = self._graph
+        if g['sig'] != self._batch_signature(batch_x, batch_target, is_features):
+            return self._step(batch_x, batch_target, is_features)                # another geometry (a last short batch): eager
+        g['x'].copy_(batch_x, non_blocking=True)
+        for k, v in batch_target.items():
+            if torch.is_tensor(v):
+                g['target'][k].copy_(v, non_blocking=True)
+        self._refresh_hyper(g)
+        self.net.train()
+        g['graph'].replay()
+        return g['out']
+
+    def _step(self, batch_x, batch_target, is_features=False, hyper=None):
         net = self.net
         net.train()
         x = self.af(batch_x) if (self.af is not None and not is_features) else batch_x
@@ -116,5 +191,5 @@ class FusedTrainer:
             if parts:
                 grad_norm = torch.linalg.vector_norm(torch.cat(parts)).view(1)
         net.fused_adamw_step(self.lr, max_norm=self.max_norm, betas=self.betas, eps=self.eps, weight_decay=self.wd,
-                             grad_scale=1.0 / self.world, grad_norm=grad_norm)
+                             grad_scale=1.0 / self.world, grad_norm=grad_norm, hyper=hyper)
         return loss_dict

@@ -668,3 +668,36 @@ def test_fine_tuning_all_reduces_only_the_trainable_elements(dev):
         assert (res[0][2] - res[1][2]).abs().max().item() < 1e-5
     finally:
         dist.destroy_process_group()
+
+
+def test_hipgraph_replayed_steps_equal_eager_steps(dev):
+    """trainer.py use_graph: three eager steps, one captured, then replays — the parameters, the running BN statistics and the
+    losses after 8 steps (StepLR moving the learning rate in between) equal those of 8 eager steps (fp32 atomics in the
+    relative-position-bias gradient leave ~1e-7 noise; the learning rate is small because this formula-weighted tiny network
+    amplifies one flipped bf16 rounding into 1e-3 of loss within two steps at 1e-3). Regression test for the accumulator of
+    d(bias_table): zeroed by a hipMemsetAsync NODE it held stale sums from the fourth replay on."""
+    from pseldnets_amd.trainer import FusedTrainer
+
+    def run(use_graph):
+        from pseldnets_amd.models import multi_accdoa
+        net, _ = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev, torch.bfloat16)
+        tr = FusedTrainer(net, None, 'adpit', lr=2e-5, max_norm=1.0, step_size=1, gamma=0.5, use_graph=use_graph, graph_warmup=3)
+        losses = []
+        for i in range(8):
+            x = oh.formula_features(2).to(dev) * (1.0 + 0.01 * i)                     # a different batch every step
+            lab = synth.formula_adpit_label(2, 100, 3).to(dev)
+            losses.append(tr.training_step(x, {'adpit_label': lab})['loss_all'].item())
+            if i % 3 == 2:
+                tr.end_epoch()
+        assert (tr._graph is not None) == use_graph
+        return losses, net.arena.flat.detach().float().cpu().clone(), net._rm.detach().cpu().clone(), net.arena.step
+
+    le, fe, re_, se = run(False)
+    lg, fg, rg, sg = run(True)
+    assert se == sg == 8
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-5 * abs(a), (le, lg)
+    rel = ((fe - fg).norm() / fe.norm()).item()
+    print('graph vs eager parameter rel L2', rel)
+    assert rel < 2e-6
+    assert (re_ - rg).abs().max().item() < 1e-6
