@@ -97,3 +97,41 @@ def test_near_silent_bins_are_bounded_by_fp32_round_off(dev):
     assert (out - ref64).abs().max().item() <= 2 * noise + 1e-3
     p, pr = 10.0 ** (out[:, :4] / 10), 10.0 ** (ref64[:, :4] / 10)
     assert ((p - pr).abs() <= 2e-3 * pr + 1e-9).all()
+
+
+def test_oracle_stft_matches_scipy_a_third_implementation():
+    """torchaudio's Spectrogram is not in /root/reference (a pinned pip dependency), so the STFT convention the oracle restates
+    (centred frames, reflect padding, periodic Hann, one-sided, no normalisation) is checked against a third, unrelated
+    implementation: scipy.signal.stft on the reflect-padded signal, with scipy's 1/sum(window) scaling undone."""
+    import scipy.signal as ss
+    x = _wave(1, 2, 7200, seed=3)
+    n_fft, hop = 1024, 240
+    win_t = torch.hann_window(n_fft, periodic=True)
+    spec = of.spectrogram_complex(x, n_fft, hop, win_t).numpy()                 # [1, 2, 513, T]
+    xp = np.pad(x.numpy().astype(np.float64), ((0, 0), (0, 0), (n_fft // 2, n_fft // 2)), mode='reflect')
+    win = ss.get_window('hann', n_fft, fftbins=True)                            # periodic
+    f, t, Z = ss.stft(xp, fs=24000, window=win, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary=None, padded=False,
+                      return_onesided=True, detrend=False)
+    Z = Z * win.sum()                                                           # scipy divides by sum(window)
+    assert Z.shape[-2] == 513 and Z.shape[-1] == spec.shape[-1] == 1 + 7200 // hop
+    scale = np.abs(Z).max()
+    assert np.abs(spec - Z).max() < 2e-5 * scale
+    assert np.allclose(win, win_t.numpy(), atol=1e-7)
+
+
+def test_oracle_mel_filterbank_properties():
+    """melscale_fbanks(mel_scale='htk', norm='slaney') as torchaudio documents it and as the reference asks for it
+    (utils/feature.py:32-34): 64 triangles over 513 bins whose corner frequencies are equally spaced on the HTK mel scale
+    mel = 2595 log10(1 + f / 700) between 0 and sample_rate / 2, rising and falling linearly IN HERTZ, each divided by half its base
+    width (Slaney's area normalisation: 2 / (f[m + 2] - f[m])); at most two filters cover a bin."""
+    fb = of.melscale_fbanks(513, 0.0, 12000.0, 64, 24000).numpy().astype(np.float64)      # [513, 64]
+    assert fb.shape == (513, 64) and fb.min() >= 0.0
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    imel = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    corners = imel(np.linspace(mel(0.0), mel(12000.0), 66))
+    freqs = np.linspace(0.0, 12000.0, 513)
+    for m in (0, 1, 17, 40, 63):
+        lo, c, hi = corners[m], corners[m + 1], corners[m + 2]
+        tri = np.maximum(0.0, np.minimum((freqs - lo) / (c - lo), (hi - freqs) / (hi - c))) * 2.0 / (hi - lo)
+        assert np.abs(fb[:, m] - tri).max() < 2e-5 * tri.max(), m
+    assert ((fb > 0).sum(1) <= 2).all()
