@@ -216,7 +216,9 @@ def spawn_ranks(n):
         except subprocess.TimeoutExpired:
             pr.kill()
             codes.append(pr.wait())
-    sys.stdout.write(out0.decode() if out0 else '')
+    # only the JSON line travels up: RCCL writes a version banner to the ranks' C-level stdout at exit
+    text = out0.decode() if out0 else ''
+    sys.stdout.write(''.join(ln + '\n' for ln in text.splitlines() if ln.startswith('{')))
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -490,7 +492,20 @@ def main():
                 out["cpu_baseline"]["at_8_threads"] = cpu_baseline(threads=8)
             except Exception as e:  # the checker must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        # RCCL's version banner sits in the C library's stdout buffer until exit and would land BEHIND the JSON line: flush it
+        # out first and leave stdout closed to the C side afterwards, so that the JSON line is the last line of rank 0's output
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
+        if world > 1 or os.environ.get('PSELD_BENCH_FORCE_GROUP') == '1':
+            try:
+                devnull = os.open(os.devnull, os.O_WRONLY)
+                os.dup2(devnull, 1)                    # whatever the libraries print at teardown goes nowhere
+            except OSError:
+                pass
     if world > 1 or group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
