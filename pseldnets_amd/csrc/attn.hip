@@ -367,7 +367,9 @@ __device__ __forceinline__ void qk_tile(f32x16& acc, const char* tile, int strid
     }
 }
 
-// row stride of the per-wave [32 queries][32 keys] P / dS images: 64 (mod 128) bytes for the transposed bf16 reads
+// row stride of the per-wave [32 queries][32 keys] P / dS images: 64 (mod 128) bytes for the transposed bf16 reads; the 8-byte
+// pieces of a bf16 row are XOR-swizzled by (row >> 1) & 7 (AMma::img_piece / ld_img): written straight, 16 consecutive rows put their
+// pieces in TWO bank pairs (8-way conflicts on every image write: 60 % of the LDS-active cycles of this kernel were conflict cycles)
 template <typename T> struct ImgStride { static constexpr int value = sizeof(T) == 2 ? 64 : 144; };
 
 // Backward: one workgroup = one window x HG heads, TWO waves per head: wave (head, kt) owns key tile kt (32 keys) of its head —
@@ -517,9 +519,9 @@ __global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_ker
                 // images: row = query r of this tile, 4 consecutive keys per register group
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int key0 = 8 * g4 + 4 * h2;
-                    store4<T>(pimg + r * IMG + key0 * (int)sizeof(T), pt[4 * g4], pt[4 * g4 + 1], pt[4 * g4 + 2], pt[4 * g4 + 3]);
-                    store4<T>(simg + r * IMG + key0 * (int)sizeof(T), dpt[4 * g4], dpt[4 * g4 + 1], dpt[4 * g4 + 2], dpt[4 * g4 + 3]);
+                    const int off = M::img_piece(r, 2 * g4 + h2);     // keys 8 g4 + 4 h2 .. + 3 (bf16: swizzled 8-byte piece)
+                    store4<T>(pimg + off, pt[4 * g4], pt[4 * g4 + 1], pt[4 * g4 + 2], pt[4 * g4 + 3]);
+                    store4<T>(simg + off, dpt[4 * g4], dpt[4 * g4 + 1], dpt[4 * g4 + 2], dpt[4 * g4 + 3]);
                 }
                 // dQ[qt][d] (partial over this wave's keys) = sum_key dS^T[key][query] K[key][d]  (accumulators re-used as A operands)
 #pragma unroll
@@ -530,8 +532,8 @@ __global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_ker
                 for (int sx = 0; sx < 2; ++sx) {
                     const typename M::Frag fdo = M::ld_cols_std(tile, strideB, qt * 32 + 16 * sx, cdo, lane);
                     const typename M::Frag fq = M::ld_cols_std(tile, strideB, qt * 32 + 16 * sx, cq, lane);
-                    M::mma(M::ld_cols_std(pimg, IMG, 16 * sx, 0, lane), fdo, dv);
-                    M::mma(M::ld_cols_std(simg, IMG, 16 * sx, 0, lane), fq, dk);
+                    M::mma(M::ld_img(pimg, 16 * sx, lane), fdo, dv);
+                    M::mma(M::ld_img(simg, 16 * sx, lane), fq, dk);
                 }
                 __builtin_amdgcn_sched_barrier(0);     // the next tile's image writes stay behind this tile's image reads
             }

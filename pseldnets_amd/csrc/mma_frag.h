@@ -51,6 +51,21 @@ template <> struct AMma<bf16_t> {
         s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
         return __builtin_bit_cast(bf16x8, s);
     }
+    // ld_cols_std on a [32 rows][32 bf16] image of 64-byte rows whose 8-byte pieces are XOR-swizzled by (row >> 1) & 7
+    // (img_piece below): the 8-byte image WRITES of 16 consecutive rows then fall in 16 different bank pairs instead of 2, and
+    // the transposed reads stay conflict-free (a row's pieces are permuted inside the row)
+    static __device__ __forceinline__ Frag ld_img(const char* base, int row0, int lane) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, gsel = (lane >> 4) & 1, h2 = lane >> 5;
+        const int row = row0 + 8 * h2 + q, c = 4 * gsel + p;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(base + row * 64 + ((c ^ ((row >> 1) & 7)) << 3)));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(base + (row + 4) * 64 + ((c ^ (((row + 4) >> 1) & 7)) << 3)));
+        short8v s;
+        s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3];
+        s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, s);
+    }
+    // byte offset of the 4-key piece `piece` (0..7) of image row `row`
+    static __device__ __forceinline__ int img_piece(int row, int piece) { return row * 64 + ((piece ^ ((row >> 1) & 7)) << 3); }
 };
 template <typename T> __device__ __forceinline__ void store4(char* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<bf16_t>(char* p, float a, float b, float c, float d) {
@@ -101,6 +116,9 @@ template <> struct AMma<float> {
         for (int j = 0; j < 8; ++j) f.v[j] = *(const float*)(base + (row0 + 8 * h2 + j) * strideB + (col0 + r) * 4);
         return f;
     }
+    // the f32 images (144-byte rows of 32 floats) are not swizzled: same entry points as the bf16 struct
+    static __device__ __forceinline__ Frag ld_img(const char* base, int row0, int lane) { return ld_cols_std(base, 144, row0, 0, lane); }
+    static __device__ __forceinline__ int img_piece(int row, int piece) { return row * 144 + piece * 16; }
 };
 
 // row held by accumulator register e of a 32x32 tile for lane half h2
