@@ -262,7 +262,7 @@ __device__ __forceinline__ void store_tile(char* tile, int strideB, int col0, in
 }
 
 template <typename T, int HG>
-__global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(HG * 64, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NTHR = HG * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = a.hd;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     char* tile = smem;
     float* btab = (float*)(smem + 64 * strideB);          // [HG][225]
     long* toks = (long*)(btab + HG * 225 + (HG & 1));     // [64] (8-byte aligned)
-    int* labels = (int*)(toks + 64);                      // [64]
+    int* labels = (int*)(toks + 64);                      // [64] + [1]: "this window mixes mask regions"
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hg = blockIdx.y, wi = blockIdx.x;
@@ -279,14 +279,20 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
     const int heads_here = min(HG, a.heads - hg * HG);
     const int r = lane & 31, h2 = lane >> 5;
 
+    constexpr float LOG2E = 1.4426950408889634f;
     if (threadIdx.x < 64) {
         long tk; int lb;
         window_token(a, wi, threadIdx.x, tk, lb);
         toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
+        // wave 0 holds all 64 labels: does the window straddle mask regions at all? (only the last row / column of windows of a
+        // shifted block does; everywhere else the mask is identically zero and its 64 compare-selects per lane are skipped)
+        const int l0 = __builtin_amdgcn_readfirstlane(lb);
+        const unsigned long long diff = __ballot(lb != l0);
+        if (threadIdx.x == 0) labels[64] = diff != 0ull;
     }
     for (int i = threadIdx.x; i < heads_here * 225; i += NTHR) {
         const int hh = i / 225, idx = i - hh * 225;
-        btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh];
+        btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh] * LOG2E;     // scores are kept in log2 units (exp2 below)
     }
     __syncthreads();
     const T* qkv = (const T*)a.qkv;
@@ -304,37 +310,50 @@ __global__ __launch_bounds__(HG * 64) void attn_fwd_kernel(AttnArgs a) {
         qk_product<T>(st, tile, strideB, ck, cq, hd, lane);
         const float* bt = btab + wave * 225;
         float inv_l[2];
+        const float scale2 = a.scale * LOG2E;
+        const bool mixed = labels[64] != 0;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int qi = qt * 32 + r;
-            const int ql = labels[qi];
             const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
-            const int* labh = labels + 4 * h2;
             float m = -1e30f;
+            // key = kt*32 + (e&3) + 8*(e>>2) + 4*h2: its (y, x) = (kt*4 + (e>>2), (e&3) + 4*h2), so the table index is a
+            // per-lane base minus a compile-time constant (one address register). Scores in log2 units: s = S scale log2e + b log2e.
+            if (mixed) {
+                const int ql = labels[qi];
+                const int* labh = labels + 4 * h2;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    // key = kt*32 + (e&3) + 8*(e>>2) + 4*h2: its (y, x) = (kt*4 + (e>>2), (e&3) + 4*h2), so the
-                    // table index is a per-lane base minus a compile-time constant (one address register)
-                    float s = st[kt][qt][e] * a.scale + btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))];
-                    s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f : 0.f;   // labels are all 0 when shift == 0
-                    st[kt][qt][e] = s;
-                    m = fmaxf(m, s);
-                }
+                    for (int e = 0; e < 16; ++e) {
+                        float s = fmaf(st[kt][qt][e], scale2, btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))]);
+                        s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f * LOG2E : 0.f;
+                        st[kt][qt][e] = s;
+                        m = fmaxf(m, s);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float s = fmaf(st[kt][qt][e], scale2, btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))]);
+                        st[kt][qt][e] = s;
+                        m = fmaxf(m, s);
+                    }
+            }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float l = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float p = __expf(st[kt][qt][e] - m);
+                    const float p = __builtin_amdgcn_exp2f(st[kt][qt][e] - m);
                     st[kt][qt][e] = p;
                     l += p;
                 }
             l += __shfl_xor(l, 32, 64);
             inv_l[qt] = 1.f / l;
-            if (a.lse && h2 == 0) a.lse[toks[qi] * a.heads + head] = m + __logf(l);
+            if (a.lse && h2 == 0) a.lse[toks[qi] * a.heads + head] = (m + __log2f(l)) * 0.6931471805599453f;   // natural-log units
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -599,7 +618,7 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
     dtable[i] = accumulate ? dtable[i] + s : s;
 }
 
-template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 8 + 64 * 8 + 64 * 4; }
+template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 8 + 64 * 8 + 65 * 4; }
 template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (5 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 64 * HG * 4 + 8 + 64 * 8 + 65 * 4 + 16 + (size_t)2 * HG * (sizeof(T) == 2 ? 4096 : 2 * 32 * ImgStride<T>::value); }
 
 int check_args(const char* who, int B, int res, int C, int heads, int shift) {
