@@ -423,6 +423,7 @@ def main():
         "value_at_median_step": round(clips_per_step * world / (median_ms * 1e-3), 2),
         "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1), "comm_backend": backend if world > 1 else None,
         "hip_graph": bool(use_graph and trainer._graph is not None),      # the timed steps were replays of one captured hipGraph
+        "wgrad_side_stream": os.environ.get('PSELD_WGRAD_STREAM', '1') == '1' and args.backbone.startswith('htsat'),
     }
     if args.augment == 'augmix':
         gflop_chunk = 3 * gflop_chunk                     # every original chunk goes through the network three times
@@ -435,6 +436,10 @@ def main():
         if timer is not None:
             timer.on = True
         trainer.use_graph = False                             # the instrumented steps launch kernel by kernel
+        # ... and on ONE stream: in the timed region the weight gradients run on a second stream beside the main chain
+        # (htsat.py:_wgrad), where a kernel's duration includes the time it shares the CUs with another kernel - the per-kernel
+        # roofline below is that of the kernel running alone (rocprofv3 of `PSELD_WGRAD_STREAM=0 python3 bench.py` agrees with it)
+        os.environ['PSELD_WGRAD_STREAM'] = '0'
         for _ in range(2):
             step()
         barrier()
@@ -457,6 +462,7 @@ def main():
             pmc = pmc_traffic(args) or {}
             same = pmc.get('kernel') == sym
             out["roofline"] = {"bound": "hbm" if hbm else "mfma", "kernel": sym,
+                               "measured": "kernel alone: the instrumented steps keep the weight gradients on the main stream (PSELD_WGRAD_STREAM=0)",
                                "achieved": round(gbs if hbm else ach_tf, 2), "peak": PEAK_HBM_GBS if hbm else PEAK_FLOPS,
                                "unit": "GB/s" if hbm else "TFLOP/s",
                                "frac": round((gbs / PEAK_HBM_GBS) if hbm else (ach_tf / PEAK_FLOPS), 4),

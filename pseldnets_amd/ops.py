@@ -34,7 +34,9 @@ _ws_cache = {}
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per device (split-K slabs, reduction partials)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream): kernels of a side stream (the weight gradients, htsat.py:_wgrad) must not share scratch
+    # with the kernels of the main stream they run beside
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
