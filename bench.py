@@ -346,7 +346,10 @@ def main():
         doa[:, :, 0] = (lab[:, :, 0, 1:] * first.unsqueeze(2)).sum(-1)
         target = {'sed_label': sed, 'doa_label': doa}
 
-    step = lambda: trainer.training_step(wave, target)
+    # steady-state pipeline: the features of step i + 1 (here the same synthetic waveform) are extracted on a second stream while
+    # step i is in its backward; every timed step still contains exactly one feature extraction (PSELD_FEATURE_PREFETCH=0: in line)
+    prefetch = os.environ.get('PSELD_FEATURE_PREFETCH', '1') == '1'
+    step = lambda: trainer.training_step(wave, target, next_x=wave if prefetch else None)
     if args.augment == 'augmix':
         if einv2_mode:
             raise SystemExit("--augment augmix is wired for the ADPIT workloads")
@@ -440,6 +443,8 @@ def main():
         # (htsat.py:_wgrad), where a kernel's duration includes the time it shares the CUs with another kernel - the per-kernel
         # roofline below is that of the kernel running alone (rocprofv3 of `PSELD_WGRAD_STREAM=0 python3 bench.py` agrees with it)
         os.environ['PSELD_WGRAD_STREAM'] = '0'
+        prefetch = False
+        trainer._prefetched = None
         for _ in range(2):
             step()
         barrier()

@@ -18,6 +18,10 @@ import torch
 from . import ops
 
 
+import os
+_PREFETCH_AT = os.environ.get('PSELD_PREFETCH_AT', 'start')      # where a step issues the next batch's feature extraction (A/B knob)
+
+
 class FusedTrainer:
     def __init__(self, net, af_extractor, loss_kind='adpit', lr=1e-4, max_norm=1.0, weight_decay=0.01,
                  betas=(0.9, 0.999), eps=1e-8, step_size=20, gamma=0.1, process_group=None, sync_bn=False,
@@ -131,7 +135,38 @@ class FusedTrainer:
         g['graph'] = graph
         return g
 
-    def training_step(self, batch_x, batch_target, is_features=False):
+    # -- feature prefetch --------------------------------------------------------------------------------------------
+    def prefetch_features(self, next_x):
+        """Extract the features of the NEXT batch on a second stream, beside the backward of the current step (the feature kernel
+        is VALU-bound, the backward memory-bound; the next waveform does not depend on anything this step computes). The next
+        training_step(next_x) picks the result up. The reference extracts features inside training_step (model_module.py:47-65),
+        strictly in sequence; a DataLoader hands the next batch over early, which is all this needs."""
+        if self.af is None or not next_x.is_cuda:
+            return
+        dev = next_x.device
+        if getattr(self, '_feat_stream', None) is None or self._feat_stream.device != dev:
+            self._feat_stream = torch.cuda.Stream(device=dev)
+        side, main = self._feat_stream, torch.cuda.current_stream(dev)
+        side.wait_stream(main)                       # starts behind what the main stream holds now, runs beside what comes next
+        with torch.cuda.stream(side):
+            feats = self.af(next_x)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._prefetched = (next_x, next_x._version, feats, ev)
+
+    def _features(self, batch_x):
+        pf = getattr(self, '_prefetched', None)
+        if pf is not None:
+            self._prefetched = None
+            x, ver, feats, ev = pf
+            if x is batch_x and ver == batch_x._version:
+                main = torch.cuda.current_stream(batch_x.device)
+                main.wait_event(ev)
+                feats.record_stream(main)            # allocated on the side stream, consumed (and released) on the main stream
+                return feats
+        return self.af(batch_x)
+
+    def training_step(self, batch_x, batch_target, is_features=False, next_x=None):
         """features -> net -> loss -> backward -> (bucketed all-reduce) -> clip -> AdamW. Returns the loss dict
         (device tensors; nothing here synchronises with the host). is_features: batch_x already is the feature tensor
         (the augmentation path extracts features itself, models/model_module.py:47-65).
@@ -139,7 +174,7 @@ class FusedTrainer:
         copies), the next one is captured, and every later step of the same batch geometry is a copy-in + replay; the
         returned loss tensors are then the graph's static outputs (overwritten by the next replay)."""
         if not self.use_graph or self.net._frozen_state() is not None:
-            return self._step(batch_x, batch_target, is_features)
+            return self._step(batch_x, batch_target, is_features, next_x=next_x)
         if self._graph is None:
             if self._eager_steps < self.graph_warmup:
                 self._eager_steps += 1
@@ -157,14 +192,18 @@ class FusedTrainer:
         g['graph'].replay()
         return g['out']
 
-    def _step(self, batch_x, batch_target, is_features=False, hyper=None):
+    def _step(self, batch_x, batch_target, is_features=False, hyper=None, next_x=None):
         net = self.net
         net.train()
-        x = self.af(batch_x) if (self.af is not None and not is_features) else batch_x
+        x = self._features(batch_x) if (self.af is not None and not is_features) else batch_x
+        if next_x is not None and not is_features and _PREFETCH_AT == 'start':
+            self.prefetch_features(next_x)
         net._check_input(x)
         net._materialize(x.device)
         outs, saved = net._forward_impl(x.contiguous().float(), True)
         loss, douts, loss_dict = self._loss(outs, batch_target)
+        if next_x is not None and not is_features and _PREFETCH_AT != 'start':
+            self.prefetch_features(next_x)       # (A/B variant: beside the backward only; 'start' measured 0.13 ms better)
         net.zero_grad_arena()
         self._works, self._ranges = [], []
         grad_norm = None

@@ -703,3 +703,33 @@ def test_hipgraph_replayed_steps_equal_eager_steps(dev):
     print('graph vs eager parameter rel L2', rel)
     assert rel < 2e-6
     assert (re_ - rg).abs().max().item() < 1e-6
+
+
+def test_feature_prefetch_on_the_second_stream_changes_nothing(dev):
+    """training_step(x_i, ..., next_x=x_{i+1}) extracts the next batch's features on a second stream during step i; the losses and
+    the parameters after four steps on four different waveforms equal those of the in-line extraction. A batch that was not
+    announced (or was modified in place after the announcement) is extracted in line."""
+    from pseldnets_amd.models import multi_accdoa
+    from pseldnets_amd.trainer import FusedTrainer
+    from pseldnets_amd.utils.config import get_afextractor
+    cfg = {'data': {'nfft': 1024, 'hoplen': 240, 'window': 'hann', 'n_mels': 64, 'sample_rate': 24000, 'audio_feature': 'logmelIV'}}
+    g = torch.Generator().manual_seed(7)
+    waves = [(0.1 * torch.randn(2, 4, 240000, generator=g)).to(dev) for _ in range(4)]
+    lab = synth.formula_adpit_label(2, 100, 3).to(dev)
+
+    def run(prefetch):
+        net, _ = build(multi_accdoa, 'multi_accdoa', 3, TINY, dev, torch.bfloat16)
+        tr = FusedTrainer(net, get_afextractor(cfg).to(dev), 'adpit', lr=2e-5, max_norm=1.0)
+        losses = []
+        for i, w in enumerate(waves):
+            nxt = waves[i + 1] if (prefetch and i + 1 < len(waves)) else None
+            if prefetch and i == 2:
+                nxt = waves[3].clone()                      # announced tensor != the one passed next: falls back to in-line extraction
+            losses.append(tr.training_step(w, {'adpit_label': lab}, next_x=nxt)['loss_all'].item())
+        return losses, net.arena.flat.detach().float().cpu().clone()
+
+    l0, f0 = run(False)
+    l1, f1 = run(True)
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-5 * abs(a), (l0, l1)
+    assert ((f0 - f1).norm() / f0.norm()).item() < 2e-6
