@@ -310,10 +310,14 @@ class SELDModelModule:
                 loss_beta=getattr(self.loss, 'beta', 0.5), **agg)
         return self._trainer
 
-    def fused_training_step(self, batch_sample, process_group=None):
+    def fused_training_step(self, batch_sample, process_group=None, next_batch=None):
+        """next_batch: the batch the caller will pass next (a loader with one batch of look-ahead): its features are extracted on
+        a second stream during this step (trainer.py:prefetch_features). Ignored on the augmentation path, which extracts
+        features inside the augmentation chain."""
         batch_target = {k: v for k, v in batch_sample.items() if 'data' not in k}
         self.train()
         if self.data_aug['type'] or self.data_aug['AugMix']:
             feats, batch_target = self.augment_step(batch_sample['data'], batch_target)
             return self.fused_trainer(process_group).training_step(feats, batch_target, is_features=True)
-        return self.fused_trainer(process_group).training_step(batch_sample['data'], batch_target)
+        return self.fused_trainer(process_group).training_step(batch_sample['data'], batch_target,
+                                                               next_x=None if next_batch is None else next_batch['data'])

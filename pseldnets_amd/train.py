@@ -240,9 +240,11 @@ def main(argv=None):
         batches, n_batches = iter(sampler), min(n_batches, len(sampler)) if n_batches else len(sampler)
     for epoch in range(cfg.trainer.max_epochs):
         t0 = time.perf_counter()
+        draw = lambda: ds.batch(next(batches)) if batches is not None else synthetic_batch(cfg, cfg.model.method, device, gen)
+        nxt = draw()
         for it in range(n_batches):
-            batch = ds.batch(next(batches)) if batches is not None else synthetic_batch(cfg, cfg.model.method, device, gen)
-            loss = module.fused_training_step(batch, group)
+            batch, nxt = nxt, (draw() if it + 1 < n_batches else None)       # one batch of look-ahead: its features are prefetched
+            loss = module.fused_training_step(batch, group, next_batch=nxt)
         torch.cuda.synchronize()
         if rank == 0:
             print(f"epoch {epoch}: loss_all {loss['loss_all'].item():.5f}  lr {trainer.lr:.2e}  "
