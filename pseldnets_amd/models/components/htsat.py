@@ -12,10 +12,9 @@ into the C ABI (pseldnets_amd/ops.py). Differences from the reference that are d
   * eval-mode attention-map averaging (htsat.py:371-377) is skipped — no SELD head consumes it.
 """
 import math
+import os
 
 import torch
-
-import os
 
 from ... import ops
 
@@ -225,7 +224,7 @@ class SwinEncoder:
         (DropPath-scaled) output gradient instead of the split-K weight-gradient GEMM."""
         a = self.arena
         if not self.frozen_weights:
-            side = self._side_stream(dy.device) if not self.lora else None
+            side = self._side_stream(dy.device) if (not self.lora and getattr(self, '_side_ok', False)) else None
             if side is not None:
                 # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient / attention /
                 # LayerNorm chain of the main stream (fork here, join at the end of the stage in backward_layer). Its operands stay
@@ -330,7 +329,6 @@ class SwinEncoder:
     def _side_stream(self, device):
         """The (high-priority) stream the weight gradients run on, or None (PSELD_WGRAD_STREAM=0, or while a hipGraph is being
         captured). Measured on the headline step: 22.93 -> 22.42 ms (A/B in one session, tools: bench.py)."""
-        import os
         if os.environ.get('PSELD_WGRAD_STREAM', '1') != '1' or device.type != 'cuda' or torch.cuda.is_current_stream_capturing():
             return None
         st = getattr(self, '_side', None)
@@ -346,6 +344,9 @@ class SwinEncoder:
             self._side_keep = []
 
     def backward_layer(self, li, dx, saved, B):
+        # the second stream pays from ~64 chunks per step on: at the reference's batch of 32 the ~50 forks per step cost more host
+        # time than the overlap returns (7.26 against 7.55 ms per step measured)
+        self._side_ok = B >= int(os.environ.get('PSELD_WGRAD_STREAM_MIN_CHUNKS', '64'))
         dx = self._backward_layer(li, dx, saved, B)
         self._join_side(dx.device)            # the stage's weight gradients are complete before its gradient range is all-reduced
         return dx
