@@ -203,10 +203,12 @@ class PASST(HTSATNetBase):
             dx = self.enc.backward_block(i, dx, saved['blocks'][i], B)
             if on_range_done is not None and i in cuts and i > 0:
                 lo = a.offsets[self.enc.first_param_of_block(i)][0]
+                ops.join_wgrads(dx.device)             # the blocks' weight gradients ran on the second stream (ops.linear_wgrad_side)
                 on_range_done(lo, hi)
                 hi = lo
         dw, db = self._bn_grads()
         self.enc.backward_front(dx, saved['front'], saved['feat'], saved['mean_rstd'], dw, db, B)
+        ops.join_wgrads(dx.device)
         if on_range_done is not None:
             on_range_done(0, hi)
 

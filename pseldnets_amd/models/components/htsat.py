@@ -224,17 +224,11 @@ class SwinEncoder:
         (DropPath-scaled) output gradient instead of the split-K weight-gradient GEMM."""
         a = self.arena
         if not self.frozen_weights:
-            side = self._side_stream(dy.device) if (not self.lora and getattr(self, '_side_ok', False)) else None
-            if side is not None:
-                # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient / attention /
-                # LayerNorm chain of the main stream (fork here, join at the end of the stage in backward_layer). Its operands stay
-                # referenced until the join, so that the allocator does not hand their memory to the main stream meanwhile.
-                main = torch.cuda.current_stream(dy.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    ops.linear_wgrad(dy, x, a.g(wname), dbias=a.g(bname) if bname else None, gelu_on_x=gelu_on_x, rowscale=rowscale,
-                                     rows_per_scale=rows_per_scale)
-                self._side_keep.append((dy, x, rowscale))
+            if not self.lora and getattr(self, '_side_ok', False):
+                # on the second stream, beside the input-gradient / attention / LayerNorm chain (ops.linear_wgrad_side; joined at
+                # the end of the stage in backward_layer)
+                ops.linear_wgrad_side(dy, x, a.g(wname), dbias=a.g(bname) if bname else None, gelu_on_x=gelu_on_x, rowscale=rowscale,
+                                      rows_per_scale=rows_per_scale)
                 return
             ops.linear_wgrad(dy, x, a.g(wname), dbias=a.g(bname) if bname else None, gelu_on_x=gelu_on_x, rowscale=rowscale,
                              rows_per_scale=rows_per_scale)
@@ -326,29 +320,12 @@ class SwinEncoder:
             x = ops.linear_fwd(xm, self._w(d + 'reduction.weight', dtype))
         return x, saved
 
-    def _side_stream(self, device):
-        """The (high-priority) stream the weight gradients run on, or None (PSELD_WGRAD_STREAM=0, or while a hipGraph is being
-        captured). Measured on the headline step: 22.93 -> 22.42 ms (A/B in one session, tools: bench.py)."""
-        if os.environ.get('PSELD_WGRAD_STREAM', '1') != '1' or device.type != 'cuda' or torch.cuda.is_current_stream_capturing():
-            return None
-        st = getattr(self, '_side', None)
-        if st is None or st.device != device:
-            st = self._side = torch.cuda.Stream(device=device, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1')))
-            self._side_keep = []
-        return st
-
-    def _join_side(self, device):
-        st = getattr(self, '_side', None)
-        if st is not None and getattr(self, '_side_keep', None):
-            torch.cuda.current_stream(device).wait_stream(st)
-            self._side_keep = []
-
     def backward_layer(self, li, dx, saved, B):
         # the second stream pays from ~64 chunks per step on: at the reference's batch of 32 the ~50 forks per step cost more host
         # time than the overlap returns (7.26 against 7.55 ms per step measured)
-        self._side_ok = B >= int(os.environ.get('PSELD_WGRAD_STREAM_MIN_CHUNKS', '64'))
+        self._side_ok = ops.wgrad_side_enabled(dx.device, B)
         dx = self._backward_layer(li, dx, saved, B)
-        self._join_side(dx.device)            # the stage's weight gradients are complete before its gradient range is all-reduced
+        ops.join_wgrads(dx.device)            # the stage's weight gradients are complete before its gradient range is all-reduced
         return dx
 
     def _backward_layer(self, li, dx, saved, B):

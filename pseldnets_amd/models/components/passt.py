@@ -148,16 +148,17 @@ class PasstEncoder:
     def backward_block(self, i, dx, s, B):
         a, dtype, N, E = self.arena, dx.dtype, self.seq, self.E
         b = f'{self.prefix}blocks.{i}.'
-        ops.linear_wgrad(dx, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), rowscale=s['s2'], rows_per_scale=N)
+        wgrad = ops.linear_wgrad_side if ops.wgrad_side_enabled(dx.device, B) else ops.linear_wgrad     # joined by the caller per bucket
+        wgrad(dx, s['h'], a.g(b + 'mlp.fc2.weight'), dbias=a.g(b + 'mlp.fc2.bias'), rowscale=s['s2'], rows_per_scale=N)
         du = ops.linear_dgrad(dx, a.w(b + 'mlp.fc2.weight', dtype), wt=a.wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=N)
-        ops.linear_wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
+        wgrad(du, s['xh2'], a.g(b + 'mlp.fc1.weight'), dbias=a.g(b + 'mlp.fc1.bias'))
         dxh2 = ops.linear_dgrad(du, a.w(b + 'mlp.fc1.weight', dtype), wt=a.wt(b + 'mlp.fc1.weight', dtype))
         dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'), a.g(b + 'norm2.bias'),
                                    dres=dx, eps=1e-6)
-        ops.linear_wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=N)
+        wgrad(dx_mid, s['ao'], a.g(b + 'attn.proj.weight'), dbias=a.g(b + 'attn.proj.bias'), rowscale=s['s1'], rows_per_scale=N)
         dao = ops.linear_dgrad(dx_mid, a.w(b + 'attn.proj.weight', dtype), wt=a.wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=N)
         dqkv = ops.mhsa_bwd(s['qkv'], s['ao'], dao, s['lse'], B, N, self.heads)
-        ops.linear_wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
+        wgrad(dqkv, s['xh1'], a.g(b + 'attn.qkv.weight'), dbias=a.g(b + 'attn.qkv.bias'))
         dxh1 = ops.linear_dgrad(dqkv, a.w(b + 'attn.qkv.weight', dtype), wt=a.wt(b + 'attn.qkv.weight', dtype))
         return ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'), a.g(b + 'norm1.bias'),
                                  dres=dx_mid, eps=1e-6)

@@ -458,6 +458,7 @@ class PASST(StaticBufferMixin, HTSATNetBase):
         dw, db = self._bn_grads()
         self.doa_enc.backward_front(dxd, saved['fd'], saved['feat'], saved['mean_rstd'], dw, db, B, accumulate_bn=False)
         self.sed_enc.backward_front(dxs, saved['fs'], saved['feat'], saved['mean_rstd'], dw, db, B, accumulate_bn=True)
+        ops.join_wgrads(dxs.device)                    # the blocks' weight gradients ran on the second stream (ops.linear_wgrad_side)
         if on_range_done is not None:
             on_range_done(0, a.size)
 

@@ -93,6 +93,44 @@ def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resi
     return out
 
 
+# ---- weight gradients on a second stream ---------------------------------------------------------------------------
+# A weight gradient feeds nothing but the optimiser: the backward passes launch it on a second, high-priority HIP stream
+# beside their dependent chain (input gradients, attention / LayerNorm backward) and join before the gradients are used
+# (per stage / bucket, in front of the gradient all-reduce). Operands stay referenced until the join so that the caching
+# allocator does not hand their memory to the main stream meanwhile; scratch is per (device, stream) (workspace()).
+_side = {}           # device index -> {'stream', 'keep'}
+
+
+def wgrad_side_enabled(device, n_chunks):
+    """The second stream pays from ~64 chunks per step on (measured: at the reference's batch of 32 the ~50 forks per step cost more
+    host time than the overlap returns); never while a hipGraph is being captured. PSELD_WGRAD_STREAM=0 disables it."""
+    import os
+    return (device.type == 'cuda' and os.environ.get('PSELD_WGRAD_STREAM', '1') == '1' and
+            n_chunks >= int(os.environ.get('PSELD_WGRAD_STREAM_MIN_CHUNKS', '64')) and not torch.cuda.is_current_stream_capturing())
+
+
+def linear_wgrad_side(dy, x, dw, **kw):
+    """linear_wgrad on the device's second stream, forked from the current stream (which produced dy)."""
+    import os
+    dev = dy.device
+    st = _side.get(dev.index)
+    if st is None:
+        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1'))), 'keep': []}
+    side = st['stream']
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        linear_wgrad(dy, x, dw, **kw)
+    st['keep'].append((dy, x, kw.get('rowscale')))
+
+
+def join_wgrads(device):
+    """The current stream waits for every weight gradient launched on the second stream so far."""
+    st = _side.get(device.index) if device.type == 'cuda' else None
+    if st is not None and st['keep']:
+        torch.cuda.current_stream(device).wait_stream(st['stream'])
+        st['keep'] = []
+
+
 def linear_wgrad(dy, x, dw, dbias=None, gelu_on_x=False, accumulate=False, rowscale=None, rows_per_scale=1):
     """dw f32[N,K] (+)= (s*dy)[M,N]^T @ (gelu(x) if gelu_on_x else x)[M,K]; dbias f32[N] (+)= column sums of s*dy,
     s = rowscale[m // rows_per_scale] (DropPath factor per sample) or 1."""
