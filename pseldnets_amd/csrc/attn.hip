@@ -684,7 +684,9 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     // Persistent workgroups, one resident round: two waves per head and two waves per SIMD (<= 256 registers), i.e. one
     // 4-head (8-wave) or two 2-head (4-wave) workgroups per CU; each walks several windows, so the d(bias) flush (one atomic
     // tile per wave per workgroup) stays a small fraction of the traffic. PSELD_ATTN_HG / PSELD_ATTN_BWD_WGS: experiment knobs (tools/attn_bench.py).
-    const int hgv = (dtype == PSELD_BF16 && !getenv("PSELD_ATTN_HG")) ? (heads >= 8 ? 2 : 4) : attn_hg(dtype);
+    // (bf16: always two heads per workgroup since the image swizzle shortened the compute phase - with four heads, one workgroup per
+    //  CU, nothing covers its window loads: stage 0 ~1 % faster, same-box A/B 493 / 488 against 486 / 483 us)
+    const int hgv = (dtype == PSELD_BF16 && !getenv("PSELD_ATTN_HG")) ? 2 : attn_hg(dtype);
     const int nhg = pseld_cdiv(heads, hgv);
     const char* es = getenv("PSELD_ATTN_BWD_WGS");                  // experiment knob: total workgroups of the persistent loop
     int slots = (es ? atoi(es) : (hgv == 4 ? 256 : 512)) / nhg;
