@@ -122,6 +122,12 @@ int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, c
                           const void* dout, void* dqkv, float* dbias_table, int B, int res, int C, int heads, int shift,
                           int accumulate, float* workspace, long workspace_bytes, void* stream);
 
+/* Deferred d(bias_table): pseld_window_attn_bwd with dbias_table == NULL leaves the block's [heads][64][64] sums in `workspace` (which
+ * the caller owns and zeroed); this turns the accumulators of n blocks into their table gradients with one launch.
+ * desc = n x {accumulator offset, table-gradient offset, heads} (device longs; float offsets from acc_base / grad_base). */
+int pseld_bias_table_grad_batched(const float* acc_base, float* grad_base, const long* desc, int n, int max_heads, int accumulate,
+                                  void* stream);
+
 /* ---- global multi-head self-attention of the PaSST blocks -----------------------------------------------------------
  * passt.py:62-82 (Attention.forward: qkv split, q k^T * head_dim^-0.5, softmax, @ v, head merge), head_dim 64.
  * qkv [B, N, 3E] -> out [B, N, E]; lse f32[B, heads, N] (log-sum-exp of the scaled scores) is what backward needs

@@ -618,6 +618,29 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ acc, float* __r
     dtable[i] = accumulate ? dtable[i] + s : s;
 }
 
+__global__ void bias_table_grad_batched_kernel(const float* __restrict__ acc_base, float* __restrict__ grad_base, const long* __restrict__ desc,
+                                               int accumulate) {
+    const long* d = desc + 3 * blockIdx.y;
+    const float* acc = acc_base + d[0];
+    float* dtable = grad_base + d[1];
+    const int heads = (int)d[2];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 225 * heads) return;
+    const int idx = i / heads, h = i - idx * heads;
+    const int dy = idx / 15 - 7, dx = idx % 15 - 7;
+    float s = 0.f;
+    for (int qy = 0; qy < 8; ++qy) {
+        const int ky = qy - dy;
+        if (ky < 0 || ky > 7) continue;
+        for (int qx = 0; qx < 8; ++qx) {
+            const int kx = qx - dx;
+            if (kx < 0 || kx > 7) continue;
+            s += acc[(long)h * 4096 + (ky * 8 + kx) * 64 + qy * 8 + qx];
+        }
+    }
+    dtable[i] = accumulate ? dtable[i] + s : s;
+}
+
 template <typename T> size_t fwd_lds(int hd, int HG) { return 64 * (3 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 8 + 64 * 8 + 65 * 4; }
 template <typename T> size_t bwd_lds(int hd, int HG) { return 64 * (5 * HG * hd * sizeof(T) + 32) + HG * 225 * 4 + 64 * HG * 4 + 8 + 64 * 8 + 65 * 4 + 16 + (size_t)2 * HG * (sizeof(T) == 2 ? 4096 : 2 * 32 * ImgStride<T>::value); }
 
@@ -666,7 +689,7 @@ extern "C" long pseld_window_attn_bwd_workspace(int heads) { return (long)heads 
 extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* out, const float* lse,
                                      const void* dout, void* dqkv, float* dbias_table, int B, int res, int C, int heads, int shift,
                                      int accumulate, float* workspace, long workspace_bytes, void* stream) {
-    PSELD_CHECK_ARG(qkv && bias_table && out && lse && dout && dqkv && dbias_table && workspace, "window_attn_bwd: null pointer");
+    PSELD_CHECK_ARG(qkv && bias_table && out && lse && dout && dqkv && workspace, "window_attn_bwd: null pointer");
     int rc = check_args("window_attn_bwd", B, res, C, heads, shift);
     if (rc) return rc;
     PSELD_CHECK_ARG(workspace_bytes >= pseld_window_attn_bwd_workspace(heads), "window_attn_bwd: workspace too small");
@@ -679,8 +702,12 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     hipStream_t s = (hipStream_t)stream;
     // zeroed by a kernel, not hipMemsetAsync: inside a captured hipGraph (trainer.py use_graph) the memset NODE of this image's
     // runtime left stale sums in the accumulator after a few replays (tools/graph_debug.py: inf in d(bias_table) at the 4th replay)
-    hipLaunchKernelGGL(zero_f4_kernel, dim3(heads * 4), dim3(256), 0, s, (float4*)workspace, (long)heads * 1024);
-    PSELD_LAUNCH_CHECK("window_attn_bwd(zero)");
+    // dbias_table == NULL: deferred mode - `workspace` is this block's own accumulator, zeroed by the caller, and the caller turns
+    // the accumulators of several blocks into table gradients with ONE pseld_bias_table_grad_batched launch
+    if (dbias_table) {
+        hipLaunchKernelGGL(zero_f4_kernel, dim3(heads * 4), dim3(256), 0, s, (float4*)workspace, (long)heads * 1024);
+        PSELD_LAUNCH_CHECK("window_attn_bwd(zero)");
+    }
     // Persistent workgroups, one resident round: two waves per head and two waves per SIMD (<= 256 registers), i.e. one
     // 4-head (8-wave) or two 2-head (4-wave) workgroups per CU; each walks several windows, so the d(bias) flush (one atomic
     // tile per wave per workgroup) stays a small fraction of the traffic. PSELD_ATTN_HG / PSELD_ATTN_BWD_WGS: experiment knobs (tools/attn_bench.py).
@@ -704,7 +731,20 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
         hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), grid, dim3(256), bwd_lds<float>(a.hd, 2), s, a);
     } else { pseld_set_error("window_attn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_bwd");
-    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);
-    PSELD_LAUNCH_CHECK("bias_table_grad");
+    if (dbias_table) {
+        hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);
+        PSELD_LAUNCH_CHECK("bias_table_grad");
+    }
+    return PSELD_OK;
+}
+
+// The table gradients of n blocks in one launch: desc = n x {accumulator offset, table-gradient offset, heads} (device longs; offsets
+// in floats from acc_base / grad_base). For callers of pseld_window_attn_bwd's deferred mode (dbias_table == NULL).
+extern "C" int pseld_bias_table_grad_batched(const float* acc_base, float* grad_base, const long* desc, int n, int max_heads,
+                                             int accumulate, void* stream) {
+    PSELD_CHECK_ARG(acc_base && grad_base && desc && n > 0 && max_heads > 0, "bias_table_grad_batched: bad arguments");
+    hipLaunchKernelGGL(bias_table_grad_batched_kernel, dim3(pseld_cdiv(225 * max_heads, 256), n), dim3(256), 0, (hipStream_t)stream,
+                       acc_base, grad_base, desc, accumulate);
+    PSELD_LAUNCH_CHECK("bias_table_grad_batched");
     return PSELD_OK;
 }

@@ -324,9 +324,32 @@ class SwinEncoder:
         # the second stream pays from ~64 chunks per step on: at the reference's batch of 32 the ~50 forks per step cost more host
         # time than the overlap returns (7.26 against 7.55 ms per step measured)
         self._side_ok = ops.wgrad_side_enabled(dx.device, B)
+        rpb = self._rpb_state(dx.device)
+        if li == self.nl - 1:
+            rpb['acc'].zero_()                # the backward starts at the last stage: every block's accumulator, one launch
         dx = self._backward_layer(li, dx, saved, B)
+        ops.bias_table_grad_batched(rpb['acc'], self.arena.grad, rpb['desc'][li], self.depths[li], self.stage_dims(li)[1])
         ops.join_wgrads(dx.device)            # the stage's weight gradients are complete before its gradient range is all-reduced
         return dx
+
+    def _rpb_state(self, device):
+        """Accumulators of d(relative_position_bias_table) for every block (fp32 [heads][64 keys][64 queries] each) and, per stage, the
+        descriptors pseld_bias_table_grad_batched reads: {accumulator offset, offset of the table's gradient in the arena, heads}."""
+        st = getattr(self, '_rpb', None)
+        if st is not None and st['acc'].device == device and st['grad'] is self.arena.grad:
+            return st
+        off, desc, total = {}, [], 0
+        for li in range(self.nl):
+            heads = self.stage_dims(li)[1]
+            rows = []
+            for bi in range(self.depths[li]):
+                off[(li, bi)] = total
+                name = f'{self.prefix}layers.{li}.blocks.{bi}.attn.relative_position_bias_table'
+                rows += [total, self.arena.offsets[name][0], heads]
+                total += heads * 4096
+            desc.append(torch.tensor(rows, dtype=torch.long, device=device))
+        self._rpb = dict(acc=torch.zeros(total, dtype=torch.float32, device=device), desc=desc, off=off, grad=self.arena.grad)
+        return self._rpb
 
     def _backward_layer(self, li, dx, saved, B):
         a, p, dtype = self.arena, self.prefix, dx.dtype
@@ -365,8 +388,11 @@ class SwinEncoder:
             else:
                 self._wgrad(dx_mid, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias', rowscale=s['s1'], rows_per_scale=L, per_scale_elems=L * C)
                 dao = ops.linear_dgrad(dx_mid, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
+            # d(relative_position_bias_table): the block leaves its [heads][64][64] sums in its own accumulator; one launch per stage
+            # turns them into the table gradients (backward_layer)
+            o = self._rpb['off'][(li, bi)]
             dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), s['ao'], s['lse'], dao,
-                                       a.g(b + 'attn.relative_position_bias_table'), B, res, heads, s['shift'])
+                                       None, B, res, heads, s['shift'], acc=self._rpb['acc'][o:o + heads * 4096])
             self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
             dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=self._wt(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),

@@ -268,17 +268,26 @@ def window_attn_fwd(qkv, bias_table, B, res, heads, shift, need_lse=True):
     return out, lse
 
 
-def window_attn_bwd(qkv, bias_table, out, lse, dout, dbias_table, B, res, heads, shift, accumulate=False):
-    _chk(qkv, bias_table, out, lse, dout, dbias_table)
+def window_attn_bwd(qkv, bias_table, out, lse, dout, dbias_table, B, res, heads, shift, accumulate=False, acc=None):
+    """acc (with dbias_table=None): deferred mode - this block's own zeroed [heads * 4096] fp32 accumulator; the table gradients of
+    several blocks then come from one bias_table_grad_batched launch."""
+    _chk(qkv, bias_table, out, lse, dout, dbias_table, acc)
+    assert (dbias_table is None) == (acc is not None)
     C = qkv.shape[1] // 3
     L = _lib.lib()
-    ws = workspace(L.pseld_window_attn_bwd_workspace(heads), qkv.device)
+    ws = acc if acc is not None else workspace(L.pseld_window_attn_bwd_workspace(heads), qkv.device)
     dqkv = torch.empty_like(qkv)
     rc = L.pseld_window_attn_bwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(dout),
                                  _lib.ptr(dqkv), _lib.ptr(dbias_table), B, res, C, heads, shift, int(accumulate), _lib.ptr(ws),
                                  ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_window_attn_bwd")
     return dqkv
+
+
+def bias_table_grad_batched(acc_all, grad_base, desc, n, max_heads, accumulate=False):
+    _chk(acc_all, grad_base, desc)
+    _lib.check(_lib.lib().pseld_bias_table_grad_batched(_lib.ptr(acc_all), _lib.ptr(grad_base), _lib.ptr(desc), n, max_heads,
+                                                        int(accumulate), _lib.stream_ptr()), "pseld_bias_table_grad_batched")
 
 
 # ---------------------------------------------------------------------------------------------------------
