@@ -74,6 +74,10 @@ long pseld_layernorm_bwd_workspace(long M, int C);
 int pseld_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const void* dres, void* dx,
                         float* dgamma, float* dbeta, long M, int C, int merge_res, float eps, int accumulate,
                         float* workspace, long workspace_bytes, void* stream);
+/* accumulate & 2 in pseld_layernorm_bwd: DEFERRED parameter gradients - the call leaves its column-sum partials
+ * [nb = workspace_bytes / (8 C)][2][C] in `workspace` and the caller reduces the partials of several LayerNorms with one launch: */
+int pseld_reduce_slabs_batched(const void* const* src, void* const* dst, const int* n, const int* splits, const int* stride, int count,
+                               int accumulate, void* stream);
 
 /* ---- the 7 "scalar" BatchNorm2d(mel) + pad + time->frequency fold + 4x4 patch extraction ----------------------
  * models/accdoa.py:223-227 (in-place per-channel BN), htsat.py:493-511 (reshape_wav2img), im2col of

@@ -540,7 +540,59 @@ __global__ __launch_bounds__(256) void cross_stitch_bwd_kernel(const T* __restri
     }
 }
 
+// up to 32 independent slab reductions in one launch (blockIdx.y = entry): the column-sum partials of several LayerNorm backward
+// passes are reduced together at the end of a stage instead of by one small launch each on the dependent chain. Same algorithm
+// (and summation order) as reduce_slabs_wide_kernel<4>.
+struct ReduceBatch {
+    const float* src[32];
+    float* dst[32];
+    int n[32], splits[32], stride[32];
+    int accumulate;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_batched_kernel(ReduceBatch b) {
+    constexpr int CW = 4, SG = 256 / CW;
+    __shared__ float red[SG][CW + 1];
+    const int e = blockIdx.y;
+    const int n = b.n[e];
+    if ((int)blockIdx.x * CW >= n) return;
+    const float* __restrict__ slabs = b.src[e];
+    float* __restrict__ out = b.dst[e];
+    const int splits = b.splits[e];
+    const long slab_stride = b.stride[e];
+    const int c = threadIdx.x % CW, sg = threadIdx.x / CW;
+    const long i = (long)blockIdx.x * CW + c;
+    float s = 0.f;
+    if (i < n)
+        for (int z = sg; z < splits; z += SG) s += slabs[z * slab_stride + i];
+    red[sg][c] = s;
+    __syncthreads();
+    if (sg == 0 && i < n) {
+        float t = b.accumulate ? out[i] : 0.f;
+#pragma unroll 16
+        for (int k = 0; k < SG; ++k) t += red[k][c];
+        out[i] = t;
+    }
+}
+
 }  // namespace
+
+// count <= 32 reductions dst[e][0..n[e]) (+)= sum over splits[e] slabs of src[e] (slab stride stride[e] floats); host arrays.
+extern "C" int pseld_reduce_slabs_batched(const void* const* src, void* const* dst, const int* n, const int* splits, const int* stride,
+                                          int count, int accumulate, void* stream) {
+    PSELD_CHECK_ARG(src && dst && n && splits && stride && count > 0 && count <= 32, "reduce_slabs_batched: bad arguments (count %d)", count);
+    ReduceBatch b;
+    memset(&b, 0, sizeof(b));
+    int max_n = 0;
+    for (int e = 0; e < count; ++e) {
+        PSELD_CHECK_ARG(src[e] && dst[e] && n[e] > 0 && splits[e] > 0, "reduce_slabs_batched: bad entry %d", e);
+        b.src[e] = (const float*)src[e]; b.dst[e] = (float*)dst[e]; b.n[e] = n[e]; b.splits[e] = splits[e]; b.stride[e] = stride[e];
+        if (n[e] > max_n) max_n = n[e];
+    }
+    b.accumulate = accumulate;
+    hipLaunchKernelGGL(reduce_slabs_batched_kernel, dim3(pseld_cdiv(max_n, 4), count), dim3(256), 0, (hipStream_t)stream, b);
+    PSELD_LAUNCH_CHECK("reduce_slabs_batched");
+    return PSELD_OK;
+}
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
                         hipStream_t stream) {
@@ -595,6 +647,7 @@ extern "C" int pseld_layernorm_bwd(int dtype, const void* dy, const void* x, con
     else if (dtype == PSELD_F32) rc = merge_res ? launch_ln<float, true>(a, true, rows, nb, s) : launch_ln<float, false>(a, true, rows, nb, s);
     else { pseld_set_error("layernorm_bwd: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
     if (rc != PSELD_OK) return rc;
+    if (accumulate & 2) return PSELD_OK;      // deferred: the caller reduces the [nb][2][C] partials (pseld_reduce_slabs_batched)
     // partial layout [nb][2][C]: reduce the two halves separately
     if (dbeta == dgamma + C) {   // adjacent in the parameter arena: one reduction for both
         pseld_reduce_slabs(workspace, dgamma, (long)2 * C, nb, (long)2 * C, accumulate, s);

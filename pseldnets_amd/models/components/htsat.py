@@ -327,7 +327,13 @@ class SwinEncoder:
         rpb = self._rpb_state(dx.device)
         if li == self.nl - 1:
             rpb['acc'].zero_()                # the backward starts at the last stage: every block's accumulator, one launch
+        if os.environ.get('PSELD_LN_DEFER', '1') != '1':
+            self._defer = None                                       # (A/B knob: every LayerNorm reduces its own partials)
+        elif getattr(self, '_defer', None) is None or self._defer.buf.device != dx.device:
+            self._defer = ops.DeferredReductions(dx.device)      # d(gamma) / d(beta) partials of the stage's LayerNorms: one reduction
         dx = self._backward_layer(li, dx, saved, B)
+        if self._defer is not None:
+            self._defer.flush()
         ops.bias_table_grad_batched(rpb['acc'], self.arena.grad, rpb['desc'][li], self.depths[li], self.stage_dims(li)[1])
         ops.join_wgrads(dx.device)            # the stage's weight gradients are complete before its gradient range is all-reduced
         return dx
@@ -360,7 +366,7 @@ class SwinEncoder:
             self._wgrad(dx, saved['xm'], d + 'reduction.weight')
             dxm = ops.linear_dgrad(dx, self._w(d + 'reduction.weight', dtype), wt=self._wt(d + 'reduction.weight', dtype))
             dx = ops.layernorm_bwd(dxm, saved['x_pre'], a.p(d + 'norm.weight'), a.g(d + 'norm.weight'),
-                                   a.g(d + 'norm.bias'), merge_res=res)
+                                   a.g(d + 'norm.bias'), merge_res=res, defer=self._defer)
         for bi in reversed(range(self.depths[li])):
             b = f'{p}layers.{li}.blocks.{bi}.'
             s = saved['blocks'][bi]
@@ -378,7 +384,7 @@ class SwinEncoder:
                 dxh2_ad = self._adapter_bwd(dxs, s['xh2'], s['ad']['mlp'], b + 'mlp.adapter.')
             dxh2 = ops.linear_dgrad(du, self._w(b + 'mlp.fc1.weight', dtype), wt=self._wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
-                                       a.g(b + 'norm2.bias'), dres=dx)
+                                       a.g(b + 'norm2.bias'), dres=dx, defer=self._defer)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
             if self.attn_adapter:
                 da1 = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
@@ -396,7 +402,7 @@ class SwinEncoder:
             self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
             dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=self._wt(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
-                                   a.g(b + 'norm1.bias'), dres=dx_mid)
+                                   a.g(b + 'norm1.bias'), dres=dx_mid, defer=self._defer)
         return dx
 
     def forward_final(self, x):

@@ -178,18 +178,63 @@ def layernorm_fwd(x, gamma, beta, merge_res=0, eps=1e-5, out_rows=None):
     return y
 
 
-def layernorm_bwd(dy, x, gamma, dgamma, dbeta, dres=None, merge_res=0, eps=1e-5, accumulate=False):
-    """Returns dx (same geometry as x). dgamma/dbeta (fp32) are overwritten or accumulated."""
+class DeferredReductions:
+    """Column-sum partials of several kernels (the d(gamma) / d(beta) of the LayerNorm backward passes of a stage), reduced by ONE
+    launch at flush() instead of one small launch each on the dependent chain (a step carries ~8 us of fixed cost per launch).
+    Partials live in a bump arena owned by this object until the flush."""
+
+    def __init__(self, device, arena_floats=8 << 20):
+        self.buf = torch.empty(arena_floats, dtype=torch.float32, device=device)
+        self.used, self.entries = 0, []
+
+    def alloc(self, nfloats):
+        nfloats = (nfloats + 3) // 4 * 4
+        if self.used + nfloats > self.buf.numel() or len(self.entries) >= 30:
+            self.flush()
+        assert nfloats <= self.buf.numel()
+        out = self.buf[self.used:self.used + nfloats]
+        self.used += nfloats
+        return out
+
+    def add(self, src, dst, n, splits, stride, accumulate):
+        if self.entries and self.entries[0][5] != accumulate:
+            self.flush()
+        self.entries.append((src.data_ptr(), dst.data_ptr(), n, splits, stride, accumulate))
+
+    def flush(self):
+        if self.entries:
+            import ctypes
+            k = len(self.entries)
+            src = (ctypes.c_void_p * k)(*[e[0] for e in self.entries])
+            dst = (ctypes.c_void_p * k)(*[e[1] for e in self.entries])
+            n = (ctypes.c_int * k)(*[e[2] for e in self.entries])
+            sp = (ctypes.c_int * k)(*[e[3] for e in self.entries])
+            st = (ctypes.c_int * k)(*[e[4] for e in self.entries])
+            _lib.check(_lib.lib().pseld_reduce_slabs_batched(src, dst, n, sp, st, k, int(self.entries[0][5]), _lib.stream_ptr()),
+                       "pseld_reduce_slabs_batched")
+        self.used, self.entries = 0, []
+
+
+def layernorm_bwd(dy, x, gamma, dgamma, dbeta, dres=None, merge_res=0, eps=1e-5, accumulate=False, defer=None):
+    """Returns dx (same geometry as x). dgamma/dbeta (fp32) are overwritten or accumulated - at once, or, with defer (a
+    DeferredReductions), when the caller flushes it."""
     _chk(dy, x, gamma, dgamma, dbeta, dres)
     M, C = dy.shape
     L = _lib.lib()
     need = L.pseld_layernorm_bwd_workspace(M, C)
-    ws = workspace(need, dy.device)
+    ws = workspace(need, dy.device) if defer is None else defer.alloc(need // 4)
     dx = torch.empty_like(x)
     rc = L.pseld_layernorm_bwd(dtype_code(dy), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx),
-                               _lib.ptr(dgamma), _lib.ptr(dbeta), M, C, merge_res, eps, int(accumulate), _lib.ptr(ws),
-                               ws.numel() * 4, _lib.stream_ptr())
+                               _lib.ptr(dgamma), _lib.ptr(dbeta), M, C, merge_res, eps, int(accumulate) | (2 if defer is not None else 0),
+                               _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_layernorm_bwd")
+    if defer is not None:
+        nb = need // (8 * C)                                   # partial layout [nb][2][C]
+        if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C:
+            defer.add(ws, dgamma, 2 * C, nb, 2 * C, bool(accumulate))
+        else:
+            defer.add(ws, dgamma, C, nb, 2 * C, bool(accumulate))
+            defer.add(ws[C:], dbeta, C, nb, 2 * C, bool(accumulate))
     return dx
 
 
