@@ -501,9 +501,11 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline()                       # every host core
-                # BASELINE.md section 3's comparability line: the survey's probe of the REFERENCE ran on 8 threads (0.45 clips/s)
-                out["cpu_baseline"]["at_8_threads"] = cpu_baseline(threads=8)
+                # the headline CPU figure is BASELINE.md section 3's comparability line: 8 threads (the survey's probe of the REFERENCE on
+                # 8 threads: 0.45 clips/s). Every host core is reported beside it: on these shared 128-thread hosts the oversubscribed run
+                # is both slower and erratic (0.06 - 0.28 clips/s between boxes), so it is not the number to compare against
+                out["cpu_baseline"] = cpu_baseline(threads=8)
+                out["cpu_baseline"]["at_all_host_threads"] = cpu_baseline()
             except Exception as e:  # the checker must never take the measurement down
                 out["cpu_baseline"] = {"error": repr(e)}
         # RCCL's version banner sits in the C library's stdout buffer until exit and would land BEHIND the JSON line: flush it
