@@ -208,14 +208,32 @@ def spawn_ranks(n):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for pr in procs[1:]:
-        try:
-            codes.append(pr.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            codes.append(pr.wait())
+    # rank 0's pipe is drained by a thread while EVERY child is polled: a rank that dies at start-up (bad device index, out of
+    # memory) would otherwise leave rank 0 in the rendezvous until the store / RCCL timeout, many minutes later
+    import threading
+    box = []
+    th = threading.Thread(target=lambda: box.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, pr in enumerate(procs):                 # first failure: stop the others by their exact PIDs
+                if codes[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+            break
+        time.sleep(0.2)
+    th.join(timeout=30)
+    out0 = box[0] if box else b''
     # only the JSON line travels up: RCCL writes a version banner to the ranks' C-level stdout at exit
     text = out0.decode() if out0 else ''
     sys.stdout.write(''.join(ln + '\n' for ln in text.splitlines() if ln.startswith('{')))

@@ -198,10 +198,12 @@ class DeferredReductions:
 
     def add(self, src, dst, n, splits, stride, accumulate):
         if self.entries and self.entries[0][5] != accumulate:
-            self.flush()
+            # the entry being added already owns a slice of the arena (alloc() ran before the kernel that wrote it): reduce the
+            # earlier entries but keep the bump pointer, so that the next alloc() cannot hand that slice out again
+            self.flush(reset=False)
         self.entries.append((src.data_ptr(), dst.data_ptr(), n, splits, stride, accumulate))
 
-    def flush(self):
+    def flush(self, reset=True):
         if self.entries:
             import ctypes
             k = len(self.entries)
@@ -212,7 +214,9 @@ class DeferredReductions:
             st = (ctypes.c_int * k)(*[e[4] for e in self.entries])
             _lib.check(_lib.lib().pseld_reduce_slabs_batched(src, dst, n, sp, st, k, int(self.entries[0][5]), _lib.stream_ptr()),
                        "pseld_reduce_slabs_batched")
-        self.used, self.entries = 0, []
+        self.entries = []
+        if reset:
+            self.used = 0
 
 
 def layernorm_bwd(dy, x, gamma, dgamma, dbeta, dres=None, merge_res=0, eps=1e-5, accumulate=False, defer=None):

