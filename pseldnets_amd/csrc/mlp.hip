@@ -1,0 +1,802 @@
+// Fused Swin MLP block for the HBM-bound stages of HTS-AT (C = 96 / 192), forward and backward, on gfx950.
+//
+// Replaces, per SwinTransformerBlock, the chain  x + drop_path(mlp(norm2(x)))  of the reference
+//   htsat.py:262-264 (block tail), model_utilities.py:159-171 (Mlp: fc1 -> GELU -> fc2), :216-232 (DropPath)
+// which the layer-wise path runs as LayerNorm + two GEMMs (15 row-tensors of M*C elements through HBM forward, 24 backward:
+// the [M, 4C] hidden tensors are 8 of every 10 bytes). Here the hidden activations never leave the CU:
+//
+//   pseld_mlp_fwd     y = x + s * (W2 gelu(W1 LN(x) + b1) + b2)                  reads x, writes y (+ mean / rstd per token)
+//   pseld_mlp_bwd_dx  dXh = ((s dY) W2 * gelu'(U)) W1,  U recomputed from x      reads x, dY, writes dXh
+//   pseld_mlp_bwd_dw  dW1, db1, dW2, db2 (U, H recomputed once more)             reads x, dY, writes fp32 split slabs
+//
+// Orientation is what makes the chain register-resident (MI355X guide, "an accumulator tile as the next MFMA's operand"):
+//   forward / dx: a wave owns 32 TOKENS on its lanes. U^T[j][m] = W1 . xh^T leaves the hidden unit in the accumulator ROWS, so
+//     gelu(U^T) converted to bf16 IS the B operand of Out^T[c][m] = W2 . H^T (contraction over accumulator rows): no LDS round
+//     trip, no transpose. The k-order of an accumulator operand is permuted (row 16s + 8(j>>2) + 4h + (j&3)); instead of
+//     permuting the W2 fragments, the W1 ROWS are fetched permuted (lane r reads row swap23(r)), after which accumulator row
+//     order == natural hidden order and every weight fragment is one plain 16-byte LDS read.
+//     Weights stream through LDS in chunks of JC hidden units by LDS-DMA (double buffered, source-swizzled, shared by the waves).
+//   dw: the contraction runs over TOKENS, so a wave owns 32 HIDDEN units on its lanes (U[m][j], rows = tokens); H and dU
+//     accumulators are the A operands of dW2^T[j][c] += H^T dYs and dW1[j][c] += dU^T Xh, whose B operands are transposed LDS
+//     reads (ds_read_b64_tr_b16) of the token-major images. W1 / W2^T fragments of the wave's 32 hidden units stay in registers,
+//     the dW accumulators too; a workgroup owns 32*NW hidden units and one token range (split-K slabs, one reduce).
+// Two kernels for the backward because the two contractions want the two dual ownerships; the price is one more recompute of
+// U (K = C: 6 or 12 MFMA per 32x32 tile) against 19 fewer row-tensors of HBM traffic.
+//
+// Roofline: the three kernels move 2 / 3 / 2 row-tensors; at C = 96 they are bound by VALU issue (the exact-erf GELU costs
+// ~18 vector instructions per hidden element against 12-24 MFMA per 32x32 tile), at C = 192 by MFMA issue.
+// f32 (parity mode) instantiates the same bodies on v_mfma_f32_32x32x2_f32 with smaller tiles.
+#include "mma_frag.h"
+
+void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate, hipStream_t stream);
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct MlpArgs {
+    const void* x;          // [M, C] block input (the residual stream)
+    const void* dy;         // [M, C] gradient wrt the block output (backward)
+    void* y;                // fwd: [M, C] block output; bwd_dx: dXh [M, C] (gradient wrt the LayerNorm output)
+    const void* w1;         // fc1.weight [H, C]
+    const void* w2;         // fc2.weight [C, H]            (forward)
+    const void* w1t;        // fc1.weight^T [C, H]          (bwd_dx)
+    const void* w2t;        // fc2.weight^T [H, C]          (backward)
+    const float* b1;        // [H]
+    const float* b2;        // [C]
+    const float* gamma;     // [C]
+    const float* beta;      // [C]
+    const float* rowscale;  // DropPath factor per sample (null: 1)
+    float* mean_rstd;       // [M][2]: written by fwd (may be null), read by the backward kernels
+    float* slab;            // bwd_dw: [splits][2*H*C + H + C] fp32
+    long M;
+    int rows_per_scale;
+    int tok_per_split, nsplits;
+    float eps;
+};
+
+// ---- LDS images: rows of NCH 16-byte chunks, chunk index XOR-swizzled by a function of the row so that (a) 16 different
+// rows read at the same chunk (ds_read_b128 operand fragments) and (b) 4 consecutive rows read as one 64-byte segment each
+// (ds_read_b64_tr_b16) are bank-conflict free. The image is written lane-linear (LDS-DMA: the SOURCE chunk is swizzled).
+template <int NCH> __device__ __forceinline__ int swz(int row) {
+    if constexpr (NCH % 16 == 0) return row & 15;
+    else if constexpr (NCH % 8 == 0) return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
+    else { static_assert(NCH % 4 == 0, "rows must be multiples of 64 bytes"); return (row >> 2) & 3; }
+}
+template <int NCH> __device__ __forceinline__ int chunk_off(int row, int ch) { return row * (NCH * 16) + ((ch ^ swz<NCH>(row)) << 4); }
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS at a wave-uniform address.
+// Inline asm (not the builtin): hipcc cannot prove that the slot being filled and the slot the next ds_read touches differ
+// and would drain the prefetch with s_waitcnt vmcnt(0); the waits are placed by hand below.
+__device__ __forceinline__ void dma16(char* lds_dst, const void* src) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_ptr)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+// rows [0, NROWS) of NCH chunks each: instruction i of the image is issued by wave (i % nwaves == wave)
+template <int NCH, int NROWS>
+__device__ __forceinline__ void dma_image(char* img, const char* gsrc, long ld_bytes, int wave, int nwaves, int lane) {
+    constexpr int NINSTR = NROWS * NCH / 64;
+    static_assert(NROWS * NCH % 64 == 0, "image must be a whole number of 1 KiB DMA instructions");
+    for (int i = wave; i < NINSTR; i += nwaves) {
+        const int q = i * 64 + lane, row = q / NCH, ch = q - row * NCH;
+        dma16(img + i * 1024, gsrc + (long)row * ld_bytes + ((ch ^ swz<NCH>(row)) << 4));
+    }
+}
+
+template <typename T> struct Ops;
+template <> struct Ops<bf16_t> {
+    using Frag = bf16x8;
+    static constexpr int EPC = 8;      // elements per 16-byte chunk
+    // 8 consecutive elements k8*8 .. k8*8+7 of image row `row`
+    template <int NCH> static __device__ __forceinline__ Frag ldrow(const char* img, int row, int k8) {
+        return *(const bf16x8*)(img + chunk_off<NCH>(row, k8));
+    }
+    static __device__ __forceinline__ void unpack(const Frag& f, float (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)f[j];
+    }
+    static __device__ __forceinline__ Frag pack(const float (&v)[8]) {
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (bf16_t)v[j];
+        return f;
+    }
+    static __device__ __forceinline__ Frag ldglobal(const void* p) { return *(const bf16x8*)p; }
+    // element j = img[row0 + 8*(j>>2) + 4*h + (j&3)][col0 + (lane&31)]: the k-order of an accumulator operand
+    template <int NCH> static __device__ __forceinline__ Frag ldcols(const char* img, int row0, int col0, int lane) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
+        const int row = row0 + 4 * h + q, col = col0 + 16 * gsel + 4 * p;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(img + chunk_off<NCH>(row, col >> 3) + (col & 7) * 2));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(img + chunk_off<NCH>(row + 8, col >> 3) + (col & 7) * 2));
+        short8v s;
+        s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3];
+        s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, s);
+    }
+    static __device__ __forceinline__ float fragsum(const Frag& f) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)f[j];
+        return s;
+    }
+};
+template <> struct Ops<float> {
+    using Frag = AFragF32;
+    static constexpr int EPC = 4;
+    template <int NCH> static __device__ __forceinline__ Frag ldrow(const char* img, int row, int k8) {
+        const f32x4 a = *(const f32x4*)(img + chunk_off<NCH>(row, 2 * k8));
+        const f32x4 b = *(const f32x4*)(img + chunk_off<NCH>(row, 2 * k8 + 1));
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+        return f;
+    }
+    static __device__ __forceinline__ void unpack(const Frag& f, float (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f.v[j];
+    }
+    static __device__ __forceinline__ Frag pack(const float (&v)[8]) {
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = v[j];
+        return f;
+    }
+    static __device__ __forceinline__ Frag ldglobal(const void* p) {
+        const f32x4 a = ((const f32x4*)p)[0], b = ((const f32x4*)p)[1];
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+        return f;
+    }
+    template <int NCH> static __device__ __forceinline__ Frag ldcols(const char* img, int row0, int col0, int lane) {
+        const int r = lane & 31, h = lane >> 5, col = col0 + r;
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row0 + 8 * (j >> 2) + 4 * h + (j & 3);
+            f.v[j] = *(const float*)(img + chunk_off<NCH>(row, col >> 2) + (col & 3) * 4);
+        }
+        return f;
+    }
+    static __device__ __forceinline__ float fragsum(const Frag& f) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f.v[j];
+        return s;
+    }
+};
+
+__device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// LayerNorm of the wave's 32 token rows (wave-private image, row r on lanes r and r + 32, each holding half of the channels):
+// statistics in registers, the normalised row returned as the B-operand fragments xh[kk] (k = channel). Same arithmetic as
+// norm.hip:ln_fwd_kernel (two passes; mean = sum / C, rstd = rsqrt(sum (x - mean)^2 / C + eps)).
+template <typename T, int C, bool RECOMPUTE>
+__device__ __forceinline__ void ln_frags(const char* ximg, const float* gam, const float* bet, float eps, int lane,
+                                         typename Ops<T>::Frag (&xh)[C / 16], float& mean, float& rstd) {
+    constexpr int KS = C / 16, NCH = C / Ops<T>::EPC;
+    const int r = lane & 31, h = lane >> 5;
+    // the image is re-read per pass (three cheap LDS sweeps) instead of holding the 48 / 96 fp32 values of the half row in registers
+    if constexpr (RECOMPUTE) {
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            float v[8];
+            Ops<T>::unpack(Ops<T>::template ldrow<NCH>(ximg, r, 2 * kk + h), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        s += __shfl_xor(s, 32, 64);
+        mean = s / C;
+        float q = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            float v[8];
+            Ops<T>::unpack(Ops<T>::template ldrow<NCH>(ximg, r, 2 * kk + h), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q += d * d; }
+        }
+        q += __shfl_xor(q, 32, 64);
+        rstd = rsqrtf(q / C + eps);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        float v[8];
+        Ops<T>::unpack(Ops<T>::template ldrow<NCH>(ximg, r, 2 * kk + h), v);
+        const f32x4 g0 = *(const f32x4*)(gam + 16 * kk + 8 * h), g1 = *(const f32x4*)(gam + 16 * kk + 8 * h + 4);
+        const f32x4 b0 = *(const f32x4*)(bet + 16 * kk + 8 * h), b1 = *(const f32x4*)(bet + 16 * kk + 8 * h + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (v[j] - mean) * rstd * g0[j] + b0[j];
+            o[4 + j] = (v[4 + j] - mean) * rstd * g1[j] + b1[j];
+        }
+        xh[kk] = Ops<T>::pack(o);
+    }
+}
+
+// accumulator init with the bias of its ROWS: register e of lane half h is (after the swap23 row fetch) hidden unit
+// base + (e & 7) + 8 h + 16 (e >> 3)
+__device__ __forceinline__ void acc_bias_rows(f32x16& u, const float* b1s, int base, int h) {
+    const f32x4 a0 = *(const f32x4*)(b1s + base + 8 * h), a1 = *(const f32x4*)(b1s + base + 8 * h + 4);
+    const f32x4 c0 = *(const f32x4*)(b1s + base + 16 + 8 * h), c1 = *(const f32x4*)(b1s + base + 16 + 8 * h + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u[j] = a0[j]; u[4 + j] = a1[j]; u[8 + j] = c0[j]; u[12 + j] = c1[j]; }
+}
+
+// =====================================================================================================================
+// forward
+// LDS: [NBUF weight chunks: W1 rows jc..jc+JC (JC x C) | W2 columns jc..jc+JC (C x JC)] [NW wave-private x tiles] [tables]
+template <typename T, int C, int NW, int JC, int NBUF>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs a) {
+    using O = Ops<T>;
+    using Frag = typename O::Frag;
+    constexpr int H = 4 * C, ES = (int)sizeof(T), EPC = O::EPC, KS = C / 16, CT = C / 32, NJ = H / JC, SUBS = JC / 32;
+    constexpr int NCH1 = C / EPC, NCH2 = JC / EPC;                   // chunks per row: W1 chunk / x tile; W2 chunk
+    constexpr int W1B = JC * C * ES, WB = 2 * W1B, XB = 32 * C * ES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wbuf = smem;
+    char* ximg = smem + NBUF * WB + (threadIdx.x >> 6) * XB;
+    float* tab = (float*)(smem + NBUF * WB + NW * XB);               // gamma[C] beta[C] b2[C] b1[H]
+    float* gam = tab; float* bet = tab + C; float* b2s = tab + 2 * C; float* b1s = tab + 3 * C;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long m0 = ((long)blockIdx.x * NW + wave) * 32;
+    const bool live = m0 < a.M;
+    const long m0c = live ? m0 : 0;                                   // idle waves of the last workgroup shadow tile 0 (no stores)
+
+    auto issue_chunk = [&](int jc) {
+        char* wb = wbuf + (jc % NBUF) * WB;
+        dma_image<NCH1, JC>(wb, (const char*)a.w1 + (long)jc * JC * C * ES, (long)C * ES, wave, NW, lane);
+        dma_image<NCH2, C>(wb + W1B, (const char*)a.w2 + (long)jc * JC * ES, (long)H * ES, wave, NW, lane);
+    };
+    issue_chunk(0);
+    dma_image<NCH1, 32>(ximg, (const char*)a.x + m0c * C * ES, (long)C * ES, 0, 1, lane);
+    for (int i = tid; i < C; i += NW * 64) { gam[i] = a.gamma[i]; bet[i] = a.beta[i]; b2s[i] = a.b2[i]; }
+    for (int i = tid; i < H; i += NW * 64) b1s[i] = a.b1[i];
+    const float sc = a.rowscale ? a.rowscale[(m0c + r) / a.rows_per_scale] : 1.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    Frag xh[KS];
+    float mean, rstd;
+    ln_frags<T, C, true>(ximg, gam, bet, a.eps, lane, xh, mean, rstd);
+    if (a.mean_rstd && live && h == 0) *(f32x2*)(a.mean_rstd + (m0 + r) * 2) = f32x2{mean, rstd};
+
+    f32x16 out[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[ct][e] = 0.f;
+
+    for (int jc = 0; jc < NJ; ++jc) {
+        if (NBUF == 2 && jc + 1 < NJ) issue_chunk(jc + 1);
+        const char* w1i = wbuf + (jc % NBUF) * WB;
+        const char* w2i = w1i + W1B;
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub) {
+            f32x16 u;
+            acc_bias_rows(u, b1s, jc * JC + 32 * sub, h);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                AMma<T>::mma(O::template ldrow<NCH1>(w1i, 32 * sub + swap23(r), 2 * kk + h), xh[kk], u);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) u[e] = gelu_f(u[e]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag hb = AMma<T>::from_acc(u, s);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    AMma<T>::mma(O::template ldrow<NCH2>(w2i, 32 * ct + r, 4 * sub + 2 * s + h), hb, out[ct]);
+            }
+        }
+        if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of chunk jc + 1 has landed
+            __syncthreads();                                        // ... everybody's has, and everybody is done with chunk jc
+        } else if (jc + 1 < NJ) {
+            __syncthreads();
+            issue_chunk(jc + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // y[m][c] = x + sc * (out + b2): Out^T register e of tile ct is channel 32 ct + (e & 3) + 8 (e >> 2) + 4 h of token r. The wave
+    // rewrites its x image in place (4 channels per access), then streams the image out as whole 16-byte chunks.
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * ct + 8 * g + 4 * h;
+            char* p = ximg + chunk_off<NCH1>(r, c0 / EPC) + (c0 % EPC) * ES;
+            const f32x4 bb = *(const f32x4*)(b2s + c0);
+            float xv[4];
+            if constexpr (ES == 2) { const bf16x4 t = *(const bf16x4*)p; for (int j = 0; j < 4; ++j) xv[j] = (float)t[j]; }
+            else { const f32x4 t = *(const f32x4*)p; for (int j = 0; j < 4; ++j) xv[j] = t[j]; }
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(out[ct][4 * g + j] + bb[j], sc, xv[j]);
+            store4<T>(p, o[0], o[1], o[2], o[3]);
+        }
+    if (live) {
+        char* yg = (char*)a.y + m0 * C * ES;
+#pragma unroll
+        for (int i = 0; i < 32 * NCH1 / 64; ++i) {
+            const int q = i * 64 + lane, row = q / NCH1, ch = q - row * NCH1;
+            *(f32x4*)(yg + (long)row * C * ES + ((ch ^ swz<NCH1>(row)) << 4)) = *(const f32x4*)(ximg + q * 16);
+        }
+    }
+}
+
+// =====================================================================================================================
+// backward, input gradient:  dXh^T[c][m] = sum_j W1[j][c] dU^T[j][m],  dU^T = (W2^T dYs^T) * gelu'(U^T),  dYs = s * dY
+// LDS: [NBUF chunks: W1 rows (JC x C) | W2^T rows (JC x C) | W1^T columns (C x JC)] [NW x (x tile, dY tile)] [tables]
+// SHARE: the x tile and the dY tile use ONE wave-private region, one after the other (C = 192: two regions do not fit beside the
+// double-buffered weight chunks)
+template <typename T, int C, int NW, int JC, int NBUF, bool SHARE>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpArgs a) {
+    using O = Ops<T>;
+    using Frag = typename O::Frag;
+    constexpr int H = 4 * C, ES = (int)sizeof(T), EPC = O::EPC, KS = C / 16, CT = C / 32, NJ = H / JC, SUBS = JC / 32;
+    constexpr int NCH1 = C / EPC, NCH2 = JC / EPC;
+    constexpr int W1B = JC * C * ES, WB = 3 * W1B, XB = 32 * C * ES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wbuf = smem;
+    constexpr int NST = SHARE ? 1 : 2;
+    char* ximg = smem + NBUF * WB + (threadIdx.x >> 6) * NST * XB;
+    char* dimg = SHARE ? ximg : ximg + XB;
+    float* tab = (float*)(smem + NBUF * WB + NW * NST * XB);         // gamma[C] beta[C] b1[H]
+    float* gam = tab; float* bet = tab + C; float* b1s = tab + 2 * C;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long m0 = ((long)blockIdx.x * NW + wave) * 32;
+    const bool live = m0 < a.M;
+    const long m0c = live ? m0 : 0;
+
+    auto issue_chunk = [&](int jc) {
+        char* wb = wbuf + (jc % NBUF) * WB;
+        dma_image<NCH1, JC>(wb, (const char*)a.w1 + (long)jc * JC * C * ES, (long)C * ES, wave, NW, lane);
+        dma_image<NCH1, JC>(wb + W1B, (const char*)a.w2t + (long)jc * JC * C * ES, (long)C * ES, wave, NW, lane);
+        dma_image<NCH2, C>(wb + 2 * W1B, (const char*)a.w1t + (long)jc * JC * ES, (long)H * ES, wave, NW, lane);
+    };
+    issue_chunk(0);
+    dma_image<NCH1, 32>(ximg, (const char*)a.x + m0c * C * ES, (long)C * ES, 0, 1, lane);
+    if constexpr (!SHARE) dma_image<NCH1, 32>(dimg, (const char*)a.dy + m0c * C * ES, (long)C * ES, 0, 1, lane);
+    for (int i = tid; i < C; i += NW * 64) { gam[i] = a.gamma[i]; bet[i] = a.beta[i]; }
+    for (int i = tid; i < H; i += NW * 64) b1s[i] = a.b1[i];
+    const float sc = a.rowscale ? a.rowscale[(m0c + r) / a.rows_per_scale] : 1.f;
+    const f32x2 mr = *(const f32x2*)(a.mean_rstd + (m0c + r) * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    Frag xh[KS], dys[KS];
+    {
+        float mean = mr[0], rstd = mr[1];
+        ln_frags<T, C, false>(ximg, gam, bet, 0.f, lane, xh, mean, rstd);
+    }
+    if constexpr (SHARE) {
+        // the wave has its x rows in registers: the same region now takes its dY rows (wave-private: only this wave's own
+        // reads, drained by the lgkmcnt, and its own DMA, retired by the vmcnt, are involved)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_image<NCH1, 32>(dimg, (const char*)a.dy + m0c * C * ES, (long)C * ES, 0, 1, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        float v[8];
+        O::unpack(O::template ldrow<NCH1>(dimg, r, 2 * kk + h), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+        dys[kk] = O::pack(v);
+    }
+
+    f32x16 dxh[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dxh[ct][e] = 0.f;
+
+    for (int jc = 0; jc < NJ; ++jc) {
+        if (NBUF == 2 && jc + 1 < NJ) issue_chunk(jc + 1);
+        const char* w1i = wbuf + (jc % NBUF) * WB;
+        const char* w2ti = w1i + W1B;
+        const char* w1ti = w1i + 2 * W1B;
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub) {
+            f32x16 u, dh;
+            acc_bias_rows(u, b1s, jc * JC + 32 * sub, h);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dh[e] = 0.f;
+            const int wrow = 32 * sub + swap23(r);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                AMma<T>::mma(O::template ldrow<NCH1>(w1i, wrow, 2 * kk + h), xh[kk], u);
+                AMma<T>::mma(O::template ldrow<NCH1>(w2ti, wrow, 2 * kk + h), dys[kk], dh);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) u[e] = dh[e] * gelu_grad_f(u[e]);        // dU^T
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag ub = AMma<T>::from_acc(u, s);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    AMma<T>::mma(O::template ldrow<NCH2>(w1ti, 32 * ct + r, 4 * sub + 2 * s + h), ub, dxh[ct]);
+            }
+        }
+        if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else if (jc + 1 < NJ) {
+            __syncthreads();
+            issue_chunk(jc + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    // dXh[m][c] through the wave's dY image (same chunk order as the input tiles), then out as 16-byte chunks
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * ct + 8 * g + 4 * h;
+            char* p = dimg + chunk_off<NCH1>(r, c0 / EPC) + (c0 % EPC) * ES;
+            store4<T>(p, dxh[ct][4 * g], dxh[ct][4 * g + 1], dxh[ct][4 * g + 2], dxh[ct][4 * g + 3]);
+        }
+    if (live) {
+        char* yg = (char*)a.y + m0 * C * ES;
+#pragma unroll
+        for (int i = 0; i < 32 * NCH1 / 64; ++i) {
+            const int q = i * 64 + lane, row = q / NCH1, ch = q - row * NCH1;
+            *(f32x4*)(yg + (long)row * C * ES + ((ch ^ swz<NCH1>(row)) << 4)) = *(const f32x4*)(dimg + q * 16);
+        }
+    }
+}
+
+// =====================================================================================================================
+// backward, weight gradients. Workgroup = (token split, owner of 32*NW hidden units); wave = 32 hidden units on its lanes.
+//   U[m][j]  = Xh W1^T + b1          A = Xh rows (image), B = W1 rows of the wave's hidden units (registers)
+//   dH[m][j] = dY W2                 A = dY rows,         B = W2^T rows (registers)
+//   dW2^T[j][c] += (s H)^T dY, dW1[j][c] += dU^T Xh, dU = s dH gelu'(U)
+//                                    A = the accumulators (rows = tokens), B = transposed reads of the images
+// The DropPath factor s is uniform over a 32-token sub-tile (rows_per_scale % 32 == 0) and is applied to the accumulators.
+// Token tiles arrive raw by LDS-DMA one tile ahead (x, dY, mean / rstd); a conversion pass (LDS -> registers -> LDS) normalises
+// x into the swizzled Xh image and copies dY into its image, so no staging register lives across the MFMA phase.
+// LDS: [2 x raw (x TT x C | dY TT x C | mean,rstd 1 KiB)] [Xh image | dY image] [gamma, beta]
+template <typename T, int C, int NW, int TT, bool WREG, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
+    using O = Ops<T>;
+    using Frag = typename O::Frag;
+    constexpr int H = 4 * C, ES = (int)sizeof(T), EPC = O::EPC, KS = C / 16, CT = C / 32, NTH = NW * 64;
+    constexpr int NCH = C / EPC, IMG = TT * C * ES, NOWN = H / (32 * NW), RAW = 2 * IMG + 1024;
+    constexpr int CPT = TT * NCH / NTH;                               // 16-byte chunks per thread per image per tile
+    constexpr int NINSTR = IMG / 1024;                                // DMA instructions per raw image
+    static_assert(TT * NCH % NTH == 0 && H % (32 * NW) == 0 && TT % 32 == 0 && TT <= 128, "tile geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xi = smem + 2 * RAW;
+    char* di = xi + IMG;
+    float* gam = (float*)(di + IMG);
+    float* bet = gam + C;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // the NOWN owners of one token split get ids that are congruent mod 8: one XCD, so the split's x / dY tiles are fetched
+    // from HBM once and served to the other owners by that XCD's L2 (speed only)
+    const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+    const int owner = jj % NOWN, split = (jj / NOWN) * 8 + xcd;
+    if (split >= a.nsplits) return;
+    const long tok0 = (long)split * a.tok_per_split;
+    const long tok1 = min(a.M, tok0 + a.tok_per_split);
+    const int ntiles = (int)((tok1 - tok0 + TT - 1) / TT);
+    const int j0 = (owner * NW + wave) * 32;                           // this wave's hidden units j0 .. j0 + 31 (lane r <-> j0 + r)
+
+    auto issue_raw = [&](int t) {
+        char* raw = smem + (t & 1) * RAW;
+        const long tbase = tok0 + (long)t * TT;
+        for (int i = wave; i < NINSTR; i += NW) {
+            const int q = i * 64 + lane, row = q / NCH, ch = q - row * NCH;
+            const long off = (min(tbase + row, a.M - 1) * C + ch * EPC) * ES;          // rows past the end shadow the last token
+            dma16(raw + i * 1024, (const char*)a.x + off);
+            dma16(raw + IMG + i * 1024, (const char*)a.dy + off);
+        }
+        if (wave == 0) dma16(raw + 2 * IMG, (const char*)(a.mean_rstd + min(tbase + 2 * lane, a.M - 2) * 2));   // 2 rows per lane
+    };
+    issue_raw(0);
+    for (int i = tid; i < C; i += NTH) { gam[i] = a.gamma[i]; bet[i] = a.beta[i]; }
+
+    Frag w1f[WREG ? KS : 1], w2tf[WREG ? KS : 1];
+    const char* w1p = (const char*)a.w1 + ((long)(j0 + r) * C + 8 * h) * ES;
+    const char* w2tp = (const char*)a.w2t + ((long)(j0 + r) * C + 8 * h) * ES;
+    if constexpr (WREG) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) { w1f[kk] = O::ldglobal(w1p + kk * 16 * ES); w2tf[kk] = O::ldglobal(w2tp + kk * 16 * ES); }
+    }
+    const float b1v = a.b1[j0 + r];
+    auto scale_of = [&](int t, int mt) -> float {
+        const long tok = min(tok0 + (long)t * TT + 32 * mt, a.M - 1);
+        return a.rowscale ? a.rowscale[tok / a.rows_per_scale] : 1.f;
+    };
+    float scn[TT / 32];
+#pragma unroll
+    for (int mt = 0; mt < TT / 32; ++mt) scn[mt] = scale_of(0, mt);
+
+    f32x16 dw2t[CT], dw1[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dw2t[ct][e] = 0.f; dw1[ct][e] = 0.f; }
+    float db1 = 0.f, db2[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) db2[ct] = 0.f;
+    const bool do_db2 = owner == 0 && wave == 0;
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's share of raw tile t (and the first pass's tables / weights)
+        __syncthreads();                                               // ... everybody's; and everybody has left the images of tile t - 1
+        if (t + 1 < ntiles) issue_raw(t + 1);                          // its buffer was last read by the conversion of tile t - 1
+        float sc[TT / 32];
+#pragma unroll
+        for (int mt = 0; mt < TT / 32; ++mt) sc[mt] = scn[mt];
+        if (t + 1 < ntiles) {
+#pragma unroll
+            for (int mt = 0; mt < TT / 32; ++mt) scn[mt] = scale_of(t + 1, mt);
+        }
+        {   // conversion: raw tile -> Xh image (LayerNorm applied, compute dtype) and dY image; rows past the split become zeros
+            const char* raw = smem + (t & 1) * RAW;
+            const float* mr = (const float*)(raw + 2 * IMG);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int q = tid + i * NTH, row = q / NCH, ch = q - row * NCH;
+                const bool in = tok0 + (long)t * TT + row < tok1;
+                const f32x4 vx = *(const f32x4*)(raw + q * 16), vd = *(const f32x4*)(raw + IMG + q * 16);
+                const float mean = mr[2 * row], rstd = mr[2 * row + 1];
+                f32x4 ox, od;
+                const float keep = in ? 1.f : 0.f;                     // (straight-line: every load unconditional)
+                if constexpr (ES == 2) {
+                    const bf16x8 bx = __builtin_bit_cast(bf16x8, vx);
+                    const f32x4 g0 = *(const f32x4*)(gam + ch * 8), g1 = *(const f32x4*)(gam + ch * 8 + 4);
+                    const f32x4 e0 = *(const f32x4*)(bet + ch * 8), e1 = *(const f32x4*)(bet + ch * 8 + 4);
+                    bf16x8 px;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        px[k] = (bf16_t)((((float)bx[k] - mean) * rstd * g0[k] + e0[k]) * keep);
+                        px[4 + k] = (bf16_t)((((float)bx[4 + k] - mean) * rstd * g1[k] + e1[k]) * keep);
+                    }
+                    ox = __builtin_bit_cast(f32x4, px);
+                } else {
+                    const f32x4 g0 = *(const f32x4*)(gam + ch * 4), e0 = *(const f32x4*)(bet + ch * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ox[k] = ((vx[k] - mean) * rstd * g0[k] + e0[k]) * keep;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float v = vd[k]; od[k] = in ? v : 0.f; }   // (bit pattern kept: a pure select)
+                *(f32x4*)(xi + chunk_off<NCH>(row, ch)) = ox;
+                *(f32x4*)(di + chunk_off<NCH>(row, ch)) = od;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int mt = 0; mt < TT / 32; ++mt) {
+            float s_mt = sc[0];
+#pragma unroll
+            for (int k = 1; k < TT / 32; ++k) s_mt = (mt == k) ? sc[k] : s_mt;
+            f32x16 u, dh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { u[e] = b1v; dh[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                Frag bw1, bw2;
+                if constexpr (WREG) { bw1 = w1f[kk]; bw2 = w2tf[kk]; }
+                else { bw1 = O::ldglobal(w1p + kk * 16 * ES); bw2 = O::ldglobal(w2tp + kk * 16 * ES); }
+                AMma<T>::mma(O::template ldrow<NCH>(xi, 32 * mt + r, 2 * kk + h), bw1, u);
+                AMma<T>::mma(O::template ldrow<NCH>(di, 32 * mt + r, 2 * kk + h), bw2, dh);
+            }
+            // (rows of padding tokens: xh = 0 gives u = b1, but their dY rows are 0: dU = 0, and H meets dY = 0)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float hv, gv;
+                gelu_both(u[e], hv, gv);
+                u[e] = hv * s_mt;                                      // s H
+                dh[e] *= gv * s_mt;                                    // dU
+                db1 += dh[e];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag ah = AMma<T>::from_acc(u, s), au = AMma<T>::from_acc(dh, s);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const Frag bd = O::template ldcols<NCH>(di, 32 * mt + 16 * s, 32 * ct, lane);
+                    const Frag bx = O::template ldcols<NCH>(xi, 32 * mt + 16 * s, 32 * ct, lane);
+                    AMma<T>::mma(ah, bd, dw2t[ct]);
+                    AMma<T>::mma(au, bx, dw1[ct]);
+                }
+            }
+            if (do_db2) {       // one wave of one owner per split: d(b2) = column sums of s dY (outside the MFMA sequence)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) db2[ct] += s_mt * O::fragsum(O::template ldcols<NCH>(di, 32 * mt + 16 * s, 32 * ct, lane));
+            }
+        }
+    }
+
+    // ---- slab of this split: [dW1 (H x C) | db1 (H) | dW2 (C x H) | db2 (C)] -- the arena order of fc1.weight .. fc2.bias
+    float* slab = a.slab + (long)split * (2L * H * C + H + C);
+    float* s_w1 = slab;
+    float* s_b1 = slab + (long)H * C;
+    float* s_w2 = s_b1 + H;
+    float* s_b2 = s_w2 + (long)C * H;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s_w1[(long)(j0 + acc_row(e, h)) * C + 32 * ct + r] = dw1[ct][e];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(f32x4*)(s_w2 + (long)(32 * ct + r) * H + j0 + 8 * g + 4 * h) =
+                f32x4{dw2t[ct][4 * g], dw2t[ct][4 * g + 1], dw2t[ct][4 * g + 2], dw2t[ct][4 * g + 3]};
+    }
+    db1 += __shfl_xor(db1, 32, 64);
+    if (h == 0) s_b1[j0 + r] = db1;
+    if (do_db2) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float v = db2[ct] + __shfl_xor(db2[ct], 32, 64);
+            if (h == 0) s_b2[32 * ct + r] = v;
+        }
+    }
+}
+
+// ---- launch configurations -------------------------------------------------------------------------------------------------
+template <typename T, int C> struct Cfg;
+//   forward: waves, hidden units per chunk, chunk buffers | dx: the same + shared tile region | dw: waves, token tile, W in registers, waves / SIMD
+template <> struct Cfg<bf16_t, 96>  { static constexpr int FNW = 8, FJC = 64, FNB = 2, XNW = 8, XJC = 32, XNB = 2, XSH = 0, DNW = 4, DTT = 64, DWR = 1, DWPS = 2; };
+template <> struct Cfg<bf16_t, 192> { static constexpr int FNW = 8, FJC = 32, FNB = 2, XNW = 4, XJC = 32, XNB = 2, XSH = 1, DNW = 4, DTT = 64, DWR = 1, DWPS = 1; };
+template <> struct Cfg<float, 96>   { static constexpr int FNW = 4, FJC = 32, FNB = 2, XNW = 4, XJC = 32, XNB = 1, XSH = 0, DNW = 4, DTT = 32, DWR = 1, DWPS = 1; };
+template <> struct Cfg<float, 192>  { static constexpr int FNW = 4, FJC = 32, FNB = 1, XNW = 2, XJC = 32, XNB = 1, XSH = 1, DNW = 4, DTT = 32, DWR = 0, DWPS = 1; };
+
+template <typename K> int set_lds(K kernel, int lds, bool& done) {
+    if (done) return PSELD_OK;
+    done = true;
+    if (lds > 160 * 1024) { pseld_set_error("mlp: configuration needs %d bytes of LDS", lds); return PSELD_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        pseld_set_error("mlp: cannot raise the dynamic LDS limit to %d", lds);
+        return PSELD_ERR_HIP;
+    }
+    return PSELD_OK;
+}
+
+template <typename T, int C> int launch_fwd(const MlpArgs& a, hipStream_t s) {
+    using G = Cfg<T, C>;
+    constexpr int ES = (int)sizeof(T), H = 4 * C;
+    constexpr int LDS = G::FNB * 2 * G::FJC * C * ES + G::FNW * 32 * C * ES + (3 * C + H) * 4;
+    static_assert(LDS <= 160 * 1024, "forward: LDS budget");
+    auto k = mlp_fwd_kernel<T, C, G::FNW, G::FJC, G::FNB>;
+    static bool done = false;
+    if (int rc = set_lds(k, LDS, done)) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)((a.M / 32 + G::FNW - 1) / G::FNW)), dim3(G::FNW * 64), LDS, s, a);
+    PSELD_LAUNCH_CHECK("mlp_fwd");
+    return PSELD_OK;
+}
+template <typename T, int C> int launch_dx(const MlpArgs& a, hipStream_t s) {
+    using G = Cfg<T, C>;
+    constexpr int ES = (int)sizeof(T), H = 4 * C;
+    constexpr int LDS = G::XNB * 3 * G::XJC * C * ES + G::XNW * (G::XSH ? 1 : 2) * 32 * C * ES + (2 * C + H) * 4;
+    static_assert(LDS <= 160 * 1024, "dx: LDS budget");
+    auto k = mlp_bwd_dx_kernel<T, C, G::XNW, G::XJC, G::XNB, (bool)G::XSH>;
+    static bool done = false;
+    if (int rc = set_lds(k, LDS, done)) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)((a.M / 32 + G::XNW - 1) / G::XNW)), dim3(G::XNW * 64), LDS, s, a);
+    PSELD_LAUNCH_CHECK("mlp_bwd_dx");
+    return PSELD_OK;
+}
+// token splits of the weight-gradient kernel: about one resident round of workgroups (two per CU where they fit), whole tiles
+template <typename T, int C> void dw_plan(long M, int& tok_per_split, int& nsplits) {
+    using G = Cfg<T, C>;
+    constexpr int NOWN = 4 * C / (32 * G::DNW);
+    constexpr int LDS = 6 * G::DTT * C * (int)sizeof(T) + 2048 + 2 * C * 4;
+    const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
+    int want = 256 * per_cu / NOWN;
+    want = want / 8 * 8;
+    if (want < 8) want = 8;
+    long tps = (M + want - 1) / want;
+    if (tps < 512) tps = 512;                                         // short splits: the slab traffic would dominate
+    tps = (tps + G::DTT - 1) / G::DTT * G::DTT;
+    tok_per_split = (int)tps;
+    nsplits = (int)((M + tps - 1) / tps);
+}
+template <typename T, int C> int launch_dw(MlpArgs a, hipStream_t s) {
+    using G = Cfg<T, C>;
+    constexpr int NOWN = 4 * C / (32 * G::DNW);
+    constexpr int LDS = 6 * G::DTT * C * (int)sizeof(T) + 2048 + 2 * C * 4;
+    dw_plan<T, C>(a.M, a.tok_per_split, a.nsplits);
+    static_assert(LDS <= 160 * 1024, "dw: LDS budget");
+    auto k = mlp_bwd_dw_kernel<T, C, G::DNW, G::DTT, (bool)G::DWR, G::DWPS>;
+    static bool done = false;
+    if (int rc = set_lds(k, LDS, done)) return rc;
+    const unsigned grid = 8u * (unsigned)((a.nsplits + 7) / 8) * NOWN;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(G::DNW * 64), LDS, s, a);
+    PSELD_LAUNCH_CHECK("mlp_bwd_dw");
+    return PSELD_OK;
+}
+
+bool shape_ok(int dtype, long M, int C) { return (dtype == PSELD_BF16 || dtype == PSELD_F32) && (C == 96 || C == 192) && M > 0 && M % 32 == 0; }
+bool scale_ok(const float* rowscale, int rows_per_scale) { return !rowscale || (rows_per_scale > 0 && rows_per_scale % 32 == 0); }
+
+#define MLP_DISPATCH(fn, a, s)                                                                  \
+    (dtype == PSELD_BF16 ? (C == 96 ? fn<bf16_t, 96>(a, s) : fn<bf16_t, 192>(a, s))             \
+                         : (C == 96 ? fn<float, 96>(a, s) : fn<float, 192>(a, s)))
+
+}  // namespace
+
+extern "C" int pseld_mlp_supported(int dtype, long M, int C, int rows_per_scale) {
+    return shape_ok(dtype, M, C) && rows_per_scale > 0 && rows_per_scale % 32 == 0 ? 1 : 0;
+}
+
+extern "C" int pseld_mlp_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
+                             const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, float* mean_rstd,
+                             long M, int C, float eps, void* stream) {
+    PSELD_CHECK_ARG(x && gamma && beta && w1 && b1 && w2 && b2 && y, "mlp_fwd: null pointer");
+    PSELD_CHECK_ARG(shape_ok(dtype, M, C), "mlp_fwd: built for C = 96 / 192, M a multiple of 32, bf16 / f32 (M=%ld C=%d dtype=%d)", M, C, dtype);
+    PSELD_CHECK_ARG(!rowscale || rows_per_scale > 0, "mlp_fwd: rows_per_scale");
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.mean_rstd = mean_rstd; a.M = M; a.eps = eps;
+    return MLP_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+}
+
+extern "C" int pseld_mlp_bwd_dx(int dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* beta,
+                                const void* w1, const float* b1, const void* w2t, const void* w1t, const float* rowscale,
+                                int rows_per_scale, void* dxh, long M, int C, void* stream) {
+    PSELD_CHECK_ARG(x && dy && mean_rstd && gamma && beta && w1 && b1 && w2t && w1t && dxh, "mlp_bwd_dx: null pointer");
+    PSELD_CHECK_ARG(shape_ok(dtype, M, C), "mlp_bwd_dx: built for C = 96 / 192, M a multiple of 32 (M=%ld C=%d)", M, C);
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.y = dxh; a.w1 = w1; a.w1t = w1t; a.w2t = w2t; a.b1 = b1; a.gamma = gamma; a.beta = beta;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.mean_rstd = (float*)mean_rstd; a.M = M;
+    return MLP_DISPATCH(launch_dx, a, (hipStream_t)stream);
+}
+
+static long mlp_dw_splits(int dtype, long M, int C) {
+    int tps = 0, ns = 0;
+    if (dtype == PSELD_BF16) { if (C == 96) dw_plan<bf16_t, 96>(M, tps, ns); else dw_plan<bf16_t, 192>(M, tps, ns); }
+    else { if (C == 96) dw_plan<float, 96>(M, tps, ns); else dw_plan<float, 192>(M, tps, ns); }
+    return ns;
+}
+extern "C" long pseld_mlp_bwd_dw_workspace(int dtype, long M, int C) {
+    if (!shape_ok(dtype, M, C)) return 0;
+    return mlp_dw_splits(dtype, M, C) * (8L * C * C + 5L * C) * (long)sizeof(float);
+}
+// dw1 [4C, C], db1 [4C], dw2 [C, 4C], db2 [C] (fp32): overwritten, or accumulated into when `accumulate`
+extern "C" int pseld_mlp_bwd_dw(int dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* beta,
+                                const void* w1, const float* b1, const void* w2t, const float* rowscale, int rows_per_scale,
+                                float* dw1, float* db1, float* dw2, float* db2, long M, int C, int accumulate, float* workspace,
+                                long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(x && dy && mean_rstd && gamma && beta && w1 && b1 && w2t && dw1 && db1 && dw2 && db2 && workspace, "mlp_bwd_dw: null pointer");
+    PSELD_CHECK_ARG(shape_ok(dtype, M, C), "mlp_bwd_dw: built for C = 96 / 192, M a multiple of 32 (M=%ld C=%d)", M, C);
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_mlp_bwd_dw_workspace(dtype, M, C), "mlp_bwd_dw: workspace too small");
+    PSELD_CHECK_ARG(scale_ok(rowscale, rows_per_scale), "mlp_bwd_dw: rows_per_scale must be a multiple of 32 (a 32-token tile lies in one sample)");
+    const int H = 4 * C;
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.w1 = w1; a.w2t = w2t; a.b1 = b1; a.gamma = gamma; a.beta = beta;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.mean_rstd = (float*)mean_rstd; a.M = M;
+    a.slab = workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = MLP_DISPATCH(launch_dw, a, s);
+    if (rc != PSELD_OK) return rc;
+    const long ns = mlp_dw_splits(dtype, M, C), stride = 2L * H * C + H + C;
+    if (db1 == dw1 + (long)H * C && dw2 == db1 + H && db2 == dw2 + (long)C * H) {
+        pseld_reduce_slabs(workspace, dw1, stride, (int)ns, stride, accumulate, s);      // the arena keeps the four tensors back to back
+    } else {
+        pseld_reduce_slabs(workspace, dw1, (long)H * C, (int)ns, stride, accumulate, s);
+        pseld_reduce_slabs(workspace + (long)H * C, db1, H, (int)ns, stride, accumulate, s);
+        pseld_reduce_slabs(workspace + (long)H * C + H, dw2, (long)C * H, (int)ns, stride, accumulate, s);
+        pseld_reduce_slabs(workspace + 2L * H * C + H, db2, C, (int)ns, stride, accumulate, s);
+    }
+    PSELD_LAUNCH_CHECK("mlp_bwd_dw(reduce)");
+    return PSELD_OK;
+}

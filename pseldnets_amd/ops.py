@@ -162,6 +162,65 @@ def colsum(x, out, accumulate=False):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# fused Swin MLP block (stages with C = 96 / 192): the [M, 4C] hidden activations stay on the CU
+def mlp_fused_supported(x, rows_per_scale):
+    return bool(x.is_cuda and x.dim() == 2 and _lib.lib().pseld_mlp_supported(dtype_code(x), x.shape[0], x.shape[1], max(int(rows_per_scale), 1)))
+
+
+def mlp_fwd(x, gamma, beta, w1, b1, w2, b2, rowscale=None, rows_per_scale=1, eps=1e-5):
+    """y = x + s * (gelu(LN(x) w1^T + b1) w2^T + b2) and the per-token LayerNorm statistics f32[M, 2] the backward reads."""
+    _chk(x, gamma, beta, w1, b1, w2, b2, rowscale)
+    M, C = x.shape
+    assert w1.shape == (4 * C, C) and w2.shape == (C, 4 * C) and w1.dtype == x.dtype and w2.dtype == x.dtype
+    y = torch.empty_like(x)
+    mean_rstd = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pseld_mlp_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+                                  _lib.ptr(b2), _lib.ptr(rowscale), rows_per_scale, _lib.ptr(y), _lib.ptr(mean_rstd), M, C, eps,
+                                  _lib.stream_ptr())
+    _lib.check(rc, "pseld_mlp_fwd")
+    return y, mean_rstd
+
+
+def mlp_bwd_dx(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, w1t, rowscale=None, rows_per_scale=1):
+    """Gradient wrt LN(x) of the fused block: ((s dy) w2 * gelu'(u)) w1. w2t = w2^T [4C, C], w1t = w1^T [C, 4C]."""
+    _chk(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, w1t, rowscale)
+    M, C = x.shape
+    assert dy.shape == x.shape and w2t.shape == (4 * C, C) and w1t.shape == (C, 4 * C)
+    dxh = torch.empty_like(x)
+    rc = _lib.lib().pseld_mlp_bwd_dx(dtype_code(x), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(mean_rstd), _lib.ptr(gamma), _lib.ptr(beta),
+                                     _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(w1t), _lib.ptr(rowscale), rows_per_scale,
+                                     _lib.ptr(dxh), M, C, _lib.stream_ptr())
+    _lib.check(rc, "pseld_mlp_bwd_dx")
+    return dxh
+
+
+def mlp_bwd_dw(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, dw1, db1, dw2, db2, rowscale=None, rows_per_scale=1, accumulate=False):
+    """The four parameter gradients of the fused block (fp32, overwritten or accumulated)."""
+    _chk(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, dw1, db1, dw2, db2, rowscale)
+    M, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.pseld_mlp_bwd_dw_workspace(dtype_code(x), M, C), x.device)
+    rc = L.pseld_mlp_bwd_dw(dtype_code(x), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(mean_rstd), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(w1),
+                            _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(rowscale), rows_per_scale, _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2),
+                            _lib.ptr(db2), M, C, int(accumulate), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_mlp_bwd_dw")
+
+
+def mlp_bwd_dw_side(x, dy, *args, **kw):
+    """mlp_bwd_dw on the device's second stream (see linear_wgrad_side)."""
+    import os
+    dev = dy.device
+    st = _side.get(dev.index)
+    if st is None:
+        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1'))), 'keep': []}
+    side = st['stream']
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        mlp_bwd_dw(x, dy, *args, **kw)
+    st['keep'].append((x, dy, args[0], kw.get('rowscale')))
+
+
+# ---------------------------------------------------------------------------------------------------------
 # LayerNorm
 def layernorm_fwd(x, gamma, beta, merge_res=0, eps=1e-5, out_rows=None):
     """x [M, C] -> LN(x); merge mode: x is the token grid [B*res*res, Cs], output rows [B*(res/2)^2, 4*Cs]."""
