@@ -58,25 +58,26 @@ int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float*
  * htsat.py:262-264  x = x + drop_path(mlp(norm2(x)));  model_utilities.py:159-171 Mlp (fc1 -> exact-erf GELU -> fc2),
  * :216-232 DropPath (rowscale = per-sample factor mask / keep_prob, rows_per_scale = tokens per sample, a multiple of 32).
  * One kernel per direction keeps the [M, 4C] hidden activations on the CU (registers / LDS); SURVEY 8b `pseld_mlp_{fwd,bwd}`.
- *   pseld_mlp_fwd:    y = x + s * (gelu(LN(x) W1^T + b1) W2^T + b2); mean_rstd (optional, f32[M][2]) receives the LayerNorm
- *                     statistics the backward kernels read. w1 [4C, C], w2 [C, 4C] in the compute dtype; b1, b2, gamma, beta fp32.
- *   pseld_mlp_bwd_dx: dxh[M, C] = gradient wrt LN(x) = ((s dy) W2 * gelu'(u)) W1 with u recomputed from x. w2t = W2^T [4C, C],
- *                     w1t = W1^T [C, 4C]. (The residual path and the LayerNorm backward are pseld_layernorm_bwd with dres = dy.)
+ *   pseld_mlp_fwd:    y = x + s * (gelu(LN(x) W1^T + b1) W2^T + b2); xh_out (optional, [M, C] in the compute dtype) receives
+ *                     LN(x), the operand the two backward kernels read. w1 [4C, C], w2 [C, 4C] in the compute dtype; b1, b2,
+ *                     gamma, beta fp32.
+ *   pseld_mlp_bwd_dx: dxh[M, C] = gradient wrt LN(x) = ((s dy) W2 * gelu'(u)) W1 with u = xh W1^T + b1 recomputed. w2t = W2^T
+ *                     [4C, C], w1t = W1^T [C, 4C]. (The residual path and the LayerNorm backward: pseld_layernorm_bwd, dres = dy.)
  *   pseld_mlp_bwd_dw: dw1 f32[4C, C], db1 f32[4C], dw2 f32[C, 4C], db2 f32[C] (+)= the four parameter gradients (u and
  *                     gelu(u) recomputed); split over tokens into fp32 slabs in `workspace`, reduced in a fixed order.
  * pseld_mlp_supported: 1 when the fused kernels take (dtype, M, C, rows_per_scale), else 0 (callers then run the layer-wise path). */
 int pseld_mlp_supported(int dtype, long M, int C, int rows_per_scale);
 int pseld_mlp_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
-                  const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, float* mean_rstd,
+                  const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, void* xh_out,
                   long M, int C, float eps, void* stream);
-int pseld_mlp_bwd_dx(int dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* beta,
-                     const void* w1, const float* b1, const void* w2t, const void* w1t, const float* rowscale,
-                     int rows_per_scale, void* dxh, long M, int C, void* stream);
-long pseld_mlp_bwd_dw_workspace(int dtype, long M, int C);
-int pseld_mlp_bwd_dw(int dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* beta,
-                     const void* w1, const float* b1, const void* w2t, const float* rowscale, int rows_per_scale,
-                     float* dw1, float* db1, float* dw2, float* db2, long M, int C, int accumulate, float* workspace,
-                     long workspace_bytes, void* stream);
+int pseld_mlp_bwd_dx(int dtype, const void* xh, const void* dy, const void* w1, const float* b1, const void* w2t,
+                     const void* w1t, const float* rowscale, int rows_per_scale, void* dxh, long M, int C, void* stream);
+long pseld_mlp_bwd_dw_workspace(int dtype, long M, int C, int rows_per_scale);
+/* Diagnostic only: device buffer of 32 x u64 per wave; the forward kernel then records s_memtime stamps (NULL disables). */
+void pseld_mlp_set_debug_buffer(void* device_buffer);
+int pseld_mlp_bwd_dw(int dtype, const void* xh, const void* dy, const void* w1, const float* b1, const void* w2t,
+                     const float* rowscale, int rows_per_scale, float* dw1, float* db1, float* dw2, float* db2, long M,
+                     int C, int accumulate, float* workspace, long workspace_bytes, void* stream);
 
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */

@@ -27,6 +27,7 @@
 // ~18 vector instructions per hidden element against 12-24 MFMA per 32x32 tile), at C = 192 by MFMA issue.
 // f32 (parity mode) instantiates the same bodies on v_mfma_f32_32x32x2_f32 with smaller tiles.
 #include "mma_frag.h"
+#include <stdlib.h>
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate, hipStream_t stream);
 
@@ -35,7 +36,7 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 struct MlpArgs {
-    const void* x;          // [M, C] block input (the residual stream)
+    const void* x;          // fwd: [M, C] block input (the residual stream); backward: LN(x) as saved by the forward
     const void* dy;         // [M, C] gradient wrt the block output (backward)
     void* y;                // fwd: [M, C] block output; bwd_dx: dXh [M, C] (gradient wrt the LayerNorm output)
     const void* w1;         // fc1.weight [H, C]
@@ -47,12 +48,14 @@ struct MlpArgs {
     const float* gamma;     // [C]
     const float* beta;      // [C]
     const float* rowscale;  // DropPath factor per sample (null: 1)
-    float* mean_rstd;       // [M][2]: written by fwd (may be null), read by the backward kernels
+    void* xh_out;           // fwd: LN(x) in the compute dtype [M, C] (null: not wanted) - what the backward kernels read as `x`
     float* slab;            // bwd_dw: [splits][2*H*C + H + C] fp32
     long M;
     int rows_per_scale;
     int tok_per_split, nsplits;
     float eps;
+    unsigned long long* dbg; // diagnostics: per-wave s_memtime stamps of the forward kernel (pseld_mlp_set_debug_buffer), 32 per wave
+    int variant;            // diagnostics (PSELD_MLP_VARIANT): bit 0 = GELU replaced by the identity (wrong results, timing only)
 };
 
 // ---- LDS images: rows of NCH 16-byte chunks, chunk index XOR-swizzled by a function of the row so that (a) 16 different
@@ -73,6 +76,13 @@ __device__ __forceinline__ void dma16(char* lds_dst, const void* src) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+// the same with the source as (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): one VGPR per address
+__device__ __forceinline__ void dma16_so(char* lds_dst, const void* sbase, unsigned voff) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_ptr)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sbase) : "memory");
 }
 // rows [0, NROWS) of NCH chunks each: instruction i of the image is issued by wave (i % nwaves == wave)
 template <int NCH, int NROWS>
@@ -227,9 +237,10 @@ __device__ __forceinline__ void acc_bias_rows(f32x16& u, const float* b1s, int b
 }
 
 // =====================================================================================================================
-// forward
-// LDS: [NBUF weight chunks: W1 rows jc..jc+JC (JC x C) | W2 columns jc..jc+JC (C x JC)] [NW wave-private x tiles] [tables]
-template <typename T, int C, int NW, int JC, int NBUF>
+// forward. A wave owns NT tiles of 32 tokens: the weight fragments it reads from LDS serve all of them, and the GELU of one tile
+// (VALU) is independent of the MFMAs of the other (the two streams interleave inside one wave as well as across waves).
+// LDS: [NBUF weight chunks: W1 rows jc..jc+JC (JC x C) | W2 columns jc..jc+JC (C x JC)] [NW x NT wave-private x tiles] [tables]
+template <typename T, int C, int NW, int NT, int JC, int NBUF, bool PIPE>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs a) {
     using O = Ops<T>;
     using Frag = typename O::Frag;
@@ -238,64 +249,170 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs 
     constexpr int W1B = JC * C * ES, WB = 2 * W1B, XB = 32 * C * ES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wbuf = smem;
-    char* ximg = smem + NBUF * WB + (threadIdx.x >> 6) * XB;
-    float* tab = (float*)(smem + NBUF * WB + NW * XB);               // gamma[C] beta[C] b2[C] b1[H]
+    char* ximg = smem + NBUF * WB + (threadIdx.x >> 6) * NT * XB;    // this wave's NT tiles, back to back
+    float* tab = (float*)(smem + NBUF * WB + NW * NT * XB);          // gamma[C] beta[C] b2[C] b1[H]
     float* gam = tab; float* bet = tab + C; float* b2s = tab + 2 * C; float* b1s = tab + 3 * C;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const long m0 = ((long)blockIdx.x * NW + wave) * 32;
-    const bool live = m0 < a.M;
-    const long m0c = live ? m0 : 0;                                   // idle waves of the last workgroup shadow tile 0 (no stores)
+    const long m0 = ((long)blockIdx.x * NW + wave) * NT * 32;
+    const int ntl = (int)max(0L, min((long)NT, (a.M - m0) / 32));    // live tiles of this wave (the last workgroup may have idle ones)
 
     auto issue_chunk = [&](int jc) {
         char* wb = wbuf + (jc % NBUF) * WB;
         dma_image<NCH1, JC>(wb, (const char*)a.w1 + (long)jc * JC * C * ES, (long)C * ES, wave, NW, lane);
         dma_image<NCH2, C>(wb + W1B, (const char*)a.w2 + (long)jc * JC * ES, (long)H * ES, wave, NW, lane);
     };
+    unsigned long long* dbg = a.dbg ? a.dbg + ((long)blockIdx.x * NW + wave) * 32 : nullptr;
+    int nst = 0;
+    auto stamp = [&]() { if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0 && nst < 32) dbg[nst] = t; ++nst; } };
+    stamp();                                                          // 0: start
     issue_chunk(0);
-    dma_image<NCH1, 32>(ximg, (const char*)a.x + m0c * C * ES, (long)C * ES, 0, 1, lane);
+    float sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long mt = t < ntl ? m0 + 32 * t : 0;                    // idle tiles shadow tile 0 (computed, never stored)
+        dma_image<NCH1, 32>(ximg + t * XB, (const char*)a.x + mt * C * ES, (long)C * ES, 0, 1, lane);
+        sc[t] = a.rowscale ? a.rowscale[(mt + r) / a.rows_per_scale] : 1.f;
+    }
     for (int i = tid; i < C; i += NW * 64) { gam[i] = a.gamma[i]; bet[i] = a.beta[i]; b2s[i] = a.b2[i]; }
     for (int i = tid; i < H; i += NW * 64) b1s[i] = a.b1[i];
-    const float sc = a.rowscale ? a.rowscale[(m0c + r) / a.rows_per_scale] : 1.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();                                                          // 1: own prologue loads landed
     __syncthreads();
+    stamp();                                                          // 2: everybody's
 
-    Frag xh[KS];
-    float mean, rstd;
-    ln_frags<T, C, true>(ximg, gam, bet, a.eps, lane, xh, mean, rstd);
-    if (a.mean_rstd && live && h == 0) *(f32x2*)(a.mean_rstd + (m0 + r) * 2) = f32x2{mean, rstd};
-
-    f32x16 out[CT];
+    Frag xh[NT][KS];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int t = 0; t < NT; ++t) {
+        float mean, rstd;
+        ln_frags<T, C, true>(ximg + t * XB, gam, bet, a.eps, lane, xh[t], mean, rstd);
+        if (a.xh_out && t < ntl) {
+            // the normalised rows for the backward kernels, straight from the fragments: lanes r / r + 32 write the two 16-byte
+            // (32-byte in f32) pieces of one 32-byte row segment per k-step; the six / twelve stores of a row meet in L2
+            char* xo = (char*)a.xh_out + ((m0 + 32 * t + r) * C + 8 * h) * ES;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) out[ct][e] = 0.f;
+            for (int kk = 0; kk < KS; ++kk) {
+                if constexpr (ES == 2) *(bf16x8*)(xo + kk * 32) = xh[t][kk];
+                else {
+                    float v[8];
+                    O::unpack(xh[t][kk], v);
+                    store8<float>((float*)(xo + kk * 64), v);
+                }
+            }
+        }
+    }
 
+    f32x16 out[NT][CT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[t][ct][e] = 0.f;
+
+    stamp();                                                          // 3: LayerNorm done, xh stored
     for (int jc = 0; jc < NJ; ++jc) {
         if (NBUF == 2 && jc + 1 < NJ) issue_chunk(jc + 1);
         const char* w1i = wbuf + (jc % NBUF) * WB;
         const char* w2i = w1i + W1B;
+        if constexpr (PIPE) {
+            // Software pipeline over the chunk's 32-unit steps (one tile per wave): while the VALU evaluates gelu(U_s), the matrix
+            // pipe runs the out-MFMAs of step s - 1 and the U-MFMAs of step s + 1, interleaved in PROGRAM order (an in-order wave
+            // cannot issue VALU work behind a queued MFMA): a step is cut into 8 slices of {1-2 MFMAs whose operand fragments were
+            // read one slice earlier, one pair of GELU evaluations}, pinned by sched_barrier(0). The two waves of a SIMD run this
+            // loop in lock-step (one barrier per chunk re-aligns them), so without the interleave the two pipes alternate instead
+            // of overlapping - s_memtime stamps: chunk time = MFMA-only time + GELU-only time.
+            static_assert(NT == 1, "the pipelined loop is written for one tile per wave");
+            constexpr int NOP = 2 * CT + KS, NSL = 8;                 // MFMA operations of a full step; slices per step
+            f32x16 uu[2];
+            Frag hb[2][2];
+            // operation k of step `sub`: k < 2 CT: out[ct] += W2[.., step sub - 1, half s] * h(step sub - 1); else U(step sub + 1) += W1 * xh[kk]
+            auto op_frag = [&](int sub, int k) -> Frag {
+                if (k < 2 * CT) return O::template ldrow<NCH2>(w2i, 32 * (k % CT) + r, 4 * (sub - 1) + 2 * (k / CT) + h);
+                return O::template ldrow<NCH1>(w1i, 32 * (sub + 1) + swap23(r), 2 * (k - 2 * CT) + h);
+            };
+            auto op_run = [&](int sub, int k, const Frag& w) {
+                if (k < 2 * CT) AMma<T>::mma(w, hb[(sub - 1) & 1][k / CT], out[0][k % CT]);
+                else AMma<T>::mma(w, xh[0][k - 2 * CT], uu[(sub + 1) & 1]);
+            };
+            {   // U of the chunk's first step: nothing to hide it behind
+                acc_bias_rows(uu[0], b1s, jc * JC, h);
 #pragma unroll
-        for (int sub = 0; sub < SUBS; ++sub) {
-            f32x16 u;
-            acc_bias_rows(u, b1s, jc * JC + 32 * sub, h);
+                for (int kk = 0; kk < KS; ++kk) AMma<T>::mma(O::template ldrow<NCH1>(w1i, swap23(r), 2 * kk + h), xh[0][kk], uu[0]);
+            }
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-                AMma<T>::mma(O::template ldrow<NCH1>(w1i, 32 * sub + swap23(r), 2 * kk + h), xh[kk], u);
+            for (int sub = 0; sub < SUBS; ++sub) {
+                const int k0 = sub > 0 ? 0 : 2 * CT, k1 = sub + 1 < SUBS ? NOP : 2 * CT, nk = k1 - k0;   // this step's operations [k0, k1)
+                if (sub + 1 < SUBS) acc_bias_rows(uu[(sub + 1) & 1], b1s, jc * JC + 32 * (sub + 1), h);
+                Frag fr[2];                                            // operand fragments of the coming slice (at most 2 operations per slice)
+                {
+                    const int e1 = nk / NSL;                          // operations of slice 0: [0, e1)
+                    if (0 < e1) fr[0] = op_frag(sub, k0);
+                    if (1 < e1) fr[1] = op_frag(sub, k0 + 1);
+                }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) u[e] = gelu_f(u[e]);
+                for (int i = 0; i < NSL; ++i) {
+                    const int b0 = i * nk / NSL, b1 = (i + 1) * nk / NSL, b2 = (i + 2) * nk / NSL;
+                    const Frag f0 = fr[0], f1 = fr[1];
+                    if (b0 < b1) op_run(sub, k0 + b0, f0);
+                    if (b0 + 1 < b1) op_run(sub, k0 + b0 + 1, f1);
+                    if (i + 1 < NSL) {
+                        if (b1 < b2) fr[0] = op_frag(sub, k0 + b1);
+                        if (b1 + 1 < b2) fr[1] = op_frag(sub, k0 + b1 + 1);
+                    }
+                    uu[sub & 1][2 * i] = gelu_f(uu[sub & 1][2 * i]);
+                    uu[sub & 1][2 * i + 1] = gelu_f(uu[sub & 1][2 * i + 1]);
+                    // the slice as a scheduling pipeline: its MFMAs, the operand reads of the next slice, then the GELU pair
+                    if (b1 - b0 == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (b1 - b0 == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (i + 1 < NSL && b2 - b1 == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i + 1 < NSL && b2 - b1 == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 28, 0);
+                }
+                hb[sub & 1][0] = AMma<T>::from_acc(uu[sub & 1], 0);
+                hb[sub & 1][1] = AMma<T>::from_acc(uu[sub & 1], 1);
+            }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const Frag hb = AMma<T>::from_acc(u, s);
+            for (int k = 0; k < 2 * CT; ++k) op_run(SUBS, k, op_frag(SUBS, k));     // out-MFMAs of the chunk's last step
+        } else {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    AMma<T>::mma(O::template ldrow<NCH2>(w2i, 32 * ct + r, 4 * sub + 2 * s + h), hb, out[ct]);
+            for (int sub = 0; sub < SUBS; ++sub) {
+                f32x16 u[NT];
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) acc_bias_rows(u[t], b1s, jc * JC + 32 * sub, h);
+    #pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const Frag w = O::template ldrow<NCH1>(w1i, 32 * sub + swap23(r), 2 * kk + h);
+    #pragma unroll
+                    for (int t = 0; t < NT; ++t) AMma<T>::mma(w, xh[t][kk], u[t]);
+                }
+                Frag hb[NT][2];
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (!(a.variant & 1)) {
+    #pragma unroll
+                        for (int e = 0; e < 16; ++e) u[t][e] = gelu_f(u[t][e]);
+                    }
+                    hb[t][0] = AMma<T>::from_acc(u[t], 0);
+                    hb[t][1] = AMma<T>::from_acc(u[t], 1);
+                }
+    #pragma unroll
+                for (int s = 0; s < 2; ++s)
+    #pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const Frag w = O::template ldrow<NCH2>(w2i, 32 * ct + r, 4 * sub + 2 * s + h);
+    #pragma unroll
+                        for (int t = 0; t < NT; ++t) AMma<T>::mma(w, hb[t][s], out[t][ct]);
+                    }
             }
         }
         if (NBUF == 2) {
+            stamp();                                                // 4 + 3 jc: chunk computed
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of chunk jc + 1 has landed
+            stamp();                                                // 5 + 3 jc
             __syncthreads();                                        // ... everybody's has, and everybody is done with chunk jc
+            stamp();                                                // 6 + 3 jc
         } else if (jc + 1 < NJ) {
             __syncthreads();
             issue_chunk(jc + 1);
@@ -305,57 +422,61 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs 
     }
 
     // y[m][c] = x + sc * (out + b2): Out^T register e of tile ct is channel 32 ct + (e & 3) + 8 (e >> 2) + 4 h of token r. The wave
-    // rewrites its x image in place (4 channels per access), then streams the image out as whole 16-byte chunks.
+    // rewrites its x images in place (4 channels per access), then streams them out as whole 16-byte chunks.
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int t = 0; t < NT; ++t) {
+        char* xim = ximg + t * XB;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 32 * ct + 8 * g + 4 * h;
-            char* p = ximg + chunk_off<NCH1>(r, c0 / EPC) + (c0 % EPC) * ES;
-            const f32x4 bb = *(const f32x4*)(b2s + c0);
-            float xv[4];
-            if constexpr (ES == 2) { const bf16x4 t = *(const bf16x4*)p; for (int j = 0; j < 4; ++j) xv[j] = (float)t[j]; }
-            else { const f32x4 t = *(const f32x4*)p; for (int j = 0; j < 4; ++j) xv[j] = t[j]; }
-            float o[4];
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = fmaf(out[ct][4 * g + j] + bb[j], sc, xv[j]);
-            store4<T>(p, o[0], o[1], o[2], o[3]);
-        }
-    if (live) {
-        char* yg = (char*)a.y + m0 * C * ES;
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * ct + 8 * g + 4 * h;
+                char* p = xim + chunk_off<NCH1>(r, c0 / EPC) + (c0 % EPC) * ES;
+                const f32x4 bb = *(const f32x4*)(b2s + c0);
+                float xv[4];
+                if constexpr (ES == 2) { const bf16x4 v = *(const bf16x4*)p; for (int j = 0; j < 4; ++j) xv[j] = (float)v[j]; }
+                else { const f32x4 v = *(const f32x4*)p; for (int j = 0; j < 4; ++j) xv[j] = v[j]; }
+                float o[4];
 #pragma unroll
-        for (int i = 0; i < 32 * NCH1 / 64; ++i) {
-            const int q = i * 64 + lane, row = q / NCH1, ch = q - row * NCH1;
-            *(f32x4*)(yg + (long)row * C * ES + ((ch ^ swz<NCH1>(row)) << 4)) = *(const f32x4*)(ximg + q * 16);
+                for (int j = 0; j < 4; ++j) o[j] = fmaf(out[t][ct][4 * g + j] + bb[j], sc[t], xv[j]);
+                store4<T>(p, o[0], o[1], o[2], o[3]);
+            }
+        if (t < ntl) {
+            char* yg = (char*)a.y + (m0 + 32 * t) * C * ES;
+#pragma unroll
+            for (int i = 0; i < 32 * NCH1 / 64; ++i) {
+                const int q = i * 64 + lane, row = q / NCH1, ch = q - row * NCH1;
+                *(f32x4*)(yg + (long)row * C * ES + ((ch ^ swz<NCH1>(row)) << 4)) = *(const f32x4*)(xim + q * 16);
+            }
         }
     }
+    stamp();                                                          // last: stores issued
 }
 
 // =====================================================================================================================
 // backward, input gradient:  dXh^T[c][m] = sum_j W1[j][c] dU^T[j][m],  dU^T = (W2^T dYs^T) * gelu'(U^T),  dYs = s * dY
-// LDS: [NBUF chunks: W1 rows (JC x C) | W2^T rows (JC x C) | W1^T columns (C x JC)] [NW x (x tile, dY tile)] [tables]
-// SHARE: the x tile and the dY tile use ONE wave-private region, one after the other (C = 192: two regions do not fit beside the
-// double-buffered weight chunks)
-template <typename T, int C, int NW, int JC, int NBUF, bool SHARE>
+// LDS: [NBUF chunks: W1 rows (JC x C) | W2^T rows (JC x C) | W1^T columns (C x JC)] [NW x NT x (Xh tile, dY tile)] [b1]
+// SHARE: the Xh tile and the dY tile use ONE wave-private region, one after the other (C = 192: two regions do not fit beside the
+// double-buffered weight chunks; needs XREG). XREG: the Xh / dYs operand fragments stay in registers; otherwise (NT = 2) they are
+// re-read from the wave's images per 32-unit step, the dY image having been scaled by the DropPath factor in place.
+template <typename T, int C, int NW, int NT, int JC, int NBUF, bool SHARE, bool XREG>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpArgs a) {
     using O = Ops<T>;
     using Frag = typename O::Frag;
+    static_assert(!SHARE || XREG, "a shared tile region keeps the operands in registers");
     constexpr int H = 4 * C, ES = (int)sizeof(T), EPC = O::EPC, KS = C / 16, CT = C / 32, NJ = H / JC, SUBS = JC / 32;
     constexpr int NCH1 = C / EPC, NCH2 = JC / EPC;
     constexpr int W1B = JC * C * ES, WB = 3 * W1B, XB = 32 * C * ES;
+    constexpr int NREG = SHARE ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wbuf = smem;
-    constexpr int NST = SHARE ? 1 : 2;
-    char* ximg = smem + NBUF * WB + (threadIdx.x >> 6) * NST * XB;
-    char* dimg = SHARE ? ximg : ximg + XB;
-    float* tab = (float*)(smem + NBUF * WB + NW * NST * XB);         // gamma[C] beta[C] b1[H]
-    float* gam = tab; float* bet = tab + C; float* b1s = tab + 2 * C;
+    char* tiles = smem + NBUF * WB + (threadIdx.x >> 6) * NT * NREG * XB;     // tile t: Xh image, then (unless shared) its dY image
+    float* b1s = (float*)(smem + NBUF * WB + NW * NT * NREG * XB);            // b1[H]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const long m0 = ((long)blockIdx.x * NW + wave) * 32;
-    const bool live = m0 < a.M;
-    const long m0c = live ? m0 : 0;
+    const long m0 = ((long)blockIdx.x * NW + wave) * NT * 32;
+    const int ntl = (int)max(0L, min((long)NT, (a.M - m0) / 32));
 
     auto issue_chunk = [&](int jc) {
         char* wb = wbuf + (jc % NBUF) * WB;
@@ -364,41 +485,61 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
         dma_image<NCH2, C>(wb + 2 * W1B, (const char*)a.w1t + (long)jc * JC * ES, (long)H * ES, wave, NW, lane);
     };
     issue_chunk(0);
-    dma_image<NCH1, 32>(ximg, (const char*)a.x + m0c * C * ES, (long)C * ES, 0, 1, lane);
-    if constexpr (!SHARE) dma_image<NCH1, 32>(dimg, (const char*)a.dy + m0c * C * ES, (long)C * ES, 0, 1, lane);
-    for (int i = tid; i < C; i += NW * 64) { gam[i] = a.gamma[i]; bet[i] = a.beta[i]; }
+    float sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long mt = t < ntl ? m0 + 32 * t : 0;
+        char* xim = tiles + t * NREG * XB;
+        dma_image<NCH1, 32>(xim, (const char*)a.x + mt * C * ES, (long)C * ES, 0, 1, lane);
+        if constexpr (!SHARE) dma_image<NCH1, 32>(xim + XB, (const char*)a.dy + mt * C * ES, (long)C * ES, 0, 1, lane);
+        sc[t] = a.rowscale ? a.rowscale[(mt + r) / a.rows_per_scale] : 1.f;
+    }
     for (int i = tid; i < H; i += NW * 64) b1s[i] = a.b1[i];
-    const float sc = a.rowscale ? a.rowscale[(m0c + r) / a.rows_per_scale] : 1.f;
-    const f32x2 mr = *(const f32x2*)(a.mean_rstd + (m0c + r) * 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    Frag xh[KS], dys[KS];
-    {
-        float mean = mr[0], rstd = mr[1];
-        ln_frags<T, C, false>(ximg, gam, bet, 0.f, lane, xh, mean, rstd);
-    }
-    if constexpr (SHARE) {
-        // the wave has its x rows in registers: the same region now takes its dY rows (wave-private: only this wave's own
-        // reads, drained by the lgkmcnt, and its own DMA, retired by the vmcnt, are involved)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_image<NCH1, 32>(dimg, (const char*)a.dy + m0c * C * ES, (long)C * ES, 0, 1, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    Frag xh[XREG ? NT : 1][KS], dys[XREG ? NT : 1][KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        float v[8];
-        O::unpack(O::template ldrow<NCH1>(dimg, r, 2 * kk + h), v);
+    for (int t = 0; t < NT; ++t) {
+        char* xim = tiles + t * NREG * XB;
+        char* dim = SHARE ? xim : xim + XB;
+        if constexpr (XREG) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= sc;
-        dys[kk] = O::pack(v);
+            for (int kk = 0; kk < KS; ++kk) xh[t][kk] = O::template ldrow<NCH1>(xim, r, 2 * kk + h);
+        }
+        if constexpr (SHARE) {
+            // the wave has its Xh rows in registers: the same region now takes its dY rows (wave-private: only this wave's own
+            // reads, drained by the lgkmcnt, and its own DMA, retired by the vmcnt, are involved)
+            const long mt = t < ntl ? m0 + 32 * t : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_image<NCH1, 32>(dim, (const char*)a.dy + mt * C * ES, (long)C * ES, 0, 1, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            float v[8];
+            O::unpack(O::template ldrow<NCH1>(dim, r, 2 * kk + h), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= sc[t];
+            if constexpr (XREG) dys[t][kk] = O::pack(v);
+            else {                                                    // scaled in place: each lane owns the chunks it will read back
+                const Frag f = O::pack(v);
+                if constexpr (ES == 2) *(bf16x8*)(dim + chunk_off<NCH1>(r, 2 * kk + h)) = f;
+                else {
+                    store4<float>(dim + chunk_off<NCH1>(r, 2 * (2 * kk + h)), v[0], v[1], v[2], v[3]);
+                    store4<float>(dim + chunk_off<NCH1>(r, 2 * (2 * kk + h) + 1), v[4], v[5], v[6], v[7]);
+                }
+            }
+        }
     }
 
-    f32x16 dxh[CT];
+    f32x16 dxh[NT][CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dxh[ct][e] = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dxh[t][ct][e] = 0.f;
 
     for (int jc = 0; jc < NJ; ++jc) {
         if (NBUF == 2 && jc + 1 < NJ) issue_chunk(jc + 1);
@@ -407,25 +548,51 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
         const char* w1ti = w1i + 2 * W1B;
 #pragma unroll
         for (int sub = 0; sub < SUBS; ++sub) {
-            f32x16 u, dh;
-            acc_bias_rows(u, b1s, jc * JC + 32 * sub, h);
+            f32x16 u[NT], dh[NT];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dh[e] = 0.f;
+            for (int t = 0; t < NT; ++t) {
+                acc_bias_rows(u[t], b1s, jc * JC + 32 * sub, h);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dh[t][e] = 0.f;
+            }
             const int wrow = 32 * sub + swap23(r);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                AMma<T>::mma(O::template ldrow<NCH1>(w1i, wrow, 2 * kk + h), xh[kk], u);
-                AMma<T>::mma(O::template ldrow<NCH1>(w2ti, wrow, 2 * kk + h), dys[kk], dh);
+                const Frag wa = O::template ldrow<NCH1>(w1i, wrow, 2 * kk + h);
+                const Frag wb = O::template ldrow<NCH1>(w2ti, wrow, 2 * kk + h);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (XREG) {
+                        AMma<T>::mma(wa, xh[t][kk], u[t]);
+                        AMma<T>::mma(wb, dys[t][kk], dh[t]);
+                    } else {
+                        const char* xim = tiles + t * NREG * XB;
+                        AMma<T>::mma(wa, O::template ldrow<NCH1>(xim, r, 2 * kk + h), u[t]);
+                        AMma<T>::mma(wb, O::template ldrow<NCH1>(xim + XB, r, 2 * kk + h), dh[t]);
+                    }
+                }
+            }
+            Frag ub[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (!(a.variant & 1)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * gelu_grad_f(u[t][e]);        // dU^T
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * u[t][e];
+                }
+                ub[t][0] = AMma<T>::from_acc(u[t], 0);
+                ub[t][1] = AMma<T>::from_acc(u[t], 1);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) u[e] = dh[e] * gelu_grad_f(u[e]);        // dU^T
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const Frag ub = AMma<T>::from_acc(u, s);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const Frag w = O::template ldrow<NCH2>(w1ti, 32 * ct + r, 4 * sub + 2 * s + h);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    AMma<T>::mma(O::template ldrow<NCH2>(w1ti, 32 * ct + r, 4 * sub + 2 * s + h), ub, dxh[ct]);
-            }
+                    for (int t = 0; t < NT; ++t) AMma<T>::mma(w, ub[t][s], dxh[t][ct]);
+                }
         }
         if (NBUF == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,19 +606,23 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
     }
     // dXh[m][c] through the wave's dY image (same chunk order as the input tiles), then out as 16-byte chunks
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int t = 0; t < NT; ++t) {
+        char* dim = tiles + t * NREG * XB + (SHARE ? 0 : XB);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 32 * ct + 8 * g + 4 * h;
-            char* p = dimg + chunk_off<NCH1>(r, c0 / EPC) + (c0 % EPC) * ES;
-            store4<T>(p, dxh[ct][4 * g], dxh[ct][4 * g + 1], dxh[ct][4 * g + 2], dxh[ct][4 * g + 3]);
-        }
-    if (live) {
-        char* yg = (char*)a.y + m0 * C * ES;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int i = 0; i < 32 * NCH1 / 64; ++i) {
-            const int q = i * 64 + lane, row = q / NCH1, ch = q - row * NCH1;
-            *(f32x4*)(yg + (long)row * C * ES + ((ch ^ swz<NCH1>(row)) << 4)) = *(const f32x4*)(dimg + q * 16);
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * ct + 8 * g + 4 * h;
+                char* p = dim + chunk_off<NCH1>(r, c0 / EPC) + (c0 % EPC) * ES;
+                store4<T>(p, dxh[t][ct][4 * g], dxh[t][ct][4 * g + 1], dxh[t][ct][4 * g + 2], dxh[t][ct][4 * g + 3]);
+            }
+        if (t < ntl) {
+            char* yg = (char*)a.y + (m0 + 32 * t) * C * ES;
+#pragma unroll
+            for (int i = 0; i < 32 * NCH1 / 64; ++i) {
+                const int q = i * 64 + lane, row = q / NCH1, ch = q - row * NCH1;
+                *(f32x4*)(yg + (long)row * C * ES + ((ch ^ swz<NCH1>(row)) << 4)) = *(const f32x4*)(dim + q * 16);
+            }
         }
     }
 }
@@ -462,29 +633,24 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
 //   dH[m][j] = dY W2                 A = dY rows,         B = W2^T rows (registers)
 //   dW2^T[j][c] += (s H)^T dY, dW1[j][c] += dU^T Xh, dU = s dH gelu'(U)
 //                                    A = the accumulators (rows = tokens), B = transposed reads of the images
-// The DropPath factor s is uniform over a 32-token sub-tile (rows_per_scale % 32 == 0) and is applied to the accumulators.
-// Token tiles arrive raw by LDS-DMA one tile ahead (x, dY, mean / rstd); a conversion pass (LDS -> registers -> LDS) normalises
-// x into the swizzled Xh image and copies dY into its image, so no staging register lives across the MFMA phase.
-// LDS: [2 x raw (x TT x C | dY TT x C | mean,rstd 1 KiB)] [Xh image | dY image] [gamma, beta]
-template <typename T, int C, int NW, int TT, bool WREG, int WPS>
+// The DropPath factor s is uniform over a 32-token sub-tile (rows_per_scale % 32 == 0) and is applied to the accumulators; the
+// factors of the (at most 4 / 8) samples a split touches are fetched once. Token tiles (Xh rows, dY rows) arrive by LDS-DMA straight
+// into their swizzled images, NST - 1 tiles ahead (counted vmcnt, one barrier per tile): nothing is staged through registers.
+// LDS: [NST x (Xh image TT x C | dY image TT x C)]
+template <typename T, int C, int NW, int TT, int NST, bool WREG, int WPS>
 __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
     using O = Ops<T>;
     using Frag = typename O::Frag;
-    constexpr int H = 4 * C, ES = (int)sizeof(T), EPC = O::EPC, KS = C / 16, CT = C / 32, NTH = NW * 64;
-    constexpr int NCH = C / EPC, IMG = TT * C * ES, NOWN = H / (32 * NW), RAW = 2 * IMG + 1024;
-    constexpr int CPT = TT * NCH / NTH;                               // 16-byte chunks per thread per image per tile
-    constexpr int NINSTR = IMG / 1024;                                // DMA instructions per raw image
-    static_assert(TT * NCH % NTH == 0 && H % (32 * NW) == 0 && TT % 32 == 0 && TT <= 128, "tile geometry");
+    constexpr int H = 4 * C, ES = (int)sizeof(T), EPC = O::EPC, KS = C / 16, CT = C / 32;
+    constexpr int NCH = C / EPC, IMG = TT * C * ES, NOWN = H / (32 * NW);
+    constexpr int NINSTR = IMG / 1024, LPW = 2 * NINSTR / NW;         // DMA instructions per image; per wave per tile
+    static_assert(2 * NINSTR % NW == 0 && H % (32 * NW) == 0 && TT % 32 == 0 && NST >= 2, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xi = smem + 2 * RAW;
-    char* di = xi + IMG;
-    float* gam = (float*)(di + IMG);
-    float* bet = gam + C;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // the NOWN owners of one token split get ids that are congruent mod 8: one XCD, so the split's x / dY tiles are fetched
-    // from HBM once and served to the other owners by that XCD's L2 (speed only)
+    // the NOWN owners of one token split get ids that are congruent mod 8: one XCD, so the split's tiles are fetched from HBM
+    // once and served to the other owners by that XCD's L2 (speed only)
     const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
     const int owner = jj % NOWN, split = (jj / NOWN) * 8 + xcd;
     if (split >= a.nsplits) return;
@@ -492,20 +658,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
     const long tok1 = min(a.M, tok0 + a.tok_per_split);
     const int ntiles = (int)((tok1 - tok0 + TT - 1) / TT);
     const int j0 = (owner * NW + wave) * 32;                           // this wave's hidden units j0 .. j0 + 31 (lane r <-> j0 + r)
-
-    auto issue_raw = [&](int t) {
-        char* raw = smem + (t & 1) * RAW;
-        const long tbase = tok0 + (long)t * TT;
-        for (int i = wave; i < NINSTR; i += NW) {
-            const int q = i * 64 + lane, row = q / NCH, ch = q - row * NCH;
-            const long off = (min(tbase + row, a.M - 1) * C + ch * EPC) * ES;          // rows past the end shadow the last token
-            dma16(raw + i * 1024, (const char*)a.x + off);
-            dma16(raw + IMG + i * 1024, (const char*)a.dy + off);
-        }
-        if (wave == 0) dma16(raw + 2 * IMG, (const char*)(a.mean_rstd + min(tbase + 2 * lane, a.M - 2) * 2));   // 2 rows per lane
-    };
-    issue_raw(0);
-    for (int i = tid; i < C; i += NTH) { gam[i] = a.gamma[i]; bet[i] = a.beta[i]; }
 
     Frag w1f[WREG ? KS : 1], w2tf[WREG ? KS : 1];
     const char* w1p = (const char*)a.w1 + ((long)(j0 + r) * C + 8 * h) * ES;
@@ -515,13 +667,62 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
         for (int kk = 0; kk < KS; ++kk) { w1f[kk] = O::ldglobal(w1p + kk * 16 * ES); w2tf[kk] = O::ldglobal(w2tp + kk * 16 * ES); }
     }
     const float b1v = a.b1[j0 + r];
-    auto scale_of = [&](int t, int mt) -> float {
-        const long tok = min(tok0 + (long)t * TT + 32 * mt, a.M - 1);
-        return a.rowscale ? a.rowscale[tok / a.rows_per_scale] : 1.f;
-    };
-    float scn[TT / 32];
+    const int samp0 = (int)(tok0 / a.rows_per_scale), samp_last = (int)((a.M - 1) / a.rows_per_scale);
+    constexpr int NSC = WPS > 1 ? 4 : 8;                               // samples a split may touch (dw_plan caps the split length)
+    float scv[NSC];
 #pragma unroll
-    for (int mt = 0; mt < TT / 32; ++mt) scn[mt] = scale_of(0, mt);
+    for (int i = 0; i < NSC; ++i) scv[i] = a.rowscale ? a.rowscale[min(samp0 + i, samp_last)] : 1.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the compiler-visible loads are retired before the DMA ring starts
+
+    // sources as (split base in SGPRs) + (32-bit lane offset), recomputed per tile from a laundered lane id: hoisted out of the tile
+    // loop the LPW 64-bit lane addresses get spilled, and their reload (a scratch load hipcc waits for with vmcnt) drains the ring
+    const char* xs = (const char*)a.x + tok0 * (long)(C * ES);
+    const char* ds = (const char*)a.dy + tok0 * (long)(C * ES);
+    const int rel_last = (int)(a.M - 1 - tok0);
+    auto issue = [&](int t) {
+        char* slot = smem + (t % NST) * 2 * IMG;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int k = 0; k < LPW; ++k) {
+            const int i = wave + NW * k;                               // instruction i of the tile: [0, NINSTR) Xh image, then the dY image
+            const int ii = i < NINSTR ? i : i - NINSTR;
+            const int q = ii * 64 + ln, row = q / NCH, ch = q - row * NCH;
+            const unsigned off = (unsigned)(min(t * TT + row, rel_last) * (C * ES) + ((ch ^ swz<NCH>(row)) << 4));   // rows past the end: never read
+            dma16_so(slot + i * 1024, __builtin_amdgcn_readfirstlane(i < NINSTR) ? xs : ds, off);
+        }
+    };
+
+    // Operand addresses. Generic: chunk_off() per fragment (the compiler keeps ~36 lane-dependent addresses live). For the 192-byte
+    // rows of C = 96 bf16 the swizzle term is a lane constant once the row is written as tile base + lane part: four lane constants
+    // and immediates replace them (what lets this kernel run two waves per SIMD without spilling - a spill reload inside the loop
+    // makes hipcc wait vmcnt(0), which drains the hand-counted DMA ring).
+    constexpr bool FASTADDR = (NCH == 12 && ES == 2);
+    int ar0 = 0, ar1 = 0, ac0 = 0, ac1 = 0;
+    if constexpr (FASTADDR) {
+        const int sr = (r >> 2) & 3;                                   // rows 32 mt + r: ((row >> 2) & 3) == ((r >> 2) & 3)
+        ar0 = r * 192 + ((h ^ sr) << 4);                               // k-steps kk even: chunk 4 (kk >> 1) + (h ^ sr)
+        ar1 = r * 192 + (((2 + h) ^ sr) << 4);                         //          kk odd:  chunk 4 (kk >> 1) + ((2 + h) ^ sr)
+        const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, gsel = (lane >> 4) & 1, lo2 = 2 * gsel + (p4 >> 1);
+        // transposed reads: rows 32 mt + 16 s + 4 h + q (swizzle term h) and + 8 (term h + 2), columns 32 ct + 16 gsel + 4 p4
+        ac0 = (4 * h + q) * 192 + ((lo2 ^ h) << 4) + (p4 & 1) * 8;
+        ac1 = (4 * h + q + 8) * 192 + ((lo2 ^ (h + 2)) << 4) + (p4 & 1) * 8;
+    }
+    auto rowfrag = [&](const char* img, int mt, int kk) -> Frag {
+        if constexpr (FASTADDR) return *(const bf16x8*)(img + ((kk & 1) ? ar1 : ar0) + mt * (32 * 192) + (kk >> 1) * 64);
+        else return O::template ldrow<NCH>(img, 32 * mt + r, 2 * kk + h);
+    };
+    auto colfrag = [&](const char* img, int mt, int s, int ct) -> Frag {
+        if constexpr (FASTADDR) {
+            const char* b = img + (32 * mt + 16 * s) * 192 + ct * 64;
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(b + ac0));
+            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(b + ac1));
+            short8v v;
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            return __builtin_bit_cast(Frag, v);
+        } else return O::template ldcols<NCH>(img, 32 * mt + 16 * s, 32 * ct, lane);
+    };
 
     f32x16 dw2t[CT], dw1[CT];
 #pragma unroll
@@ -533,56 +734,32 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
     for (int ct = 0; ct < CT; ++ct) db2[ct] = 0.f;
     const bool do_db2 = owner == 0 && wave == 0;
 
+    unsigned long long* dbg = a.dbg ? a.dbg + ((long)blockIdx.x * NW + wave) * 32 : nullptr;
+    int nst = 0;
+    auto stamp = [&]() { if (dbg) { const unsigned long long tm = __builtin_amdgcn_s_memtime(); if (lane == 0 && nst < 32) dbg[nst] = tm; ++nst; } };
+    stamp();
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < ntiles) issue(p);
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's share of raw tile t (and the first pass's tables / weights)
-        __syncthreads();                                               // ... everybody's; and everybody has left the images of tile t - 1
-        if (t + 1 < ntiles) issue_raw(t + 1);                          // its buffer was last read by the conversion of tile t - 1
-        float sc[TT / 32];
-#pragma unroll
-        for (int mt = 0; mt < TT / 32; ++mt) sc[mt] = scn[mt];
-        if (t + 1 < ntiles) {
-#pragma unroll
-            for (int mt = 0; mt < TT / 32; ++mt) scn[mt] = scale_of(t + 1, mt);
-        }
-        {   // conversion: raw tile -> Xh image (LayerNorm applied, compute dtype) and dY image; rows past the split become zeros
-            const char* raw = smem + (t & 1) * RAW;
-            const float* mr = (const float*)(raw + 2 * IMG);
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const int q = tid + i * NTH, row = q / NCH, ch = q - row * NCH;
-                const bool in = tok0 + (long)t * TT + row < tok1;
-                const f32x4 vx = *(const f32x4*)(raw + q * 16), vd = *(const f32x4*)(raw + IMG + q * 16);
-                const float mean = mr[2 * row], rstd = mr[2 * row + 1];
-                f32x4 ox, od;
-                const float keep = in ? 1.f : 0.f;                     // (straight-line: every load unconditional)
-                if constexpr (ES == 2) {
-                    const bf16x8 bx = __builtin_bit_cast(bf16x8, vx);
-                    const f32x4 g0 = *(const f32x4*)(gam + ch * 8), g1 = *(const f32x4*)(gam + ch * 8 + 4);
-                    const f32x4 e0 = *(const f32x4*)(bet + ch * 8), e1 = *(const f32x4*)(bet + ch * 8 + 4);
-                    bf16x8 px;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        px[k] = (bf16_t)((((float)bx[k] - mean) * rstd * g0[k] + e0[k]) * keep);
-                        px[4 + k] = (bf16_t)((((float)bx[4 + k] - mean) * rstd * g1[k] + e1[k]) * keep);
-                    }
-                    ox = __builtin_bit_cast(f32x4, px);
-                } else {
-                    const f32x4 g0 = *(const f32x4*)(gam + ch * 4), e0 = *(const f32x4*)(bet + ch * 4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) ox[k] = ((vx[k] - mean) * rstd * g0[k] + e0[k]) * keep;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { const float v = vd[k]; od[k] = in ? v : 0.f; }   // (bit pattern kept: a pure select)
-                *(f32x4*)(xi + chunk_off<NCH>(row, ch)) = ox;
-                *(f32x4*)(di + chunk_off<NCH>(row, ch)) = od;
-            }
-        }
-        __syncthreads();
+        if (t >= 4 && t < 11) stamp();                                 // (diagnostic: tiles 4..10: top, after the wait, after the barrier + issue)
+        // tile t has landed once at most the younger tiles' DMAs of this wave are outstanding (the tail has none in flight)
+        if (ntiles - 1 - t >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t >= 4 && t < 11) stamp();
+        __builtin_amdgcn_s_barrier();                                  // everybody's share has; and everybody has left tile t - 1
+        if (t + NST - 1 < ntiles) issue(t + NST - 1);                  // into the slot of tile t - 1
+        if (t >= 4 && t < 11) stamp();
+        const char* xi = smem + (t % NST) * 2 * IMG;
+        const char* di = xi + IMG;
+        const long tbase = tok0 + (long)t * TT;
+        const int nsub = (int)(min((long)TT, tok1 - tbase) / 32);
 #pragma unroll 1
-        for (int mt = 0; mt < TT / 32; ++mt) {
-            float s_mt = sc[0];
+        for (int mt = 0; mt < nsub; ++mt) {
+            const int rel = (int)((tbase + 32 * mt) / a.rows_per_scale) - samp0;
+            float s_mt = scv[0];
 #pragma unroll
-            for (int k = 1; k < TT / 32; ++k) s_mt = (mt == k) ? sc[k] : s_mt;
+            for (int k = 1; k < NSC; ++k) s_mt = (rel == k) ? scv[k] : s_mt;
             f32x16 u, dh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { u[e] = b1v; dh[e] = 0.f; }
@@ -591,25 +768,31 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
                 Frag bw1, bw2;
                 if constexpr (WREG) { bw1 = w1f[kk]; bw2 = w2tf[kk]; }
                 else { bw1 = O::ldglobal(w1p + kk * 16 * ES); bw2 = O::ldglobal(w2tp + kk * 16 * ES); }
-                AMma<T>::mma(O::template ldrow<NCH>(xi, 32 * mt + r, 2 * kk + h), bw1, u);
-                AMma<T>::mma(O::template ldrow<NCH>(di, 32 * mt + r, 2 * kk + h), bw2, dh);
+                AMma<T>::mma(rowfrag(xi, mt, kk), bw1, u);
+                AMma<T>::mma(rowfrag(di, mt, kk), bw2, dh);
             }
-            // (rows of padding tokens: xh = 0 gives u = b1, but their dY rows are 0: dU = 0, and H meets dY = 0)
+            if (!(a.variant & 1)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float hv, gv;
-                gelu_both(u[e], hv, gv);
-                u[e] = hv * s_mt;                                      // s H
-                dh[e] *= gv * s_mt;                                    // dU
-                db1 += dh[e];
+                for (int e = 0; e < 16; ++e) {
+                    float hv, gv;
+                    gelu_both(u[e], hv, gv);
+                    u[e] = hv * s_mt;                                      // s H
+                    dh[e] *= gv * s_mt;                                    // dU
+                    db1 += dh[e];
+                    // four evaluations in flight at a time: left alone the scheduler interleaves all sixteen (~100 live temporaries)
+                    if (WPS > 1 && (e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { dh[e] *= u[e] * s_mt; u[e] *= s_mt; db1 += dh[e]; }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag ah = AMma<T>::from_acc(u, s), au = AMma<T>::from_acc(dh, s);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const Frag bd = O::template ldcols<NCH>(di, 32 * mt + 16 * s, 32 * ct, lane);
-                    const Frag bx = O::template ldcols<NCH>(xi, 32 * mt + 16 * s, 32 * ct, lane);
+                    const Frag bd = colfrag(di, mt, s, ct);
+                    const Frag bx = colfrag(xi, mt, s, ct);
                     AMma<T>::mma(ah, bd, dw2t[ct]);
                     AMma<T>::mma(au, bx, dw1[ct]);
                 }
@@ -618,7 +801,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) db2[ct] += s_mt * O::fragsum(O::template ldcols<NCH>(di, 32 * mt + 16 * s, 32 * ct, lane));
+                    for (int ct = 0; ct < CT; ++ct) db2[ct] += s_mt * O::fragsum(colfrag(di, mt, s, ct));
             }
         }
     }
@@ -651,16 +834,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
 
 // ---- launch configurations -------------------------------------------------------------------------------------------------
 template <typename T, int C> struct Cfg;
-//   forward: waves, hidden units per chunk, chunk buffers | dx: the same + shared tile region | dw: waves, token tile, W in registers, waves / SIMD
-template <> struct Cfg<bf16_t, 96>  { static constexpr int FNW = 8, FJC = 64, FNB = 2, XNW = 8, XJC = 32, XNB = 2, XSH = 0, DNW = 4, DTT = 64, DWR = 1, DWPS = 2; };
-template <> struct Cfg<bf16_t, 192> { static constexpr int FNW = 8, FJC = 32, FNB = 2, XNW = 4, XJC = 32, XNB = 2, XSH = 1, DNW = 4, DTT = 64, DWR = 1, DWPS = 1; };
-template <> struct Cfg<float, 96>   { static constexpr int FNW = 4, FJC = 32, FNB = 2, XNW = 4, XJC = 32, XNB = 1, XSH = 0, DNW = 4, DTT = 32, DWR = 1, DWPS = 1; };
-template <> struct Cfg<float, 192>  { static constexpr int FNW = 4, FJC = 32, FNB = 1, XNW = 2, XJC = 32, XNB = 1, XSH = 1, DNW = 4, DTT = 32, DWR = 0, DWPS = 1; };
+//   forward: waves, tiles per wave, hidden units per chunk, chunk buffers | dx: the same + shared tile region + operands in registers |
+//   dw: waves, token tile, ring depth, W in registers, waves / SIMD
+template <> struct Cfg<bf16_t, 96>  { static constexpr int FNW = 8, FNT = 2, FJC = 64, FNB = 2, XNW = 4, XNT = 2, XJC = 32, XNB = 2, XSH = 0, XRG = 1, DNW = 4, DTT = 64, DNS = 3, DWR = 1, DWPS = 2; };
+template <> struct Cfg<bf16_t, 192> { static constexpr int FNW = 8, FNT = 1, FJC = 32, FNB = 2, XNW = 4, XNT = 1, XJC = 32, XNB = 2, XSH = 1, XRG = 1, DNW = 4, DTT = 64, DNS = 3, DWR = 1, DWPS = 1; };
+template <> struct Cfg<float, 96>   { static constexpr int FNW = 4, FNT = 1, FJC = 32, FNB = 2, XNW = 2, XNT = 2, XJC = 32, XNB = 1, XSH = 0, XRG = 0, DNW = 4, DTT = 32, DNS = 3, DWR = 1, DWPS = 1; };
+template <> struct Cfg<float, 192>  { static constexpr int FNW = 4, FNT = 1, FJC = 32, FNB = 1, XNW = 2, XNT = 1, XJC = 32, XNB = 1, XSH = 1, XRG = 1, DNW = 4, DTT = 32, DNS = 3, DWR = 0, DWPS = 1; };
 
 template <typename K> int set_lds(K kernel, int lds, bool& done) {
     if (done) return PSELD_OK;
     done = true;
-    if (lds > 160 * 1024) { pseld_set_error("mlp: configuration needs %d bytes of LDS", lds); return PSELD_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
         pseld_set_error("mlp: cannot raise the dynamic LDS limit to %d", lds);
         return PSELD_ERR_HIP;
@@ -668,58 +851,82 @@ template <typename K> int set_lds(K kernel, int lds, bool& done) {
     return PSELD_OK;
 }
 
-template <typename T, int C> int launch_fwd(const MlpArgs& a, hipStream_t s) {
-    using G = Cfg<T, C>;
+template <typename T, int C, int NW, int NT, int JC, int NB, bool PIPE = false> int launch_fwd_cfg(const MlpArgs& a, hipStream_t s) {
     constexpr int ES = (int)sizeof(T), H = 4 * C;
-    constexpr int LDS = G::FNB * 2 * G::FJC * C * ES + G::FNW * 32 * C * ES + (3 * C + H) * 4;
+    constexpr int LDS = NB * 2 * JC * C * ES + NW * NT * 32 * C * ES + (3 * C + H) * 4;
     static_assert(LDS <= 160 * 1024, "forward: LDS budget");
-    auto k = mlp_fwd_kernel<T, C, G::FNW, G::FJC, G::FNB>;
+    auto k = mlp_fwd_kernel<T, C, NW, NT, JC, NB, PIPE>;
     static bool done = false;
     if (int rc = set_lds(k, LDS, done)) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)((a.M / 32 + G::FNW - 1) / G::FNW)), dim3(G::FNW * 64), LDS, s, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)((a.M / 32 + NW * NT - 1) / (NW * NT))), dim3(NW * 64), LDS, s, a);
     PSELD_LAUNCH_CHECK("mlp_fwd");
+    return PSELD_OK;
+}
+template <typename T, int C> int launch_fwd(const MlpArgs& a, hipStream_t s) {
+    using G = Cfg<T, C>;
+    if constexpr (sizeof(T) == 2 && C == 96) {
+        if (a.variant & 2) return launch_fwd_cfg<T, C, 8, 1, 64, 2>(a, s);        // (A/B: one tile per wave)
+        if (a.variant & 4) return launch_fwd_cfg<T, C, 4, 2, 64, 2>(a, s);        // (A/B: one wave per SIMD)
+        if (a.variant & 8) return launch_fwd_cfg<T, C, 8, 1, 128, 2, true>(a, s); // (A/B: software-pipelined steps)
+    }
+    return launch_fwd_cfg<T, C, G::FNW, G::FNT, G::FJC, G::FNB>(a, s);
+}
+template <typename T, int C, int NW, int NT, int JC, int NB, bool SH, bool RG> int launch_dx_cfg(const MlpArgs& a, hipStream_t s) {
+    constexpr int ES = (int)sizeof(T), H = 4 * C;
+    constexpr int LDS = NB * 3 * JC * C * ES + NW * NT * (SH ? 1 : 2) * 32 * C * ES + H * 4;
+    static_assert(LDS <= 160 * 1024, "dx: LDS budget");
+    auto k = mlp_bwd_dx_kernel<T, C, NW, NT, JC, NB, SH, RG>;
+    static bool done = false;
+    if (int rc = set_lds(k, LDS, done)) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)((a.M / 32 + NW * NT - 1) / (NW * NT))), dim3(NW * 64), LDS, s, a);
+    PSELD_LAUNCH_CHECK("mlp_bwd_dx");
     return PSELD_OK;
 }
 template <typename T, int C> int launch_dx(const MlpArgs& a, hipStream_t s) {
     using G = Cfg<T, C>;
-    constexpr int ES = (int)sizeof(T), H = 4 * C;
-    constexpr int LDS = G::XNB * 3 * G::XJC * C * ES + G::XNW * (G::XSH ? 1 : 2) * 32 * C * ES + (2 * C + H) * 4;
-    static_assert(LDS <= 160 * 1024, "dx: LDS budget");
-    auto k = mlp_bwd_dx_kernel<T, C, G::XNW, G::XJC, G::XNB, (bool)G::XSH>;
-    static bool done = false;
-    if (int rc = set_lds(k, LDS, done)) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)((a.M / 32 + G::XNW - 1) / G::XNW)), dim3(G::XNW * 64), LDS, s, a);
-    PSELD_LAUNCH_CHECK("mlp_bwd_dx");
-    return PSELD_OK;
+    if constexpr (sizeof(T) == 2 && C == 96) {
+        if (a.variant & 2) return launch_dx_cfg<T, C, 8, 1, 32, 2, false, true>(a, s);   // (A/B: one tile per wave, operands in registers)
+    }
+    return launch_dx_cfg<T, C, G::XNW, G::XNT, G::XJC, G::XNB, (bool)G::XSH, (bool)G::XRG>(a, s);
 }
-// token splits of the weight-gradient kernel: about one resident round of workgroups (two per CU where they fit), whole tiles
-template <typename T, int C> void dw_plan(long M, int& tok_per_split, int& nsplits) {
+// token splits of the weight-gradient kernel: about one resident round of workgroups (two per CU where they fit), whole tiles,
+// a bounded number of samples per split
+template <typename T, int C> void dw_plan(long M, int rows_per_scale, int& tok_per_split, int& nsplits) {
     using G = Cfg<T, C>;
     constexpr int NOWN = 4 * C / (32 * G::DNW);
-    constexpr int LDS = 6 * G::DTT * C * (int)sizeof(T) + 2048 + 2 * C * 4;
+    constexpr int LDS = G::DNS * 2 * G::DTT * C * (int)sizeof(T);
     const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
     int want = 256 * per_cu / NOWN;
     want = want / 8 * 8;
     if (want < 8) want = 8;
     long tps = (M + want - 1) / want;
     if (tps < 512) tps = 512;                                         // short splits: the slab traffic would dominate
+    const long cap = (G::DWPS > 1 ? 2L : 6L) * rows_per_scale;         // the kernel keeps the factors of 4 / 8 consecutive samples
+    if (rows_per_scale > 0 && tps > cap) tps = cap;
     tps = (tps + G::DTT - 1) / G::DTT * G::DTT;
     tok_per_split = (int)tps;
     nsplits = (int)((M + tps - 1) / tps);
 }
-template <typename T, int C> int launch_dw(MlpArgs a, hipStream_t s) {
-    using G = Cfg<T, C>;
-    constexpr int NOWN = 4 * C / (32 * G::DNW);
-    constexpr int LDS = 6 * G::DTT * C * (int)sizeof(T) + 2048 + 2 * C * 4;
-    dw_plan<T, C>(a.M, a.tok_per_split, a.nsplits);
+template <typename T, int C, int NW, int TT, int NS, bool WR, int WPS> int launch_dw_cfg(const MlpArgs& a, hipStream_t s) {
+    constexpr int NOWN = 4 * C / (32 * NW);
+    constexpr int LDS = NS * 2 * TT * C * (int)sizeof(T);
     static_assert(LDS <= 160 * 1024, "dw: LDS budget");
-    auto k = mlp_bwd_dw_kernel<T, C, G::DNW, G::DTT, (bool)G::DWR, G::DWPS>;
+    auto k = mlp_bwd_dw_kernel<T, C, NW, TT, NS, WR, WPS>;
     static bool done = false;
     if (int rc = set_lds(k, LDS, done)) return rc;
     const unsigned grid = 8u * (unsigned)((a.nsplits + 7) / 8) * NOWN;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(G::DNW * 64), LDS, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), LDS, s, a);
     PSELD_LAUNCH_CHECK("mlp_bwd_dw");
     return PSELD_OK;
+}
+template <typename T, int C> int launch_dw(MlpArgs a, hipStream_t s) {
+    using G = Cfg<T, C>;
+    dw_plan<T, C>(a.M, a.rowscale ? a.rows_per_scale : 0, a.tok_per_split, a.nsplits);
+    if constexpr (sizeof(T) == 2 && C == 96) {
+        if (a.variant & 16) return launch_dw_cfg<T, C, 4, 64, 3, true, 1>(a, s);      // (A/B: 512 registers, no spills)
+        if (a.variant & 32) return launch_dw_cfg<T, C, 4, 64, 6, true, 1>(a, s);      // (A/B: ... and a 6-deep ring, one workgroup per CU)
+    }
+    return launch_dw_cfg<T, C, G::DNW, G::DTT, G::DNS, (bool)G::DWR, G::DWPS>(a, s);
 }
 
 bool shape_ok(int dtype, long M, int C) { return (dtype == PSELD_BF16 || dtype == PSELD_F32) && (C == 96 || C == 192) && M > 0 && M % 32 == 0; }
@@ -731,12 +938,16 @@ bool scale_ok(const float* rowscale, int rows_per_scale) { return !rowscale || (
 
 }  // namespace
 
+static unsigned long long* g_mlp_dbg = nullptr;
+extern "C" void pseld_mlp_set_debug_buffer(void* p) { g_mlp_dbg = (unsigned long long*)p; }
+static int mlp_variant() { const char* e = getenv("PSELD_MLP_VARIANT"); return e ? atoi(e) : 0; }
+
 extern "C" int pseld_mlp_supported(int dtype, long M, int C, int rows_per_scale) {
     return shape_ok(dtype, M, C) && rows_per_scale > 0 && rows_per_scale % 32 == 0 ? 1 : 0;
 }
 
 extern "C" int pseld_mlp_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
-                             const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, float* mean_rstd,
+                             const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, void* xh_out,
                              long M, int C, float eps, void* stream) {
     PSELD_CHECK_ARG(x && gamma && beta && w1 && b1 && w2 && b2 && y, "mlp_fwd: null pointer");
     PSELD_CHECK_ARG(shape_ok(dtype, M, C), "mlp_fwd: built for C = 96 / 192, M a multiple of 32, bf16 / f32 (M=%ld C=%d dtype=%d)", M, C, dtype);
@@ -744,51 +955,51 @@ extern "C" int pseld_mlp_fwd(int dtype, const void* x, const float* gamma, const
     MlpArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta;
-    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.mean_rstd = mean_rstd; a.M = M; a.eps = eps;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.xh_out = xh_out; a.M = M; a.eps = eps; a.variant = mlp_variant(); a.dbg = g_mlp_dbg;
     return MLP_DISPATCH(launch_fwd, a, (hipStream_t)stream);
 }
 
-extern "C" int pseld_mlp_bwd_dx(int dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* beta,
-                                const void* w1, const float* b1, const void* w2t, const void* w1t, const float* rowscale,
-                                int rows_per_scale, void* dxh, long M, int C, void* stream) {
-    PSELD_CHECK_ARG(x && dy && mean_rstd && gamma && beta && w1 && b1 && w2t && w1t && dxh, "mlp_bwd_dx: null pointer");
+extern "C" int pseld_mlp_bwd_dx(int dtype, const void* xh, const void* dy, const void* w1, const float* b1, const void* w2t,
+                                const void* w1t, const float* rowscale, int rows_per_scale, void* dxh, long M, int C, void* stream) {
+    PSELD_CHECK_ARG(xh && dy && w1 && b1 && w2t && w1t && dxh, "mlp_bwd_dx: null pointer");
     PSELD_CHECK_ARG(shape_ok(dtype, M, C), "mlp_bwd_dx: built for C = 96 / 192, M a multiple of 32 (M=%ld C=%d)", M, C);
     MlpArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.dy = dy; a.y = dxh; a.w1 = w1; a.w1t = w1t; a.w2t = w2t; a.b1 = b1; a.gamma = gamma; a.beta = beta;
-    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.mean_rstd = (float*)mean_rstd; a.M = M;
+    a.x = xh; a.dy = dy; a.y = dxh; a.w1 = w1; a.w1t = w1t; a.w2t = w2t; a.b1 = b1;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.M = M; a.variant = mlp_variant();
     return MLP_DISPATCH(launch_dx, a, (hipStream_t)stream);
 }
 
-static long mlp_dw_splits(int dtype, long M, int C) {
+static long mlp_dw_splits(int dtype, long M, int C, int rows_per_scale) {
     int tps = 0, ns = 0;
-    if (dtype == PSELD_BF16) { if (C == 96) dw_plan<bf16_t, 96>(M, tps, ns); else dw_plan<bf16_t, 192>(M, tps, ns); }
-    else { if (C == 96) dw_plan<float, 96>(M, tps, ns); else dw_plan<float, 192>(M, tps, ns); }
+    if (dtype == PSELD_BF16) { if (C == 96) dw_plan<bf16_t, 96>(M, rows_per_scale, tps, ns); else dw_plan<bf16_t, 192>(M, rows_per_scale, tps, ns); }
+    else { if (C == 96) dw_plan<float, 96>(M, rows_per_scale, tps, ns); else dw_plan<float, 192>(M, rows_per_scale, tps, ns); }
     return ns;
 }
-extern "C" long pseld_mlp_bwd_dw_workspace(int dtype, long M, int C) {
+/* rows_per_scale: as it will be passed to pseld_mlp_bwd_dw with a non-null rowscale (0: no DropPath factors) */
+extern "C" long pseld_mlp_bwd_dw_workspace(int dtype, long M, int C, int rows_per_scale) {
     if (!shape_ok(dtype, M, C)) return 0;
-    return mlp_dw_splits(dtype, M, C) * (8L * C * C + 5L * C) * (long)sizeof(float);
+    return mlp_dw_splits(dtype, M, C, rows_per_scale) * (8L * C * C + 5L * C) * (long)sizeof(float);
 }
 // dw1 [4C, C], db1 [4C], dw2 [C, 4C], db2 [C] (fp32): overwritten, or accumulated into when `accumulate`
-extern "C" int pseld_mlp_bwd_dw(int dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* beta,
-                                const void* w1, const float* b1, const void* w2t, const float* rowscale, int rows_per_scale,
-                                float* dw1, float* db1, float* dw2, float* db2, long M, int C, int accumulate, float* workspace,
-                                long workspace_bytes, void* stream) {
-    PSELD_CHECK_ARG(x && dy && mean_rstd && gamma && beta && w1 && b1 && w2t && dw1 && db1 && dw2 && db2 && workspace, "mlp_bwd_dw: null pointer");
+extern "C" int pseld_mlp_bwd_dw(int dtype, const void* xh, const void* dy, const void* w1, const float* b1, const void* w2t,
+                                const float* rowscale, int rows_per_scale, float* dw1, float* db1, float* dw2, float* db2, long M,
+                                int C, int accumulate, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(xh && dy && w1 && b1 && w2t && dw1 && db1 && dw2 && db2 && workspace, "mlp_bwd_dw: null pointer");
     PSELD_CHECK_ARG(shape_ok(dtype, M, C), "mlp_bwd_dw: built for C = 96 / 192, M a multiple of 32 (M=%ld C=%d)", M, C);
-    PSELD_CHECK_ARG(workspace_bytes >= pseld_mlp_bwd_dw_workspace(dtype, M, C), "mlp_bwd_dw: workspace too small");
     PSELD_CHECK_ARG(scale_ok(rowscale, rows_per_scale), "mlp_bwd_dw: rows_per_scale must be a multiple of 32 (a 32-token tile lies in one sample)");
+    const int rps = rowscale ? rows_per_scale : 0;
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_mlp_bwd_dw_workspace(dtype, M, C, rps), "mlp_bwd_dw: workspace too small");
     const int H = 4 * C;
     MlpArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.dy = dy; a.w1 = w1; a.w2t = w2t; a.b1 = b1; a.gamma = gamma; a.beta = beta;
-    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.mean_rstd = (float*)mean_rstd; a.M = M;
-    a.slab = workspace;
+    a.x = xh; a.dy = dy; a.w1 = w1; a.w2t = w2t; a.b1 = b1;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.M = M;
+    a.slab = workspace; a.variant = mlp_variant(); a.dbg = g_mlp_dbg;
     hipStream_t s = (hipStream_t)stream;
     const int rc = MLP_DISPATCH(launch_dw, a, s);
     if (rc != PSELD_OK) return rc;
-    const long ns = mlp_dw_splits(dtype, M, C), stride = 2L * H * C + H + C;
+    const long ns = mlp_dw_splits(dtype, M, C, rps), stride = 2L * H * C + H + C;
     if (db1 == dw1 + (long)H * C && dw2 == db1 + H && db2 == dw2 + (long)C * H) {
         pseld_reduce_slabs(workspace, dw1, stride, (int)ns, stride, accumulate, s);      // the arena keeps the four tensors back to back
     } else {

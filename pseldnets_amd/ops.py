@@ -167,42 +167,43 @@ def mlp_fused_supported(x, rows_per_scale):
     return bool(x.is_cuda and x.dim() == 2 and _lib.lib().pseld_mlp_supported(dtype_code(x), x.shape[0], x.shape[1], max(int(rows_per_scale), 1)))
 
 
-def mlp_fwd(x, gamma, beta, w1, b1, w2, b2, rowscale=None, rows_per_scale=1, eps=1e-5):
-    """y = x + s * (gelu(LN(x) w1^T + b1) w2^T + b2) and the per-token LayerNorm statistics f32[M, 2] the backward reads."""
+def mlp_fwd(x, gamma, beta, w1, b1, w2, b2, rowscale=None, rows_per_scale=1, eps=1e-5, need_xh=True):
+    """y = x + s * (gelu(LN(x) w1^T + b1) w2^T + b2); also returns xh = LN(x) (compute dtype), the operand of the two backward
+    kernels (None when need_xh is False: inference)."""
     _chk(x, gamma, beta, w1, b1, w2, b2, rowscale)
     M, C = x.shape
     assert w1.shape == (4 * C, C) and w2.shape == (C, 4 * C) and w1.dtype == x.dtype and w2.dtype == x.dtype
     y = torch.empty_like(x)
-    mean_rstd = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    xh = torch.empty_like(x) if need_xh else None
     rc = _lib.lib().pseld_mlp_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
-                                  _lib.ptr(b2), _lib.ptr(rowscale), rows_per_scale, _lib.ptr(y), _lib.ptr(mean_rstd), M, C, eps,
+                                  _lib.ptr(b2), _lib.ptr(rowscale), rows_per_scale, _lib.ptr(y), _lib.ptr(xh), M, C, eps,
                                   _lib.stream_ptr())
     _lib.check(rc, "pseld_mlp_fwd")
-    return y, mean_rstd
+    return y, xh
 
 
-def mlp_bwd_dx(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, w1t, rowscale=None, rows_per_scale=1):
-    """Gradient wrt LN(x) of the fused block: ((s dy) w2 * gelu'(u)) w1. w2t = w2^T [4C, C], w1t = w1^T [C, 4C]."""
-    _chk(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, w1t, rowscale)
-    M, C = x.shape
-    assert dy.shape == x.shape and w2t.shape == (4 * C, C) and w1t.shape == (C, 4 * C)
-    dxh = torch.empty_like(x)
-    rc = _lib.lib().pseld_mlp_bwd_dx(dtype_code(x), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(mean_rstd), _lib.ptr(gamma), _lib.ptr(beta),
-                                     _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(w1t), _lib.ptr(rowscale), rows_per_scale,
-                                     _lib.ptr(dxh), M, C, _lib.stream_ptr())
+def mlp_bwd_dx(xh, dy, w1, b1, w2t, w1t, rowscale=None, rows_per_scale=1):
+    """Gradient wrt xh = LN(x) of the fused block: ((s dy) w2 * gelu'(u)) w1. w2t = w2^T [4C, C], w1t = w1^T [C, 4C]."""
+    _chk(xh, dy, w1, b1, w2t, w1t, rowscale)
+    M, C = xh.shape
+    assert dy.shape == xh.shape and w2t.shape == (4 * C, C) and w1t.shape == (C, 4 * C)
+    dxh = torch.empty_like(xh)
+    rc = _lib.lib().pseld_mlp_bwd_dx(dtype_code(xh), _lib.ptr(xh), _lib.ptr(dy), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(w1t),
+                                     _lib.ptr(rowscale), rows_per_scale, _lib.ptr(dxh), M, C, _lib.stream_ptr())
     _lib.check(rc, "pseld_mlp_bwd_dx")
     return dxh
 
 
-def mlp_bwd_dw(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, dw1, db1, dw2, db2, rowscale=None, rows_per_scale=1, accumulate=False):
+def mlp_bwd_dw(xh, dy, w1, b1, w2t, dw1, db1, dw2, db2, rowscale=None, rows_per_scale=1, accumulate=False):
     """The four parameter gradients of the fused block (fp32, overwritten or accumulated)."""
-    _chk(x, dy, mean_rstd, gamma, beta, w1, b1, w2t, dw1, db1, dw2, db2, rowscale)
-    M, C = x.shape
+    _chk(xh, dy, w1, b1, w2t, dw1, db1, dw2, db2, rowscale)
+    M, C = xh.shape
     L = _lib.lib()
-    ws = workspace(L.pseld_mlp_bwd_dw_workspace(dtype_code(x), M, C), x.device)
-    rc = L.pseld_mlp_bwd_dw(dtype_code(x), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(mean_rstd), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(w1),
-                            _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(rowscale), rows_per_scale, _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2),
-                            _lib.ptr(db2), M, C, int(accumulate), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    rps = rows_per_scale if rowscale is not None else 0
+    ws = workspace(L.pseld_mlp_bwd_dw_workspace(dtype_code(xh), M, C, rps), xh.device)
+    rc = L.pseld_mlp_bwd_dw(dtype_code(xh), _lib.ptr(xh), _lib.ptr(dy), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(rowscale),
+                            rows_per_scale, _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2), M, C, int(accumulate), _lib.ptr(ws),
+                            ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "pseld_mlp_bwd_dw")
 
 
@@ -217,7 +218,7 @@ def mlp_bwd_dw_side(x, dy, *args, **kw):
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         mlp_bwd_dw(x, dy, *args, **kw)
-    st['keep'].append((x, dy, args[0], kw.get('rowscale')))
+    st['keep'].append((x, dy, kw.get('rowscale')))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -45,31 +45,31 @@ def main():
         dw1, db1 = flat[:H * C].view(H, C), flat[H * C:H * C + H]
         dw2, db2 = flat[H * C + H:2 * H * C + H].view(C, H), flat[2 * H * C + H:]
         dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-        y, mr = ops.mlp_fwd(x, gamma, beta, w1, b1, w2, b2, rowscale=sc, rows_per_scale=L)
+        y, xh = ops.mlp_fwd(x, gamma, beta, w1, b1, w2, b2, rowscale=sc, rows_per_scale=L)
 
         def lw_fwd():
             xh = ops.layernorm_fwd(x, gamma, beta)
             h, gg = ops.linear_fwd(xh, w1, b1, gelu_dual=True)
             return xh, h, gg, ops.linear_fwd(h, w2, b2, resid=x, rowscale=sc, rows_per_scale=L)
-        xh, h, gg, _ = lw_fwd()
+        xh_lw, h, gg, _ = lw_fwd()
 
         def lw_bwd():
             ops.linear_wgrad(dy, h, dw2, dbias=db2, rowscale=sc, rows_per_scale=L)
             du = ops.linear_dgrad(dy, w2, wt=w2t, mul=gg, rowscale=sc, rows_per_scale=L)
-            ops.linear_wgrad(du, xh, dw1, dbias=db1)
+            ops.linear_wgrad(du, xh_lw, dw1, dbias=db1)
             dxh = ops.linear_dgrad(du, w1, wt=w1t)
             return ops.layernorm_bwd(dxh, x, gamma, dgam, dbet, dres=dy)
 
         def fu_dx():
-            dxh = ops.mlp_bwd_dx(x, dy, mr, gamma, beta, w1, b1, w2t, w1t, rowscale=sc, rows_per_scale=L)
+            dxh = ops.mlp_bwd_dx(xh, dy, w1, b1, w2t, w1t, rowscale=sc, rows_per_scale=L)
             return ops.layernorm_bwd(dxh, x, gamma, dgam, dbet, dres=dy)
         row_mb = M * C * 2 / 1e6
         res = {}
         for _ in range(args.rounds):
             for name, fn in (('layerwise fwd', lw_fwd), ('fused fwd', lambda: ops.mlp_fwd(x, gamma, beta, w1, b1, w2, b2, rowscale=sc, rows_per_scale=L)),
                              ('layerwise bwd', lw_bwd), ('fused bwd dx (+LN bwd)', fu_dx),
-                             ('fused bwd dx alone', lambda: ops.mlp_bwd_dx(x, dy, mr, gamma, beta, w1, b1, w2t, w1t, rowscale=sc, rows_per_scale=L)),
-                             ('fused bwd dw', lambda: ops.mlp_bwd_dw(x, dy, mr, gamma, beta, w1, b1, w2t, dw1, db1, dw2, db2, rowscale=sc, rows_per_scale=L))):
+                             ('fused bwd dx alone', lambda: ops.mlp_bwd_dx(xh, dy, w1, b1, w2t, w1t, rowscale=sc, rows_per_scale=L)),
+                             ('fused bwd dw', lambda: ops.mlp_bwd_dw(xh, dy, w1, b1, w2t, dw1, db1, dw2, db2, rowscale=sc, rows_per_scale=L))):
                 res.setdefault(name, []).append(timed(fn, 3))
         print(f'C={C} M={M} (row tensor {row_mb:.0f} MB; fwd flops {4 * M * C * H / 1e9:.0f} G)')
         for k, v in res.items():
