@@ -19,6 +19,20 @@ import torch
 from ... import ops
 
 GELU_DUAL = os.environ.get('PSELD_GELU_DUAL', '1') != '0'
+# Fused MLP blocks (csrc/mlp.hip: LN2 -> fc1 -> GELU -> fc2 -> DropPath + residual in one kernel, backward by recompute).
+# PSELD_FUSED_MLP: comma-separated channel widths that take the fused kernels ('' = none). Default: C = 96 (stage 0 of HTS-AT),
+# where the layer-wise chain is HBM-bound and the fused one measures faster; at C = 192 the recompute costs more than the traffic
+# it saves (tools/mlp_bench.py), C >= 384 is MFMA-bound and was never a candidate.
+FUSED_MLP_WIDTHS = tuple(int(v) for v in os.environ.get('PSELD_FUSED_MLP', '96').split(',') if v.strip())
+_inference = [False]      # set by the no-grad forward (seld_net._run): nothing is saved for a backward pass
+
+
+class inference_mode:
+    def __enter__(self):
+        self.prev, _inference[0] = _inference[0], True
+
+    def __exit__(self, *exc):
+        _inference[0] = self.prev
 
 DEFAULTS = dict(spec_size=256, patch_size=4, patch_stride=(4, 4), embed_dim=96, depths=(2, 2, 6, 2),
                 num_heads=(4, 8, 16, 32), window_size=8, mlp_ratio=4.0, qkv_bias=True, drop_rate=0.0,
@@ -265,6 +279,12 @@ class SwinEncoder:
         ops.linear_wgrad(dh, x, a.g(pre + 'fc1.weight'), dbias=a.g(pre + 'fc1.bias'))
         return ops.linear_dgrad(dh, a.w(pre + 'fc1.weight', dtype), wt=a.wt(pre + 'fc1.weight', dtype), resid=dresid)
 
+    def _mlp_fused(self, x, L):
+        """The block MLP runs on the fused kernels: full fine-tuning (no adapters / LoRA / frozen weights), a width they were built
+        and enabled for, whole 32-token tiles per sample."""
+        return (x.shape[1] in FUSED_MLP_WIDTHS and not (self.mlp_adapter or self.lora or self.frozen_weights)
+                and ops.mlp_fused_supported(x, L))
+
     def forward_layer(self, li, x, B, drop_scale=None):
         """BasicLayer li (htsat.py:364-378): its blocks, then PatchMerging. drop_scale: f32[n_blocks_total, 2, B]."""
         a, p, dtype = self.arena, self.prefix, x.dtype
@@ -291,6 +311,16 @@ class SwinEncoder:
             else:
                 x_mid = ops.linear_fwd(ao, self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
                                        rowscale=s1, rows_per_scale=L)
+            if self._mlp_fused(x_mid, L):
+                # x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))) + b2) in ONE kernel; the backward recomputes the hidden activations
+                # from xh2 = LN2(x_mid), the only activation saved besides the residual stream
+                x_out, xh2 = ops.mlp_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'), self._w(b + 'mlp.fc1.weight', dtype),
+                                         a.p(b + 'mlp.fc1.bias'), self._w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'),
+                                         rowscale=s2, rows_per_scale=L, need_xh=not _inference[0])
+                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, xh2=xh2, fused_mlp=True, s1=s1, s2=s2,
+                                         shift=shift, ad=ad))
+                x = x_out
+                continue
             xh2 = ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
             if self.mlp_adapter:
                 xs, ad['mlp'] = self._adapter_fwd(xh2, b + 'mlp.adapter.')          # xs = adapter(x) (model_utilities.py:160-170)
@@ -371,18 +401,31 @@ class SwinEncoder:
             b = f'{p}layers.{li}.blocks.{bi}.'
             s = saved['blocks'][bi]
             # ---- MLP branch:  x_out = x_mid + s2 * (fc2(gelu(u)) + b2) ------------------------------------
-            if 'h' in s:
+            if s.get('fused_mlp'):
+                w1, w2 = self._w(b + 'mlp.fc1.weight', dtype), self._w(b + 'mlp.fc2.weight', dtype)
+                w1t, w2t = self._wt(b + 'mlp.fc1.weight', dtype), self._wt(b + 'mlp.fc2.weight', dtype)
+                if w1t is None:                                   # f32 (parity) mode keeps no transposed copies
+                    w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
+                dwargs = (s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, a.g(b + 'mlp.fc1.weight'), a.g(b + 'mlp.fc1.bias'),
+                          a.g(b + 'mlp.fc2.weight'), a.g(b + 'mlp.fc2.bias'))
+                if getattr(self, '_side_ok', False):
+                    ops.mlp_bwd_dw_side(*dwargs, rowscale=s['s2'], rows_per_scale=L)     # the four parameter gradients, second stream
+                else:
+                    ops.mlp_bwd_dw(*dwargs, rowscale=s['s2'], rows_per_scale=L)
+                dxh2 = ops.mlp_bwd_dx(s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, w1t, rowscale=s['s2'], rows_per_scale=L)
+            elif 'h' in s:
                 self._wgrad(dx, s['h'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
                 du = ops.linear_dgrad(dx, self._w(b + 'mlp.fc2.weight', dtype), wt=self._wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
             else:
                 self._wgrad(dx, s['u'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', gelu_on_x=True, rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
                 du = ops.linear_dgrad(dx, self._w(b + 'mlp.fc2.weight', dtype), wt=self._wt(b + 'mlp.fc2.weight', dtype), gelu_grad_of=s['u'], rowscale=s['s2'], rows_per_scale=L)
-            self._wgrad(du, s['xh2'], b + 'mlp.fc1.weight', b + 'mlp.fc1.bias')
-            dxh2_ad = None
-            if self.mlp_adapter:            # the adapter branch sees the same DropPath-scaled gradient
-                dxs = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
-                dxh2_ad = self._adapter_bwd(dxs, s['xh2'], s['ad']['mlp'], b + 'mlp.adapter.')
-            dxh2 = ops.linear_dgrad(du, self._w(b + 'mlp.fc1.weight', dtype), wt=self._wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
+            if not s.get('fused_mlp'):
+                self._wgrad(du, s['xh2'], b + 'mlp.fc1.weight', b + 'mlp.fc1.bias')
+                dxh2_ad = None
+                if self.mlp_adapter:            # the adapter branch sees the same DropPath-scaled gradient
+                    dxs = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
+                    dxh2_ad = self._adapter_bwd(dxs, s['xh2'], s['ad']['mlp'], b + 'mlp.adapter.')
+                dxh2 = ops.linear_dgrad(du, self._w(b + 'mlp.fc1.weight', dtype), wt=self._wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
             dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
                                        a.g(b + 'norm2.bias'), dres=dx, defer=self._defer)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------

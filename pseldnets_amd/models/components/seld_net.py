@@ -206,7 +206,9 @@ class HTSATNetBase(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             params = [_get(self, n) for n in self.arena.entries]
             return _NetFn.apply(self, x, *params)
-        outs, _ = self._forward_impl(x, self.training)
+        from .htsat import inference_mode
+        with inference_mode():                # no backward will follow: the fused blocks skip what they would save for it
+            outs, _ = self._forward_impl(x, self.training)
         return outs
 
     # -- fused optimiser over the arena ------------------------------------------------------------------------
