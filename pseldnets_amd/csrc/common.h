@@ -162,6 +162,18 @@ __device__ __forceinline__ void gelu_both2(f32x2 x, f32x2& y, f32x2& dy) {
     y = x * cdf;
     dy = x * 0.3989422804014327f * e + cdf;
 }
+// gelu'(x) alone, one exponential (the A&S erf and the Gaussian density share exp(-x^2 / 2))
+__device__ __forceinline__ float gelu_grad_shared(float x) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-ax * ax);                 // = exp(-x^2 / 2)
+    const float cdf = 0.5f + copysignf(0.5f - 0.5f * p * t * e, x);
+    return fmaf(x * 0.3989422804014327f, e, cdf);
+}
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
             for (int t = 0; t < NT; ++t) {
                 if (!(a.variant & 1)) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * gelu_grad_f(u[t][e]);        // dU^T
+                    for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * gelu_grad_shared(u[t][e]);        // dU^T
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * u[t][e];
