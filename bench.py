@@ -149,7 +149,7 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel family from the PMC counters. Counters cannot be read from inside
     this process: the figure is the one measured with rocprofv3 on this same command (two separate --pmc passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/."""
-    path = os.path.join(ROOT, 'profiles', 'r02_dominant_kernel_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r03_dominant_kernel_pmc.json')
     if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -269,6 +269,9 @@ def main():
                     help="adapter = configs/adapt/adapter.yaml fine-tuning (HTS-AT only): adapters + biases + head train. Not the headline.")
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the training step as one hipGraph (trainer.py use_graph). auto = off: measured, the replay is no faster than the eager launches at 32 or at 192 chunks (the step is GPU-bound at both)')
+    ap.add_argument('--grad-dtype', default='f32', choices=['f32', 'bf16'],
+                    help='payload of the gradient all-reduce (N > 1): f32 = the arena in place (138 MB), bf16 = cast buckets (69 MB), '
+                         'summed on the wire in bf16 and accumulated back into the fp32 arena')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
@@ -353,6 +356,7 @@ def main():
         args.graph == 'on'
     trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
                            process_group=group, sync_bn=sync_bn, use_graph=use_graph, graph_warmup=min(3, args.warmup - 1))
+    trainer.grad_dtype = args.grad_dtype
     clips_per_step = n_chunks / CHUNKS_PER_CLIP
     if einv2_mode:     # track-wise labels: track 0 carries the ADPIT A0 events, tracks 1-2 silent
         lab = target['adpit_label']
@@ -400,6 +404,8 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
+    if group is not None:
+        trainer.enable_comm_diag()        # HIP events around every collective wait of the timed steps (the N > 1 line explains itself)
     # HIP events at the step boundaries on the launch stream: per-step durations (median) beside the whole-region clock
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -451,6 +457,11 @@ def main():
     }
     if args.augment == 'augmix':
         gflop_chunk = 3 * gflop_chunk                     # every original chunk goes through the network three times
+    if group is not None:
+        # what the compute stream paid for the collectives: per bucket (issued back to front while earlier layers are still in backward)
+        # the time from issue to the end of its wait, and the part of it the stream actually stalled; rank 0's view
+        out["comm"] = trainer.comm_report()
+        trainer.enable_comm_diag(False)
     step_tflops = clips_per_s * CHUNKS_PER_CLIP * gflop_chunk / 1e3
     out["roofline_step"] = {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4)}
@@ -502,7 +513,7 @@ def main():
                                "traffic": round(pmc['traffic_bytes_per_launch'], 1) if same else None,
                                "mfma_busy": pmc.get('mfma_busy') if same else None,
                                "rocprof_avg_launch_ms": pmc.get('rocprof_avg_launch_ms') if same else None,
-                               "pmc_source": ("profiles/r02_dominant_kernel_pmc.json (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
+                               "pmc_source": ("profiles/r03_dominant_kernel_pmc.json (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
                                               "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes over this command)") if same else None}
         if gem:
             tms, n, fl, nb, roof_ms, mfma_bound_ms = gem[0]

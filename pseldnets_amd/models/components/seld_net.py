@@ -164,7 +164,15 @@ class HTSATNetBase(nn.Module):
         if overlap is not None:
             overlap()
         if work is not None:
-            work.wait()
+            diag = getattr(self, 'comm_diag', None)               # trainer.comm_diag: events around the wait = the time the compute stream stalled
+            if diag is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                work.wait()
+                e1.record()
+                diag['sync_bn'].append((e0, e1))
+            else:
+                work.wait()
         mean_rstd, scale_shift = ops.bn_scalar_finalize(sums, count, centered, w, b, self._rm.view(-1), self._rv.view(-1),
                                                        self._nbt, training, self.bn_momentum, self.bn_eps)
         return mean_rstd, scale_shift

@@ -45,6 +45,10 @@ class FusedTrainer:
                                               "run CRNN backbones with trainer.sync_batchnorm=false")
                 net.sync_bn_group = process_group
         self._works, self._ranges = [], []
+        # gradient all-reduce payload: 'f32' (the arena's gradients in place) or 'bf16' (each bucket is cast to bf16, summed on the wire
+        # in bf16 and added back into the fp32 arena: half the bytes over xGMI; bench.py --grad-dtype, default f32)
+        self.grad_dtype = 'f32'
+        self.comm_diag = None        # enable_comm_diag(): per-step events around the collectives' waits (bench.py's N > 1 line)
         self._train_idx = None       # adapter / LoRA fine-tuning: arena indices of the trainable elements (the only ones all-reduced)
         # hipGraph capture of the whole step (single process only: collectives stay outside graphs here)
         self.use_graph = bool(use_graph)
@@ -67,8 +71,43 @@ class FusedTrainer:
         if self.group is None or b <= a:
             return
         import torch.distributed as dist
-        self._works.append(dist.all_reduce(self.net.arena.grad[a:b], group=self.group, async_op=True))
+        g = self.net.arena.grad[a:b]
+        ev = None
+        if self.comm_diag is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                              # bucket issued (on the compute stream, behind the kernels that produced it)
+        if self.grad_dtype == 'bf16':
+            buf = g.to(torch.bfloat16)                               # (plumbing: a cast, not arithmetic of the model)
+            self._works.append((dist.all_reduce(buf, group=self.group, async_op=True), buf, g, ev))
+        else:
+            self._works.append((dist.all_reduce(g, group=self.group, async_op=True), None, g, ev))
         self._ranges.append((a, b))
+
+    def enable_comm_diag(self, on=True):
+        """Record, per step, HIP events around every collective wait: `allreduce_exposed_ms` / `sync_bn_exposed_ms` are the times the
+        compute stream stalled, `issue -> complete` per bucket an upper bound of the collective's own duration (bench.py, world > 1)."""
+        self.comm_diag = {'buckets': [], 'sync_bn': []} if on else None
+        self.net.comm_diag = self.comm_diag
+
+    def comm_report(self):
+        """Averages over the steps recorded since enable_comm_diag() (call after a synchronize)."""
+        d = self.comm_diag
+        if not d or not d['buckets']:
+            return None
+        steps = {}
+        for step, idx, nbytes, e_issue, e0, e1 in d['buckets']:
+            steps.setdefault(step, []).append((idx, nbytes, e_issue.elapsed_time(e1), e0.elapsed_time(e1)))
+        n = len(steps)
+        nb = max(len(v) for v in steps.values())
+        per_bucket = []
+        for i in range(nb):
+            rows = [v[i] for v in steps.values() if len(v) > i]
+            per_bucket.append({"bytes": rows[0][1], "issue_to_complete_ms": round(sum(r[2] for r in rows) / len(rows), 4),
+                               "exposed_ms": round(sum(r[3] for r in rows) / len(rows), 4)})
+        bn = [e0.elapsed_time(e1) for e0, e1 in d['sync_bn']]
+        return {"steps": n, "allreduce_bytes": sum(b["bytes"] for b in per_bucket), "grad_dtype": self.grad_dtype, "buckets": per_bucket,
+                "allreduce_exposed_ms": round(sum(b["exposed_ms"] for b in per_bucket), 4),
+                "sync_bn_exposed_ms": round(sum(bn) / max(n, 1), 4) if bn else 0.0}
 
     def _trainable_index(self):
         """Arena indices of the trainable elements when part of the network is frozen (configs/adapt/*.yaml), else None."""
@@ -230,8 +269,18 @@ class FusedTrainer:
             # in issue order and its share of the clipping norm is taken at once, while the later buckets are still on the wire
             net._backward_impl(saved, douts, on_range_done=self._reduce_range)
             parts = []
-            for (a, b), w in zip(self._ranges, self._works):
-                w.wait()
+            self._step_no = getattr(self, '_step_no', 0) + 1
+            for i, ((a, b), (w, buf, g, ev)) in enumerate(zip(self._ranges, self._works)):
+                if self.comm_diag is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    w.wait()
+                    e1.record()
+                    self.comm_diag['buckets'].append((self._step_no, i, (buf if buf is not None else g).numel() * (2 if buf is not None else 4), ev, e0, e1))
+                else:
+                    w.wait()
+                if buf is not None:
+                    g.copy_(buf)                                      # bf16 sum back into the fp32 arena (fp32 from here on: clip, AdamW)
                 if self.max_norm:
                     parts.append(ops.grad_norm(net.arena.grad[a:b]))
             if parts:
