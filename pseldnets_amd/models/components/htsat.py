@@ -408,11 +408,18 @@ class SwinEncoder:
                     w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
                 dwargs = (s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, a.g(b + 'mlp.fc1.weight'), a.g(b + 'mlp.fc1.bias'),
                           a.g(b + 'mlp.fc2.weight'), a.g(b + 'mlp.fc2.bias'))
+                # the weight-gradient kernel is forked onto the second stream BEFORE dx is launched: the earlier the side chain of the
+                # block starts the better (A/B PSELD_MLP_DW_FIRST=0 - fork behind dx, so that dw runs beside the HBM-bound kernels that
+                # follow instead of beside the equally VALU-bound dx - measured 21.33 against 20.99 ms per step)
+                dw_first = os.environ.get('PSELD_MLP_DW_FIRST', '1') == '1'
+                if not dw_first:
+                    dxh2 = ops.mlp_bwd_dx(s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, w1t, rowscale=s['s2'], rows_per_scale=L)
                 if getattr(self, '_side_ok', False):
                     ops.mlp_bwd_dw_side(*dwargs, rowscale=s['s2'], rows_per_scale=L)     # the four parameter gradients, second stream
                 else:
                     ops.mlp_bwd_dw(*dwargs, rowscale=s['s2'], rows_per_scale=L)
-                dxh2 = ops.mlp_bwd_dx(s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, w1t, rowscale=s['s2'], rows_per_scale=L)
+                if dw_first:
+                    dxh2 = ops.mlp_bwd_dx(s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, w1t, rowscale=s['s2'], rows_per_scale=L)
             elif 'h' in s:
                 self._wgrad(dx, s['h'], b + 'mlp.fc2.weight', b + 'mlp.fc2.bias', rowscale=s['s2'], rows_per_scale=L, per_scale_elems=L * C)
                 du = ops.linear_dgrad(dx, self._w(b + 'mlp.fc2.weight', dtype), wt=self._wt(b + 'mlp.fc2.weight', dtype), mul=s['g'], rowscale=s['s2'], rows_per_scale=L)
