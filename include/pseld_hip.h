@@ -79,6 +79,17 @@ int pseld_mlp_bwd_dw(int dtype, const void* xh, const void* dy, const void* w1, 
                      const float* rowscale, int rows_per_scale, float* dw1, float* db1, float* dw2, float* db2, long M,
                      int C, int accumulate, float* workspace, long workspace_bytes, void* stream);
 
+/* ---- fused front half of the Swin attention branch (C = 96, 4 heads, bf16): LayerNorm -> qkv Linear -> window attention -----
+ * htsat.py:234 (norm1), :118-138 (WindowAttention.forward up to the head merge), :23-50,239-242,257-260 (partition / reverse / roll as an
+ * address map). One persistent kernel per block; x is read once; outputs exactly what pseld_layernorm_fwd + pseld_gemm (qkv) +
+ * pseld_window_attn_fwd leave for the projection GEMM and for the (unchanged) backward kernels: qkv [M, 3C], out [M, C] (heads merged),
+ * xh = LN(x) [M, C] (optional), lse f32[M, heads] (optional). SURVEY 8b `pseld_swin_attn_fwd` (proj + residual stay pseld_gemm with
+ * its fused epilogue). pseld_swin_attn_supported: 1 when the kernel takes (dtype, res, C, heads). */
+int pseld_swin_attn_supported(int dtype, int res, int C, int heads);
+int pseld_swin_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
+                        const float* bias_table, void* qkv, void* out, void* xh, float* lse, int B, int res, int C, int heads,
+                        int shift, float eps, void* stream);
+
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */
 void pseld_gemm_set_debug_buffer(void* device_buffer);

@@ -222,6 +222,28 @@ def mlp_bwd_dw_side(x, dy, *args, **kw):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# fused front half of the Swin attention branch (C = 96, bf16): LayerNorm -> qkv -> window attention in one kernel
+def swin_attn_fused_supported(x, res, heads):
+    return bool(x.is_cuda and x.dim() == 2 and _lib.lib().pseld_swin_attn_supported(dtype_code(x), res, x.shape[1], heads))
+
+
+def swin_attn_fwd(x, gamma, beta, wqkv, bqkv, bias_table, B, res, heads, shift, eps=1e-5, need_saved=True):
+    """Returns (ao [M, C], qkv [M, 3C], xh = LN(x) [M, C] or None, lse f32[M, heads] or None)."""
+    _chk(x, gamma, beta, wqkv, bqkv, bias_table)
+    M, C = x.shape
+    assert M == B * res * res and wqkv.shape == (3 * C, C) and wqkv.dtype == x.dtype
+    qkv = torch.empty((M, 3 * C), dtype=x.dtype, device=x.device)
+    ao = torch.empty_like(x)
+    xh = torch.empty_like(x) if need_saved else None
+    lse = torch.empty((M, heads), dtype=torch.float32, device=x.device) if need_saved else None
+    rc = _lib.lib().pseld_swin_attn_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(wqkv), _lib.ptr(bqkv),
+                                        _lib.ptr(bias_table), _lib.ptr(qkv), _lib.ptr(ao), _lib.ptr(xh), _lib.ptr(lse), B, res, C, heads,
+                                        shift, eps, _lib.stream_ptr())
+    _lib.check(rc, "pseld_swin_attn_fwd")
+    return ao, qkv, xh, lse
+
+
+# ---------------------------------------------------------------------------------------------------------
 # LayerNorm
 def layernorm_fwd(x, gamma, beta, merge_res=0, eps=1e-5, out_rows=None):
     """x [M, C] -> LN(x); merge mode: x is the token grid [B*res*res, Cs], output rows [B*(res/2)^2, 4*Cs]."""

@@ -1,0 +1,99 @@
+"""Fused LayerNorm -> QKV -> window attention kernel (csrc/swin.hip: pseld_swin_attn_fwd) through the C ABI against (a) the
+layer-wise kernels it replaces (pseld_layernorm_fwd + pseld_gemm + pseld_window_attn_fwd: same rounding points, so near-identical
+bf16 values) and (b) a float64 torch restatement of the reference arithmetic (htsat.py:118-138,234-260: norm1, qkv Linear,
+q * scale, + relative_position_bias, + shift mask, softmax, @ v, with window_partition / roll as an index map)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def _case(B, res, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    C, heads = 96, 4
+    M = B * res * res
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).to(dev).bfloat16()
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).to(dev).bfloat16()
+    bqkv = (0.2 * torch.randn(3 * C, generator=g)).to(dev)
+    table = (0.5 * torch.randn(225, heads, generator=g)).to(dev)
+    return x, gamma, beta, wqkv, bqkv, table
+
+
+def _reference64(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift):
+    """float64, natural token order in and out."""
+    C = x.shape[1]
+    hd = C // heads
+    xh = torch.nn.functional.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5)
+    qkv = xh @ wqkv.double().t() + bqkv.double()
+    g = qkv.view(B, res, res, 3 * C)
+    if shift:
+        g = torch.roll(g, (-shift, -shift), (1, 2))
+    nw = res // 8
+    w = g.view(B, nw, 8, nw, 8, 3, heads, hd).permute(0, 1, 3, 5, 6, 2, 4, 7).reshape(B * nw * nw, 3, heads, 64, hd)
+    q, k, v = w[:, 0], w[:, 1], w[:, 2]
+    att = (q * hd ** -0.5) @ k.transpose(-1, -2)
+    ys, xs = torch.meshgrid(torch.arange(8), torch.arange(8), indexing='ij')
+    cy, cx = ys.flatten(), xs.flatten()
+    idx = (cy[:, None] - cy[None, :] + 7) * 15 + (cx[:, None] - cx[None, :] + 7)
+    att = att + table.double()[idx.to(table.device)].permute(2, 0, 1)
+    if shift:
+        img = torch.zeros(res, res)
+        cnt = 0
+        for hs in (slice(0, -8), slice(-8, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -8), slice(-8, -shift), slice(-shift, None)):
+                img[hs, wsl] = cnt
+                cnt += 1
+        mw = img.view(nw, 8, nw, 8).permute(0, 2, 1, 3).reshape(nw * nw, 64)
+        mask = (mw[:, None, :] - mw[:, :, None] != 0).double() * -100.0
+        att = att.view(B, nw * nw, heads, 64, 64) + mask.to(att.device)[None, :, None]
+        att = att.view(B * nw * nw, heads, 64, 64)
+    lse = torch.logsumexp(att, -1)
+    o = torch.softmax(att, -1) @ v                                            # [nWin, heads, 64, hd]
+    def back(t, c):                                                           # windows -> natural order
+        t = t.reshape(B, nw, nw, heads, 8, 8, c).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, res, res, heads * c)
+        if shift:
+            t = torch.roll(t, (shift, shift), (1, 2))
+        return t.reshape(B * res * res, heads * c)
+    return xh, qkv, back(o, hd), back(lse.unsqueeze(-1), 1)
+
+
+@pytest.mark.parametrize('B,res,shift', [(3, 64, 0), (3, 64, 4), (5, 32, 4), (1, 8, 0), (2, 16, 4), (7, 8, 0)])
+def test_fused_swin_attention_vs_layerwise_kernels_and_float64(dev, B, res, shift):
+    from pseldnets_amd import ops
+    heads = 4
+    x, gamma, beta, wqkv, bqkv, table = _case(B, res, dev, seed=B * 100 + res + shift)
+    assert ops.swin_attn_fused_supported(x, res, heads)
+    ao, qkv, xh, lse = ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift)
+    xh_lw = ops.layernorm_fwd(x, gamma, beta)
+    qkv_lw = ops.linear_fwd(xh_lw, wqkv, bqkv)
+    ao_lw, lse_lw = ops.window_attn_fwd(qkv_lw, table, B, res, heads, shift)
+    xh64, qkv64, ao64, lse64 = _reference64(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift)
+    e = dict(xh=_rel(xh, xh64), qkv=_rel(qkv, qkv64), ao=_rel(ao, ao64), lse=_rel(lse, lse64),
+             xh_lw=_rel(xh_lw, xh64), qkv_lw=_rel(qkv_lw, qkv64), ao_lw=_rel(ao_lw, ao64), lse_lw=_rel(lse_lw, lse64),
+             d_xh=_rel(xh, xh_lw), d_qkv=_rel(qkv, qkv_lw), d_ao=_rel(ao, ao_lw), d_lse=_rel(lse, lse_lw))
+    print('fused swin attention', B, res, shift, {k: f'{v:.2e}' for k, v in e.items()})
+    for t in (ao, qkv, xh, lse):
+        assert torch.isfinite(t.float()).all()
+    # bf16 storage rounding (2^-9 per element) on xh, qkv and the output; never worse than the layer-wise chain by more than noise
+    assert e['xh'] < 3e-3 and e['qkv'] < 5e-3 and e['ao'] < 1e-2 and e['lse'] < 5e-3, e
+    assert e['qkv'] <= 1.2 * e['qkv_lw'] + 1e-4 and e['ao'] <= 1.2 * e['ao_lw'] + 1e-4, e
+    assert e['d_xh'] < 3e-3 and e['d_qkv'] < 5e-3 and e['d_ao'] < 1e-2, e
+
+
+def test_fused_swin_attention_without_saved_operands_and_rejections(dev):
+    from pseldnets_amd import _lib, ops
+    x, gamma, beta, wqkv, bqkv, table = _case(2, 16, dev, seed=5)
+    ao, qkv, xh, lse = ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, 2, 16, 4, 0, need_saved=False)
+    assert xh is None and lse is None
+    ao2, *_ = ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, 2, 16, 4, 0)
+    assert torch.equal(ao, ao2)
+    assert not ops.swin_attn_fused_supported(x.float(), 16, 4)                  # parity mode keeps the layer-wise kernels
+    assert not ops.swin_attn_fused_supported(torch.zeros(512, 192, device=dev, dtype=torch.bfloat16), 16, 8)
+    with pytest.raises(_lib.PseldError):
+        ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, 2, 16, 4, 9)
