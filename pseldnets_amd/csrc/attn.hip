@@ -49,6 +49,7 @@ struct AttnArgs {
     unsigned long long* dbg;  // diagnostic: s_memtime stamps of workgroup 0's first windows
     int B, res, C, heads, hd, shift;
     int n_win_total;          // B * (res/8)^2
+    int variant;              // timing experiments (PSELD_ATTN_VARIANT): results are wrong when set
     float scale;
 };
 
@@ -594,6 +595,249 @@ __global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_ker
     }
 }
 
+// ---- Backward, bf16, head_dim 24 (every stage of HTS-AT), 4 heads per workgroup, ONE wave per head --------------------------------
+// The generic kernel above splits a head over two waves (key tiles), drops every P / dS tile into LDS images to read it back
+// transposed, exchanges dQ partials through LDS and stores its results with 2-byte LDS writes: 2.5x its HBM floor at every stage
+// (tools/attn_bench.py: 506 / 240 / 138 / 79 us). Here a wave owns a whole head of a window (all 64 x 64 scores, tile by tile), so
+//   * dQ^T[d][q] = K^T dS^T contracts over the ROWS of the dS^T accumulator: accumulator-as-operand, as before;
+//   * dV^T[d][k] = dO^T P and dK^T[d][k] = Q^T dS contract over queries, the LANES of P^T / dS^T: the tiles are transposed BY THE
+//     MATRIX PIPE (bf16(P^T) as the A operand times an identity B fragment: exact), which idles anyway - no images, no image traffic;
+//   * row fragments are read through lane r -> LDS row swap23(r) and transposed column reads fetch column swap23(lane) (the 4-column
+//     piece index of ds_read_b64_tr_b16 is bit-swapped): every accumulator operand then sees the natural k-order and a lane's
+//     accumulator registers are 8 CONSECUTIVE head dims - dq / dk / dv go back into the tile as 16-byte pieces;
+//   * d(bias table) is binned on the fly into [4 heads][225] LDS counters by ds_add_f32 (64 per lane and window) and flushed once per
+//     workgroup onto ONE representative (key, query) pair per table index of the [heads][64][64] accumulator the callers reduce.
+__global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
+    using M = AMma<bf16_t>;
+    constexpr int HG = 4, HD = 24, GW = HG * HD, STR = 5 * GW * 2 + 16;          // 976-byte token rows: q | k | v | dO | O of 4 heads + pad
+    static_assert(((STR >> 4) & 1) == 1, "row stride must be an odd number of 16-byte slots");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tile = smem;
+    float* btab = (float*)(smem + 64 * STR);              // [4][225] bias x log2(e)
+    float* lse_s = btab + HG * 225;                       // [64][4]
+    long* toks = (long*)(lse_s + 64 * HG);
+    int* labels = (int*)(toks + 64);                      // [64] + [1]
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    const int lane0 = threadIdx.x & 63, hl = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int hg = blockIdx.y;
+    for (int i = threadIdx.x; i < HG * 225; i += 256) {
+        const int hh = i / 225, idx = i - hh * 225;
+        btab[i] = a.bias_table[idx * a.heads + hg * HG + hh] * LOG2E;
+    }
+    // sum over this workgroup's windows of dS^T, by (query tile - key tile) + 1: the tiles (0, 0) and (1, 1) hold the same relative
+    // positions lane by lane and register by register, and the callers only ever sum the accumulator by relative position
+    f32x16 dsum[3];
+#pragma unroll
+    for (int y = 0; y < 3; ++y)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dsum[y][e] = 0.f;
+    const bf16_t* qkv = (const bf16_t*)a.qkv;
+    const bf16_t* dout = (const bf16_t*)a.dout;
+    const bf16_t* osv = (const bf16_t*)a.osaved;
+    const int cq = hl * HD, ck = GW + hl * HD, cv = 2 * GW + hl * HD, cdo = 3 * GW + hl * HD, co = 4 * GW + hl * HD;
+    const float* bt = btab + hl * 225;
+    const float scale2 = a.scale * LOG2E;
+
+    int it = 0;
+    const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 64;
+    for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x, ++it) {
+        __syncthreads();                                  // the previous window's rows have left the tile
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 0] = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x < 64) {
+            long tk; int lb;
+            window_token(a, wi, threadIdx.x, tk, lb);
+            toks[threadIdx.x] = tk; labels[threadIdx.x] = lb;
+            const int l0 = __builtin_amdgcn_readfirstlane(lb);
+            const unsigned long long diff = __ballot(lb != l0);
+            if (threadIdx.x == 0) labels[64] = diff != 0ull;
+        }
+        __syncthreads();
+        {
+            // one DMA instruction per token row: lane -> (segment, 16-byte chunk) of the 61-slot row (60 live), as window_dma_load; the lane
+            // constants are recomputed per window (laundered lane id) instead of living in registers across the loop
+            int ln = lane0;
+            asm volatile("" : "+v"(ln));
+            const int seg = ln / 12, k = ln - seg * 12;
+            if (ln < 60) {
+                const int C = a.C;
+                const bf16_t* base = seg < 3 ? qkv : (seg == 3 ? dout : osv);
+                const int ld = seg < 3 ? 3 * C : C;
+                const int gcol = (seg < 3 ? seg * C : 0) + hg * GW + k * 8;
+                for (int i = hl; i < 64; i += HG)
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr_a)(base + toks[i] * ld + gcol), (lds_void_ptr_a)(tile + i * STR), 16, 0, 0);
+            }
+            int tx = threadIdx.x;
+            asm volatile("" : "+v"(tx));
+            lse_s[tx] = a.lse[toks[tx >> 2] * a.heads + hg * HG + (tx & 3)];
+        }
+        __syncthreads();                                  // (hipcc drains the DMA with vmcnt(0) in front of this barrier)
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 1] = __builtin_amdgcn_s_memtime();
+
+        const bool mixed = labels[64] != 0;
+        // identity fragments of the transposing products: element j of step s is 1 where 16 s + 8 h2 + j == lane & 31
+        bf16x8 idf[2];
+        float nlse[2], delta[2];
+        {
+            const int r = lane0 & 31, h2 = lane0 >> 5, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) idf[s][j] = (bf16_t)((16 * s + 8 * h2 + j == r) ? 1.f : 0.f);
+            // per-lane constants of its two queries (lane r <-> query swap23(r) of the tile): -lse log2(e) and delta = sum_d dO O
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int qi = qt * 32 + pr;
+                nlse[qt] = -lse_s[qi * HG + hl] * LOG2E;
+                float dsum_q = 0.f;
+                for (int c = h2; c < 3; c += 2) {             // the lane halves split the three 8-dim chunks of the row
+                    float od[8], dd[8];
+                    load8<bf16_t>((const bf16_t*)(tile + qi * STR + (co + c * 8) * 2), od);
+                    load8<bf16_t>((const bf16_t*)(tile + qi * STR + (cdo + c * 8) * 2), dd);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dsum_q = fmaf(od[j], dd[j], dsum_q);
+                }
+                delta[qt] = dsum_q + __shfl_xor(dsum_q, 32, 64);
+            }
+        }
+        // transposed column fragment: element j = tile[row0 + 8 h2 + j][col0 + swap23(lane & 31)] (lanes 4p..4p+3 of a 16-lane group fetch
+        // the 4-column piece bitswap(p))
+        auto ld_colp = [&](int row0, int col0, int lane) {
+            const int i = lane & 15, q = i >> 2, p = i & 3, gsel = (lane >> 4) & 1, h2 = lane >> 5;
+            const int pp = ((p & 1) << 1) | (p >> 1);
+            const char* addr = tile + (row0 + 8 * h2 + q) * STR + (col0 + 16 * gsel + 4 * pp) * 2;
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr));
+            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 4 * STR));
+            short8v sv;
+            sv[0] = lo[0]; sv[1] = lo[1]; sv[2] = lo[2]; sv[3] = lo[3];
+            sv[4] = hi[0]; sv[5] = hi[1]; sv[6] = hi[2]; sv[7] = hi[3];
+            return __builtin_bit_cast(bf16x8, sv);
+        };
+        // a [32 tokens][24 dims] result (rows = dims through swap23: register e of lane half h2 is dim (e & 7) + 8 h2 + 16 (e >> 3); lane =
+        // token row `row`) back into the tile: 16-byte pieces
+        auto put = [&](const f32x16& z, float mul, int row, int col0, int h2) {
+            bf16x8 f0, f1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f0[j] = (bf16_t)(z[j] * mul); f1[j] = (bf16_t)(z[8 + j] * mul); }
+            char* p = tile + row * STR + (col0 + 8 * h2) * 2;
+            *(bf16x8*)p = f0;
+            if (h2 == 0) *(bf16x8*)(p + 32) = f1;
+        };
+
+        f32x16 dqT[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dqT[qt][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 dvT, dkT;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dvT[e] = 0.f; dkT[e] = 0.f; }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                // (the lane id is laundered per tile: otherwise hipcc hoists every fragment address out of the window loop)
+                int lane = lane0;
+                asm volatile("" : "+v"(lane));
+                const int r = lane & 31, h2 = lane >> 5, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+                f32x16 pt, dpt;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { pt[e] = 0.f; dpt[e] = 0.f; }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    // (the key-side fragments are re-read per tile rather than kept across the query tiles: 24 registers)
+                    const bool live = 16 * kk + 8 * h2 < HD;
+                    const bf16x8 kr = M::keep_if(M::ld_row(tile + (kt * 32 + pr) * STR + (ck + 16 * kk + 8 * h2) * 2), live);
+                    const bf16x8 vr = M::keep_if(M::ld_row(tile + (kt * 32 + pr) * STR + (cv + 16 * kk + 8 * h2) * 2), live);
+                    const bf16x8 qr = M::keep_if(M::ld_row(tile + (qt * 32 + pr) * STR + (cq + 16 * kk + 8 * h2) * 2), live);
+                    const bf16x8 dor = M::keep_if(M::ld_row(tile + (qt * 32 + pr) * STR + (cdo + 16 * kk + 8 * h2) * 2), live);
+                    M::mma(kr, qr, pt);                   // S^T[key][query]: row i <-> key swap23(i), lane <-> query swap23(lane)
+                    M::mma(vr, dor, dpt);                 // dP^T
+                }
+                // accumulator register e of lane half h2 is key kt*32 + (e & 7) + 8 h2 + 16 (e >> 3): (y, x) = (kt*4 + 2 (e>>3) + h2, e & 7)
+                const int qi = qt * 32 + pr;
+                const int lidx = (qi >> 3) * 15 + (qi & 7) + 112 - 15 * h2 - 97;        // table index = lidx + 97 - (kt*60 + 30 (e>>3) + (e&7))
+                const float* btq = bt + lidx;
+                const float nl = nlse[qt], dl = delta[qt];
+                if (mixed) {
+                    const int ql = labels[qi];
+                    const int* labh = labels + kt * 32 + 8 * h2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float b = btq[97 - (kt * 60 + 30 * (e >> 3) + (e & 7))] + nl;
+                        b -= (labh[16 * (e >> 3) + (e & 7)] != ql) ? 100.f * LOG2E : 0.f;
+                        pt[e] = __builtin_amdgcn_exp2f(fmaf(pt[e], scale2, b));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        pt[e] = __builtin_amdgcn_exp2f(fmaf(pt[e], scale2, btq[97 - (kt * 60 + 30 * (e >> 3) + (e & 7))] + nl));
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float ds = pt[e] * (dpt[e] - dl);
+                    dpt[e] = ds;                           // dS^T
+                    dsum[qt - kt + 1][e] += ds;
+                }
+                const bf16x8 pf0 = M::from_acc(pt, 0), pf1 = M::from_acc(pt, 1), sf0 = M::from_acc(dpt, 0), sf1 = M::from_acc(dpt, 1);
+                // dQ^T[d][query] += K^T dS^T (contraction over the key rows of the accumulator)
+                M::mma(ld_colp(kt * 32, ck, lane), sf0, dqT[qt]);
+                M::mma(ld_colp(kt * 32 + 16, ck, lane), sf1, dqT[qt]);
+                // transposes through the matrix pipe: rows = queries (lane order), lanes = keys (natural)
+                f32x16 pq, sq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { pq[e] = 0.f; sq[e] = 0.f; }
+                if (!(a.variant & 2)) {
+                M::mma(pf0, idf[0], pq); M::mma(pf1, idf[1], pq);
+                M::mma(sf0, idf[0], sq); M::mma(sf1, idf[1], sq);
+                }
+                // dV^T[d][key] += dO^T P, dK^T[d][key] += Q^T dS (contraction over the query rows)
+                if (!(a.variant & 4))
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    M::mma(ld_colp(qt * 32 + 16 * s, cdo, lane), M::from_acc(pq, s), dvT);
+                    M::mma(ld_colp(qt * 32 + 16 * s, cq, lane), M::from_acc(sq, s), dkT);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // nobody reads this head's k / v rows of key tile kt again
+            {
+                int lane = lane0;
+                asm volatile("" : "+v"(lane));
+                put(dvT, 1.f, kt * 32 + (lane & 31), cv, lane >> 5);
+                put(dkT, a.scale, kt * 32 + (lane & 31), ck, lane >> 5);
+            }
+        }
+        {
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            const int r = lane & 31, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+            put(dqT[0], a.scale, pr, cq, lane >> 5);
+            put(dqT[1], a.scale, 32 + pr, cq, lane >> 5);
+        }
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 2] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamp && it < 8) { a.dbg[(blockIdx.x * 8 + it) * 8 + 3] = __builtin_amdgcn_s_memtime(); a.dbg[(blockIdx.x * 8 + it) * 8 + 4] = a.dbg[(blockIdx.x * 8 + it) * 8 + 3]; }
+        if (!(a.variant & 8))
+        for (int sel = 0; sel < 3; ++sel)
+            window_copy<bf16_t, false>(tile, STR, (bf16_t*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, GW, toks);
+        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 5] = __builtin_amdgcn_s_memtime();
+    }
+    // flush d(bias): dbias_acc[head][key][query] += dsum (row i <-> key swap23(i), lane <-> query swap23(lane))
+    {
+        const int r = lane0 & 31, h2 = lane0 >> 5, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+        float* dst = a.dbias_acc + (long)(hg * HG + hl) * 4096;
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+            const int kt = y == 0 ? 1 : 0, qt = y == 2 ? 1 : 0;       // (1, 0), (0, 0) [+ (1, 1)], (0, 1)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                atomicAdd(dst + (kt * 32 + 16 * (e >> 3) + 8 * h2 + (e & 7)) * 64 + qt * 32 + pr, dsum[y][e]);
+        }
+    }
+}
+constexpr size_t BWD24_LDS = 64 * 976 + 4 * 225 * 4 + 64 * 4 * 4 + 64 * 8 + 65 * 4 + 12;
+
 __global__ void zero_f4_kernel(float4* __restrict__ p, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -720,7 +964,18 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     if (slots > a.n_win_total) slots = a.n_win_total;
     if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);
-    if (dtype == PSELD_BF16) {
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("PSELD_ATTN_BWD_V2"); v2 = !(e && atoi(e) == 0); }
+    { const char* e = getenv("PSELD_ATTN_VARIANT"); a.variant = e ? atoi(e) : 0; }
+    if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && v2) {
+        // one wave per head, four heads per workgroup, two workgroups per CU, persistent
+        int sl = (es ? atoi(es) : 512) / (heads / 4);
+        if (sl > a.n_win_total) sl = a.n_win_total;
+        if (sl < 1) sl = 1;
+        static bool attr24 = false;
+        if (!attr24) { (void)hipFuncSetAttribute((const void*)attn_bwd24_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD24_LDS); attr24 = true; }
+        hipLaunchKernelGGL(attn_bwd24_kernel, dim3(sl, heads / 4), dim3(256), BWD24_LDS, s, a);
+    } else if (dtype == PSELD_BF16) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         if (hgv == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(512), bwd_lds<bf16_t>(a.hd, 4), s, a);
