@@ -8,7 +8,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpseld_hip.so")
+# PSELD_LIB_PATH: another build of the same library (in-session A/B of kernel variants, tools/); the default is the in-tree product
+LIB_PATH = os.environ.get("PSELD_LIB_PATH") or os.path.join(_HERE, "libpseld_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "pseld_hip.h")
 
 F32, BF16 = 0, 1
