@@ -253,7 +253,7 @@ def main():
                     help='N > 0: time the reference-native chunk batch (N ten-second chunks per GPU per step, '
                          'configs/experiment/synth_maccdoa.yaml:8 batch_size 32) instead of --clips whole clips; clips/s = (N/6)*world/step')
     ap.add_argument('--sync-bn', default='auto', choices=['auto', 'on', 'off'],
-                    help="all-reduce the scalar-BatchNorm statistics over the ranks (configs/trainer/gpu.yaml:9 sync_batchnorm: True). "
+                    help="all-reduce every BatchNorm's train-mode statistics over the ranks (configs/trainer/gpu.yaml:9 sync_batchnorm: True). "
                          "auto = on when N > 1 (the reference's DDP recipe)")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--backbone', default='htsat', choices=['htsat', 'passt', 'htsat_einv2', 'crnn', 'passt_einv2', 'crnn_einv2'],
@@ -349,7 +349,7 @@ def main():
         for p in net.parameters():            # identical initial weights on every rank
             dist.broadcast(p.data, 0)
     einv2_mode = args.backbone.endswith('_einv2')
-    sync_bn = group is not None and (args.sync_bn == 'on' or (args.sync_bn == 'auto' and not args.backbone.startswith('crnn')))
+    sync_bn = group is not None and args.sync_bn != 'off'      # every BatchNorm (scalar front, conv stack, Conformer) synchronised
     wave, target = synthetic_batch(args.clips, device, 2024 + rank, chunks=args.chunks or None)
     n_chunks = wave.shape[0]
     use_graph = group is None and args.adapt == 'none' and args.warmup >= 2 and \

@@ -249,6 +249,14 @@ int pseld_bn_relu_fwd(int dtype, const void* X, const float* scale_shift, void* 
 int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd, const float* gamma,
                       void* dX, float* dgamma, float* dbeta, long rows, int C, float* workspace, long workspace_bytes,
                       void* stream);
+/* The same backward in two halves for data-parallel runs with synchronised BatchNorm (configs/trainer/gpu.yaml:9 `sync_batchnorm: true`
+ * = torch.nn.SyncBatchNorm on every BatchNorm of the CRNN conv stack / the Conformer): the caller all-reduces `sums` f32[C][2] =
+ * (sum g * xhat, sum g) between the two calls and passes inv_count = 1 / (rows over all ranks); dgamma / dbeta are the rank-local sums
+ * (the gradient all-reduce averages them). The forward side needs no new entry point: pseld_bn2d_stats' raw sums add across ranks. */
+int pseld_bn_relu_bwd_sums(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd, float* sums, float* dgamma,
+                           float* dbeta, long rows, int C, float* workspace, long workspace_bytes, void* stream);
+int pseld_bn_relu_bwd_apply(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd, const float* gamma,
+                            const float* sums, float inv_count, void* dX, long rows, int C, void* stream);
 /* the BatchNorm1d of the Conformer conv module (conformer/convolution.py:129): same statistics kernels, no ReLU; its
  * backward is pseld_bn_relu_bwd with Y = NULL */
 int pseld_bn_affine_fwd(int dtype, const void* X, const float* scale_shift, void* Y, long rows, int C, void* stream);

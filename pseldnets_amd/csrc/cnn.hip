@@ -436,30 +436,50 @@ extern "C" int pseld_bn_affine_fwd(int dtype, const void* X, const float* scale_
     CNN_DISPATCH("bn_affine_fwd", hipLaunchKernelGGL(bn_relu_fwd_kernel<T>, dim3(pseld_cdiv(total, 256)), dim3(256), 0, s, (const T*)X,
                                                      scale_shift, (T*)Y, C, total, -INFINITY));
 }
-/* backward of y = relu(bn(x)): dX, dgamma (+)=, dbeta (+)= (train-mode batch statistics) */
+/* backward of y = relu(bn(x)) in two halves, so that a data-parallel caller can all-reduce the per-channel sums in between
+ * (torch.nn.SyncBatchNorm, which configs/trainer/gpu.yaml:9 `sync_batchnorm: true` installs on every BatchNorm):
+ *   sums:  sums f32[C][2] = (sum g * xhat, sum g) over this rank's rows, g = dY * (Y > 0) (Y = NULL: no ReLU); dgamma / dbeta are
+ *          written from these rank-local sums (the gradient all-reduce averages them like every other parameter gradient)
+ *   apply: dX = gamma * rstd * (g - sums[c][1] * inv_count - xhat * sums[c][0] * inv_count) with the (summed) sums and
+ *          inv_count = 1 / (rows over all ranks). */
+extern "C" int pseld_bn_relu_bwd_sums(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd, float* sums,
+                                      float* dgamma, float* dbeta, long rows, int C, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(X && dY && mean_rstd && sums && dgamma && dbeta && workspace, "bn_relu_bwd_sums: null pointer");
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn_relu_bwd_sums: workspace too small");
+    PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_bwd_sums: C must be a multiple of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = bn2d_rows_per_block(rows, C), nb = pseld_cdiv(rows, rpb);
+    const dim3 grid(nb, pseld_cdiv(C / 8, C / 8 < 256 ? C / 8 : 256));
+    if (dtype == PSELD_BF16)
+        hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, workspace, rows, C, rpb);
+    else if (dtype == PSELD_F32)
+        hipLaunchKernelGGL((bn2d_sums_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, (const float*)Y, (const float*)dY, mean_rstd, workspace, rows, C, rpb);
+    else { pseld_set_error("bn_relu_bwd_sums: unknown dtype"); return PSELD_ERR_BAD_ARG; }
+    pseld_reduce_slabs(workspace, sums, (long)C * 2, nb, (long)C * 2, 0, s);
+    hipLaunchKernelGGL(deinterleave2_kernel, dim3(pseld_cdiv(C, 256)), dim3(256), 0, s, sums, C, dgamma, dbeta);
+    PSELD_LAUNCH_CHECK("bn_relu_bwd_sums");
+    return PSELD_OK;
+}
+extern "C" int pseld_bn_relu_bwd_apply(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd, const float* gamma,
+                                       const float* sums, float inv_count, void* dX, long rows, int C, void* stream) {
+    PSELD_CHECK_ARG(X && dY && mean_rstd && gamma && sums && dX && rows > 0 && inv_count > 0.f, "bn_relu_bwd_apply: bad argument");
+    PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_bwd_apply: C must be a multiple of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = rows * C / 8;
+    CNN_DISPATCH("bn_relu_bwd_apply", hipLaunchKernelGGL(bn_relu_bwd_kernel<T>, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, (const T*)X, (const T*)Y,
+                                                         (const T*)dY, mean_rstd, gamma, sums, inv_count, (T*)dX, C, n));
+}
+/* both halves on one rank: dX, dgamma, dbeta (train-mode batch statistics) */
 extern "C" int pseld_bn_relu_bwd(int dtype, const void* X, const void* Y, const void* dY, const float* mean_rstd,
                                  const float* gamma, void* dX, float* dgamma, float* dbeta, long rows, int C, float* workspace,
                                  long workspace_bytes, void* stream) {
     PSELD_CHECK_ARG(X && dY && mean_rstd && gamma && dX && dgamma && dbeta && workspace, "bn_relu_bwd: null pointer");
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn2d_workspace(rows, C), "bn_relu_bwd: workspace too small");
-    hipStream_t s = (hipStream_t)stream;
     const int rpb = bn2d_rows_per_block(rows, C), nb = pseld_cdiv(rows, rpb);
-    PSELD_CHECK_ARG(C % 8 == 0, "bn_relu_bwd: C must be a multiple of 8");
-    const dim3 grid(nb, pseld_cdiv(C / 8, C / 8 < 256 ? C / 8 : 256));
-    float* total = workspace + (long)nb * C * 2;
-    const long n = rows * C / 8;
-    if (dtype == PSELD_BF16) {
-        hipLaunchKernelGGL((bn2d_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, workspace, rows, C, rpb);
-        pseld_reduce_slabs(workspace, total, (long)C * 2, nb, (long)C * 2, 0, s);
-        hipLaunchKernelGGL(bn_relu_bwd_kernel<bf16_t>, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)Y, (const bf16_t*)dY, mean_rstd, gamma, total, 1.f / (float)rows, (bf16_t*)dX, C, n);
-    } else if (dtype == PSELD_F32) {
-        hipLaunchKernelGGL((bn2d_sums_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, (const float*)Y, (const float*)dY, mean_rstd, workspace, rows, C, rpb);
-        pseld_reduce_slabs(workspace, total, (long)C * 2, nb, (long)C * 2, 0, s);
-        hipLaunchKernelGGL(bn_relu_bwd_kernel<float>, dim3(pseld_cdiv(n, 256)), dim3(256), 0, s, (const float*)X, (const float*)Y, (const float*)dY, mean_rstd, gamma, total, 1.f / (float)rows, (float*)dX, C, n);
-    } else { pseld_set_error("bn_relu_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(deinterleave2_kernel, dim3(pseld_cdiv(C, 256)), dim3(256), 0, s, total, C, dgamma, dbeta);
-    PSELD_LAUNCH_CHECK("bn_relu_bwd");
-    return PSELD_OK;
+    float* total = workspace + (long)nb * C * 2;          // (the workspace has one extra [C][2] row for the reduced sums)
+    int rc = pseld_bn_relu_bwd_sums(dtype, X, Y, dY, mean_rstd, total, dgamma, dbeta, rows, C, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return pseld_bn_relu_bwd_apply(dtype, X, Y, dY, mean_rstd, gamma, total, 1.f / (float)rows, dX, rows, C, stream);
 }
 
 extern "C" int pseld_avgpool_fwd(int dtype, const void* X, void* Y, int B, int Tn, int Fn, int C, int pt, int pf, void* stream) {

@@ -854,7 +854,38 @@ def conv3x3_wgrad(dY, X, dWp, B, T, F, accumulate=False):
     return dWp
 
 
+# Synchronised BatchNorm for the conv-stack BatchNorm2d / Conformer BatchNorm1d layers (configs/trainer/gpu.yaml:9 converts EVERY BatchNorm
+# to torch.nn.SyncBatchNorm): with a process group set (FusedTrainer, sync_bn=True) the train-mode statistics (forward: sum x, sum x^2;
+# backward: sum g xhat, sum g) are summed over the ranks between the two halves of each kernel pair, and the counts are the global ones.
+_sync_bn = {'group': None, 'world': 1, 'diag': None}
+
+
+def set_sync_bn_group(group, diag=None):
+    """group: a torch.distributed process group or None (rank-local statistics). diag: a list that receives (event, event) pairs around
+    every statistics all-reduce (trainer.enable_comm_diag)."""
+    _sync_bn['group'] = group
+    _sync_bn['diag'] = diag
+    if group is not None:
+        import torch.distributed as dist
+        _sync_bn['world'] = dist.get_world_size(group)
+    else:
+        _sync_bn['world'] = 1
+
+
+def _sync_bn_allreduce(sums):
+    import torch.distributed as dist
+    diag = _sync_bn['diag']
+    if diag is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    dist.all_reduce(sums, group=_sync_bn['group'])
+    if diag is not None:
+        e1.record()
+        diag.append((e0, e1))
+
+
 def bn2d_stats(X):
+    """Train-mode statistics f32[C][2] = (sum x, sum x^2) over the rows - of ALL ranks when a sync-BN group is set."""
     _chk(X)
     rows, C = X.shape
     L = _lib.lib()
@@ -862,6 +893,8 @@ def bn2d_stats(X):
     sums = torch.empty(2 * C, dtype=torch.float32, device=X.device)
     _lib.check(L.pseld_bn2d_stats(dtype_code(X), _lib.ptr(X), _lib.ptr(sums), rows, C, _lib.ptr(ws), ws.numel() * 4,
                                   _lib.stream_ptr()), "pseld_bn2d_stats")
+    if _sync_bn['group'] is not None:
+        _sync_bn_allreduce(sums)
     return sums
 
 
@@ -874,11 +907,23 @@ def bn_relu_fwd(X, scale_shift):
 
 
 def bn_relu_bwd(X, Y, dY, mean_rstd, gamma, dgamma, dbeta):
+    """Backward of relu(bn(x)) (Y = None: of the affine BatchNorm alone). With a sync-BN group: the per-channel sums are all-reduced between
+    the two halves (pseld_bn_relu_bwd_sums / _apply), as torch.nn.SyncBatchNorm's backward does; d(gamma) / d(beta) stay rank-local."""
     _chk(X, Y, dY, mean_rstd, gamma, dgamma, dbeta)
     rows, C = X.shape
     L = _lib.lib()
     ws = workspace(L.pseld_bn2d_workspace(rows, C), X.device)
     dX = torch.empty_like(X)
+    if _sync_bn['group'] is not None:
+        sums = torch.empty(2 * C, dtype=torch.float32, device=X.device)
+        _lib.check(L.pseld_bn_relu_bwd_sums(dtype_code(X), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(dY), _lib.ptr(mean_rstd), _lib.ptr(sums),
+                                            _lib.ptr(dgamma), _lib.ptr(dbeta), rows, C, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                   "pseld_bn_relu_bwd_sums")
+        _sync_bn_allreduce(sums)
+        _lib.check(L.pseld_bn_relu_bwd_apply(dtype_code(X), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(dY), _lib.ptr(mean_rstd), _lib.ptr(gamma),
+                                             _lib.ptr(sums), 1.0 / (rows * _sync_bn['world']), _lib.ptr(dX), rows, C, _lib.stream_ptr()),
+                   "pseld_bn_relu_bwd_apply")
+        return dX
     _lib.check(L.pseld_bn_relu_bwd(dtype_code(X), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(dY), _lib.ptr(mean_rstd), _lib.ptr(gamma),
                                    _lib.ptr(dX), _lib.ptr(dgamma), _lib.ptr(dbeta), rows, C, _lib.ptr(ws), ws.numel() * 4,
                                    _lib.stream_ptr()), "pseld_bn_relu_bwd")
@@ -927,6 +972,8 @@ def bn2d_finalize(sums, count, weight, bias, running_mean, running_var, num_batc
     C = weight.numel()
     mean_rstd = torch.empty(C * 2, dtype=torch.float32, device=weight.device)
     scale_shift = torch.empty(C * 2, dtype=torch.float32, device=weight.device)
+    if training and _sync_bn['group'] is not None:
+        count = count * _sync_bn['world']          # bn2d_stats returned the sums of all ranks
     rc = _lib.lib().pseld_bn_scalar_finalize(_lib.ptr(sums), float(count), 0, _lib.ptr(weight), _lib.ptr(bias),
                                              _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches),
                                              _lib.ptr(mean_rstd), _lib.ptr(scale_shift), 1, C, momentum, eps,
@@ -946,15 +993,7 @@ def bn_affine_fwd(X, scale_shift):
 
 
 def bn_affine_bwd(X, dY, mean_rstd, gamma, dgamma, dbeta):
-    _chk(X, dY, mean_rstd, gamma, dgamma, dbeta)
-    rows, C = X.shape
-    L = _lib.lib()
-    ws = workspace(L.pseld_bn2d_workspace(rows, C), X.device)
-    dX = torch.empty_like(X)
-    _lib.check(L.pseld_bn_relu_bwd(dtype_code(X), _lib.ptr(X), None, _lib.ptr(dY), _lib.ptr(mean_rstd), _lib.ptr(gamma),
-                                   _lib.ptr(dX), _lib.ptr(dgamma), _lib.ptr(dbeta), rows, C, _lib.ptr(ws), ws.numel() * 4,
-                                   _lib.stream_ptr()), "pseld_bn_relu_bwd")
-    return dX
+    return bn_relu_bwd(X, None, dY, mean_rstd, gamma, dgamma, dbeta)
 
 
 def axpby(x, y, a, b, out=None):

@@ -203,3 +203,166 @@ def test_bench_starts_its_own_ranks_without_a_launcher(dev):
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env1,
                        capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode != 0 and 'must agree' in (r.stderr + r.stdout)
+
+
+# ---- CRNN (BASELINE config 1's family): every BatchNorm of the conv stack synchronised (configs/trainer/gpu.yaml:9) ----------------
+CRNN_TINY = [8, 16, 32, 64, 128, 256]
+
+
+def _build_crnn(dev, decoder=None):
+    from oracle import crnn as oc
+    from pseldnets_amd.models import multi_accdoa
+    cfg = A(data=A(n_mels=64, sample_rate=24000, hoplen=240), adapt=A(), model=A(decoder=decoder, num_decoder_layers=1))
+    net = multi_accdoa.CRNN(cfg, 3, 7, encoder='CNN12', pretrained_path=None, num_features=CRNN_TINY)
+    net.load_state_dict(oc.random_state('multi_accdoa', 3, 7, 'CNN12', CRNN_TINY, seed=0) if decoder is None
+                        else net.state_dict(), strict=True)
+    return net.to(dev)
+
+
+def _run_crnn(net, x, lab, group, steps=2):
+    from pseldnets_amd.trainer import FusedTrainer
+    tr = FusedTrainer(net, None, 'adpit', lr=1e-4, max_norm=1.0, process_group=group, sync_bn=group is not None)
+    if group is not None:
+        tr.enable_comm_diag()
+    losses, grad1 = [], None
+    for st in range(steps):
+        losses.append(tr.training_step(x, {'adpit_label': lab})['loss_all'].item())
+        if st == 0:
+            grad1 = net.arena.grad.detach().cpu().clone() / tr.world      # the all-reduce SUMS; AdamW applies 1 / world
+    n_bn_syncs = None
+    if group is not None:
+        torch.cuda.synchronize()
+        n_bn_syncs = len(tr.comm_diag['sync_bn']) // steps
+    sd = net.state_dict()
+    rv = torch.cat([v.detach().float().flatten().cpu() for k, v in sorted(sd.items()) if k.endswith('running_var')])
+    return losses, net.arena.flat.detach().cpu().clone(), rv, n_bn_syncs, grad1
+
+
+def _worker_crnn(rank, world, port, q, env=None):
+    from oracle import crnn as oc
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.update(env or {})
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    x = oc.random_features(4, seed=1)[2 * rank: 2 * rank + 2].contiguous().to(dev)
+    lab = synth.formula_adpit_label(4, 100, 3)[2 * rank: 2 * rank + 2].contiguous().to(dev)
+    if os.environ.get('PSELD_TEST_NO_CONV_BN_SYNC') == '1':           # negative control: scalar front synchronised, conv stack rank-local
+        from pseldnets_amd import ops
+        real = ops.set_sync_bn_group
+        ops.set_sync_bn_group = lambda group, diag=None: real(None)
+    losses, flat, rv, n_sync, grad1 = _run_crnn(_build_crnn(dev), x, lab, dist.group.WORLD)
+    q.put((rank, losses, flat.numpy(), rv.numpy(), n_sync, grad1.numpy()))
+    dist.destroy_process_group()
+
+
+def _two_crnn_ranks(port, env=None):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_crnn, args=(r, 2, port, q, env)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def _top_and_all(net, g2, g1):
+    """Relative L2 error of the gradient of the layers ABOVE the first ReLU mask that can flip (fc, conv_block6.conv2 / bn2) and of the
+    whole arena."""
+    base = net.arena.grad.data_ptr()
+    num = den = 0.0
+    for n in net.arena.entries:
+        if n.startswith('fc.') or n.startswith('convs.conv_block6.bn2') or n == 'convs.conv_block6.conv2.weight':
+            gv = net.arena.g(n)
+            off, k = (gv.data_ptr() - base) // 4, gv.numel()
+            num += (g2[off:off + k] - g1[off:off + k]).pow(2).sum().item()
+            den += g1[off:off + k].pow(2).sum().item()
+    return (num / den) ** 0.5, ((g2 - g1).norm() / g1.norm()).item()
+
+
+def test_crnn_two_ranks_with_synchronised_conv_batchnorm_equal_one_process(dev):
+    """2 ranks x 2 chunks == 1 process x 4 chunks for the CNN12 conv stack (12 BatchNorm2d layers + the scalar front): forward statistics
+    and the backward's per-channel sums are all-reduced (ops.bn2d_stats / ops.bn_relu_bwd -> pseld_bn_relu_bwd_sums / _apply), as
+    torch.nn.SyncBatchNorm does under the reference's `sync_batchnorm: true`. The first step's averaged gradient is compared with the
+    one-process gradient: < 5e-5 relative L2 on the layers above the first ReLU that can flip (they see every layer's FORWARD statistics
+    and the top BatchNorm's backward), < 2e-2 on the whole arena (one pre-activation within rounding of zero flips its ReLU mask and
+    moves the gradient below it by ~4e-3: measured, tools/dbg), against 1e-2 / 0.5 for the negative control with rank-local conv-stack
+    statistics. The exact backward equality is test_sync_bn_ops_two_ranks_equal_one_process."""
+    from oracle import crnn as oc
+    res = _two_crnn_ranks(35600 + os.getpid() % 2000)
+    x = oc.random_features(4, seed=1).to(dev)
+    lab = synth.formula_adpit_label(4, 100, 3).to(dev)
+    net = _build_crnn(dev)
+    losses1, flat1, rv1, _, grad1 = _run_crnn(net, x, lab, None)
+    for step in range(2):
+        mean2 = 0.5 * (res[0][1][step] + res[1][1][step])
+        assert abs(mean2 - losses1[step]) < 2e-4 * abs(losses1[step]), (step, mean2, losses1[step])
+    f0, f1 = torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])
+    assert torch.equal(f0, f1)                                         # ranks stay bit-identical
+    top, whole = _top_and_all(net, torch.from_numpy(res[0][5]), grad1)
+    rvd = ((torch.from_numpy(res[0][3]) - rv1).norm() / rv1.norm()).item()
+    print('CRNN 2-rank vs 1-process: gradient rel L2 top layers', top, 'whole arena', whole, 'running_var rel L2', rvd,
+          'BN all-reduces per step', res[0][4])
+    assert top < 5e-5 and whole < 2e-2 and rvd < 1e-4
+    assert res[0][4] >= 1 + 2 * 12                                     # scalar front + forward and backward of the 12 conv BatchNorms
+    ctl = _two_crnn_ranks(37600 + os.getpid() % 2000, dict(PSELD_TEST_NO_CONV_BN_SYNC='1'))
+    ctop, cwhole = _top_and_all(net, torch.from_numpy(ctl[0][5]), grad1)
+    print('negative control (rank-local conv BatchNorm statistics): top layers', ctop, 'whole arena', cwhole)
+    assert ctop > 100 * top and cwhole > 10 * whole
+
+
+def _bn_op_data(rows, C):
+    g = torch.Generator().manual_seed(3)
+    return (torch.randn(rows, C, generator=g) * 2 + 0.7, torch.randn(rows, C, generator=g) + 0.3, 1 + 0.1 * torch.randn(C, generator=g),
+            0.1 * torch.randn(C, generator=g))
+
+
+def _bn_op_run(X, dY, gamma, beta, dev, relu):
+    from pseldnets_amd import ops
+    X, dY, gamma, beta = X.to(dev), dY.to(dev), gamma.to(dev), beta.to(dev)
+    C = X.shape[1]
+    rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros(1, dtype=torch.long, device=dev)
+    mr, ss = ops.bn2d_finalize(ops.bn2d_stats(X), X.shape[0], gamma, beta, rm, rv, nbt, True)
+    Y = ops.bn_relu_fwd(X, ss) if relu else ops.bn_affine_fwd(X, ss)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dX = ops.bn_relu_bwd(X, Y, dY, mr, gamma, dg, db) if relu else ops.bn_affine_bwd(X, dY, mr, gamma, dg, db)
+    return [t.cpu() for t in (Y, dX, dg, db, mr, rv)]
+
+
+def _bn_op_worker(rank, port, q, rows, C, relu):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    from pseldnets_amd import ops
+    ops.set_sync_bn_group(dist.group.WORLD)
+    X, dY, gamma, beta = _bn_op_data(rows, C)
+    h = rows // 2
+    out = _bn_op_run(X[rank * h:(rank + 1) * h].contiguous(), dY[rank * h:(rank + 1) * h].contiguous(), gamma, beta, torch.device('cuda:0'), relu)
+    q.put((rank, [t.numpy() for t in out]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('rows,C,relu', [(248, 256, True), (4096, 64, True), (1000, 128, False)])
+def test_sync_bn_ops_two_ranks_equal_one_process(dev, rows, C, relu):
+    """BatchNorm2d (+ReLU) / BatchNorm1d kernels with the statistics summed over two ranks (the forward's sum x, sum x^2 and the backward's
+    sum g xhat, sum g between pseld_bn_relu_bwd_sums and _apply) == the same kernels on the concatenated rows: outputs, input gradients,
+    d(gamma) / d(beta) (summed over the ranks), mean / rstd and the running variance, all to fp32 round-off."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 39600 + (os.getpid() + rows) % 2000
+    procs = [ctx.Process(target=_bn_op_worker, args=(r, port, q, rows, C, relu)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    from pseldnets_amd import ops
+    ops.set_sync_bn_group(None)
+    Y, dX, dg, db, mr, rv = _bn_op_run(*_bn_op_data(rows, C), dev, relu)
+    r0, r1 = [torch.from_numpy(t) for t in res[0][1]], [torch.from_numpy(t) for t in res[1][1]]
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    errs = dict(Y=rel(torch.cat([r0[0], r1[0]]), Y), dX=rel(torch.cat([r0[1], r1[1]]), dX), dgamma=rel(r0[2] + r1[2], dg), dbeta=rel(r0[3] + r1[3], db),
+                mean_rstd=rel(r0[4], mr), running_var=rel(r0[5], rv))
+    print('sync-BN ops', rows, C, relu, errs)
+    assert max(errs.values()) < 2e-6, errs
+    assert torch.equal(r0[4], r1[4])

@@ -48,8 +48,8 @@ def _worker(rank, world, port, q):
         tr._reduce_range(lo, hi)
         hi = lo
     tr._reduce_range(0, hi)
-    for w in tr._works:
-        w.wait()
+    for work, _buf, _g, _ev in tr._works:          # (work handle, bf16 staging buffer or None, gradient range, issue event or None)
+        work.wait()
     # validation / test epoch end: every rank's step outputs gathered back into the sampler's order (components/model_module.py:178-184:
     # all_gather, then value.transpose(0, 1).reshape(-1, ...) per step — rank r holds samples r, r + world, ... of each global batch)
     from pseldnets_amd.models.model_module import SELDModelModule
