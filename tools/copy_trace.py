@@ -17,15 +17,21 @@ from pseldnets_amd.utils.config import get_afextractor  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--chunks', type=int, default=192)
+    ap.add_argument('--group', action='store_true', help='train through a one-rank RCCL group with sync-BN (the data-parallel code path)')
     args = ap.parse_args()
     device = torch.device('cuda:0')
+    group = None
+    if args.group:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29878', rank=0, world_size=1, device_id=device)
+        group = dist.group.WORLD
     cfg = bench.make_cfg()
     torch.manual_seed(2024)
     net = multi_accdoa.HTSAT(cfg, bench.CLASSES, 7, pretrained_path=None)
     net.compute_dtype = torch.bfloat16
     net.to(device)
     wave, target = bench.synthetic_batch(32, device, 2024, chunks=args.chunks)
-    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'adpit', lr=1e-4, max_norm=1.0, process_group=None, sync_bn=False,
+    trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'adpit', lr=1e-4, max_norm=1.0, process_group=group, sync_bn=group is not None,
                            use_graph=False)
     step = lambda: trainer.training_step(wave, target, next_x=wave)
     for _ in range(3):
@@ -35,7 +41,7 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
-    names = ('aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::fill_', 'aten::zero_', 'aten::_to_copy', 'aten::cat', 'aten::index_copy_')
+    names = ('c10d::allreduce_', 'aten::empty', 'aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::fill_', 'aten::zero_', 'aten::_to_copy', 'aten::cat', 'aten::index_copy_')
     by = collections.Counter()
     for ev in prof.events():
         if ev.name in names:
