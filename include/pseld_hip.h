@@ -89,6 +89,14 @@ int pseld_swin_attn_supported(int dtype, int res, int C, int heads);
 int pseld_swin_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
                         const float* bias_table, void* qkv, void* out, void* xh, float* lse, int B, int res, int C, int heads,
                         int shift, float eps, void* stream);
+/* The whole attention half of a Swin block in one kernel (SURVEY 8b `pseld_swin_attn_fwd`: LN -> QKV -> window attention -> proj -> DropPath
+ * + shortcut; reference htsat.py:234-260 with WindowAttention.forward :118-145): xmid = x + s * (attention(norm1(x)) Wproj^T + bproj),
+ * s = rowscale[sample of the token] (DropPath mask / keep_prob, model_utilities.py:216-232) or 1 when rowscale is NULL. qkv [M,3C], out
+ * [M,C] (merged heads, before proj), xh = LN(x) [M,C] and lse f32 [M,heads] are the operands of the backward kernels; all four may be NULL
+ * (no-grad forward: x is read, xmid is written, nothing else). Same support set as pseld_swin_attn_supported. */
+int pseld_swin_block_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
+                              const float* bias_table, const void* wproj, const float* bproj, const float* rowscale, void* qkv, void* out,
+                              void* xh, float* lse, void* xmid, int B, int res, int C, int heads, int shift, float eps, void* stream);
 
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */

@@ -37,6 +37,11 @@ struct SwinArgs {
     void* ao;                 // out [M, C] attention output (heads merged)
     void* xh;                 // out [M, C] LN(x) (operand of the QKV weight gradient); may be null
     float* lse;               // out [M, heads] (may be null)
+    // the block's attention tail (proj -> DropPath -> + shortcut), fused when wproj != null
+    const void* wproj;        // [C, C] attn.proj.weight
+    const float* bproj;       // [C]
+    const float* rowscale;    // [B] DropPath factor per sample (mask / keep_prob), or null
+    void* xmid;               // out [M, C] = x + s * (ao Wproj^T + bproj)
     int B, res, heads, shift, n_win_total;
     float scale, eps;
 };
@@ -78,19 +83,22 @@ __device__ __forceinline__ bf16x8 pack8f(const f32x16& a, int e0) {
     return f;
 }
 
-// LDS: [W image: 288 weight rows + 1 zero row, 192 B each, chunk-swizzled] [2 buffers x 2 windows x 64 token rows] [tables]
-constexpr int WROWS = 3 * SC + 1, WIMG = WROWS * SRB;
-constexpr int SW_LDS = WIMG + 4 * XBUF + (904 + 256 + 2 * SC) * 4 + (4 * 64 + 4 * 68) * 4;
+// LDS: [W image: 288 qkv weight rows + 1 zero row + 96 proj weight rows, 192 B each, chunk-swizzled] [2 buffers x 2 windows x 64 raw token rows]
+// [2 windows x 64 rows: LN(x), later the heads' attention output] [tables]
+constexpr int WROWS = 3 * SC + 1 + SC, WIMG = WROWS * SRB, PROW0 = 3 * SC + 1;
+constexpr int SW_LDS = WIMG + 6 * XBUF + (904 + 256 + 3 * SC) * 4 + (4 * 64 + 4 * 68) * 4;
 
 __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wimg = smem;                                   // rows: q dims of head 0..3, k dims, v dims (row = which * 96 + head * 24 + d); row 288 = zeros
     char* xbuf = smem + WIMG;                            // [2 buffers][2 windows][64 rows x 192 B], chunk-swizzled
-    float* btab = (float*)(xbuf + 4 * XBUF);             // [4][225] relative-position bias x log2(e), padded to 904
+    char* hbuf = xbuf + 4 * XBUF;                        // [2 windows][64 rows x 192 B]: LN(x) of the current pair; then the merged attention output
+    float* btab = (float*)(hbuf + 2 * XBUF);             // [4][225] relative-position bias x log2(e), padded to 904
     float* bqk = btab + 904;                             // [2 (q, k)][4 heads][32] biases by head dim (0 for dims >= 24)
     float* gam = bqk + 256;                              // [96]
     float* bet = gam + SC;                               // [96]
-    int* toks_all = (int*)(bet + SC);                    // [2 buffers][2 windows][64] natural token index of the window's slots
+    float* bpr = bet + SC;                               // [96] proj bias
+    int* toks_all = (int*)(bpr + SC);                    // [2 buffers][2 windows][64] natural token index of the window's slots
     int* labels_all = toks_all + 256;                    // [2][2][68] mask-region labels + "this window mixes regions"
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,7 +116,8 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
         const int which = tid >> 7, hh = (tid >> 5) & 3, d = tid & 31;
         bqk[tid] = d < SHD ? a.bqkv[which * SC + hh * SHD + d] : 0.f;
     }
-    if (tid < SC) { gam[tid] = a.gamma[tid]; bet[tid] = a.beta[tid]; }
+    const bool tail = a.wproj != nullptr;
+    if (tid < SC) { gam[tid] = a.gamma[tid]; bet[tid] = a.beta[tid]; bpr[tid] = tail ? a.bproj[tid] : 0.f; }
     if (tid < SNCH) *(f32x4*)(wimg + schunk(3 * SC, tid)) = f32x4{0.f, 0.f, 0.f, 0.f};
     const int dl = sswap23(r);                           // this lane's head dim in every accumulator row / column map below
     const float bv = dl < SHD ? a.bqkv[2 * SC + head * SHD + dl] : 0.f;
@@ -117,6 +126,12 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
     for (int i = wave; i < 3 * SC * SNCH / 64; i += 8) {
         const int q = i * 64 + lane, row = q / SNCH, ch = q - row * SNCH;
         sdma16(wimg + i * 1024, a.wqkv, (unsigned)(row * SRB + ((ch ^ sswz(row)) << 4)));
+    }
+    if (tail) {                                            // the 96 proj weight rows behind the zero row (image rows PROW0 ..)
+        for (int i = wave; i < SC * SNCH / 64; i += 8) {
+            const int q = i * 64 + lane, row = q / SNCH, ch = q - row * SNCH;
+            sdma16(wimg + PROW0 * SRB + i * 1024, a.wproj, (unsigned)(row * SRB + ((ch ^ sswz(PROW0 + row)) << 4)));
+        }
     }
     const int wrow = dl < SHD ? head * SHD + dl : -1;     // weight row of this lane inside a (q | k | v) block; padding lanes read the zero row
     const int wq_row = wrow < 0 ? 3 * SC : wrow, wk_row = wrow < 0 ? 3 * SC : SC + wrow, wv_row = wrow < 0 ? 3 * SC : 2 * SC + wrow;
@@ -153,15 +168,24 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
             const unsigned long long diff = __ballot(lb != l0);
             if (wt == 0) labels[64] = diff != 0ull;
         }
+        // DropPath factor of this window's sample by a SCALAR load (a vector-memory load here would make hipcc wait on vmcnt, i.e. on the
+        // next pair's DMA, wherever it schedules the use); complete at the s_waitcnt below
+        unsigned sc_bits = 0x3f800000u;
+        if (tail && a.rowscale && live) {
+            const float* sp = a.rowscale + __builtin_amdgcn_readfirstlane(wi / ((a.res >> 3) * (a.res >> 3)));
+            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(sc_bits) : "s"(sp) : "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the window has landed (and its last stores)
         __builtin_amdgcn_s_barrier();                       // everybody's has; everybody has left the other buffer
         if (it + 1 < n_it) issue(it + 1);
+        char* hb = hbuf + ws * XBUF;
         if (!live) {                                        // idle wave group: keep the barrier count of the iteration
             __builtin_amdgcn_s_barrier();
+            if (tail) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
             continue;
         }
 
-        // ---- LayerNorm in place: 4 threads per token row, 3 chunks (24 channels) each; same arithmetic as norm.hip:ln_fwd_kernel
+        // ---- LayerNorm, raw rows -> hb (the raw rows stay: they are the shortcut of the fused tail): 4 threads per token row, 3 chunks (24 channels) each; same arithmetic as norm.hip:ln_fwd_kernel
         {
             const int row = wt >> 2, part = wt & 3;
             float v[24];
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
                 bf16x8 f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = (bf16_t)((v[c * 8 + j] - mean) * rstd * gam[c0 + j] + bet[c0 + j]);
-                *(bf16x8*)(xb + schunk(row, part * 3 + c)) = f;
+                *(bf16x8*)(hb + schunk(row, part * 3 + c)) = f;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -198,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int q = wt + 256 * i, t = q / SNCH, chp = q - t * SNCH;      // LDS position (t, chp) holds logical chunk chp ^ swz(t)
-                *(f32x4*)((char*)a.xh + (long)toks[t] * SRB + ((chp ^ sswz(t)) << 4)) = *(const f32x4*)(xb + q * 16);
+                *(f32x4*)((char*)a.xh + (long)toks[t] * SRB + ((chp ^ sswz(t)) << 4)) = *(const f32x4*)(hb + q * 16);
             }
         }
 
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
             }
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) {
-                const bf16x8 xf = *(const bf16x8*)(xb + schunk(32 * tt + r, 2 * kk + h));       // token 32 tt + r, channels 16 kk + 8 h ..
+                const bf16x8 xf = *(const bf16x8*)(hb + schunk(32 * tt + r, 2 * kk + h));       // token 32 tt + r, channels 16 kk + 8 h ..
                 const bf16x8 wqf = *(const bf16x8*)(wimg + schunk(wq_row, 2 * kk + h));         // weight row of head dim swap23(r)
                 const bf16x8 wkf = *(const bf16x8*)(wimg + schunk(wk_row, 2 * kk + h));
                 const bf16x8 wvf = *(const bf16x8*)(wimg + schunk(wv_row, 2 * kk + h));
@@ -236,6 +260,7 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
             Qf[tt][0] = pack8f(qT, 0); Qf[tt][1] = pack8f(qT, 8);
             Kf[tt][0] = pack8f(kT, 0); Kf[tt][1] = pack8f(kT, 8);
             Vf[tt][0] = pack8f(vA, 0); Vf[tt][1] = pack8f(vA, 8);
+            if (a.qkv) {
             // q, k: lane = token, 8 consecutive dims per register group
             char* orow = (char*)a.qkv + (long)toks[32 * tt + r] * (3 * SC * 2) + (head * SHD + 8 * h) * 2;
             *(bf16x8*)(orow) = Qf[tt][0];                                             // dims 8 h .. 8 h + 7
@@ -254,7 +279,12 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
                     if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows at a time: otherwise all sixteen addresses are kept live
                 }
             }
+            }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tail) {                                         // every head of the pair has read LN(x): hb becomes the attention-output tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
 
         // ---- per 32-query tile: S^T[key tile] = K Q^T (both operands are accumulators: contraction over the head-dim rows), softmax over
@@ -322,10 +352,51 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) oT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vf[kt][s], pack8f(st[kt], 8 * s), oT, 0, 0, 0);
             // row i of O^T is V's lane i = head dim swap23(i): register e of lane half h is dim (e & 7) + 8 h + 16 (e >> 3)
-            char* orow = (char*)a.ao + (long)toks[qi] * (SC * 2) + (head * SHD + 8 * h) * 2;
-            *(bf16x8*)(orow) = pack8f(oT, 0);
-            if (h == 0) *(bf16x8*)(orow + 32) = pack8f(oT, 8);
+            const bf16x8 o0 = pack8f(oT, 0), o1 = pack8f(oT, 8);
+            if (a.ao) {
+                char* orow = (char*)a.ao + (long)toks[qi] * (SC * 2) + (head * SHD + 8 * h) * 2;
+                *(bf16x8*)(orow) = o0;
+                if (h == 0) *(bf16x8*)(orow + 32) = o1;
+            }
+            if (tail) {                                     // the same pieces into the tile: chunk = 3 head + h (and + 2 for dims 16..23)
+                *(bf16x8*)(hb + schunk(qi, 3 * head + h)) = o0;
+                if (h == 0) *(bf16x8*)(hb + schunk(qi, 3 * head + 2)) = o1;
+            }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tail) {
+            // ---- x_mid^T[c][m] = Wproj ao^T: this wave's 24 output channels (rows through swap23, as everywhere), both token tiles; then
+            // + bias, x DropPath factor of the sample, + the raw x rows still sitting in the DMA buffer: 16-byte pieces out
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int prow = wrow < 0 ? 3 * SC : PROW0 + wrow;
+            const float sc = __builtin_bit_cast(float, sc_bits);
+            const f32x4 b0 = *(const f32x4*)(bpr + head * SHD + 8 * h), b1 = *(const f32x4*)(bpr + head * SHD + 8 * h + 4);
+            const f32x4 b2 = *(const f32x4*)(bpr + head * SHD + (h ? 0 : 16)), b3 = *(const f32x4*)(bpr + head * SHD + (h ? 0 : 20));
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x16 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { y[j] = b0[j]; y[4 + j] = b1[j]; y[8 + j] = b2[j]; y[12 + j] = b3[j]; }
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    const bf16x8 wf = *(const bf16x8*)(wimg + schunk(prow, 2 * kk + h));
+                    const bf16x8 af = *(const bf16x8*)(hb + schunk(32 * tt + r, 2 * kk + h));
+                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, y, 0, 0, 0);
+                }
+                const int m = 32 * tt + r;
+                const bf16x8 x0 = *(const bf16x8*)(xb + schunk(m, 3 * head + h));
+                const bf16x8 x1 = *(const bf16x8*)(xb + schunk(m, 3 * head + 2));
+                bf16x8 r0, r1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    r0[j] = (bf16_t)fmaf((float)(bf16_t)y[j], sc, (float)x0[j]);
+                    r1[j] = (bf16_t)fmaf((float)(bf16_t)y[8 + j], sc, (float)x1[j]);
+                }
+                char* orow = (char*)a.xmid + (long)toks[m] * (SC * 2) + (head * SHD + 8 * h) * 2;
+                *(bf16x8*)(orow) = r0;
+                if (h == 0) *(bf16x8*)(orow + 32) = r1;
+            }
         }
     }
 }
@@ -336,19 +407,11 @@ extern "C" int pseld_swin_attn_supported(int dtype, int res, int C, int heads) {
     return dtype == PSELD_BF16 && C == SC && heads == 4 && res >= 8 && res % 8 == 0 ? 1 : 0;
 }
 
-// LayerNorm(norm1) -> qkv Linear -> window attention. Outputs: qkv [M, 3C], out [M, C] (heads merged, before proj), xh = LN(x)
-// [M, C] (optional), lse f32 [M, heads] (optional): exactly what pseld_layernorm_fwd + pseld_gemm + pseld_window_attn_fwd leave.
-extern "C" int pseld_swin_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
-                                   const float* bias_table, void* qkv, void* out, void* xh, float* lse, int B, int res, int C, int heads,
-                                   int shift, float eps, void* stream) {
-    PSELD_CHECK_ARG(x && gamma && beta && wqkv && bqkv && bias_table && qkv && out, "swin_attn_fwd: null pointer");
-    PSELD_CHECK_ARG(pseld_swin_attn_supported(dtype, res, C, heads), "swin_attn_fwd: built for bf16, C = 96, 4 heads (got dtype %d C %d heads %d res %d)",
-                    dtype, C, heads, res);
-    PSELD_CHECK_ARG(B > 0 && shift >= 0 && shift < 8 && (long)B * res * res * SRB < (1L << 32), "swin_attn_fwd: bad B / shift, or more than 4 GB of tokens");
-    SwinArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.gamma = gamma; a.beta = beta; a.wqkv = wqkv; a.bqkv = bqkv; a.bias_table = bias_table;
-    a.qkv = qkv; a.ao = out; a.xh = xh; a.lse = lse;
+namespace {
+int swin_launch(SwinArgs& a, int dtype, int B, int res, int C, int heads, int shift, float eps, void* stream, const char* who) {
+    PSELD_CHECK_ARG(pseld_swin_attn_supported(dtype, res, C, heads), "%s: built for bf16, C = 96, 4 heads (got dtype %d C %d heads %d res %d)",
+                    who, dtype, C, heads, res);
+    PSELD_CHECK_ARG(B > 0 && shift >= 0 && shift < 8 && (long)B * res * res * SRB < (1L << 32), "%s: bad B / shift, or more than 4 GB of tokens", who);
     a.B = B; a.res = res; a.heads = heads; a.shift = shift; a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)SHD); a.eps = eps;
     static bool attr = false;
@@ -356,6 +419,36 @@ extern "C" int pseld_swin_attn_fwd(int dtype, const void* x, const float* gamma,
     const int pairs = (a.n_win_total + 1) / 2;
     const int grid = pairs < 256 ? pairs : 256;                  // persistent: one 8-wave workgroup per CU, two windows per iteration
     hipLaunchKernelGGL(swin_attn_fwd_kernel, dim3(grid), dim3(512), SW_LDS, (hipStream_t)stream, a);
-    PSELD_LAUNCH_CHECK("swin_attn_fwd");
+    PSELD_LAUNCH_CHECK(who);
     return PSELD_OK;
+}
+}  // namespace
+
+// LayerNorm(norm1) -> qkv Linear -> window attention. Outputs: qkv [M, 3C], out [M, C] (heads merged, before proj), xh = LN(x)
+// [M, C] (optional), lse f32 [M, heads] (optional): exactly what pseld_layernorm_fwd + pseld_gemm + pseld_window_attn_fwd leave.
+extern "C" int pseld_swin_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
+                                   const float* bias_table, void* qkv, void* out, void* xh, float* lse, int B, int res, int C, int heads,
+                                   int shift, float eps, void* stream) {
+    PSELD_CHECK_ARG(x && gamma && beta && wqkv && bqkv && bias_table && qkv && out, "swin_attn_fwd: null pointer");
+    SwinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.gamma = gamma; a.beta = beta; a.wqkv = wqkv; a.bqkv = bqkv; a.bias_table = bias_table;
+    a.qkv = qkv; a.ao = out; a.xh = xh; a.lse = lse;
+    return swin_launch(a, dtype, B, res, C, heads, shift, eps, stream, "swin_attn_fwd");
+}
+
+// The whole attention half of a Swin block (htsat.py:234-260): x_mid = x + s * (proj(window_attention(qkv(norm1(x)))) + b), s = the DropPath
+// factor of the token's sample (rowscale f32[B], or NULL). qkv / out / xh / lse are the operands of the backward: all four may be NULL in
+// a no-grad forward, which then reads x and writes x_mid and nothing else.
+extern "C" int pseld_swin_block_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
+                                         const float* bias_table, const void* wproj, const float* bproj, const float* rowscale, void* qkv,
+                                         void* out, void* xh, float* lse, void* xmid, int B, int res, int C, int heads, int shift, float eps,
+                                         void* stream) {
+    PSELD_CHECK_ARG(x && gamma && beta && wqkv && bqkv && bias_table && wproj && bproj && xmid, "swin_block_attn_fwd: null pointer");
+    SwinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.gamma = gamma; a.beta = beta; a.wqkv = wqkv; a.bqkv = bqkv; a.bias_table = bias_table;
+    a.wproj = wproj; a.bproj = bproj; a.rowscale = rowscale; a.xmid = xmid;
+    a.qkv = qkv; a.ao = out; a.xh = xh; a.lse = lse;
+    return swin_launch(a, dtype, B, res, C, heads, shift, eps, stream, "swin_block_attn_fwd");
 }

@@ -24,8 +24,10 @@ GELU_DUAL = os.environ.get('PSELD_GELU_DUAL', '1') != '0'
 # where the layer-wise chain is HBM-bound and the fused one measures faster; at C = 192 the recompute costs more than the traffic
 # it saves (tools/mlp_bench.py), C >= 384 is MFMA-bound and was never a candidate.
 FUSED_MLP_WIDTHS = tuple(int(v) for v in os.environ.get('PSELD_FUSED_MLP', '96').split(',') if v.strip())
-# Fused attention front half (csrc/swin.hip: norm1 -> qkv -> window attention in one kernel; stage 0, bf16). PSELD_FUSED_ATTN=0: layer-wise.
+# Fused attention half of a block (csrc/swin.hip: norm1 -> qkv -> window attention -> proj -> DropPath + shortcut in one kernel; stage 0,
+# bf16). PSELD_FUSED_ATTN=0: layer-wise.
 FUSED_ATTN = os.environ.get('PSELD_FUSED_ATTN', '1') != '0'
+FUSED_ATTN_TAIL = os.environ.get('PSELD_FUSED_ATTN', '1') != 'front'      # 'front': stop in front of proj (A/B of the fused tail)
 _inference = [False]      # set by the no-grad forward (seld_net._run): nothing is saved for a backward pass
 
 
@@ -300,8 +302,16 @@ class SwinEncoder:
             s1 = s2 = None
             if drop_scale is not None and self.rates[gi] > 0:
                 s1, s2 = drop_scale[gi, 0], drop_scale[gi, 1]
-            if FUSED_ATTN and ops.swin_attn_fused_supported(x, res, heads):
-                # norm1 -> qkv -> window attention in ONE kernel (csrc/swin.hip); it leaves the same saved operands as the three launches
+            x_mid = None
+            if FUSED_ATTN and FUSED_ATTN_TAIL and not self.attn_adapter and ops.swin_attn_fused_supported(x, res, heads):
+                # the whole attention half - norm1 -> qkv -> window attention -> proj -> DropPath + shortcut - in ONE kernel (csrc/swin.hip); it
+                # leaves the same saved operands as the four launches (nothing but x_mid in a no-grad forward)
+                x_mid, ao, qkv, xh1, lse = ops.swin_block_attn_fwd(x, a.p(b + 'norm1.weight'), a.p(b + 'norm1.bias'), self._w(b + 'attn.qkv.weight', dtype),
+                                                                   a.p(b + 'attn.qkv.bias'), a.p(b + 'attn.relative_position_bias_table'),
+                                                                   self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), B, res, heads, shift,
+                                                                   rowscale=s1, need_saved=not _inference[0])
+            elif FUSED_ATTN and ops.swin_attn_fused_supported(x, res, heads):
+                # norm1 -> qkv -> window attention in ONE kernel; the adapter branch follows layer-wise
                 ao, qkv, xh1, lse = ops.swin_attn_fwd(x, a.p(b + 'norm1.weight'), a.p(b + 'norm1.bias'), self._w(b + 'attn.qkv.weight', dtype),
                                                       a.p(b + 'attn.qkv.bias'), a.p(b + 'attn.relative_position_bias_table'), B, res, heads,
                                                       shift, need_saved=not _inference[0])
@@ -310,7 +320,9 @@ class SwinEncoder:
                 qkv = ops.linear_fwd(xh1, self._w(b + 'attn.qkv.weight', dtype), a.p(b + 'attn.qkv.bias'))
                 ao, lse = ops.window_attn_fwd(qkv, a.p(b + 'attn.relative_position_bias_table'), B, res, heads, shift)
             ad = {}
-            if self.attn_adapter:
+            if x_mid is not None:
+                pass
+            elif self.attn_adapter:
                 # x = adapter(proj(attn)) + proj(attn) (htsat.py:141-143), then the block's DropPath + residual
                 a0 = ops.linear_fwd(ao, self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'))
                 a1, ad['attn'] = self._adapter_fwd(a0, b + 'attn.adapter.', resid=a0)

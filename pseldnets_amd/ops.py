@@ -243,6 +243,26 @@ def swin_attn_fwd(x, gamma, beta, wqkv, bqkv, bias_table, B, res, heads, shift, 
     return ao, qkv, xh, lse
 
 
+def swin_block_attn_fwd(x, gamma, beta, wqkv, bqkv, bias_table, wproj, bproj, B, res, heads, shift, rowscale=None, eps=1e-5, need_saved=True):
+    """x_mid = x + s * proj(window_attention(qkv(LN(x)))) in one kernel. Returns (x_mid, ao, qkv, xh, lse); the last four are the operands of
+    the backward and None when need_saved is False (no-grad forward: one row tensor in, one out)."""
+    _chk(x, gamma, beta, wqkv, bqkv, bias_table, wproj, bproj, rowscale)
+    M, C = x.shape
+    assert M == B * res * res and wqkv.shape == (3 * C, C) and wproj.shape == (C, C) and wqkv.dtype == x.dtype == wproj.dtype
+    assert rowscale is None or (rowscale.dtype == torch.float32 and rowscale.numel() == B)
+    xmid = torch.empty_like(x)
+    qkv = torch.empty((M, 3 * C), dtype=x.dtype, device=x.device) if need_saved else None
+    ao = torch.empty_like(x) if need_saved else None
+    xh = torch.empty_like(x) if need_saved else None
+    lse = torch.empty((M, heads), dtype=torch.float32, device=x.device) if need_saved else None
+    rc = _lib.lib().pseld_swin_block_attn_fwd(dtype_code(x), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(wqkv), _lib.ptr(bqkv),
+                                              _lib.ptr(bias_table), _lib.ptr(wproj), _lib.ptr(bproj), _lib.ptr(rowscale), _lib.ptr(qkv),
+                                              _lib.ptr(ao), _lib.ptr(xh), _lib.ptr(lse), _lib.ptr(xmid), B, res, C, heads, shift, eps,
+                                              _lib.stream_ptr())
+    _lib.check(rc, "pseld_swin_block_attn_fwd")
+    return xmid, ao, qkv, xh, lse
+
+
 # ---------------------------------------------------------------------------------------------------------
 # LayerNorm
 def layernorm_fwd(x, gamma, beta, merge_res=0, eps=1e-5, out_rows=None):

@@ -97,3 +97,33 @@ def test_fused_swin_attention_without_saved_operands_and_rejections(dev):
     assert not ops.swin_attn_fused_supported(torch.zeros(512, 192, device=dev, dtype=torch.bfloat16), 16, 8)
     with pytest.raises(_lib.PseldError):
         ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, 2, 16, 4, 9)
+
+
+@pytest.mark.parametrize('B,res,shift,drop', [(3, 64, 0, True), (3, 64, 4, False), (5, 32, 4, True), (1, 8, 0, False), (7, 8, 0, True)])
+def test_fused_swin_block_attention_half_vs_layerwise_kernels_and_float64(dev, B, res, shift, drop):
+    """pseld_swin_block_attn_fwd: x + s * proj(attention(qkv(LN(x)))) against the four layer-wise launches (LayerNorm, qkv GEMM, window
+    attention, proj GEMM with the DropPath + residual epilogue: same rounding points) and the float64 restatement; the saved operands
+    are those of pseld_swin_attn_fwd; a no-grad call (nothing saved) returns the same x_mid."""
+    from pseldnets_amd import ops
+    heads, C = 4, 96
+    x, gamma, beta, wqkv, bqkv, table = _case(B, res, dev, seed=B * 100 + res + shift + 7)
+    g = torch.Generator().manual_seed(11)
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev).bfloat16()
+    bproj = (0.2 * torch.randn(C, generator=g)).to(dev)
+    s = ((torch.rand(B, generator=g) > 0.3).float() / 0.7).to(dev) if drop else None
+    L = res * res
+    xm, ao, qkv, xh, lse = ops.swin_block_attn_fwd(x, gamma, beta, wqkv, bqkv, table, wproj, bproj, B, res, heads, shift, rowscale=s)
+    ao_f, qkv_f, xh_f, lse_f = ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift)
+    assert torch.equal(ao, ao_f) and torch.equal(qkv, qkv_f) and torch.equal(xh, xh_f) and torch.equal(lse, lse_f)
+    xm_lw = ops.linear_fwd(ao_f, wproj, bproj, resid=x, rowscale=s, rows_per_scale=L)
+    _, _, ao64, _ = _reference64(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift)
+    o64 = ao64 @ wproj.double().t() + bproj.double()
+    if s is not None:
+        o64 = o64 * s.double().repeat_interleave(L).unsqueeze(1)
+    xm64 = x.double() + o64
+    e = dict(xm=_rel(xm, xm64), xm_lw=_rel(xm_lw, xm64), d=_rel(xm, xm_lw))
+    print('fused swin block attention half', B, res, shift, drop, {k: f'{v:.2e}' for k, v in e.items()})
+    assert torch.isfinite(xm.float()).all()
+    assert e['xm'] < 5e-3 and e['xm'] <= 1.2 * e['xm_lw'] + 1e-4 and e['d'] < 3e-3, e
+    xm2, ao2, qkv2, xh2, lse2 = ops.swin_block_attn_fwd(x, gamma, beta, wqkv, bqkv, table, wproj, bproj, B, res, heads, shift, rowscale=s, need_saved=False)
+    assert ao2 is None and qkv2 is None and xh2 is None and lse2 is None and torch.equal(xm, xm2)

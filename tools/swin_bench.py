@@ -25,14 +25,24 @@ def main():
     bqkv = torch.zeros(3 * C, device=dev)
     gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     table = (0.5 * torch.randn(225, heads, generator=g)).to(dev)
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev).bfloat16()
+    bproj = torch.zeros(C, device=dev)
+    sc = ((torch.rand(B, generator=g) > 0.1).float() / 0.9).to(dev)
     res_t = {}
     for shift in (0, 4):
         def lw():
             xh = ops.layernorm_fwd(x, gamma, beta)
             qkv = ops.linear_fwd(xh, wqkv, bqkv)
             return ops.window_attn_fwd(qkv, table, B, res, heads, shift)
+
+        def lw_block():
+            ao, _ = lw()
+            return ops.linear_fwd(ao, wproj, bproj, resid=x, rowscale=sc, rows_per_scale=res * res)
         for _ in range(args.rounds):
-            for name, fn in ((f'layer-wise shift {shift}', lw),
+            for name, fn in ((f'layer-wise + proj shift {shift}', lw_block),
+                             (f'fused block half shift {shift}', lambda: ops.swin_block_attn_fwd(x, gamma, beta, wqkv, bqkv, table, wproj, bproj, B, res, heads, shift, rowscale=sc)),
+                             (f'fused block half, no-grad, shift {shift}', lambda: ops.swin_block_attn_fwd(x, gamma, beta, wqkv, bqkv, table, wproj, bproj, B, res, heads, shift, rowscale=sc, need_saved=False)),
+                             (f'layer-wise shift {shift}', lw),
                              (f'fused shift {shift}', lambda: ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift)),
                              (f'fused, no saved operands, shift {shift}', lambda: ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift, need_saved=False))):
                 res_t.setdefault(name, []).append(timed(fn, 3))
