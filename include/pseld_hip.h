@@ -97,6 +97,15 @@ int pseld_swin_attn_fwd(int dtype, const void* x, const float* gamma, const floa
 int pseld_swin_block_attn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
                               const float* bias_table, const void* wproj, const float* bproj, const float* rowscale, void* qkv, void* out,
                               void* xh, float* lse, void* xmid, int B, int res, int C, int heads, int shift, float eps, void* stream);
+/* ... and of its backward up to the qkv gradient (SURVEY 8b `pseld_swin_attn_bwd`): dy = d(x_mid) [M,C]; the gradient of the attention output,
+ * (s * dy) Wproj (attn.proj, htsat.py:139, under the block's DropPath), is formed inside the kernel from wproj_t = Wproj^T [C,C] and
+ * rowscale f32[B] (or NULL); then the backward of window attention exactly as pseld_window_attn_bwd (same workspace, same dbias_table
+ * NULL = deferred accumulator convention). The projection's weight gradient (dy, out), the qkv gemms and the LayerNorm backward stay
+ * separate calls. bf16, C = 96, 4 heads (pseld_swin_block_attn_bwd_supported). */
+int pseld_swin_block_attn_bwd_supported(int dtype, int res, int C, int heads);
+int pseld_swin_block_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* out, const float* lse, const void* dy,
+                              const void* wproj_t, const float* rowscale, void* dqkv, float* dbias_table, int B, int res, int C, int heads,
+                              int shift, int accumulate, float* workspace, long workspace_bytes, void* stream);
 
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */

@@ -50,6 +50,8 @@ struct AttnArgs {
     int B, res, C, heads, hd, shift;
     int n_win_total;          // B * (res/8)^2
     int variant;              // timing experiments (PSELD_ATTN_VARIANT): results are wrong when set
+    const void* wproj_t;      // attn_bwd24_kernel<true>: [C, C] = attn.proj.weight^T; dout is then d(x_mid), the gradient of the projection's OUTPUT
+    const float* rowscale;    // ... and the DropPath factor per sample (or null)
     float scale;
 };
 
@@ -595,6 +597,12 @@ __global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_ker
     }
 }
 
+__device__ __forceinline__ void unpack8f(const f32x4& p, float (&v)[8]) {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
+}
+
 // ---- Backward, bf16, head_dim 24 (every stage of HTS-AT), 4 heads per workgroup, ONE wave per head --------------------------------
 // The generic kernel above splits a head over two waves (key tiles), drops every P / dS tile into LDS images to read it back
 // transposed, exchanges dQ partials through LDS and stores its results with 2-byte LDS writes: 2.5x its HBM floor at every stage
@@ -607,17 +615,30 @@ __global__ __launch_bounds__(HG * 128, sizeof(T) == 2 ? 2 : 1) void attn_bwd_ker
 //     accumulator registers are 8 CONSECUTIVE head dims - dq / dk / dv go back into the tile as 16-byte pieces;
 //   * d(bias table) is binned on the fly into [4 heads][225] LDS counters by ds_add_f32 (64 per lane and window) and flushed once per
 //     workgroup onto ONE representative (key, query) pair per table index of the [heads][64][64] accumulator the callers reduce.
+// PROJ (C = 96: the four heads are the whole row): the projection's input gradient is computed in the kernel - `dout` holds d(x_mid), the
+// rows land in the dO segment by DMA like any operand, each wave turns its 24 columns into dO = (s * dY) Wproj in place (12 MFMAs against an
+// LDS image of Wproj^T, between two barriers), and the saved output O (only needed for delta) comes straight from global memory into
+// registers instead of through the tile: 4 segments, 75 KB per workgroup. = SURVEY 8b's pseld_swin_attn_bwd up to the qkv gradient.
+template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
     using M = AMma<bf16_t>;
-    constexpr int HG = 4, HD = 24, GW = HG * HD, STR = 5 * GW * 2 + 16;          // 976-byte token rows: q | k | v | dO | O of 4 heads + pad
-    static_assert(((STR >> 4) & 1) == 1, "row stride must be an odd number of 16-byte slots");
+    constexpr int HG = 4, HD = 24, GW = HG * HD, NSEG = PROJ ? 4 : 5, STR = NSEG * GW * 2 + 16;   // token rows: q | k | v | dO (| O) of 4 heads + pad
+    constexpr int WSTR = GW * 2 + 16;                                                               // Wproj^T image rows (PROJ)
+    static_assert(((STR >> 4) & 1) == 1 && ((WSTR >> 4) & 1) == 1, "row strides must be an odd number of 16-byte slots");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tile = smem;
     float* btab = (float*)(smem + 64 * STR);              // [4][225] bias x log2(e)
     float* lse_s = btab + HG * 225;                       // [64][4]
     long* toks = (long*)(lse_s + 64 * HG);
     int* labels = (int*)(toks + 64);                      // [64] + [1]
+    char* wimg = smem + (((char*)(labels + 65) - smem + 15) & ~15);      // PROJ: [96 rows c'][96 n] of Wproj^T
     constexpr float LOG2E = 1.4426950408889634f;
+    if (PROJ) {
+        for (int c = threadIdx.x; c < GW * 12; c += 256) {
+            const int row = c / 12, k = c - row * 12;
+            *(f32x4*)(wimg + row * WSTR + k * 16) = *(const f32x4*)((const char*)a.wproj_t + row * (GW * 2) + k * 16);
+        }
+    }
 
     const int lane0 = threadIdx.x & 63, hl = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int hg = blockIdx.y;
@@ -659,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
             int ln = lane0;
             asm volatile("" : "+v"(ln));
             const int seg = ln / 12, k = ln - seg * 12;
-            if (ln < 60) {
+            if (ln < NSEG * 12) {
                 const int C = a.C;
                 const bf16_t* base = seg < 3 ? qkv : (seg == 3 ? dout : osv);
                 const int ld = seg < 3 ? 3 * C : C;
@@ -671,8 +692,55 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
             asm volatile("" : "+v"(tx));
             lse_s[tx] = a.lse[toks[tx >> 2] * a.heads + hg * HG + (tx & 3)];
         }
+        // PROJ: this lane's chunks of the saved output rows of its two queries (for delta) and the sample's DropPath factor, requested with
+        // the DMA so that the same wait covers them
+        f32x4 oreg[2][2];
+        float sfac = 1.f;
+        if (PROJ) {
+            int ln = lane0;
+            asm volatile("" : "+v"(ln));
+            const int r = ln & 31, h2 = ln >> 5, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const bf16_t* orow = osv + toks[qt * 32 + pr] * a.C + hg * GW + hl * HD;
+                oreg[qt][0] = *(const f32x4*)(orow + 8 * h2);
+                oreg[qt][1] = *(const f32x4*)(orow + 16);
+            }
+            if (a.rowscale) { const int nw = a.res >> 3; sfac = a.rowscale[wi / (nw * nw)]; }
+        }
         __syncthreads();                                  // (hipcc drains the DMA with vmcnt(0) in front of this barrier)
         if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 1] = __builtin_amdgcn_s_memtime();
+        if (PROJ) {
+            // dO^T[c'][m] = Wproj^T[c'][:] . dY[m][:] for this head's 24 columns c' (rows through swap23) and both token tiles, then scaled by
+            // the DropPath factor and written over the dY rows' own columns once every wave has read the rows
+            int ln = lane0;
+            asm volatile("" : "+v"(ln));
+            const int r = ln & 31, h2 = ln >> 5, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+            const bool rowlive = pr < HD;
+            const char* wr = wimg + (hl * HD + (rowlive ? pr : 0)) * WSTR;
+            f32x16 y[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) y[tt][e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    const bf16x8 wf = M::keep_if(M::ld_row(wr + (16 * kk + 8 * h2) * 2), rowlive);
+                    const bf16x8 df = M::ld_row(tile + (tt * 32 + r) * STR + (3 * GW + 16 * kk + 8 * h2) * 2);
+                    M::mma(wf, df, y[tt]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                bf16x8 f0, f1;          // rounded where the GEMM epilogue rounds: the product, then the scaled value
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { f0[j] = (bf16_t)((float)(bf16_t)y[tt][j] * sfac); f1[j] = (bf16_t)((float)(bf16_t)y[tt][8 + j] * sfac); }
+                char* p = tile + (tt * 32 + r) * STR + (3 * GW + hl * HD + 8 * h2) * 2;
+                *(bf16x8*)p = f0;
+                if (h2 == 0) *(bf16x8*)(p + 32) = f1;
+            }
+        }
 
         const bool mixed = labels[64] != 0;
         // identity fragments of the transposing products: element j of step s is 1 where 16 s + 8 h2 + j == lane & 31
@@ -692,7 +760,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
                 float dsum_q = 0.f;
                 for (int c = h2; c < 3; c += 2) {             // the lane halves split the three 8-dim chunks of the row
                     float od[8], dd[8];
-                    load8<bf16_t>((const bf16_t*)(tile + qi * STR + (co + c * 8) * 2), od);
+                    if (PROJ) unpack8f(oreg[qt][c >> 1], od);
+                    else load8<bf16_t>((const bf16_t*)(tile + qi * STR + (co + c * 8) * 2), od);
                     load8<bf16_t>((const bf16_t*)(tile + qi * STR + (cdo + c * 8) * 2), dd);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dsum_q = fmaf(od[j], dd[j], dsum_q);
@@ -837,6 +906,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
     }
 }
 constexpr size_t BWD24_LDS = 64 * 976 + 4 * 225 * 4 + 64 * 4 * 4 + 64 * 8 + 65 * 4 + 12;
+constexpr size_t BWD24P_LDS = 64 * 784 + 4 * 225 * 4 + 64 * 4 * 4 + 64 * 8 + 65 * 4 + 12 + 16 + 96 * 208;
 
 __global__ void zero_f4_kernel(float4* __restrict__ p, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -973,8 +1043,8 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
         if (sl > a.n_win_total) sl = a.n_win_total;
         if (sl < 1) sl = 1;
         static bool attr24 = false;
-        if (!attr24) { (void)hipFuncSetAttribute((const void*)attn_bwd24_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD24_LDS); attr24 = true; }
-        hipLaunchKernelGGL(attn_bwd24_kernel, dim3(sl, heads / 4), dim3(256), BWD24_LDS, s, a);
+        if (!attr24) { (void)hipFuncSetAttribute((const void*)attn_bwd24_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD24_LDS); attr24 = true; }
+        hipLaunchKernelGGL(attn_bwd24_kernel<false>, dim3(sl, heads / 4), dim3(256), BWD24_LDS, s, a);
     } else if (dtype == PSELD_BF16) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
@@ -986,6 +1056,46 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
         hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), grid, dim3(256), bwd_lds<float>(a.hd, 2), s, a);
     } else { pseld_set_error("window_attn_bwd: unknown dtype"); return PSELD_ERR_BAD_ARG; }
     PSELD_LAUNCH_CHECK("window_attn_bwd");
+    if (dbias_table) {
+        hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);
+        PSELD_LAUNCH_CHECK("bias_table_grad");
+    }
+    return PSELD_OK;
+}
+
+// The attention half of a Swin block's backward up to the qkv gradient, for stage 0 of HTS-AT (bf16, C = 96, 4 heads): dy = d(x_mid) [B,L,C];
+// d(attention output) = (s * dy) Wproj (reference: attn.proj, htsat.py:139, under the block's DropPath :258-260) is formed inside the
+// kernel from wproj_t = Wproj^T [C, C] and rowscale f32[B] (or NULL), then the backward of window attention as pseld_window_attn_bwd.
+// The projection's weight gradient (dy, out) and everything behind dqkv stay separate calls.
+extern "C" int pseld_swin_block_attn_bwd_supported(int dtype, int res, int C, int heads) {
+    return dtype == PSELD_BF16 && C == 96 && heads == 4 && res >= 8 && res % 8 == 0 ? 1 : 0;
+}
+extern "C" int pseld_swin_block_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* out, const float* lse, const void* dy,
+                                         const void* wproj_t, const float* rowscale, void* dqkv, float* dbias_table, int B, int res, int C,
+                                         int heads, int shift, int accumulate, float* workspace, long workspace_bytes, void* stream) {
+    PSELD_CHECK_ARG(qkv && bias_table && out && lse && dy && wproj_t && dqkv && workspace, "swin_block_attn_bwd: null pointer");
+    PSELD_CHECK_ARG(pseld_swin_block_attn_bwd_supported(dtype, res, C, heads), "swin_block_attn_bwd: built for bf16, C = 96, 4 heads (got dtype %d C %d heads %d)",
+                    dtype, C, heads);
+    int rc = check_args("swin_block_attn_bwd", B, res, C, heads, shift);
+    if (rc) return rc;
+    PSELD_CHECK_ARG(workspace_bytes >= pseld_window_attn_bwd_workspace(heads), "swin_block_attn_bwd: workspace too small");
+    AttnArgs a; memset(&a, 0, sizeof(a));
+    a.qkv = qkv; a.dout = dy; a.dqkv = dqkv; a.bias_table = bias_table; a.dbias_acc = workspace;
+    a.osaved = out; a.lse = const_cast<float*>(lse); a.wproj_t = wproj_t; a.rowscale = rowscale;
+    a.B = B; a.res = res; a.C = C; a.heads = heads; a.hd = C / heads; a.shift = shift;
+    a.n_win_total = B * (res / 8) * (res / 8);
+    a.scale = 1.0f / sqrtf((float)a.hd);
+    hipStream_t s = (hipStream_t)stream;
+    if (dbias_table) {
+        hipLaunchKernelGGL(zero_f4_kernel, dim3(heads * 4), dim3(256), 0, s, (float4*)workspace, (long)heads * 1024);
+        PSELD_LAUNCH_CHECK("swin_block_attn_bwd(zero)");
+    }
+    int sl = 512;
+    if (sl > a.n_win_total) sl = a.n_win_total;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd24_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD24P_LDS); attr = true; }
+    hipLaunchKernelGGL(attn_bwd24_kernel<true>, dim3(sl, 1), dim3(256), BWD24P_LDS, s, a);
+    PSELD_LAUNCH_CHECK("swin_block_attn_bwd");
     if (dbias_table) {
         hipLaunchKernelGGL(bias_table_grad_kernel, dim3(pseld_cdiv(225 * heads, 256)), dim3(256), 0, s, workspace, dbias_table, heads, accumulate);
         PSELD_LAUNCH_CHECK("bias_table_grad");

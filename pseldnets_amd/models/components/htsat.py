@@ -463,12 +463,21 @@ class SwinEncoder:
                 dao = ops.linear_dgrad(da0, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype))
             else:
                 self._wgrad(dx_mid, s['ao'], b + 'attn.proj.weight', b + 'attn.proj.bias', rowscale=s['s1'], rows_per_scale=L, per_scale_elems=L * C)
-                dao = ops.linear_dgrad(dx_mid, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
+                dao = None
+                wpt = self._wt(b + 'attn.proj.weight', dtype)
+                if not (FUSED_ATTN and FUSED_ATTN_TAIL and wpt is not None and ops.swin_block_attn_bwd_supported(s['qkv'], res, heads)):
+                    dao = ops.linear_dgrad(dx_mid, self._w(b + 'attn.proj.weight', dtype), wt=self._wt(b + 'attn.proj.weight', dtype), rowscale=s['s1'], rows_per_scale=L)
             # d(relative_position_bias_table): the block leaves its [heads][64][64] sums in its own accumulator; one launch per stage
             # turns them into the table gradients (backward_layer)
             o = self._rpb['off'][(li, bi)]
-            dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), s['ao'], s['lse'], dao,
-                                       None, B, res, heads, s['shift'], acc=self._rpb['acc'][o:o + heads * 4096])
+            if dao is None:
+                # stage 0: the projection's input gradient is formed inside the attention backward (csrc/attn.hip: attn_bwd24_kernel<true>)
+                dqkv = ops.swin_block_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), s['ao'], s['lse'], dx_mid,
+                                               wpt, None, B, res, heads, s['shift'], rowscale=s['s1'],
+                                               acc=self._rpb['acc'][o:o + heads * 4096])
+            else:
+                dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), s['ao'], s['lse'], dao,
+                                           None, B, res, heads, s['shift'], acc=self._rpb['acc'][o:o + heads * 4096])
             self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
             dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=self._wt(b + 'attn.qkv.weight', dtype))
             dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),

@@ -435,6 +435,27 @@ def window_attn_bwd(qkv, bias_table, out, lse, dout, dbias_table, B, res, heads,
     return dqkv
 
 
+def swin_block_attn_bwd_supported(qkv, res, heads):
+    return bool(qkv.is_cuda and _lib.lib().pseld_swin_block_attn_bwd_supported(dtype_code(qkv), res, qkv.shape[1] // 3, heads))
+
+
+def swin_block_attn_bwd(qkv, bias_table, out, lse, dy, wproj_t, dbias_table, B, res, heads, shift, rowscale=None, accumulate=False, acc=None):
+    """window_attn_bwd with the projection's input gradient inside: dy = d(x_mid), d(attention output) = (rowscale * dy) @ Wproj is formed in
+    the kernel from wproj_t = Wproj^T. Same accumulator conventions as window_attn_bwd."""
+    _chk(qkv, bias_table, out, lse, dy, wproj_t, dbias_table, acc, rowscale)
+    assert (dbias_table is None) == (acc is not None)
+    C = qkv.shape[1] // 3
+    assert wproj_t.shape == (C, C) and wproj_t.dtype == qkv.dtype and dy.shape == out.shape
+    L = _lib.lib()
+    ws = acc if acc is not None else workspace(L.pseld_window_attn_bwd_workspace(heads), qkv.device)
+    dqkv = torch.empty_like(qkv)
+    rc = L.pseld_swin_block_attn_bwd(dtype_code(qkv), _lib.ptr(qkv), _lib.ptr(bias_table), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(dy),
+                                     _lib.ptr(wproj_t), _lib.ptr(rowscale), _lib.ptr(dqkv), _lib.ptr(dbias_table), B, res, C, heads, shift,
+                                     int(accumulate), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "pseld_swin_block_attn_bwd")
+    return dqkv
+
+
 def bias_table_grad_batched(acc_all, grad_base, desc, n, max_heads, accumulate=False):
     _chk(acc_all, grad_base, desc)
     _lib.check(_lib.lib().pseld_bias_table_grad_batched(_lib.ptr(acc_all), _lib.ptr(grad_base), _lib.ptr(desc), n, max_heads,

@@ -127,3 +127,60 @@ def test_fused_swin_block_attention_half_vs_layerwise_kernels_and_float64(dev, B
     assert e['xm'] < 5e-3 and e['xm'] <= 1.2 * e['xm_lw'] + 1e-4 and e['d'] < 3e-3, e
     xm2, ao2, qkv2, xh2, lse2 = ops.swin_block_attn_fwd(x, gamma, beta, wqkv, bqkv, table, wproj, bproj, B, res, heads, shift, rowscale=s, need_saved=False)
     assert ao2 is None and qkv2 is None and xh2 is None and lse2 is None and torch.equal(xm, xm2)
+
+
+@pytest.mark.parametrize('B,res,shift,drop', [(3, 64, 4, True), (2, 64, 0, False), (5, 32, 4, True), (1, 8, 0, False), (7, 8, 0, True)])
+def test_fused_swin_block_attention_backward_vs_layerwise_kernels(dev, B, res, shift, drop):
+    """pseld_swin_block_attn_bwd (projection input gradient formed inside the attention backward) against pseld_gemm (dgrad with the
+    DropPath epilogue) + pseld_window_attn_bwd: same rounding points, so dqkv agrees to bf16 round-off of a few elements and the bias-table
+    gradient to fp32 summation order; both against float64 autograd of the reference arithmetic."""
+    from pseldnets_amd import ops
+    heads, C = 4, 96
+    L = res * res
+    x, gamma, beta, wqkv, bqkv, table = _case(B, res, dev, seed=B * 100 + res + shift + 13)
+    g = torch.Generator().manual_seed(17)
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev).bfloat16()
+    dy = (0.1 * torch.randn(B * L, C, generator=g)).to(dev).bfloat16()
+    s = ((torch.rand(B, generator=g) > 0.3).float() / 0.7).to(dev) if drop else None
+    ao, qkv, xh, lse = ops.swin_attn_fwd(x, gamma, beta, wqkv, bqkv, table, B, res, heads, shift)
+    wpt = wproj.t().contiguous()
+    dtab_f = torch.zeros(225, heads, device=dev)
+    dqkv_f = ops.swin_block_attn_bwd(qkv, table, ao, lse, dy, wpt, dtab_f, B, res, heads, shift, rowscale=s)
+    dao = ops.linear_dgrad(dy, wproj, wt=wpt, rowscale=s, rows_per_scale=L)
+    dtab_l = torch.zeros(225, heads, device=dev)
+    dqkv_l = ops.window_attn_bwd(qkv, table, ao, lse, dao, dtab_l, B, res, heads, shift)
+    # float64 autograd on the same bf16 qkv: loss = <attention(qkv), dao64>, dao64 = (s * dy) Wproj
+    q64 = qkv.double().requires_grad_(True)
+    t64 = table.double().requires_grad_(True)
+    gq = q64.view(B, res, res, 3 * C)
+    if shift:
+        gq = torch.roll(gq, (-shift, -shift), (1, 2))
+    nw, hd = res // 8, C // heads
+    w = gq.view(B, nw, 8, nw, 8, 3, heads, hd).permute(0, 1, 3, 5, 6, 2, 4, 7).reshape(B * nw * nw, 3, heads, 64, hd)
+    att = (w[:, 0] * hd ** -0.5) @ w[:, 1].transpose(-1, -2)
+    ys, xs = torch.meshgrid(torch.arange(8), torch.arange(8), indexing='ij')
+    cy, cx = ys.flatten(), xs.flatten()
+    idx = ((cy[:, None] - cy[None, :] + 7) * 15 + (cx[:, None] - cx[None, :] + 7)).to(dev)
+    att = att + t64[idx].permute(2, 0, 1)
+    if shift:
+        img = torch.zeros(res, res)
+        cnt = 0
+        for hs in (slice(0, -8), slice(-8, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -8), slice(-8, -shift), slice(-shift, None)):
+                img[hs, wsl] = cnt
+                cnt += 1
+        mw = img.view(nw, 8, nw, 8).permute(0, 2, 1, 3).reshape(nw * nw, 64)
+        mask = ((mw[:, None, :] - mw[:, :, None]) != 0).double().to(dev) * -100.0
+        att = (att.view(B, nw * nw, heads, 64, 64) + mask[None, :, None]).view(B * nw * nw, heads, 64, 64)
+    o = torch.softmax(att, -1) @ w[:, 2]
+    o = o.reshape(B, nw, nw, heads, 8, 8, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, res, res, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    dao64 = dy.double() @ wproj.double()
+    if s is not None:
+        dao64 = dao64 * s.double().repeat_interleave(L).unsqueeze(1)
+    (o.reshape(B * L, C) * dao64).sum().backward()
+    e = dict(dqkv=_rel(dqkv_f, q64.grad), dqkv_lw=_rel(dqkv_l, q64.grad), d=_rel(dqkv_f, dqkv_l), dtab=_rel(dtab_f, t64.grad), dtab_lw=_rel(dtab_l, t64.grad))
+    print('fused swin block attention backward', B, res, shift, drop, {k: f'{v:.2e}' for k, v in e.items()})
+    assert torch.isfinite(dqkv_f.float()).all() and q64.grad.abs().max() > 0
+    assert e['dqkv'] < 1.5e-2 and e['dqkv'] <= 1.2 * e['dqkv_lw'] + 1e-4 and e['d'] < 5e-3 and e['dtab'] < 2e-2, e
