@@ -69,7 +69,7 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
-            if n.endswith('_workspace') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_mlp_set_debug_buffer', 'pseld_mlp_supported', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections'):
+            if n.endswith('_workspace') or n.endswith('_supported') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_mlp_set_debug_buffer', 'pseld_mlp_supported', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections'):
                 continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn
