@@ -44,6 +44,17 @@ int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, const void* B
                int lda, int ldb, int ldc, const float* bias, const void* resid, int ldr, const float* rowscale,
                int rows_per_scale, const void* aux, int ldaux, int epi, int pro, void* c2, void* stream);
 
+/* Input gradient of a Linear whose input is a LayerNorm output, with that LayerNorm's backward in the GEMM epilogue (bf16; C = 96 or 192 so
+ * that one output tile spans the row; stages 0-1 of HTS-AT: norm1 -> attn.qkv, norm2 -> mlp.fc1, htsat.py:234,262 / model_utilities.py:159):
+ *   dx[M, C] = LayerNorm'(dY[M, K] . Wt[C, K]^T; x, gamma, eps) (+ dres)
+ * i.e. pseld_gemm (the input gradient through Wt = the Linear's weight [K, C] TRANSPOSED to [C, K]) + pseld_layernorm_bwd in one launch; the
+ * intermediate d(LN output) is rounded to bf16 exactly where the two-launch path stores it. partial: fp32
+ * [pseld_gemm_dgrad_lnbwd_parts(M, C)][2][C] row-tile sums of d(gamma) and d(beta), to be reduced by pseld_reduce_slabs(_batched) like
+ * the partials of pseld_layernorm_bwd. */
+int pseld_gemm_dgrad_lnbwd_supported(int dtype, long M, int C, int K);
+long pseld_gemm_dgrad_lnbwd_parts(long M, int C);
+int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt, const void* x, const float* gamma, const void* dres, void* dx,
+                           float* partial, long M, int C, int K, int lddy, int ldwt, float eps, void* stream);
 /* Weight gradient of the same layers: dW f32[N,K] (+)= dY[Mtok,N]^T @ (gelu_on_x ? gelu(X) : X)[Mtok,K], and (when
  * dbias != NULL) the bias gradient dbias f32[N] (+)= sum_m dY[m,n] from the same pass. Split over tokens into fp32
  * slabs in `workspace`, reduced in a fixed order (bitwise reproducible). rowscale (optional, f32[Mtok / rows_per_scale]):

@@ -64,6 +64,7 @@ struct GemmArgs {
     float* colsum;          // TA only: per-split column sums of A (= bias gradient), split z at colsum + z*colsum_stride
     long colsum_stride;
     int epi, pro;
+    float ln_eps;             // gemm_dma_kernel<.., LNBWD>: epsilon of the LayerNorm whose backward runs in the epilogue
     unsigned long long* dbg;  // diagnostic build only: per-workgroup s_memtime stamps
     int nx, ny, nz;           // tile grid (N tiles, M tiles, K splits); the launch is 1-D and XCD-swizzled
     int xcd_swizzle;          // 0: plain x-fastest order (experiment knob PSELD_GEMM_XCD=0)
@@ -348,6 +349,135 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, char* smem, c
         if (okj) *(f32x4*)(Cg + orowj) = pack8(v);
     }
 }
+
+// Input-gradient product whose tile spans the LayerNorm row (BN == N = C): the LayerNorm BACKWARD runs in the epilogue. The accumulators are
+// dxh = d(LN output); staged as bf16 (the value the separate LayerNorm kernel would read back), then TPR threads per token row (24 channels
+// each) recompute mean / rstd from the LN input x (g.aux), form dx = rstd (dxh gamma - mean(dxh gamma) - xh mean(dxh gamma xh)) + dres
+// (g.resid, optional) exactly as norm.hip:ln_bwd_kernel, and leave this row tile's partial sums of d(gamma) = sum dxh xh, d(beta) = sum dxh
+// in g.C2 as [tile][2][N] fp32 (the layout pseld_reduce_slabs_batched takes from the stand-alone kernel). g.bias = gamma.
+// (the packed row chunks are laundered between the passes: otherwise hipcc keeps the 24 unpacked floats of the first pass alive)
+#define LAUNDER_XP asm volatile("" : "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]))
+template <int WM, int WN>
+__device__ __forceinline__ void lnbwd_epilogue(const GemmArgs& g, char* smem, const float* gamma_s, const f32x16 (&acc)[2][3], int m0, int by) {
+    constexpr int THREADS = WM * WN * 64, BM = WM * 64, BN = WN * 96;
+    constexpr int CS_STRIDE = BN * 2 + 16;
+    constexpr int TPR = BN / 24, RPP = THREADS / TPR, PASSES = BM / RPP;
+    static_assert(PASSES * RPP == BM && (TPR == 4 || TPR == 8), "row passes must tile the block");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    const bf16_t* Xg = (const bf16_t*)g.aux;
+    const bf16_t* Rg = (const bf16_t*)g.resid;
+    bf16_t* Cg = (bf16_t*)g.C;
+    __syncthreads();  // every wave is done with the operand images
+    char* Cs = smem;
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int ml = wm * 64 + mi * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 96 + ni * 32 + 8 * q + 4 * h;
+                bf16x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)acc[mi][ni][4 * q + j];
+                *(bf16x4*)(Cs + ml * CS_STRIDE + nl * 2) = pk;
+            }
+        }
+    __syncthreads();
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    const int part = tid2 % TPR, rsub = tid2 / TPR;
+    // register budget (3 workgroups per CU: 168): the row's x / dres chunks stay PACKED (12 + 12 registers) and are unpacked per use, the
+    // staged dxh and gamma are re-read from LDS per use; only the 48 running sums are fp32 arrays
+    float dgs[24], dbs[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { dgs[k] = 0.f; dbs[k] = 0.f; }
+    const float invn = 1.f / (float)BN;
+    const int mlast = g.M - 1;
+    const float* gam = gamma_s + part * 24;
+#pragma unroll 1
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = p * RPP + rsub, m = m0 + row;
+        const bool ok = m < g.M;
+        const long mr = (long)min(m, mlast);
+        f32x4 xp[3], rp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xp[c] = *(const f32x4*)(Xg + mr * g.ldaux + part * 24 + c * 8);
+            rp[c] = Rg ? *(const f32x4*)(Rg + mr * g.ldr + part * 24 + c * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const char* drow = Cs + row * CS_STRIDE + part * 48;
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t[8];
+            unpack8(xp[c], t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sx += t[k];
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) sx += __shfl_xor(sx, o, 64);
+        const float mean = sx * invn;
+        float q = 0.f;
+        LAUNDER_XP;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t[8];
+            unpack8(xp[c], t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float u = t[k] - mean; q += u * u; }
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q * invn + g.ln_eps);
+        float c1 = 0.f, c2 = 0.f;
+        LAUNDER_XP;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t[8], d[8];
+            unpack8(xp[c], t);
+            unpack8(*(const f32x4*)(drow + c * 16), d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = (t[k] - mean) * rstd, dyh = d[k] * gam[c * 8 + k];
+                if (ok) { dgs[c * 8 + k] += d[k] * xh; dbs[c * 8 + k] += d[k]; }
+                c1 += dyh; c2 += dyh * xh;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+        c1 *= invn; c2 *= invn;
+        LAUNDER_XP;
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t[8], d[8], rr[8], o8[8];
+                unpack8(xp[c], t);
+                unpack8(*(const f32x4*)(drow + c * 16), d);
+                unpack8(rp[c], rr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o8[k] = rstd * (d[k] * gam[c * 8 + k] - c1 - (t[k] - mean) * rstd * c2) + rr[k];
+                *(f32x4*)(Cg + (long)m * g.ldc + part * 24 + c * 8) = pack8(o8);
+            }
+        }
+    }
+    // this tile's d(gamma) / d(beta): the RPP threads that share a channel group meet through LDS (the staged tile is dead)
+    __syncthreads();
+    float* red = (float*)smem;                                  // [RPP][TPR][48]
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { red[(rsub * TPR + part) * 48 + k] = dgs[k]; red[(rsub * TPR + part) * 48 + 24 + k] = dbs[k]; }
+    __syncthreads();
+    for (int j = tid; j < 2 * BN; j += THREADS) {
+        const int which = j / BN, c = j - which * BN, pp = c / 24, idx = c - pp * 24;
+        float sum = 0.f;
+        for (int rr = 0; rr < RPP; ++rr) sum += red[(rr * TPR + pp) * 48 + which * 24 + idx];
+        ((float*)g.C2)[((long)by * 2 + which) * BN + c] = sum;
+    }
+}
+
+#undef LAUNDER_XP
 
 // linear workgroup id -> (N tile, M tile, K split); false = padding workgroup of the swizzled launch
 __device__ __forceinline__ bool tile_coords(const GemmArgs& g, int& bx, int& by, int& bz) {
@@ -648,7 +778,7 @@ __global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM * WN == 4) ? 2 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
-template <int WM, int WN, int STAGES = 2>
+template <int WM, int WN, int STAGES = 2, bool LNBWD = false>
 __global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 2) void gemm_dma_kernel(GemmArgs g) {
     constexpr int THREADS = WM * WN * 64, WAVES = WM * WN, BM = WM * 64, BN = WN * 96;
     constexpr int BKD = 32;
@@ -663,7 +793,7 @@ __global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 2) void gemm_dma_ke
     int bx, by, bz;
     if (!tile_coords(g, bx, by, bz)) return;
     const int m0 = by * BM, n0 = bx * BN;
-    if (tid < BN) bias_s[tid] = ((g.epi & EPI_BIAS) && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+    if (tid < BN) bias_s[tid] = (((g.epi & EPI_BIAS) || LNBWD) && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;   // (LNBWD: the LayerNorm's gamma)
     const bf16_t* Ag = (const bf16_t*)g.A;
     const bf16_t* Bg = (const bf16_t*)g.B;
     const int nslices = g.K / BKD;
@@ -736,6 +866,10 @@ __global__ __launch_bounds__(WM * WN * 64, STAGES == 2 ? 3 : 2) void gemm_dma_ke
 #pragma unroll
                 for (int ni = 0; ni < 3; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
         }
+    }
+    if constexpr (LNBWD) {
+        lnbwd_epilogue<WM, WN>(g, smem, bias_s, acc, m0, by);
+        return;
     }
     unsigned long long t4 = 0;
     bf16_t* Cb = (bf16_t*)g.C;
@@ -1313,6 +1447,46 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     }
     pseld_set_error("gemm: unknown dtype %d", dtype);
     return PSELD_ERR_BAD_ARG;
+}
+
+// Input gradient of a Linear that follows a LayerNorm, with that LayerNorm's backward in the epilogue (bf16; C = 96 or 192: the output
+// tile spans the row): dx[M, C] = LN'(dY[M, K] Wt[C, K]^T; x, gamma) (+ dres), i.e. pseld_gemm (input gradient through the transposed weight
+// copy Wt) + pseld_layernorm_bwd in one launch. partial: fp32 [pseld_gemm_dgrad_lnbwd_parts(M, C)][2][C], this launch's row-tile sums of
+// d(gamma) = sum dxh xh and d(beta) = sum dxh (reduce with pseld_reduce_slabs / pseld_reduce_slabs_batched, as the stand-alone kernel's).
+extern "C" int pseld_gemm_dgrad_lnbwd_supported(int dtype, long M, int C, int K) {
+    return dtype == PSELD_BF16 && (C == 96 || C == 192) && K % 32 == 0 && K >= 64 && M >= 128 ? 1 : 0;
+}
+extern "C" long pseld_gemm_dgrad_lnbwd_parts(long M, int C) { return pseld_cdiv(M, C == 96 ? 256 : 128); }
+extern "C" int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt, const void* x, const float* gamma, const void* dres, void* dx,
+                                      float* partial, long M, int C, int K, int lddy, int ldwt, float eps, void* stream) {
+    PSELD_CHECK_ARG(dY && Wt && x && gamma && dx && partial, "gemm_dgrad_lnbwd: null pointer");
+    PSELD_CHECK_ARG(pseld_gemm_dgrad_lnbwd_supported(dtype, M, C, K), "gemm_dgrad_lnbwd: built for bf16, C = 96 / 192, K %% 32 == 0 (got dtype %d C %d K %d)", dtype, C, K);
+    PSELD_CHECK_ARG(lddy % 8 == 0 && ldwt % 8 == 0 && M < (1L << 31), "gemm_dgrad_lnbwd: bad leading dimension / M");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dY; g.B = Wt; g.C = dx; g.bias = gamma; g.resid = dres; g.aux = x; g.C2 = partial;
+    g.M = (int)M; g.N = C; g.K = K; g.lda = lddy; g.ldb = ldwt; g.ldc = C; g.ldr = C; g.ldaux = C;
+    g.rows_per_scale = 1; g.kchunk = K; g.ln_eps = eps; g.dbg = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    g.nx = 1; g.nz = 1; g.xcd_swizzle = 1;
+    if (C == 96) {
+        constexpr int BM = 256, BN = 96, STAGE = (BM + BN) * 64, CS = BM * (BN * 2 + 16), RED = (256 / 4) * 4 * 48 * 4;
+        constexpr int LDS = (2 * STAGE + 1024 > CS ? 2 * STAGE + 1024 : CS) > RED ? (2 * STAGE + 1024 > CS ? 2 * STAGE + 1024 : CS) : RED;
+        g.ny = pseld_cdiv(g.M, BM);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<4, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+        hipLaunchKernelGGL((gemm_dma_kernel<4, 1, 2, true>), dim3((unsigned)(8 * pseld_cdiv(g.ny, 8))), dim3(256), LDS, s, g);
+    } else {
+        constexpr int BM = 128, BN = 192, STAGE = (BM + BN) * 64, CS = BM * (BN * 2 + 16), RED = (256 / 8) * 8 * 48 * 4;
+        constexpr int LDS = (2 * STAGE + 1024 > CS ? 2 * STAGE + 1024 : CS) > RED ? (2 * STAGE + 1024 > CS ? 2 * STAGE + 1024 : CS) : RED;
+        g.ny = pseld_cdiv(g.M, BM);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+        hipLaunchKernelGGL((gemm_dma_kernel<2, 2, 2, true>), dim3((unsigned)(8 * pseld_cdiv(g.ny, 8))), dim3(256), LDS, s, g);
+    }
+    g_last_gemm_kernel = "gemm_dma_kernel<LNBWD>";
+    PSELD_LAUNCH_CHECK("gemm_dgrad_lnbwd");
+    return PSELD_OK;
 }
 
 // Weight gradient dW[N,K] (fp32) = dY[Mtok,N]^T @ X[Mtok,K], optionally with GELU applied to X on load

@@ -27,6 +27,9 @@ FUSED_MLP_WIDTHS = tuple(int(v) for v in os.environ.get('PSELD_FUSED_MLP', '96')
 # Fused attention half of a block (csrc/swin.hip: norm1 -> qkv -> window attention -> proj -> DropPath + shortcut in one kernel; stage 0,
 # bf16). PSELD_FUSED_ATTN=0: layer-wise.
 FUSED_ATTN = os.environ.get('PSELD_FUSED_ATTN', '1') != '0'
+# Input-gradient GEMMs that end in a LayerNorm backward (norm1 <- attn.qkv, norm2 <- mlp.fc1) take pseld_gemm_dgrad_lnbwd where a tile spans the
+# row (C = 96 / 192, bf16): one launch instead of GEMM + LayerNorm backward. PSELD_FUSED_LNBWD=0: two launches.
+FUSED_LNBWD = os.environ.get('PSELD_FUSED_LNBWD', '1') != '0'
 FUSED_ATTN_TAIL = os.environ.get('PSELD_FUSED_ATTN', '1') != 'front'      # 'front': stop in front of proj (A/B of the fused tail)
 _inference = [False]      # set by the no-grad forward (seld_net._run): nothing is saved for a backward pass
 
@@ -452,9 +455,16 @@ class SwinEncoder:
                 if self.mlp_adapter:            # the adapter branch sees the same DropPath-scaled gradient
                     dxs = ops.rowscale(dx, s['s2'], L * C) if s['s2'] is not None else dx
                     dxh2_ad = self._adapter_bwd(dxs, s['xh2'], s['ad']['mlp'], b + 'mlp.adapter.')
-                dxh2 = ops.linear_dgrad(du, self._w(b + 'mlp.fc1.weight', dtype), wt=self._wt(b + 'mlp.fc1.weight', dtype), resid=dxh2_ad)
-            dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
-                                       a.g(b + 'norm2.bias'), dres=dx, defer=self._defer)
+                w1t = self._wt(b + 'mlp.fc1.weight', dtype)
+                if FUSED_LNBWD and dxh2_ad is None and w1t is not None and ops.dgrad_lnbwd_supported(du, C):
+                    dxh2 = None               # fc1's input gradient and norm2's backward in one launch
+                    dx_mid = ops.linear_dgrad_lnbwd(du, w1t, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'), a.g(b + 'norm2.bias'),
+                                                    dres=dx, defer=self._defer)
+                else:
+                    dxh2 = ops.linear_dgrad(du, self._w(b + 'mlp.fc1.weight', dtype), wt=w1t, resid=dxh2_ad)
+            if dxh2 is not None:
+                dx_mid = ops.layernorm_bwd(dxh2, s['x_mid'], a.p(b + 'norm2.weight'), a.g(b + 'norm2.weight'),
+                                           a.g(b + 'norm2.bias'), dres=dx, defer=self._defer)
             # ---- attention branch:  x_mid = x_in + s1 * (proj(attn(qkv)) + bp) ---------------------------------
             if self.attn_adapter:
                 da1 = ops.rowscale(dx_mid, s['s1'], L * C) if s['s1'] is not None else dx_mid
@@ -479,9 +489,15 @@ class SwinEncoder:
                 dqkv = ops.window_attn_bwd(s['qkv'], a.p(b + 'attn.relative_position_bias_table'), s['ao'], s['lse'], dao,
                                            None, B, res, heads, s['shift'], acc=self._rpb['acc'][o:o + heads * 4096])
             self._wgrad(dqkv, s['xh1'], b + 'attn.qkv.weight', b + 'attn.qkv.bias')
-            dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=self._wt(b + 'attn.qkv.weight', dtype))
-            dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
-                                   a.g(b + 'norm1.bias'), dres=dx_mid, defer=self._defer)
+            wqt = self._wt(b + 'attn.qkv.weight', dtype)
+            if FUSED_LNBWD and wqt is not None and ops.dgrad_lnbwd_supported(dqkv, C):
+                # qkv's input gradient and norm1's backward (+ the shortcut's gradient) in one launch
+                dx = ops.linear_dgrad_lnbwd(dqkv, wqt, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'), a.g(b + 'norm1.bias'),
+                                            dres=dx_mid, defer=self._defer)
+            else:
+                dxh1 = ops.linear_dgrad(dqkv, self._w(b + 'attn.qkv.weight', dtype), wt=wqt)
+                dx = ops.layernorm_bwd(dxh1, s['x_in'], a.p(b + 'norm1.weight'), a.g(b + 'norm1.weight'),
+                                       a.g(b + 'norm1.bias'), dres=dx_mid, defer=self._defer)
         return dx
 
     def forward_final(self, x):

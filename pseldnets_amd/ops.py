@@ -344,6 +344,40 @@ def layernorm_bwd(dy, x, gamma, dgamma, dbeta, dres=None, merge_res=0, eps=1e-5,
     return dx
 
 
+def dgrad_lnbwd_supported(dy, C):
+    return bool(dy.is_cuda and dy.dim() == 2 and _lib.lib().pseld_gemm_dgrad_lnbwd_supported(dtype_code(dy), dy.shape[0], C, dy.shape[1]))
+
+
+def linear_dgrad_lnbwd(dy, wt, x, gamma, dgamma, dbeta, dres=None, eps=1e-5, accumulate=False, defer=None):
+    """dx = LayerNorm'(dy @ wt^T; x, gamma) (+ dres): the input gradient of a Linear (wt = its weight transposed to [C, K]) and the backward of
+    the LayerNorm in front of it in ONE launch (pseld_gemm_dgrad_lnbwd). d(gamma) / d(beta) as layernorm_bwd: at once, or through `defer`."""
+    _chk(dy, wt, x, gamma, dgamma, dbeta, dres)
+    M, K = dy.shape
+    C = wt.shape[0]
+    assert wt.shape == (C, K) and x.shape == (M, C) and wt.dtype == dy.dtype == x.dtype
+    L = _lib.lib()
+    nb = L.pseld_gemm_dgrad_lnbwd_parts(M, C)
+    ws = workspace(nb * 2 * C * 4, dy.device) if defer is None else defer.alloc(nb * 2 * C)
+    dx = torch.empty_like(x)
+    rc = L.pseld_gemm_dgrad_lnbwd(dtype_code(dy), _lib.ptr(dy), _lib.ptr(wt), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx),
+                                  _lib.ptr(ws), M, C, K, dy.stride(0), wt.stride(0), eps, _lib.stream_ptr())
+    _lib.check(rc, "pseld_gemm_dgrad_lnbwd")
+    both = dbeta.data_ptr() == dgamma.data_ptr() + 4 * C
+    if defer is not None:
+        if both:
+            defer.add(ws, dgamma, 2 * C, nb, 2 * C, bool(accumulate))
+        else:
+            defer.add(ws, dgamma, C, nb, 2 * C, bool(accumulate))
+            defer.add(ws[C:], dbeta, C, nb, 2 * C, bool(accumulate))
+    else:
+        import ctypes
+        src = (ctypes.c_void_p * 2)(ws.data_ptr(), ws[C:].data_ptr())
+        dst = (ctypes.c_void_p * 2)(dgamma.data_ptr(), dbeta.data_ptr())
+        n, sp, st = (ctypes.c_int * 2)(C, C), (ctypes.c_int * 2)(nb, nb), (ctypes.c_int * 2)(2 * C, 2 * C)
+        _lib.check(L.pseld_reduce_slabs_batched(src, dst, n, sp, st, 2, int(accumulate), _lib.stream_ptr()), "pseld_reduce_slabs_batched")
+    return dx
+
+
 # ---------------------------------------------------------------------------------------------------------
 # scalar BatchNorm + fold + patchify
 def bn_scalar_stats(feat, centered=True):

@@ -279,3 +279,45 @@ def test_cross_stitch(dev, dtype, M, C):
     dx, dy = ops.cross_stitch_bwd(x.to(dev), y.to(dev), w.to(dev).view(-1, 4), gx.to(dev), gy.to(dev), dw.view(-1, 4))
     check("stitch dx", dx, xr.grad, tol(dtype)); check("stitch dy", dy, yr.grad, tol(dtype))
     check("stitch dw", dw, wr.grad, 1e-4 if dtype == torch.float32 else tol(dtype))
+
+
+@pytest.mark.parametrize("M,C,K,with_res", [(4096, 96, 288, True), (1000, 96, 288, False), (2048 + 64, 192, 576, True), (1024, 192, 768, True),
+                                            (300, 192, 768, False)])
+def test_dgrad_gemm_with_layernorm_backward_epilogue(dev, M, C, K, with_res):
+    """pseld_gemm_dgrad_lnbwd (input gradient of a Linear + the backward of the LayerNorm in front of it, one launch) against the two
+    launches it replaces (pseld_gemm + pseld_layernorm_bwd: the intermediate is rounded to bf16 at the same place, so dx agrees to a few
+    bf16 ulps and the parameter gradients to fp32 summation order) and against float64 autograd."""
+    from pseldnets_amd import ops
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(M + C + K)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.2).to(dev).to(dt)
+    dy = (0.3 * torch.randn(M, K, generator=g)).to(dev).to(dt)
+    w = (torch.randn(K, C, generator=g) / C ** 0.5).to(dev).to(dt)            # the Linear's weight [out = K, in = C]
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(dev)
+    dres = (0.3 * torch.randn(M, C, generator=g)).to(dev).to(dt) if with_res else None
+    wt = w.t().contiguous()
+    assert ops.dgrad_lnbwd_supported(dy, C)
+    gb = torch.zeros(2 * C, device=dev)
+    dx = ops.linear_dgrad_lnbwd(dy, wt, x, gamma, gb[:C], gb[C:], dres=dres)
+    dxh = ops.linear_dgrad(dy, w, wt=wt)
+    gb2 = torch.zeros(2 * C, device=dev)
+    dx2 = ops.layernorm_bwd(dxh, x, gamma, gb2[:C], gb2[C:], dres=dres)
+    x64 = x.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = torch.zeros(C, dtype=torch.float64, device=dev, requires_grad=True)
+    xh = torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-5)
+    (xh @ w.double().t() * dy.double()).sum().backward()
+    want = x64.grad + (dres.double() if with_res else 0)
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    e = dict(dx=rel(dx, want), dx_two=rel(dx2, want), d=rel(dx, dx2), dgamma=rel(gb[:C], g64.grad), dbeta=rel(gb[C:], b64.grad),
+             dgamma_two=rel(gb2[:C], g64.grad), dbeta_two=rel(gb2[C:], b64.grad))
+    print('dgrad + LN backward epilogue', M, C, K, with_res, {k: f'{v:.2e}' for k, v in e.items()})
+    assert torch.isfinite(dx.float()).all()
+    assert e['dx'] < 6e-3 and e['dx'] <= 1.2 * e['dx_two'] + 1e-4 and e['d'] < 3e-3
+    assert e['dgamma'] <= 1.2 * e['dgamma_two'] + 1e-4 and e['dbeta'] <= 1.2 * e['dbeta_two'] + 1e-4 and e['dgamma'] < 6e-3 and e['dbeta'] < 6e-3
+    # accumulate + deferred reduction: twice the gradient
+    defer = ops.DeferredReductions(dev)
+    gb3 = gb.clone()
+    ops.linear_dgrad_lnbwd(dy, wt, x, gamma, gb3[:C], gb3[C:], dres=dres, accumulate=True, defer=defer)
+    defer.flush()
+    assert rel(gb3, 2 * gb) < 1e-5
