@@ -896,7 +896,8 @@ int launch_gemm_dma(const GemmArgs& g, hipStream_t stream) {
     const long nblocks = (long)8 * pseld_cdiv(ga.ny, 8) * ga.nx;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-    g_last_gemm_kernel = (WM == 2 && STAGES == 2) ? "gemm_dma_kernel<2, 2, 2>" : (WM == 4 ? "gemm_dma_kernel<4, 1, 2>" : "gemm_dma_kernel<2, 2, 3>");
+    // (the names rocprofv3 prints: the LNBWD template flag is part of the symbol)
+    g_last_gemm_kernel = (WM == 2 && STAGES == 2) ? "gemm_dma_kernel<2, 2, 2, false>" : (WM == 4 ? "gemm_dma_kernel<4, 1, 2, false>" : "gemm_dma_kernel<2, 2, 3, false>");
     hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, STAGES>), dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, stream, ga);
     PSELD_LAUNCH_CHECK("gemm_dma");
     return PSELD_OK;
@@ -1484,7 +1485,7 @@ extern "C" int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt,
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
         hipLaunchKernelGGL((gemm_dma_kernel<2, 2, 2, true>), dim3((unsigned)(8 * pseld_cdiv(g.ny, 8))), dim3(256), LDS, s, g);
     }
-    g_last_gemm_kernel = "gemm_dma_kernel<LNBWD>";
+    g_last_gemm_kernel = C == 96 ? "gemm_dma_kernel<4, 1, 2, true>" : "gemm_dma_kernel<2, 2, 2, true>";
     PSELD_LAUNCH_CHECK("gemm_dgrad_lnbwd");
     return PSELD_OK;
 }

@@ -23,6 +23,6 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
 # PMC passes over the fused MLP kernels alone (stage-0 shape)
 for P in "FETCH_SIZE" "WRITE_SIZE"; do n=$(echo $P | cut -d' ' -f1 | cut -c1-9); timeout 300 rocprofv3 --kernel-trace --pmc $P -d $O/swin_$n -o p --output-format csv -- python3 $R/tools/swin_bench.py --rounds 1 > $O/swin_$n.log 2>&1; echo "swin pmc $n rc=$?"; done
 cd $R
-python3 tools/pmc_kernel.py "gemm_dma_kernel<2, 2, 2>" gpurun_out/r03/pmc_FETCH gpurun_out/r03/pmc_WRITE gpurun_out/r03/pmc_SQ_VA gpurun_out/r03/dominant_kernel_pmc.json | cut -c1-600
+python3 tools/pmc_kernel.py "gemm_dma_kernel<2, 2, 2, false>" gpurun_out/r03/pmc_FETCH gpurun_out/r03/pmc_WRITE gpurun_out/r03/pmc_SQ_VA gpurun_out/r03/dominant_kernel_pmc.json | cut -c1-600
 python3 tools/attn_bench.py > gpurun_out/r03/attn_bench.log 2>&1; python3 tools/swin_bench.py > gpurun_out/r03/swin_bench.log 2>&1; python3 tools/mlp_bench.py --rounds 3 > gpurun_out/r03/mlp_bench.log 2>&1; CHUNKS=192 python3 tools/gemm_shapes.py > gpurun_out/r03/gemm_shapes.log 2>&1; tail -5 gpurun_out/r03/attn_bench.log gpurun_out/r03/swin_bench.log
 ls gpurun_out/r03/ks1 | head
