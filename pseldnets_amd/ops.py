@@ -224,7 +224,9 @@ def mlp_bwd_dw_side(x, dy, *args, **kw):
 # ---------------------------------------------------------------------------------------------------------
 # fused front half of the Swin attention branch (C = 96, bf16): LayerNorm -> qkv -> window attention in one kernel
 def swin_attn_fused_supported(x, res, heads):
-    return bool(x.is_cuda and x.dim() == 2 and _lib.lib().pseld_swin_attn_supported(dtype_code(x), res, x.shape[1], heads))
+    # (the kernel addresses the token rows with 32-bit byte offsets: below 4 GB of block input, i.e. 5 461 ten-second chunks at stage 0)
+    return bool(x.is_cuda and x.dim() == 2 and x.numel() * x.element_size() < (1 << 32) and
+                _lib.lib().pseld_swin_attn_supported(dtype_code(x), res, x.shape[1], heads))
 
 
 def swin_attn_fwd(x, gamma, beta, wqkv, bqkv, bias_table, B, res, heads, shift, eps=1e-5, need_saved=True):
