@@ -94,6 +94,14 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
     *(bf16x8*)p = a;
 }
 
+// two consecutive elements
+template <typename T> __device__ __forceinline__ void load2(const T* p, float (&out)[2]);
+template <> __device__ __forceinline__ void load2<float>(const float* p, float (&out)[2]) { const f32x2 a = *(const f32x2*)p; out[0] = a[0]; out[1] = a[1]; }
+template <> __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float (&out)[2]) { const bf16x2 a = *(const bf16x2*)p; out[0] = (float)a[0]; out[1] = (float)a[1]; }
+template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b);
+template <> __device__ __forceinline__ void store2<float>(float* p, float a, float b) { *(f32x2*)p = f32x2{a, b}; }
+template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) { bf16x2 v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; *(bf16x2*)p = v; }
+
 // ---- wave-level reductions (64 lanes) -----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -105,6 +105,49 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
     }
 }
 
+// Two output columns per thread (D and ldz even: every shipped head): bf16 pairs in, float2 out, one block row covers 512 columns
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_fwd2_kernel(const T* __restrict__ z, float* __restrict__ y, const int* __restrict__ i0,
+                                                             const float* __restrict__ w, int D, int ldz, int n_out, int n_in, int act) {
+    const int row = blockIdx.y;
+    const int b = row / n_out, f = row - b * n_out;
+    const int t0 = i0[f];
+    const float w0 = w[f * 3], w1 = w[f * 3 + 1], w2 = w[f * 3 + 2];
+    const T* z0 = z + ((long)b * n_in + t0) * ldz;
+    const bool h1 = t0 + 1 < n_in, h2 = t0 + 2 < n_in;
+    for (int d = 2 * (blockIdx.x * 256 + threadIdx.x); d < D; d += gridDim.x * 512) {
+        float a0[2], a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+        load2<T>(z0 + d, a0);
+        if (h1) load2<T>(z0 + ldz + d, a1);
+        if (h2) load2<T>(z0 + 2 * ldz + d, a2);
+        float s0 = w0 * a0[0] + w1 * a1[0] + w2 * a2[0], s1 = w0 * a0[1] + w1 * a1[1] + w2 * a2[1];
+        if (act) { s0 = tanh_fast(s0); s1 = tanh_fast(s1); }
+        *(float2*)(y + (long)row * D + d) = make_float2(s0, s1);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_bwd2_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* __restrict__ dz,
+                                                             const int* __restrict__ t_cnt, const int* __restrict__ t_f,
+                                                             const float* __restrict__ t_w, int D, int ldz, int n_out, int n_in, int act,
+                                                             int max_taps) {
+    const int row = blockIdx.y;                              // b * n_in + tt
+    const int b = row / n_in, tt = row - b * n_in;
+    const int cnt = t_cnt[tt];
+    for (int d = 2 * (blockIdx.x * 256 + threadIdx.x); d < ldz; d += gridDim.x * 512) {
+        float s0 = 0.f, s1 = 0.f;
+        if (d < D) {
+            for (int k = 0; k < cnt; ++k) {
+                const long o = ((long)b * n_out + t_f[tt * max_taps + k]) * D + d;
+                float2 g = *(const float2*)(dy + o);
+                if (act) { const float2 yv = *(const float2*)(y + o); g.x *= (1.f - yv.x * yv.x); g.y *= (1.f - yv.y * yv.y); }
+                const float wk = t_w[tt * max_taps + k];
+                s0 += wk * g.x; s1 += wk * g.y;
+            }
+        }
+        store2<T>(dz + (long)row * ldz + d, s0, s1);
+    }
+}
+
 // ---- ADPIT loss (forward value + gradient in one pass) --------------------------------------------------------
 // pred [B*T, 9, C] (row stride ldp), label [B*T, 6, 4, C]; one thread per (row, class).
 __global__ __launch_bounds__(256) void adpit_kernel(const float* __restrict__ pred, const float* __restrict__ label,
@@ -467,6 +510,13 @@ extern "C" int pseld_head_pool_fwd(int dtype, const void* z, float* y, const int
                                    int n_out, int n_in, int act_tanh, void* stream) {
     PSELD_CHECK_ARG(z && y && i0 && w && B > 0 && D > 0 && ldz >= D, "head_pool_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (D % 2 == 0 && ldz % 2 == 0) {
+        const dim3 grid2(pseld_cdiv(D, 512) > 4 ? 4 : pseld_cdiv(D, 512), B * n_out);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_fwd2_kernel<bf16_t>, grid2, dim3(256), 0, s, (const bf16_t*)z, y, i0, w, D, ldz, n_out, n_in, act_tanh),
+                   hipLaunchKernelGGL(head_pool_fwd2_kernel<float>, grid2, dim3(256), 0, s, (const float*)z, y, i0, w, D, ldz, n_out, n_in, act_tanh), "head_pool_fwd");
+        PSELD_LAUNCH_CHECK("head_pool_fwd");
+        return PSELD_OK;
+    }
     const dim3 grid(pseld_cdiv(D, 256) > 4 ? 4 : pseld_cdiv(D, 256), B * n_out);
     DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh),
                hipLaunchKernelGGL(head_pool_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)z, y, i0, w, B, D, ldz, n_out, n_in, act_tanh), "head_pool_fwd");
@@ -478,6 +528,13 @@ extern "C" int pseld_head_pool_bwd(int dtype, const float* dy, const float* y, v
                                    void* stream) {
     PSELD_CHECK_ARG(dy && y && dz && t_cnt && t_f && t_w && ldz >= D, "head_pool_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (D % 2 == 0 && ldz % 2 == 0) {
+        const dim3 grid2(pseld_cdiv(ldz, 512) > 4 ? 4 : pseld_cdiv(ldz, 512), B * n_in);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, s, dy, y, (bf16_t*)dz, t_cnt, t_f, t_w, D, ldz, n_out, n_in, act_tanh, max_taps),
+                   hipLaunchKernelGGL(head_pool_bwd2_kernel<float>, grid2, dim3(256), 0, s, dy, y, (float*)dz, t_cnt, t_f, t_w, D, ldz, n_out, n_in, act_tanh, max_taps), "head_pool_bwd");
+        PSELD_LAUNCH_CHECK("head_pool_bwd");
+        return PSELD_OK;
+    }
     const dim3 grid(pseld_cdiv(ldz, 256) > 4 ? 4 : pseld_cdiv(ldz, 256), B * n_in);
     DISPATCH_T(dtype, hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dy, y, (bf16_t*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps),
                hipLaunchKernelGGL(head_pool_bwd_kernel<float>, grid, dim3(256), 0, s, dy, y, (float*)dz, t_cnt, t_f, t_w, B, D, ldz, n_out, n_in, act_tanh, max_taps), "head_pool_bwd");
