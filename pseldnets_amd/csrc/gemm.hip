@@ -30,6 +30,7 @@
 // Roofline: HBM-bound for stages 0-2 of HTS-AT (arithmetic intensity <= 307 flop/B, ridge 314), MFMA-bound for stage 3
 // and PaSST. Measured per shape: tools/gemm_shapes.py; phase stamps: tools/gemm_stamps.py.
 #include "common.h"
+#include "gemm8.h"
 #include <stdlib.h>
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate,
@@ -1422,6 +1423,25 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
         g_last_gemm_kernel = "gemm_skinny_kernel";
         PSELD_LAUNCH_CHECK("gemm_skinny");
         return PSELD_OK;
+    }
+    // MFMA-bound products (K >= 384: stages 2-3, merges, head): the persistent eight-phase kernel of gemm8.hip.
+    // PSELD_GEMM8=0 disables it, PSELD_GEMM8_MINK=<K> moves the threshold (both read per call: in-process A/B)
+    if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && (epi & ~(EPI_BIAS | EPI_RESID | EPI_MULAUX | EPI_GELU_DUAL)) == 0) {
+        const char* e8 = getenv("PSELD_GEMM8");
+        const char* ek = getenv("PSELD_GEMM8_MINK");
+        const int mink = ek ? atoi(ek) : 384;
+        if (!(e8 && e8[0] == '0') && K >= mink) {
+            Gemm8Desc d;
+            d.A = A; d.B = B; d.C = C; d.C2 = (epi & EPI_GELU_DUAL) ? c2 : nullptr;
+            d.bias = (epi & EPI_BIAS) ? bias : nullptr; d.resid = (epi & EPI_RESID) ? resid : nullptr;
+            d.aux = (epi & EPI_MULAUX) ? aux : nullptr; d.rowscale = rowscale;
+            d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.ldr = ldr; d.ldaux = ldaux;
+            d.rows_per_scale = g.rows_per_scale; d.gelu_dual = (epi & EPI_GELU_DUAL) ? 1 : 0;
+            if (pseld_gemm8_supported(d)) {
+                g_last_gemm_kernel = "gemm8_kernel";
+                return pseld_gemm8_launch(d, s);
+            }
+        }
     }
     if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0 && M >= 128) {
         const char* e = getenv("PSELD_GEMM_DMA");

@@ -1,0 +1,22 @@
+// Persistent 256 x 256 x 64 eight-phase bf16 GEMM (gemm8.hip): the descriptor pseld_gemm / pseld_gemm_wgrad hand over.
+#pragma once
+#include "common.h"
+
+struct Gemm8Desc {
+    const void* A;          // [M, lda] bf16, k-contiguous rows
+    const void* B;          // [N, ldb] bf16, k-contiguous rows (C = A B^T)
+    void* C;                // [M, ldc] bf16
+    void* C2;               // GELU-dual: second output gelu'(v), [M, ldc]
+    const float* bias;      // [N] or null
+    const void* resid;      // [M, ldr] bf16 or null
+    const void* aux;        // [M, ldaux] bf16 multiplier or null
+    const float* rowscale;  // [ceil(M / rows_per_scale)] or null
+    int M, N, K;
+    int lda, ldb, ldc, ldr, ldaux;
+    int rows_per_scale;
+    int gelu_dual;
+};
+
+// 1 when the eight-phase kernel takes the product (shape / alignment / size limits), else 0
+int pseld_gemm8_supported(const Gemm8Desc& d);
+int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream);

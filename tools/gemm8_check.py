@@ -1,0 +1,117 @@
+"""Eight-phase persistent GEMM (csrc/gemm8.hip) against torch fp32 and against the 128 x 192 kernels of gemm.hip, in one process:
+correctness on ragged shapes and every fused epilogue, then TFLOP/s at 4096^3 / 8192^3 (uniform random operands) and on the
+stage-2 / stage-3 products of the 192-chunk HTS-AT step.   python tools/gemm8_check.py [check] [square] [shapes]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pseldnets_amd import ops
+
+dev = torch.device('cuda:0'); dt = torch.bfloat16
+what = sys.argv[1:] or ['check', 'square', 'shapes']
+
+
+def timeit(fn, n=10):
+    fn(); fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+_wt = {}
+
+
+def run(mode, x, w, b, extra, rs, rps, on, cat=True):
+    os.environ['PSELD_GEMM8'] = '1' if on else '0'
+    os.environ['PSELD_GEMM8_MINK'] = '128'
+    if mode == 'plain': return ops.linear_fwd(x, w, b, rowscale=rs, rows_per_scale=rps)
+    if mode == 'resid': return ops.linear_fwd(x, w, b, resid=extra, rowscale=rs, rows_per_scale=rps)
+    if mode == 'gelu':
+        r = ops.linear_fwd(x, w, b, gelu_dual=True)
+        return torch.cat(r, 1) if cat else r
+    if mode == 'mulaux':
+        if _wt.get('k') is not w: _wt['k'] = w; _wt['v'] = w.t().contiguous()
+        return ops.linear_dgrad(x, _wt['v'], rowscale=rs, rows_per_scale=rps, mul=extra, wt=w)
+    raise ValueError(mode)
+
+
+def ref(mode, x, w, b, extra, rs, rps):
+    v = x.float() @ w.float().t()
+    if mode != 'mulaux': v = v + b
+    if rs is not None: v = v * rs.repeat_interleave(rps)[:v.shape[0], None]
+    if mode == 'resid': v = v + extra.float()
+    if mode == 'mulaux': v = v * extra.float()
+    if mode == 'gelu':
+        u = v
+        cdf = 0.5 * (1 + torch.erf(u * 0.7071067811865476))
+        v = torch.cat([u * cdf, cdf + u * torch.exp(-0.5 * u * u) * 0.3989422804014327], 1)
+    return v
+
+
+if 'check' in what:
+    torch.manual_seed(0)
+    worst = 0.0
+    for (M, N, K) in ((256, 256, 128), (512, 384, 384), (1000, 1152, 384), (4096, 1536, 384), (777, 200, 192), (2048, 768, 3072),
+                      (12288, 2304, 768), (3000, 4096, 256)):
+        for mode in ('plain', 'resid', 'gelu', 'mulaux'):
+            for scaled in (False, True):
+                if mode == 'gelu' and scaled: continue
+                x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
+                b = torch.randn(N, device=dev)
+                extra = torch.randn(M, N, device=dev).to(dt)
+                rps = 64
+                rs = (torch.rand((M + rps - 1) // rps, device=dev) + 0.5) if scaled else None
+                y8 = run(mode, x, w, b, extra, rs, rps, True).float()
+                y0 = run(mode, x, w, b, extra, rs, rps, False).float()
+                r = ref(mode, x, w, b, extra, rs, rps)
+                den = r.abs().max().item()
+                e8 = (y8 - r).abs().max().item() / den; e0 = (y0 - r).abs().max().item() / den
+                l8 = ((y8 - r).norm() / r.norm()).item(); l0 = ((y0 - r).norm() / r.norm()).item()
+                flag = '' if (e8 <= max(2 * e0, 8e-3) and l8 <= max(1.5 * l0, 3e-3)) else '   <-- FAIL'
+                worst = max(worst, l8)
+                print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
+    # race screen: the same product many times must give bit-identical results
+    x = torch.randn(49152, 384, device=dev).to(dt); w = (torch.randn(1536, 384, device=dev) * 0.05).to(dt); b = torch.randn(1536, device=dev)
+    y = run('plain', x, w, b, None, None, 1, True).clone()
+    bad = 0
+    for _ in range(30):
+        bad += int(not torch.equal(y, run('plain', x, w, b, None, None, 1, True)))
+    print("race screen (30 repeats, 49152x1536x384): mismatching repeats =", bad)
+
+if 'square' in what:
+    for n in (4096, 8192):
+        a = (torch.rand(n, n, device=dev) * 2 - 1).to(dt); bm = (torch.rand(n, n, device=dev) * 2 - 1).to(dt)
+        out = torch.empty(n, n, device=dev, dtype=dt)
+        res = {}
+        for rnd in range(3):
+            for on in (True, False):
+                os.environ['PSELD_GEMM8'] = '1' if on else '0'
+                res.setdefault(on, []).append(timeit(lambda: ops.linear_fwd(a, bm, None, out=out), 20))
+        lib = timeit(lambda: torch.matmul(a, bm.t(), out=out), 20)
+        fl = 2.0 * n ** 3
+        print(f"{n}^3 random [-1,1): gemm8 {min(res[True]):7.0f} us {fl / min(res[True]) / 1e6:6.0f} TF | 128x192 kernel {min(res[False]):7.0f} us "
+              f"{fl / min(res[False]) / 1e6:6.0f} TF | vendor library {lib:7.0f} us {fl / lib / 1e6:6.0f} TF")
+
+if 'shapes' in what:
+    B = int(os.environ.get('CHUNKS', '192'))
+    tot = {True: 0.0, False: 0.0}
+    for li, C in ((2, 384), (3, 768)):
+        M = B * (64 >> li) ** 2
+        nblk = (2, 2, 6, 2)[li]
+        rps = (64 >> li) ** 2
+        for name, K, N, mode, scaled in (('qkv fwd', C, 3 * C, 'plain', False), ('proj fwd', C, C, 'resid', True), ('fc1 fwd', C, 4 * C, 'gelu', False),
+                                         ('fc2 fwd', 4 * C, C, 'resid', True), ('qkv dgrad', 3 * C, C, 'plain', False), ('proj dgrad', C, C, 'plain', True),
+                                         ('fc1 dgrad', 4 * C, C, 'plain', False), ('fc2 dgrad', C, 4 * C, 'mulaux', True)):
+            x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt); b = torch.randn(N, device=dev)
+            extra = torch.randn(M, N, device=dev).to(dt)
+            rs = (torch.rand(M // rps, device=dev) + 0.5) if scaled else None
+            t = {}
+            for rnd in range(3):
+                for on in (True, False):
+                    t.setdefault(on, []).append(timeit(lambda: run(mode, x, w, b, extra, rs, rps, on, cat=False), 10))
+            fl = 2.0 * M * N * K
+            for on in t: tot[on] += min(t[on]) * nblk
+            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: gemm8 {min(t[True]):6.1f} us {fl / min(t[True]) / 1e6:5.0f} TF | old {min(t[False]):6.1f} us "
+                  f"{fl / min(t[False]) / 1e6:5.0f} TF")
+    print(f"per step (stage 2 x6 + stage 3 x2, fwd + dgrad): gemm8 {tot[True] / 1e3:.2f} ms | old {tot[False] / 1e3:.2f} ms")
