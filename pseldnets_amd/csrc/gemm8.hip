@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr8;
 constexpr int HALF_B = 16384;             // one half-tile image: 128 rows x 128 B (64 bf16 of K)
 constexpr int BUF_B = 4 * HALF_B;         // one K-tile: A-h0 | A-h1 | B-h0 | B-h1
 constexpr int RING_B = 2 * BUF_B;         // 128 KiB
-constexpr int BIAS_FLOATS = 4096;         // the product's whole bias vector (padded to the tile grid) lives in LDS
+constexpr int BIAS_FLOATS = 4608;         // the product's whole bias vector (padded to the tile grid) lives in LDS
 constexpr int LDS_B = RING_B + BIAS_FLOATS * 4;
 
 enum { G8_PLAIN = 0, G8_RESID = 1, G8_MULAUX = 2, G8_GELU_DUAL = 3 };   // x SCALED (DropPath factor per token row)
@@ -82,8 +82,13 @@ __device__ __forceinline__ void unpack8f(const f32x4& p, float (&v)[8]) {
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int MODE, bool SCALED, bool DBG = false>
+// NB = 16-column accumulator blocks per wave: 4 -> 256 x 256 tile (wave 128 x 64), 3 -> 256 x 192 (wave 128 x 48: the second column
+// quadrant is one block wide, B-h1 is a 64-row image, and every N of HTS-AT is a multiple of 192)
+template <int MODE, bool SCALED, int NB, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
+    constexpr int WN = NB * 16, BN = 4 * WN;
+    constexpr int NB1 = NB - 2;                  // blocks in the second column quadrant
+    constexpr int VM_STEADY = 4 + NB1;           // LDS-DMA instructions of the three youngest half-tiles (B-h0, A-h0, B-h1) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = (float*)(smem + RING_B);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,20 +105,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     const int my_n = (chunkn - slot + per - 1) / per;
     const int first = chunk0 + slot;
 
-    for (int i = tid; i < g.nx * 256; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
+    for (int i = tid; i < g.nx * BN; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
     __syncthreads();
 
     // ---- fragment read addresses (buffer 0): lane reads row l15 of a 16-row block, 16-byte chunk (4 kk + q) ^ ((row >> 1) & 7) ----
     const int sw = (lane >> 1) & 7;
     const unsigned c0 = (unsigned)((q ^ sw) << 4);
     unsigned ra0 = (unsigned)(wr * 8192 + l15 * 128) + c0, ra1 = ra0 ^ 64;
-    unsigned rb0 = (unsigned)(2 * HALF_B + wc * 4096 + l15 * 128) + c0, rb1 = rb0 ^ 64;
+    unsigned rb0 = (unsigned)(2 * HALF_B + wc * 4096 + l15 * 128) + c0, rb1 = rb0 ^ 64;                       // B-h0: rows wc*32 + nbl*16 + l15
+    unsigned rc0 = (unsigned)(3 * HALF_B + wc * (NB1 * 2048) + l15 * 128) + c0, rc1 = rc0 ^ 64;               // B-h1: rows wc*(16 NB1) + nbl*16 + l15
 
     // ---- LDS-DMA source offsets of the load cursor's tile: [half][instruction] ----
     unsigned offA[2][2], offB[2][2];
     auto set_tile = [&](int T) {
         const int mblk = T / g.nx, nblk = T - mblk * g.nx;
-        const int m0 = mblk * 256, n0 = nblk * 256;
+        const int m0 = mblk * 256, n0 = nblk * BN;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rho = wave * 16 + j * 8 + (lane >> 3);                  // image row this lane fills
@@ -123,9 +129,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
             for (int h = 0; h < 2; ++h) {
                 const int tok = min(m0 + (rho >> 6) * 128 + h * 64 + (rho & 63), g.M - 1);
                 offA[h][j] = (unsigned)tok * (unsigned)(g.lda * 2) + (unsigned)(ch * 16);
-                const int n = min(n0 + (rho >> 5) * 64 + 32 * h + 8 * (i >> 2) + 4 * ((rho >> 4) & 1) + (i & 3), g.N - 1);
-                offB[h][j] = (unsigned)n * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
             }
+            // B-h0 (and B-h1 of the 64-column wave tile): image row wc*32 + nbl*16 + i <- weight row wc*WN + 32 h + 8 (i>>2) + 4 nbl + (i&3)
+            const int nb0 = n0 + (rho >> 5) * WN + 8 * (i >> 2) + 4 * ((rho >> 4) & 1) + (i & 3);
+            offB[0][j] = (unsigned)min(nb0, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
+            if constexpr (NB == 4) offB[1][j] = (unsigned)min(nb0 + 32, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
+        }
+        if constexpr (NB == 3) {      // B-h1, one block per wave column: 64 image rows wc*16 + i <- weight row wc*48 + 32 + i; one instruction per wave
+            const int rho = wave * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((rho >> 1) & 7);
+            offB[1][0] = (unsigned)min(n0 + (rho >> 4) * WN + 32 + (rho & 15), g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
+            offB[1][1] = 0;
         }
     };
     const unsigned lds_base = (unsigned)(unsigned long)(lds_vptr8)smem;
@@ -139,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     };
     auto dmaB = [&](int h) {
         const char* sb = g.B + ld_kt * 128;
+        if (NB == 3 && h == 1) { g8_dma(lds_base + (unsigned)wave * 1024u + ld_buf + (unsigned)(3 * HALF_B), sb, offB[1][0]); return; }
 #pragma unroll
         for (int j = 0; j < 2; ++j) g8_dma(dst_w + ld_buf + (unsigned)((2 + h) * HALF_B + j * 1024), sb, offB[h][j]);
     };
@@ -150,28 +165,35 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         }
     };
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    f32x4 acc[8][4];
+    bf16x8 fa[4][2], fb0[2][2], fb1[NB1][2];
+    f32x4 acc[8][NB];
 
     auto init_acc = [&](int n0) {
-        const float* bp = bias_s + n0 + wc * 64 + 8 * q;
-        f32x4 b[4];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) b[nb] = *(const f32x4*)(bp + 32 * (nb >> 1) + 4 * (nb & 1));
+        const float* bp = bias_s + n0 + wc * WN;
+        f32x4 b[NB];
+        b[0] = *(const f32x4*)(bp + 8 * q); b[1] = *(const f32x4*)(bp + 8 * q + 4);
+        if constexpr (NB == 4) { b[2] = *(const f32x4*)(bp + 32 + 8 * q); b[3] = *(const f32x4*)(bp + 32 + 8 * q + 4); }
+        else b[2] = *(const f32x4*)(bp + 32 + 4 * q);
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = b[nb];
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = b[nb];
     };
 
-    // lane: token row m0 + wr*128 + mb*16 + l15, columns n0 + wc*64 + 32 nq + 8 q + {4 nbl + k} = acc[mb][2 nq + nbl][k]
+    // lane: token row m0 + wr*128 + mb*16 + l15; columns n0 + wc*WN + 8 q + {4 nbl + k} = acc[mb][nbl][k] (first quadrant, 16 bytes) and
+    // n0 + wc*WN + 32 + 8 q + {4 nbl + k} = acc[mb][2 + nbl][k] (NB = 4) or n0 + wc*WN + 32 + 4 q + k = acc[mb][2][k] (NB = 3, 8 bytes)
     auto epilogue = [&](int m0, int n0) {
         constexpr bool HAS_X = MODE == G8_RESID || MODE == G8_MULAUX;
-        const int rowb = m0 + wr * 128 + l15, colb = n0 + wc * 64 + 8 * q;
-        const int mlast = g.M - 1, nlast = g.N - 8;
+        constexpr int W1 = NB == 4 ? 8 : 4;                   // columns per lane in the second quadrant
+        const int rowb = m0 + wr * 128 + l15;
+        const int col0 = n0 + wc * WN + 8 * q, col1 = n0 + wc * WN + 32 + W1 * q;
+        const int mlast = g.M - 1;
+        const int c0c = min(col0, g.N - 8), c1c = min(col1, g.N - W1);
         const bf16_t* X = MODE == G8_RESID ? g.resid : g.aux;
         const int ldx = MODE == G8_RESID ? g.ldr : g.ldaux;
-        f32x4 xv[HAS_X ? 16 : 1];
+        f32x4 xv0[HAS_X ? 8 : 1];
+        f32x4 xv1[HAS_X && NB == 4 ? 8 : 1];
+        f32x2 xw1[HAS_X && NB == 3 ? 8 : 1];
         float sc[SCALED ? 8 : 1];
         // every load of the epilogue is issued first, unconditionally (clamped addresses), and waited for by ONE wait the compiler
         // knows about: no load of its own is then pending at the loop's back edge, where it would otherwise drain the LDS-DMA
@@ -182,41 +204,35 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
                 const int rowc = min(rowb + mb * 16, mlast);
                 if constexpr (SCALED) sc[mb] = g.rowscale[div_by8(rowc, g.rows_per_scale, g.inv_rps)];
                 if constexpr (HAS_X) {
-#pragma unroll
-                    for (int nq = 0; nq < 2; ++nq)
-                        xv[mb * 2 + nq] = *(const f32x4*)(X + (long)rowc * ldx + min(colb + 32 * nq, nlast));
+                    xv0[mb] = *(const f32x4*)(X + (long)rowc * ldx + c0c);
+                    if constexpr (NB == 4) xv1[mb] = *(const f32x4*)(X + (long)rowc * ldx + c1c);
+                    else xw1[mb] = *(const f32x2*)(X + (long)rowc * ldx + c1c);
                 }
             }
             G8_WAIT_VM0();
         }
+        // v (W values): the fused options on fp32, one rounding to bf16
+        auto fuse = [&](float* v, const float* x, float scm, int W) {
+            if constexpr (MODE == G8_PLAIN) {
+                if constexpr (SCALED) for (int k = 0; k < W; ++k) v[k] *= scm;
+            } else if constexpr (MODE == G8_RESID) {
+                for (int k = 0; k < W; ++k) v[k] = SCALED ? fmaf(v[k], scm, x[k]) : v[k] + x[k];
+            } else if constexpr (MODE == G8_MULAUX) {
+                for (int k = 0; k < W; ++k) v[k] *= SCALED ? x[k] * scm : x[k];
+            }
+        };
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             const int row = rowb + mb * 16;
+            const long orow = (long)min(row, mlast) * g.ldc;
+            const float scm = SCALED ? sc[SCALED ? mb : 0] : 1.f;
+            {   // first quadrant: 8 columns
+                const bool ok = row < g.M && col0 < g.N;
+                float v[8], x[8];
 #pragma unroll
-            for (int nq = 0; nq < 2; ++nq) {
-                const int col = colb + 32 * nq;
-                const bool ok = row < g.M && col < g.N;
-                const long o = (long)min(row, mlast) * g.ldc + min(col, nlast);
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] = acc[mb][2 * nq][k]; v[4 + k] = acc[mb][2 * nq + 1][k]; }
-                const float scm = SCALED ? sc[SCALED ? mb : 0] : 1.f;
-                if constexpr (MODE == G8_PLAIN) {
-                    if constexpr (SCALED) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] *= scm;
-                    }
-                } else if constexpr (MODE == G8_RESID) {
-                    float x[8];
-                    unpack8f(xv[mb * 2 + nq], x);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = SCALED ? fmaf(v[k], scm, x[k]) : v[k] + x[k];
-                } else if constexpr (MODE == G8_MULAUX) {
-                    float x[8];
-                    unpack8f(xv[mb * 2 + nq], x);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] *= SCALED ? x[k] * scm : x[k];
-                } else {
+                for (int k = 0; k < 4; ++k) { v[k] = acc[mb][0][k]; v[4 + k] = acc[mb][1][k]; }
+                if constexpr (HAS_X) unpack8f(xv0[mb], x);
+                if constexpr (MODE == G8_GELU_DUAL) {
                     float dv[8];
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) {
@@ -224,9 +240,48 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
                         gelu_both2(xx, yy, dd);
                         v[k] = yy[0]; v[k + 1] = yy[1]; dv[k] = dd[0]; dv[k + 1] = dd[1];
                     }
-                    if (ok) *(f32x4*)(g.C2 + o) = pack8f(dv);
+                    if (ok) *(f32x4*)(g.C2 + orow + c0c) = pack8f(dv);
+                } else {
+#pragma unroll
+                    for (int once = 0; once < 1; ++once) fuse(v, x, scm, 8);
                 }
-                if (ok) *(f32x4*)(g.C + o) = pack8f(v);
+                if (ok) *(f32x4*)(g.C + orow + c0c) = pack8f(v);
+            }
+            {   // second quadrant: 8 (NB = 4) or 4 (NB = 3) columns
+                const bool ok = row < g.M && col1 < g.N;
+                float v[8], x[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = acc[mb][2][k]; v[4 + k] = NB == 4 ? acc[mb][NB - 1][k] : 0.f; }
+                if constexpr (HAS_X) {
+                    if constexpr (NB == 4) unpack8f(xv1[mb], x);
+                    else {
+                        const bf16x4 xb = __builtin_bit_cast(bf16x4, xw1[mb]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[k] = (float)xb[k];
+                    }
+                }
+                float dv[8];
+                if constexpr (MODE == G8_GELU_DUAL) {
+#pragma unroll
+                    for (int k = 0; k < W1; k += 2) {
+                        f32x2 xx = {v[k], v[k + 1]}, yy, dd;
+                        gelu_both2(xx, yy, dd);
+                        v[k] = yy[0]; v[k + 1] = yy[1]; dv[k] = dd[0]; dv[k + 1] = dd[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int once = 0; once < 1; ++once) fuse(v, x, scm, W1);
+                }
+                if constexpr (NB == 4) {
+                    if constexpr (MODE == G8_GELU_DUAL) { if (ok) *(f32x4*)(g.C2 + orow + c1c) = pack8f(dv); }
+                    if (ok) *(f32x4*)(g.C + orow + c1c) = pack8f(v);
+                } else {
+                    bf16x4 pv, pd;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { pv[k] = (bf16_t)v[k]; pd[k] = (bf16_t)dv[k]; }
+                    if constexpr (MODE == G8_GELU_DUAL) { if (ok) *(bf16x4*)(g.C2 + orow + c1c) = pd; }
+                    if (ok) *(bf16x4*)(g.C + orow + c1c) = pv;
+                }
             }
         }
     };
@@ -236,16 +291,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         fa[mbl][0] = *(const bf16x8*)(smem + ra0 + (mq) * HALF_B + mbl * 2048);                                  \
         fa[mbl][1] = *(const bf16x8*)(smem + ra1 + (mq) * HALF_B + mbl * 2048);                                  \
     }
-#define G8_LD_B(fb, nq)                                                                                          \
+#define G8_LD_B0()                                                                                               \
     _Pragma("unroll") for (int nbl = 0; nbl < 2; ++nbl) {                                                        \
-        fb[nbl][0] = *(const bf16x8*)(smem + rb0 + (nq) * HALF_B + nbl * 2048);                                  \
-        fb[nbl][1] = *(const bf16x8*)(smem + rb1 + (nq) * HALF_B + nbl * 2048);                                  \
+        fb0[nbl][0] = *(const bf16x8*)(smem + rb0 + nbl * 2048);                                                 \
+        fb0[nbl][1] = *(const bf16x8*)(smem + rb1 + nbl * 2048);                                                 \
+    }
+#define G8_LD_B1()                                                                                               \
+    _Pragma("unroll") for (int nbl = 0; nbl < NB1; ++nbl) {                                                      \
+        fb1[nbl][0] = *(const bf16x8*)(smem + rc0 + nbl * 2048);                                                 \
+        fb1[nbl][1] = *(const bf16x8*)(smem + rc1 + nbl * 2048);                                                 \
     }
 #define G8_MMA(mq, nq, fb)                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                               \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
         _Pragma("unroll") for (int mbl = 0; mbl < 4; ++mbl)                                                      \
-            _Pragma("unroll") for (int nbl = 0; nbl < 2; ++nbl)                                                  \
+            _Pragma("unroll") for (int nbl = 0; nbl < ((nq) == 0 ? 2 : NB1); ++nbl)                              \
                 acc[(mq) * 4 + mbl][(nq) * 2 + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
                     fb[nbl][kk], fa[mbl][kk], acc[(mq) * 4 + mbl][(nq) * 2 + nbl], 0, 0, 0);                     \
     __builtin_amdgcn_s_setprio(0);
@@ -253,12 +313,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     // ---- prologue: stream K-tile 0 complete, the first three half-tiles of K-tile 1 in flight ----
     int cp_i = 0, cp_kt = 0;
     int T = first;
-    int m0c = (T / g.nx) * 256, n0c = (T - (T / g.nx) * g.nx) * 256;
+    int m0c = (T / g.nx) * 256, n0c = (T - (T / g.nx) * g.nx) * BN;
     set_tile(first);
     dmaB(0); dmaA(0); dmaB(1); dmaA(1); advance();
     dmaB(0); dmaA(0); dmaB(1);
     init_acc(n0c);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
     G8_BAR();
     if (wr == 1) G8_BAR();                       // the stagger: waves 4-7 run one barrier behind waves 0-3
 
@@ -267,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     if constexpr (DBG) t_start = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < total_kt; ++s) {
         // phase 1: B-h0 + A-h0 fragments | A-h1 of the next K-tile | quadrant (m 0-63, n 0-31)
-        G8_LD_B(fb0, 0);
+        G8_LD_B0();
         __builtin_amdgcn_sched_barrier(0);
         G8_LD_A(0);
         dmaA(1); advance();
@@ -276,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         G8_MMA(0, 0, fb0);
         G8_BAR();
         // phase 2: B-h1 fragments | B-h0 of K-tile + 2 | quadrant (m 0-63, n 32-63)
-        G8_LD_B(fb1, 1);
+        G8_LD_B1();
         dmaB(0);
         G8_BAR();
         G8_MMA(0, 1, fb1);
@@ -289,11 +349,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         G8_BAR();
         // phase 4: B-h1 of K-tile + 2 | everything but the three youngest half-tiles has landed | quadrant (m 64-127, n 0-31)
         dmaB(1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
         G8_BAR();
         G8_MMA(1, 0, fb0);
         G8_BAR();
-        ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B;
+        ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B; rc0 ^= BUF_B; rc1 ^= BUF_B;
         if (++cp_kt == g.nk) {
             unsigned long long t_loop = 0;
             if constexpr (DBG) t_loop = __builtin_amdgcn_s_memtime();
@@ -310,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
             if (++cp_i < my_n) {
                 T = first + cp_i * per;
                 const int mblk = T / g.nx;
-                m0c = mblk * 256; n0c = (T - mblk * g.nx) * 256;
+                m0c = mblk * 256; n0c = (T - mblk * g.nx) * BN;
                 init_acc(n0c);
             }
         }
@@ -319,13 +379,31 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the cursor's surplus DMAs must not outlive the workgroup's LDS
 }
 
-template <int MODE, bool SCALED>
+template <int MODE, bool SCALED, int NB>
 int launch8(const G8Args& a, int nwg, hipStream_t stream) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED>), dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
+    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB>), dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
     PSELD_LAUNCH_CHECK("gemm8");
     return PSELD_OK;
+}
+template <int NB>
+int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t stream) {
+    const bool sc = d.rowscale != nullptr;
+    if (a.dbg) {          // diagnostic build of three epilogue kinds: stamps to [workgroup][wave group][tile < 16][4]
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+            return PSELD_OK;
+        };
+        if (d.gelu_dual) return go(gemm8_kernel<G8_GELU_DUAL, false, NB, true>);
+        if (d.resid && sc) return go(gemm8_kernel<G8_RESID, true, NB, true>);
+        if (!d.resid && !d.aux && !sc) return go(gemm8_kernel<G8_PLAIN, false, NB, true>);
+    }
+    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB>(a, nwg, stream);
+    if (d.resid) return sc ? launch8<G8_RESID, true, NB>(a, nwg, stream) : launch8<G8_RESID, false, NB>(a, nwg, stream);
+    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB>(a, nwg, stream) : launch8<G8_MULAUX, false, NB>(a, nwg, stream);
+    return sc ? launch8<G8_PLAIN, true, NB>(a, nwg, stream) : launch8<G8_PLAIN, false, NB>(a, nwg, stream);
 }
 
 unsigned long long* g_gemm8_dbg = nullptr;
@@ -337,7 +415,7 @@ int pseld_gemm8_supported(const Gemm8Desc& d) {
     if (d.K % 64 != 0 || d.K < 128 || d.M < 256 || d.N < 128 || d.N % 8 != 0) return 0;
     if (d.lda % 8 != 0 || d.ldb % 8 != 0 || d.ldc % 8 != 0 || (d.resid && d.ldr % 8 != 0) || (d.aux && d.ldaux % 8 != 0)) return 0;
     if ((long)d.M * d.lda * 2 >= (1L << 32) || (long)d.N * d.ldb * 2 >= (1L << 32) || d.M >= (1 << 24)) return 0;
-    if (pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS) return 0;
+    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS) return 0;
     if ((((unsigned long)d.A | (unsigned long)d.B | (unsigned long)d.C | (unsigned long)d.C2 | (unsigned long)d.resid | (unsigned long)d.aux) & 15) != 0) return 0;
     if (d.resid && d.aux) return 0;
     if (d.gelu_dual && (d.resid || d.aux || d.rowscale || !d.C2)) return 0;
@@ -351,25 +429,21 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldaux = d.ldaux;
     a.rows_per_scale = d.rows_per_scale > 0 ? d.rows_per_scale : 1;
     a.inv_rps = 1.0f / (float)a.rows_per_scale;
-    a.nx = pseld_cdiv(d.N, 256);
-    a.ntiles = a.nx * pseld_cdiv(d.M, 256);
     a.nk = d.K / 64;
+    a.dbg = g_gemm8_dbg;
+    // tile width: 192 when that wastes fewer columns / fills the rounds better (PSELD_GEMM8_BN=256 / 192 forces one: A/B knob)
+    const char* eb = getenv("PSELD_GEMM8_BN");
+    int bn = eb ? atoi(eb) : 0;
+    if (bn != 256 && bn != 192) {
+        auto cost = [&](int w) {                      // rounds x (loop cost of one tile ~ DMA bytes per K-tile)
+            const long tiles = (long)pseld_cdiv(d.N, w) * pseld_cdiv(d.M, 256);
+            return (double)((tiles + 255) / 256) * (256 + w);
+        };
+        bn = cost(192) < cost(256) ? 192 : 256;
+    }
+    a.nx = pseld_cdiv(d.N, bn);
+    a.ntiles = a.nx * pseld_cdiv(d.M, 256);
     int nwg = (a.ntiles + 7) / 8 * 8;
     if (nwg > 256) nwg = 256;
-    a.dbg = g_gemm8_dbg;
-    if (a.dbg) {          // diagnostic build of three epilogue kinds: stamps to [workgroup][wave group][tile < 16][4]
-        auto go = [&](auto kern) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
-            return PSELD_OK;
-        };
-        if (d.gelu_dual) return go(gemm8_kernel<G8_GELU_DUAL, false, true>);
-        if (d.resid && d.rowscale) return go(gemm8_kernel<G8_RESID, true, true>);
-        if (!d.resid && !d.aux && !d.rowscale) return go(gemm8_kernel<G8_PLAIN, false, true>);
-    }
-    const bool sc = d.rowscale != nullptr;
-    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false>(a, nwg, stream);
-    if (d.resid) return sc ? launch8<G8_RESID, true>(a, nwg, stream) : launch8<G8_RESID, false>(a, nwg, stream);
-    if (d.aux) return sc ? launch8<G8_MULAUX, true>(a, nwg, stream) : launch8<G8_MULAUX, false>(a, nwg, stream);
-    return sc ? launch8<G8_PLAIN, true>(a, nwg, stream) : launch8<G8_PLAIN, false>(a, nwg, stream);
+    return bn == 192 ? launch8_mode<3>(d, a, nwg, stream) : launch8_mode<4>(d, a, nwg, stream);
 }

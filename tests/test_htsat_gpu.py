@@ -99,7 +99,9 @@ def test_tiny_train_step_vs_golden(dev):
     assert int(sdn['scalar.3.num_batches_tracked']) == 1
 
 
-@pytest.mark.parametrize("dtype,gate", [(torch.float32, 1e-3), (torch.bfloat16, 2.5e-1)])
+# bf16 gate = 2 x measured (1.13e-1 on the adversarial closed-form weights of the golden; 2.4e-2 on realistic weights, gated in
+# test_bf16_drift_on_default_initialised_weights)
+@pytest.mark.parametrize("dtype,gate", [(torch.float32, 1e-3), (torch.bfloat16, 2.3e-1)])
 def test_full_size_forward_vs_golden(dev, dtype, gate):
     from pseldnets_amd.models import multi_accdoa
     g = np.load(os.path.join(G, 'htsat_full.npz'))
@@ -114,7 +116,9 @@ def test_full_size_forward_vs_golden(dev, dtype, gate):
     assert r < gate
 
 
-@pytest.mark.parametrize("dtype,gate", [(torch.float32, 1e-3), (torch.bfloat16, 1e-1)])
+# bf16 gates = 2 x measured (third-step loss 3.1e-2 off the oracle on the adversarial tiny state; parameters 2.2e-3 rel-L2, 30 % of the
+# elements off by more than lr / 2 after three sign-like Adam updates)
+@pytest.mark.parametrize("dtype,gate", [(torch.float32, 1e-3), (torch.bfloat16, 6.2e-2)])
 def test_fused_train_steps_match_oracle(dev, dtype, gate):
     """3 steps of net->ADPIT->backward->clip(1.0)->AdamW(lr 1e-4) on the tiny config vs the oracle stepping the same
     state with its own AdamW restatement. Adam's first updates are +-lr*sign(g): parameters whose gradient is
@@ -158,7 +162,7 @@ def test_fused_train_steps_match_oracle(dev, dtype, gate):
     rel_l2 = ((hip - orc).norm() / orc.norm()).item()
     frac_off = ((hip - orc).abs() > lr / 2).float().mean().item()
     print(f'param rel L2 diff after 3 steps {rel_l2:.3e}; fraction off by > lr/2: {frac_off:.4f}')
-    assert rel_l2 < (2e-4 if dtype == torch.float32 else 6e-3)
+    assert rel_l2 < (2e-4 if dtype == torch.float32 else 4.4e-3)
     assert frac_off < (0.02 if dtype == torch.float32 else 0.6)
 
 
@@ -596,6 +600,9 @@ def _default_init_net(dev, dtype, seed=21):
     return net.to(dev)
 
 
+GRAD_L2_GATE, GRAD_WORST_GATE = 1.6e-2, 3e-2      # 2 x measured (7.8e-3 whole arena, 1.4e-2 worst parameter: patch_embed.proj.weight)
+
+
 def test_bf16_drift_on_default_initialised_weights(dev):
     """bf16 (throughput) mode against f32 (parity) mode on REALISTIC weights — the reference constructors' defaults (kaiming-
     uniform Linear / Conv, trunc_normal(0.02) bias tables, unit norms; components/htsat.py:default_init), not the adversarial
@@ -610,12 +617,23 @@ def test_bf16_drift_on_default_initialised_weights(dev):
     lab[:, :, 0, 0] = act
     lab[:, :, 0, 1:] = torch.nn.functional.normalize(torch.randn(B, 100, 3, 170, generator=gcpu), dim=2) * act.unsqueeze(2)
     target = {'adpit_label': lab.to(dev)}
-    outs, curves = {}, {}
+    from pseldnets_amd import ops
+    outs, curves, grads = {}, {}, {}
     for dtype in (torch.float32, torch.bfloat16):
         net = _default_init_net(dev, dtype)
         net.eval()
         with torch.no_grad():
             outs[dtype] = net(x.clone())['multi_accdoa'].float().cpu()
+        # one backward with every fused kernel of the timed mode on (block kernels, LayerNorm-backward epilogues, eight-phase GEMMs):
+        # the parameter gradients of the bf16 path against the f32 path (which test_full_size_f32_train_step_vs_oracle ties to the oracle)
+        net.train()
+        net._materialize(dev)
+        yt, saved = net._forward_impl(x.clone(), True)
+        _, dpred = ops.adpit_loss(yt, target['adpit_label'])
+        net.zero_grad_arena()
+        net._backward_impl(saved, (dpred,))
+        grads[dtype] = (net.arena.grad.clone(), {n: net.arena.view(net.arena.grad, n).float().clone() for n in net.arena.entries})
+        del saved
         tr = FusedTrainer(net, None, 'adpit', lr=1e-4, max_norm=1.0)
         ls = []
         for _ in range(200):
@@ -628,9 +646,17 @@ def test_bf16_drift_on_default_initialised_weights(dev):
     dev_curve = ((cb - cf).abs() / cf.abs()).max().item()
     print(f'bf16 vs f32, default init: eval forward max-abs rel {fwd_rel:.3e}, rel-L2 {fwd_l2:.3e}; 200-step loss curve '
           f'f32 {cf[0].item():.6f} -> {cf[-1].item():.6f}, bf16 {cb[0].item():.6f} -> {cb[-1].item():.6f}, max rel deviation {dev_curve:.3e}')
+    g32, g16 = grads[torch.float32], grads[torch.bfloat16]
+    grad_l2 = ((g16[0] - g32[0]).norm() / g32[0].norm()).item()
+    worst = ('', 0.0)
+    for n, a in g32[1].items():
+        if a.norm().item() > 1e-3 * g32[0].norm().item():            # parameters that carry gradient (not the analytically-zero key biases)
+            worst = max(worst, (n, ((g16[1][n] - a).norm() / a.norm()).item()), key=lambda t: t[1])
+    print(f'bf16 vs f32 parameter gradients (all fused kernels on): arena rel-L2 {grad_l2:.3e}; worst parameter {worst}')
     assert torch.isfinite(cb).all() and cf[-1] < cf[0] and cb[-1] < cb[0]
+    assert grad_l2 < GRAD_L2_GATE and worst[1] < GRAD_WORST_GATE, (grad_l2, worst)
     assert fwd_rel < 5e-2 and fwd_l2 < 2e-2, (fwd_rel, fwd_l2)
-    assert dev_curve < 5e-3, dev_curve      # measured 1.3e-3 (round 2)
+    assert dev_curve < 3.5e-3, dev_curve      # 2 x measured (1.7e-3, round 4; 1.3e-3 in round 2)
 
 
 def test_weights_changed_behind_the_arena_are_seen(dev):

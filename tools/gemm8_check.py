@@ -24,6 +24,7 @@ _wt = {}
 
 def run(mode, x, w, b, extra, rs, rps, on, cat=True):
     os.environ['PSELD_GEMM8'] = '1' if on else '0'
+    if on: os.environ['PSELD_GEMM8_BN'] = str(on if on in (192, 256) else 0)
     os.environ['PSELD_GEMM8_MINK'] = '128'
     if mode == 'plain': return ops.linear_fwd(x, w, b, rowscale=rs, rows_per_scale=rps)
     if mode == 'resid': return ops.linear_fwd(x, w, b, resid=extra, rowscale=rs, rows_per_scale=rps)
@@ -55,6 +56,7 @@ if 'check' in what:
     for (M, N, K) in ((256, 256, 128), (512, 384, 384), (1000, 1152, 384), (4096, 1536, 384), (777, 200, 192), (2048, 768, 3072),
                       (12288, 2304, 768), (3000, 4096, 256)):
         for mode in ('plain', 'resid', 'gelu', 'mulaux'):
+          for bn in (256, 192):
             for scaled in (False, True):
                 if mode == 'gelu' and scaled: continue
                 x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
@@ -62,7 +64,7 @@ if 'check' in what:
                 extra = torch.randn(M, N, device=dev).to(dt)
                 rps = 64
                 rs = (torch.rand((M + rps - 1) // rps, device=dev) + 0.5) if scaled else None
-                y8 = run(mode, x, w, b, extra, rs, rps, True).float()
+                y8 = run(mode, x, w, b, extra, rs, rps, bn).float()
                 y0 = run(mode, x, w, b, extra, rs, rps, False).float()
                 r = ref(mode, x, w, b, extra, rs, rps)
                 den = r.abs().max().item()
@@ -70,14 +72,15 @@ if 'check' in what:
                 l8 = ((y8 - r).norm() / r.norm()).item(); l0 = ((y0 - r).norm() / r.norm()).item()
                 flag = '' if (e8 <= max(2 * e0, 8e-3) and l8 <= max(1.5 * l0, 3e-3)) else '   <-- FAIL'
                 worst = max(worst, l8)
-                print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
+                print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} bn={bn} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
     # race screen: the same product many times must give bit-identical results
     x = torch.randn(49152, 384, device=dev).to(dt); w = (torch.randn(1536, 384, device=dev) * 0.05).to(dt); b = torch.randn(1536, device=dev)
-    y = run('plain', x, w, b, None, None, 1, True).clone()
-    bad = 0
-    for _ in range(30):
-        bad += int(not torch.equal(y, run('plain', x, w, b, None, None, 1, True)))
-    print("race screen (30 repeats, 49152x1536x384): mismatching repeats =", bad)
+    for bn in (256, 192):
+        y = run('plain', x, w, b, None, None, 1, bn).clone()
+        bad = 0
+        for _ in range(30):
+            bad += int(not torch.equal(y, run('plain', x, w, b, None, None, 1, bn)))
+        print(f"race screen (30 repeats, 49152x1536x384, bn={bn}): mismatching repeats =", bad)
 
 if 'square' in what:
     for n in (4096, 8192):
@@ -85,17 +88,18 @@ if 'square' in what:
         out = torch.empty(n, n, device=dev, dtype=dt)
         res = {}
         for rnd in range(3):
-            for on in (True, False):
+            for on in (256, 192, False):
                 os.environ['PSELD_GEMM8'] = '1' if on else '0'
+                os.environ['PSELD_GEMM8_BN'] = str(on) if on else '0'
                 res.setdefault(on, []).append(timeit(lambda: ops.linear_fwd(a, bm, None, out=out), 20))
         lib = timeit(lambda: torch.matmul(a, bm.t(), out=out), 20)
         fl = 2.0 * n ** 3
-        print(f"{n}^3 random [-1,1): gemm8 {min(res[True]):7.0f} us {fl / min(res[True]) / 1e6:6.0f} TF | 128x192 kernel {min(res[False]):7.0f} us "
+        print(f"{n}^3 random [-1,1): gemm8 256x256 {min(res[256]):7.0f} us {fl / min(res[256]) / 1e6:6.0f} TF | 256x192 {min(res[192]):7.0f} us {fl / min(res[192]) / 1e6:6.0f} TF | 128x192 kernel {min(res[False]):7.0f} us "
               f"{fl / min(res[False]) / 1e6:6.0f} TF | vendor library {lib:7.0f} us {fl / lib / 1e6:6.0f} TF")
 
 if 'shapes' in what:
     B = int(os.environ.get('CHUNKS', '192'))
-    tot = {True: 0.0, False: 0.0}
+    tot = {256: 0.0, 192: 0.0, True: 0.0, False: 0.0}
     for li, C in ((2, 384), (3, 768)):
         M = B * (64 >> li) ** 2
         nblk = (2, 2, 6, 2)[li]
@@ -108,10 +112,10 @@ if 'shapes' in what:
             rs = (torch.rand(M // rps, device=dev) + 0.5) if scaled else None
             t = {}
             for rnd in range(3):
-                for on in (True, False):
+                for on in (256, 192, True, False):
                     t.setdefault(on, []).append(timeit(lambda: run(mode, x, w, b, extra, rs, rps, on, cat=False), 10))
             fl = 2.0 * M * N * K
             for on in t: tot[on] += min(t[on]) * nblk
-            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: gemm8 {min(t[True]):6.1f} us {fl / min(t[True]) / 1e6:5.0f} TF | old {min(t[False]):6.1f} us "
-                  f"{fl / min(t[False]) / 1e6:5.0f} TF")
-    print(f"per step (stage 2 x6 + stage 3 x2, fwd + dgrad): gemm8 {tot[True] / 1e3:.2f} ms | old {tot[False] / 1e3:.2f} ms")
+            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: " + " | ".join(f"{lbl} {min(t[k]):6.1f} us {fl / min(t[k]) / 1e6:5.0f} TF" for k, lbl in
+                  ((256, 'bn256'), (192, 'bn192'), (True, 'auto'), (False, 'old'))))
+    print("per step (stage 2 x6 + stage 3 x2, fwd + dgrad), ms: " + " | ".join(f"{lbl} {tot[k] / 1e3:.2f}" for k, lbl in ((256, 'bn256'), (192, 'bn192'), (True, 'auto'), (False, 'old'))))
