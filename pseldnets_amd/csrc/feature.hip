@@ -56,7 +56,7 @@ constexpr int EX_LD = 33;                  // transpose row stride (elements): l
 constexpr int FFT_LDS = 32 * EX_LD;        // elements per FFT region (also holds the 1024-point spectrum afterwards)
 constexpr int WAVES2 = 8;                  // waves (= frames in flight) per workgroup
 constexpr int FPB2 = 32;                   // frames per workgroup (the 14 KB of tables are re-read per workgroup: amortised over 4 frames per wave)
-constexpr int V2_WAVE_BYTES = 2 * FFT_LDS * 8 + 64;
+constexpr int V2_WAVE_BYTES = 2 * FFT_LDS * 8;
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -115,163 +115,261 @@ __device__ __forceinline__ void fft32(float2 (&x)[32]) {
     }
 }
 
+// ---- round 4: frame-invariant tables in registers / LDS, one pass over the spectrum, balanced mel projection -------------------
+// What changed against the round-1..3 kernel (3 590 vector instructions per frame, stamps: mel projection 43 %, spectrum split 24 %):
+//  * the 31 inter-stage twiddles W_1024^(t k1) are a per-workgroup LDS table (one ds_read_b64 + one complex multiply each; they were
+//    rebuilt per frame from five base powers: 80 complex multiplies); the window is held in 32 registers across the frame loop;
+//  * the spectrum split reads every Z[k], Z[N-k] it needs FIRST (one wave owns the region: its LDS operations execute in program
+//    order), then writes the seven per-bin values as two dense planes VP[k] = (P0..P3), VI[k] = (I1..I3, -) indexed by the bin - no
+//    mirrored in-place slots, no per-bin pointer selects; raw v_sqrt / v_rcp instead of the IEEE sequences, the factors 1/2 of the
+//    real / imaginary split folded into one 1/4 on the mel sums and into the IV epsilon;
+//  * mel projection: the 998 (filter, bin) weights are cut into runs of <= 12 consecutive bins of one filter (115 runs for the
+//    64-mel HTK bank); a lane owns one run per pass (2 passes), its 12 weights live in registers across the frame loop, a bin's
+//    seven values arrive as two ds_read_b128 (was: five dependent LDS reads per weight, the widest filter setting the trip count
+//    of all 16 filters of its pass: 26 iterations of 25 instructions), the runs of one filter meet by two lane shuffles;
+//  * the next frame's samples are requested before the split / mel phase of the current one.
+constexpr int MEL_CAP = 12;                // bins per run
+constexpr int VBINS = 528;                 // bins per value plane (513 + the overhang of a zero-weighted run tail)
+constexpr int VI_OFF = VBINS * 16;         // byte offset of the IV plane inside a wave's region (2 * 8448 = 16896 = 2 * FFT_LDS * 8)
+static_assert(2 * VBINS * 16 == 2 * FFT_LDS * 8, "value planes must overlay the two spectrum regions exactly");
+
 __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* melw = (float*)smem;                       // [MAX_NNZ]
-    int* mlo = (int*)(melw + MAX_NNZ);                // [MAX_MELS]
-    int* mcnt = mlo + MAX_MELS;
-    int* moff = mcnt + MAX_MELS;
-    float* win_s = (float*)(moff + MAX_MELS);         // [NFFT]
-    char* wave_base = (char*)(win_s + NFFT);
+    float2* tws = (float2*)smem;                      // [32 k1][32 t]: W_1024^(t k1)
+    int* sched = (int*)(tws + 32 * 32);               // [128 runs][2]: {k0 | band << 16 | first << 24 | following runs << 25, weight offset | n << 16}
+    int* sched_ok = sched + 256;                      // [4]
+    float* mws = (float*)(sched_ok + 4);              // [128 runs][12]: zero-padded weights of each run
+    float* wins = mws + 128 * MEL_CAP;                // [32 t][36]: window[t + 32 m], rows padded to 144 B (conflict-free ds_read_b128)
+    char* wave_base = (char*)(wins + 32 * 36);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float2* spec = (float2*)(wave_base + wave * V2_WAVE_BYTES);   // [2 pairs][FFT_LDS]: transpose, spectrum, then values
-    float2* spc = spec + 2 * FFT_LDS;                             // [2][4]: the self-mirrored bins 0 and 512
+    char* region = wave_base + wave * V2_WAVE_BYTES;
+    float2* spec = (float2*)region;                   // [2 pairs][FFT_LDS]: transpose buffer, then the spectrum, then the value planes
 
-    for (int n = tid; n < a.nnz; n += WAVES2 * 64) melw[n] = a.mel_w[n];
-    for (int n = tid; n < a.n_mels; n += WAVES2 * 64) { mlo[n] = a.mel_lo[n]; mcnt[n] = a.mel_cnt[n]; moff[n] = a.mel_off[n]; }
-    for (int n = tid; n < NFFT; n += WAVES2 * 64) win_s[n] = a.window[n];
+    const int pr = lane >> 5, t = lane & 31;
+    for (int n = tid; n < 32 * 32; n += WAVES2 * 64) tws[n] = a.twid[((n & 31) * (n >> 5)) & (NFFT - 1)];
+    for (int n = tid; n < 256; n += WAVES2 * 64) sched[n] = 0;
+    for (int n = tid; n < NFFT; n += WAVES2 * 64) wins[(n & 31) * 36 + (n >> 5)] = a.window[n];
+    __syncthreads();
+    if (wave == 0) {
+        // runs of filter m = lane: ceil(cnt / 12), laid out in filter order; a filter's runs never straddle the pass boundary (run 64)
+        const int m = lane;
+        const int cnt = m < a.n_mels ? a.mel_cnt[m] : 0, lo = m < a.n_mels ? a.mel_lo[m] : 0, off = m < a.n_mels ? a.mel_off[m] : 0;
+        const int parts = (cnt + MEL_CAP - 1) / MEL_CAP;
+        int incl = parts;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        int start = incl - parts;
+        const unsigned long long strad = __ballot(start < 64 && start + parts > 64);
+        int pad = 0;
+        if (strad) {
+            const int bs = __builtin_ctzll(strad);
+            pad = 64 - __shfl(start, bs, 64);
+            if (m >= bs) start += pad;
+        }
+        const int total = __shfl(incl, 63, 64) + pad;
+        const unsigned long long toolong = __ballot(parts > 8);
+        const bool ok = a.n_mels <= 64 && total <= 128 && !toolong;
+        if (ok)
+            for (int p = 0; p < parts; ++p) {
+                const int n = min(MEL_CAP, cnt - p * MEL_CAP);
+                sched[2 * (start + p)] = (lo + p * MEL_CAP) | (m << 16) | ((p == 0) << 24) | ((parts - 1 - p) << 25);
+                sched[2 * (start + p) + 1] = (off + p * MEL_CAP) | (n << 16);
+            }
+        if (lane == 0) sched_ok[0] = ok;
+    }
+    __syncthreads();
+    const bool fast_mel = sched_ok[0] != 0;
+    // this lane's two runs (frame-invariant): first bin, filter, combine role; the runs' zero-padded weights go to the LDS table
+    int mk0[2], mband[2], mfirst[2], mfollow[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int e0 = sched[2 * (p * 64 + lane)];
+        mk0[p] = e0 & 0xffff; mband[p] = (e0 >> 16) & 0xff; mfirst[p] = (e0 >> 24) & 1; mfollow[p] = (e0 >> 25) & 15;
+    }
+    for (int n = tid; n < 128 * MEL_CAP; n += WAVES2 * 64) {
+        const int r = n / MEL_CAP, i = n - r * MEL_CAP, e1 = sched[2 * r + 1];
+        mws[n] = (fast_mel && i < (e1 >> 16)) ? a.mel_w[(e1 & 0xffff) + i] : 0.f;
+    }
     __syncthreads();
 
     const int b = blockIdx.y;
-    const int pr = lane >> 5, t = lane & 31;
     const int c0 = 2 * pr, c1 = 2 * pr + 1;
     const bool has0 = c0 < a.n_ch, has1 = c1 < a.n_ch;
     const float* wv = a.wave + (long)b * a.n_ch * a.L;
     const float* w0 = wv + (long)(has0 ? c0 : 0) * a.L;
     const float* w1 = wv + (long)(has1 ? c1 : 0) * a.L;
-    const float k0 = has0 ? 1.f : 0.f, k1m = has1 ? 1.f : 0.f;    // missing channels: load channel 0, scale by zero
+    const float k0f = has0 ? 1.f : 0.f, k1f = has1 ? 1.f : 0.f;   // missing channels: load channel 0, scale by zero
     float2* ex = spec + pr * FFT_LDS;
-    float2* sp0 = spec;
-    float2* sp1 = spec + FFT_LDS;
-    // twiddle bases W^(t * 2^j): every W_1024^(t k1) is a product of at most five of them
-    const float2 P1 = a.twid[t], P2 = a.twid[(2 * t) & (NFFT - 1)], P4 = a.twid[(4 * t) & (NFFT - 1)],
-                 P8 = a.twid[(8 * t) & (NFFT - 1)], P16 = a.twid[(16 * t) & (NFFT - 1)];
+    const float2* sp0 = spec;
+    const float2* sp1 = spec + FFT_LDS;
+    const float eps4 = 4.f * a.iv_eps;
 
-    for (int f = wave; f < FPB2; f += WAVES2) {
-        const int frame = blockIdx.x * FPB2 + f;
-        if (frame >= a.T) break;                                   // uniform across the wave
+    auto interior = [&](int frame) { const long s0 = (long)frame * a.hop - NFFT / 2; return s0 >= 0 && s0 + NFFT <= a.L; };
+    auto load_interior = [&](int frame, float2 (&x)[32]) {        // 64 loads at immediate offsets from two base pointers
         const long s0 = (long)frame * a.hop - NFFT / 2;
-        const bool interior = s0 >= 0 && s0 + NFFT <= a.L;
-        float2 x[32];
-        if (interior) {
-            // all 64 loads are issued before anything consumes them
-            const float* p0 = w0 + s0 + t;
-            const float* p1 = w1 + s0 + t;
+        const float* p0 = w0 + s0 + t;
+        const float* p1 = w1 + s0 + t;
 #pragma unroll
-            for (int m = 0; m < 32; ++m) x[m] = make_float2(p0[32 * m], p1[32 * m]);
-        } else {
-#pragma unroll
-            for (int m = 0; m < 32; ++m) {
-                long sx = s0 + t + 32 * m;
-                if (sx < 0) sx = -sx;
-                if (sx >= a.L) sx = 2 * (a.L - 1) - sx;
-                x[m] = make_float2(w0[sx], w1[sx]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
+        for (int m = 0; m < 32; ++m) x[m] = make_float2(p0[32 * m], p1[32 * m]);
+    };
+    // the 6 frames of a chunk that reach over its ends (reflect padding): a ROLLED loop stages the samples in the wave's (idle)
+    // transpose buffer - unrolled, the 64 reflected 64-bit addresses cost the whole kernel 80 registers
+    auto load_edge = [&](int frame, float2 (&x)[32]) {
+        const long s0 = (long)frame * a.hop - NFFT / 2;
+#pragma unroll 1
         for (int m = 0; m < 32; ++m) {
-            const float wn = win_s[t + 32 * m];
-            x[m] = make_float2(x[m].x * (wn * k0), x[m].y * (wn * k1m));
+            long sx = s0 + t + 32 * m;
+            if (sx < 0) sx = -sx;
+            if (sx >= a.L) sx = 2 * (a.L - 1) - sx;
+            ex[m * 32 + t] = make_float2(w0[sx], w1[sx]);
+        }
+#pragma unroll
+        for (int m = 0; m < 32; ++m) x[m] = ex[m * 32 + t];
+    };
+
+    const int frame0 = blockIdx.x * FPB2;
+    float2 xr[32];
+    if (frame0 + wave < a.T) { if (interior(frame0 + wave)) load_interior(frame0 + wave, xr); else load_edge(frame0 + wave, xr); }
+    for (int f = wave; f < FPB2; f += WAVES2) {
+        const int frame = frame0 + f;
+        if (frame >= a.T) break;                                   // uniform across the wave
+        float2 x[32];
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4) {
+            const f32x4 wn = *(const f32x4*)(wins + t * 36 + 4 * m4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[4 * m4 + i] = make_float2(xr[4 * m4 + i].x * wn[i], xr[4 * m4 + i].y * wn[i]);
+        }
+        if (a.n_ch < 4) {
+#pragma unroll
+            for (int m = 0; m < 32; ++m) x[m] = make_float2(x[m].x * k0f, x[m].y * k1f);
         }
         fft32(x);                                                  // slot fslot(k1) = sum_m x[t + 32 m] W_32^(m k1)
-        // twiddle W_1024^(t k1) = product over the set bits of k1 of W^(t 2^j), applied factor by factor so that no
-        // table of 32 powers is ever live
 #pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) {
-            float2 v = x[fslot(k1)];
-            if (k1 & 1) v = cmul(v, P1);
-            if (k1 & 2) v = cmul(v, P2);
-            if (k1 & 4) v = cmul(v, P4);
-            if (k1 & 8) v = cmul(v, P8);
-            if (k1 & 16) v = cmul(v, P16);
-            ex[k1 * EX_LD + t] = v;
-        }
+        for (int k1 = 1; k1 < 32; ++k1) ex[k1 * EX_LD + t] = cmul(x[fslot(k1)], tws[k1 * 32 + t]);
         ex[t] = x[0];
+        asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
         // transpose: lane k1' = t gathers row k1' (the 32 t-values of that k1)
 #pragma unroll
         for (int tt = 0; tt < 32; ++tt) x[tt] = ex[t * EX_LD + tt];
+        asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
         fft32(x);                                                  // slot fslot(k2) = X[t + 32 k2]
 #pragma unroll
         for (int k2 = 0; k2 < 32; ++k2) ex[t + 32 * k2] = x[fslot(k2)];   // natural-order spectrum over the transpose buffer
-
-        // ---- split the packed spectra, power + intensity per bin (wave-local: this wave owns both pairs) ----------
-        // IN PLACE: bin k's seven values overwrite exactly the four complex slots they were computed from
-        // (pair0[k] = (P0, P1), pair0[N-k] = (P2, P3), pair1[k] = (I1, I2), pair1[N-k] = (I3, -)); bins 0 and 512 mirror
-        // onto themselves and go to a 64-byte side area.
-#pragma unroll 3
-        for (int k = lane; k < NBIN; k += 64) {
-            const int kn = (NFFT - k) & (NFFT - 1);
-            const float2 z0 = sp0[k], zn0 = sp0[kn], z1 = sp1[k], zn1 = sp1[kn];
-            float re[4], im[4], v[7];
-            re[0] = 0.5f * (z0.x + zn0.x); im[0] = 0.5f * (z0.y - zn0.y);
-            re[1] = 0.5f * (z0.y + zn0.y); im[1] = 0.5f * (zn0.x - z0.x);
-            re[2] = 0.5f * (z1.x + zn1.x); im[2] = 0.5f * (z1.y - zn1.y);
-            re[3] = 0.5f * (z1.y + zn1.y); im[3] = 0.5f * (zn1.x - z1.x);
+        asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
+        // ---- split the packed spectra, power + intensity per bin: ALL reads, then the value planes over the same region ----
+        float2 z0[9], zn0[9], z1[9], zn1[9];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (c < a.n_ch) ? re[c] * re[c] + im[c] * im[c] : 0.f;
-            v[4] = v[5] = v[6] = 0.f;
-            if (a.with_iv) {
-                const float i1 = re[0] * re[1] + im[0] * im[1];
-                const float i2 = re[0] * re[2] + im[0] * im[2];
-                const float i3 = re[0] * re[3] + im[0] * im[3];
-                const float inv = 1.f / (sqrtf(i1 * i1 + i2 * i2 + i3 * i3) + a.iv_eps);
-                v[4] = i1 * inv; v[5] = i2 * inv; v[6] = i3 * inv;
-            }
-            const bool self = kn == k;                              // k = 0 or 512
-            float2* d0 = self ? spc + (k ? 4 : 0) : sp0 + k;
-            float2* d1 = self ? spc + (k ? 5 : 1) : sp0 + kn;
-            float2* d2 = self ? spc + (k ? 6 : 2) : sp1 + k;
-            float2* d3 = self ? spc + (k ? 7 : 3) : sp1 + kn;
-            *d0 = make_float2(v[0], v[1]);
-            *d1 = make_float2(v[2], v[3]);
-            *d2 = make_float2(v[4], v[5]);
-            *d3 = make_float2(v[6], 0.f);
+        for (int j = 0; j < 9; ++j) {
+            const int k = min(lane + 64 * j, NBIN - 1), kn = (NFFT - k) & (NFFT - 1);
+            z0[j] = sp0[k]; zn0[j] = sp0[kn]; z1[j] = sp1[k]; zn1[j] = sp1[kn];
         }
-        // ---- mel projection: 4 lanes per mel filter interleave its compact support (16 filters per pass), all 7
-        // channels per weight read (4 ds_read_b64), then two quad shuffles combine the quarters ------------------------
-        for (int mb = 0; mb < a.n_mels; mb += 16) {
-            const int m = mb + (lane >> 2), q = lane & 3;
-            const bool live = m < a.n_mels;
-            float acc[7];
+        asm volatile("" ::: "memory");       // no read of the spectrum may be re-issued behind the plane stores below
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 7; ++c) acc[c] = 0.f;
-            const int lo = live ? mlo[m] : 0, cnt = live ? mcnt[m] : 0;
-            const float* wr = melw + (live ? moff[m] : 0);
-            for (int i0 = q; i0 < cnt; i0 += 4) {
-                const float w = wr[i0];
-                const int kb = lo + i0, kn = (NFFT - kb) & (NFFT - 1);
-                const bool self = kn == kb;
-                const float2 A = *(self ? spc + (kb ? 4 : 0) : sp0 + kb);
-                const float2 Bv = *(self ? spc + (kb ? 5 : 1) : sp0 + kn);
-                const float2 Cv = *(self ? spc + (kb ? 6 : 2) : sp1 + kb);
-                const float2 Dv = *(self ? spc + (kb ? 7 : 3) : sp1 + kn);
-                acc[0] = fmaf(A.x, w, acc[0]); acc[1] = fmaf(A.y, w, acc[1]);
-                acc[2] = fmaf(Bv.x, w, acc[2]); acc[3] = fmaf(Bv.y, w, acc[3]);
-                acc[4] = fmaf(Cv.x, w, acc[4]); acc[5] = fmaf(Cv.y, w, acc[5]);
-                acc[6] = fmaf(Dv.x, w, acc[6]);
+        for (int j = 0; j < 9; ++j) {
+            const int k = lane + 64 * j;
+            // ch0 = a / 2, ch1 = b / (2i), ch2 = c / 2, ch3 = d / (2i)  with  a = z + conj(zn), b = z - conj(zn)
+            const float ax = z0[j].x + zn0[j].x, ay = z0[j].y - zn0[j].y, bx = z0[j].x - zn0[j].x, by = z0[j].y + zn0[j].y;
+            const float cx = z1[j].x + zn1[j].x, cy = z1[j].y - zn1[j].y, dx = z1[j].x - zn1[j].x, dy = z1[j].y + zn1[j].y;
+            f32x4 pw = {fmaf(ax, ax, ay * ay), fmaf(bx, bx, by * by), fmaf(cx, cx, cy * cy), fmaf(dx, dx, dy * dy)};   // 4 x power
+            f32x4 iv = {0.f, 0.f, 0.f, 0.f};
+            if (a.with_iv) {
+                const float i1 = fmaf(ax, by, -ay * bx), i2 = fmaf(ax, cx, ay * cy), i3 = fmaf(ax, dy, -ay * dx);            // 4 x intensity
+                const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(i1, i1, fmaf(i2, i2, i3 * i3))) + eps4);
+                iv[0] = i1 * inv; iv[1] = i2 * inv; iv[2] = i3 * inv;
             }
-#pragma unroll
-            for (int c = 0; c < 7; ++c) {
-                acc[c] += __shfl_xor(acc[c], 1, 64);
-                acc[c] += __shfl_xor(acc[c], 2, 64);
+            if (k < NBIN) {
+                *(f32x4*)(region + k * 16) = pw;
+                *(f32x4*)(region + VI_OFF + k * 16) = iv;
             }
-            if (live) {
-                // lane q writes output channels q and q + 4 (value rows: power 0..n_ch-1, IV 4..6)
+        }
+        asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
+        // the next frame's samples travel while this frame is projected onto the mel bands
+        const bool more = f + WAVES2 < FPB2 && frame + WAVES2 < a.T;
+        const bool more_in = more && interior(frame + WAVES2);
+        if (more_in) load_interior(frame + WAVES2, xr);
+        if (fast_mel) {
 #pragma unroll
-                for (int rep = 0; rep < 2; ++rep) {
-                    const int oc = q + 4 * rep;
-                    if (oc < a.n_out) {
-                        const int vc = (oc < a.n_ch) ? oc : (4 + oc - a.n_ch);
+            for (int p = 0; p < 2; ++p) {
+                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const char* vp = region + mk0[p] * 16;
+                f32x4 w4[MEL_CAP / 4];
+#pragma unroll
+                for (int i = 0; i < MEL_CAP / 4; ++i) w4[i] = *(const f32x4*)(mws + (p * 64 + lane) * MEL_CAP + 4 * i);
+#pragma unroll
+                for (int i = 0; i < MEL_CAP; ++i) {
+                    const f32x4 P = *(const f32x4*)(vp + i * 16);
+                    const f32x4 I = *(const f32x4*)(vp + VI_OFF + i * 16);
+                    const float w = w4[i >> 2][i & 3];
+                    acc[0] = fmaf(P[0], w, acc[0]); acc[1] = fmaf(P[1], w, acc[1]); acc[2] = fmaf(P[2], w, acc[2]); acc[3] = fmaf(P[3], w, acc[3]);
+                    acc[4] = fmaf(I[0], w, acc[4]); acc[5] = fmaf(I[1], w, acc[5]); acc[6] = fmaf(I[2], w, acc[6]);
+                }
+                // the runs of one filter sit on consecutive lanes: run r collects the runs behind it (up to 7)
+#pragma unroll
+                for (int o = 1; o <= 4; o <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) {
+                        const float v = __shfl_down(acc[c], o, 64);
+                        acc[c] += (mfollow[p] >= o) ? v : 0.f;
+                    }
+                }
+                if (mfirst[p]) {
+                    const int m = mband[p];
+#pragma unroll
+                    for (int oc = 0; oc < 7; ++oc) {
+                        if (oc < a.n_out) {
+                            float v;
+                            if (oc < a.n_ch) {
+                                float pv = 0.f;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) pv = (c == oc) ? acc[c] : pv;
+                                v = 3.01029995663981f * __builtin_amdgcn_logf(fmaxf(0.25f * pv, a.amin));      // 10 log10(x) = 10 log10(2) log2(x)
+                            } else {
+                                v = 0.f;
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) v = (c == oc - a.n_ch) ? acc[4 + c] : v;
+                            }
+                            a.feat[(((long)b * a.n_out + oc) * a.T + frame) * a.n_mels + m] = v;
+                        }
+                    }
+                }
+            }
+        } else {
+            // any other filter bank: 4 lanes per filter interleave its support (16 filters per pass)
+            for (int mb = 0; mb < a.n_mels; mb += 16) {
+                const int m = mb + (lane >> 2), q = lane & 3;
+                const bool live = m < a.n_mels;
+                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const int lo = live ? a.mel_lo[m] : 0, cnt = live ? a.mel_cnt[m] : 0;
+                const float* wr = a.mel_w + (live ? a.mel_off[m] : 0);
+                for (int i0 = q; i0 < cnt; i0 += 4) {
+                    const float w = wr[i0];
+                    const f32x4 P = *(const f32x4*)(region + (lo + i0) * 16);
+                    const f32x4 I = *(const f32x4*)(region + VI_OFF + (lo + i0) * 16);
+                    acc[0] = fmaf(P[0], w, acc[0]); acc[1] = fmaf(P[1], w, acc[1]); acc[2] = fmaf(P[2], w, acc[2]); acc[3] = fmaf(P[3], w, acc[3]);
+                    acc[4] = fmaf(I[0], w, acc[4]); acc[5] = fmaf(I[1], w, acc[5]); acc[6] = fmaf(I[2], w, acc[6]);
+                }
+#pragma unroll
+                for (int c = 0; c < 7; ++c) {
+                    acc[c] += __shfl_xor(acc[c], 1, 64);
+                    acc[c] += __shfl_xor(acc[c], 2, 64);
+                }
+                if (live && q == 0) {
+                    for (int oc = 0; oc < a.n_out; ++oc) {
                         float v = 0.f;
+                        const int vc = (oc < a.n_ch) ? oc : (4 + oc - a.n_ch);
 #pragma unroll
                         for (int c = 0; c < 7; ++c) v = (c == vc) ? acc[c] : v;
-                        if (oc < a.n_ch) v = 10.0f * log10f(fmaxf(v, a.amin));
+                        if (oc < a.n_ch) v = 3.01029995663981f * __builtin_amdgcn_logf(fmaxf(0.25f * v, a.amin));
                         a.feat[(((long)b * a.n_out + oc) * a.T + frame) * a.n_mels + m] = v;
                     }
                 }
             }
         }
+        asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
+        if (more && !more_in) load_edge(frame + WAVES2, xr);     // (the region is idle again)
+        asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
     }
 }
 
@@ -294,7 +392,8 @@ extern "C" int pseld_logmel_iv_fwd(const float* wave, float* feat, int B, int n_
     a.mel_lo = mel_lo; a.mel_cnt = mel_cnt; a.mel_off = mel_off; a.mel_w = mel_w;
     a.L = L; a.T = (int)(1 + L / hop); a.hop = hop; a.n_ch = n_ch; a.n_out = n_ch + (with_iv ? 3 : 0);
     a.n_mels = n_mels; a.nnz = nnz; a.with_iv = with_iv; a.amin = amin; a.iv_eps = iv_eps;
-    const size_t lds = MAX_NNZ * sizeof(float) + 3 * MAX_MELS * sizeof(int) + NFFT * sizeof(float) + (size_t)WAVES2 * V2_WAVE_BYTES;
+    const size_t lds = 32 * 32 * sizeof(float2) + 256 * sizeof(int) + 4 * sizeof(int) + 128 * MEL_CAP * sizeof(float) + 32 * 36 * sizeof(float) +
+                       (size_t)WAVES2 * V2_WAVE_BYTES;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)logmel_iv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     dim3 grid(pseld_cdiv(a.T, FPB2), B, 1);
