@@ -1597,6 +1597,33 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     PSELD_CHECK_ARG(lddw == K, "gemm_wgrad: dW must be dense [N,K]");
     const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr);
     PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
+    // MFMA-bound weight gradients: the eight-phase kernel of gemm8w.hip (PSELD_WGRAD8=0 disables it; read per call: in-process A/B)
+    if (dtype == PSELD_BF16 && !gelu_on_x && N >= 256 && K >= 192 && Mtok >= 4096) {
+        const char* e8 = getenv("PSELD_WGRAD8");
+        if (!(e8 && e8[0] == '0')) {
+            int bn8 = 0, kchunk8 = 0;
+            const long per_split = ((long)N * K + N) * (long)sizeof(float);
+            const int max_splits = (int)(workspace_bytes / per_split);
+            const int s8 = pseld_gemm8w_plan(Mtok, N, K, lddy, ldx, rows_per_scale > 0 ? rows_per_scale : 1, rowscale != nullptr, max_splits, &bn8, &kchunk8);
+            if (s8 > 0) {
+                const bool fused = dbias && dbias == dW + (long)N * K;
+                const long stride = fused ? (long)N * K + N : (long)N * K;
+                float* cs = fused ? workspace + (long)N * K : (dbias ? workspace + (long)s8 * N * K : nullptr);
+                g_last_gemm_kernel = "gemm8w_kernel";
+                const int rc8 = pseld_gemm8w_launch(dY, X, workspace, cs, stride, fused ? stride : (long)N, Mtok, N, K, lddy, ldx, bn8, kchunk8, s8,
+                                                    rowscale, rows_per_scale > 0 ? rows_per_scale : 1, (hipStream_t)stream);
+                if (rc8 != PSELD_OK) return rc8;
+                const long n8 = (long)N * K;
+                if (fused) pseld_reduce_slabs(workspace, dW, n8 + N, s8, stride, accumulate, (hipStream_t)stream);
+                else {
+                    pseld_reduce_slabs(workspace, dW, n8, s8, stride, accumulate, (hipStream_t)stream);
+                    if (dbias) pseld_reduce_slabs(cs, dbias, (long)N, s8, (long)N, accumulate, (hipStream_t)stream);
+                }
+                PSELD_LAUNCH_CHECK("splitk_reduce");
+                return PSELD_OK;
+            }
+        }
+    }
     int splits = wgrad_splits_for(dtype, Mtok, N, K);
     int ring_splits = 0;
     const int ring_mt = wgrad_ring_plan(dtype, Mtok, N, K, gelu_on_x, rows_per_scale > 0 ? rows_per_scale : 1, rowscale != nullptr, &ring_splits);

@@ -20,3 +20,8 @@ struct Gemm8Desc {
 // 1 when the eight-phase kernel takes the product (shape / alignment / size limits), else 0
 int pseld_gemm8_supported(const Gemm8Desc& d);
 int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream);
+
+// weight gradient on the same loop (gemm8w.hip): plan returns the split count (0 = shape not taken), tile width and tokens per split
+int pseld_gemm8w_plan(int Mtok, int N, int K, int lddy, int ldx, int rows_per_scale, int has_rowscale, int max_splits, int* bn_out, int* kchunk_out);
+int pseld_gemm8w_launch(const void* dY, const void* X, float* slabs, float* colsum, long slab_stride, long colsum_stride, int Mtok, int N,
+                        int K, int lddy, int ldx, int bn, int kchunk, int splits, const float* rowscale, int rows_per_scale, hipStream_t stream);

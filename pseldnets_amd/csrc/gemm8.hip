@@ -88,7 +88,11 @@ template <int MODE, bool SCALED, int NB, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     constexpr int WN = NB * 16, BN = 4 * WN;
     constexpr int NB1 = NB - 2;                  // blocks in the second column quadrant
-    constexpr int VM_STEADY = 4 + NB1;           // LDS-DMA instructions of the three youngest half-tiles (B-h0, A-h0, B-h1) per wave
+    // Just-in-time waits: a half-tile is waited for in the phase BEFORE the one that reads it, so the five youngest half-tiles stay in
+    // flight at every wait (B-h1 is NB1 instructions per wave, the others two): every load has five phases to land (three with the
+    // single wait per K-tile of the guide's template - too few for operands that come from HBM rather than L2)
+    constexpr int VM_P4 = 6 + 2 * NB1, VM_P1 = 8 + NB1, VM_P2 = 8 + NB1;
+    constexpr int NST = MODE == G8_GELU_DUAL ? 32 : 16;      // stores of one epilogue per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = (float*)(smem + RING_B);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     dmaB(0); dmaA(0); dmaB(1); dmaA(1); advance();
     dmaB(0); dmaA(0); dmaB(1);
     init_acc(n0c);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P4) : "memory");
     G8_BAR();
     if (wr == 1) G8_BAR();                       // the stagger: waves 4-7 run one barrier behind waves 0-3
 
@@ -332,12 +336,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         G8_LD_A(0);
         dmaA(1); advance();
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the B-h0 reads have left LDS: B-h0 may be refilled next phase
+        // B-h1 of this K-tile has landed (read next phase); behind an epilogue its stores sit in the queue too and may stay there
+        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1 + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1) : "memory");
         G8_BAR();
         G8_MMA(0, 0, fb0);
         G8_BAR();
         // phase 2: B-h1 fragments | B-h0 of K-tile + 2 | quadrant (m 0-63, n 32-63)
         G8_LD_B1();
         dmaB(0);
+        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2 + NST) : "memory");   // A-h1 of this K-tile has landed
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2) : "memory");
         G8_BAR();
         G8_MMA(0, 1, fb1);
         G8_BAR();
@@ -347,9 +356,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         G8_BAR();
         G8_MMA(1, 1, fb1);
         G8_BAR();
-        // phase 4: B-h1 of K-tile + 2 | everything but the three youngest half-tiles has landed | quadrant (m 64-127, n 0-31)
+        // phase 4: B-h1 of K-tile + 2 | B-h0 and A-h0 of the next K-tile have landed | quadrant (m 64-127, n 0-31)
         dmaB(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P4) : "memory");
         G8_BAR();
         G8_MMA(1, 0, fb0);
         G8_BAR();
