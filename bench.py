@@ -60,6 +60,9 @@ def synthetic_batch(clips, device, seed, chunks=None):
     return wave, {'adpit_label': label}
 
 
+from pseldnets_amd import ops as ops_mod   # (its stage tag names the part of the step a launch belongs to)
+
+
 class KernelTimer:
     """HIP-event timing of every C-ABI launch on the stream it is enqueued on (torch's current stream)."""
 
@@ -69,7 +72,7 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
-            if n.endswith('_workspace') or n.endswith('_supported') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_mlp_set_debug_buffer', 'pseld_mlp_supported', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections'):
+            if n.endswith('_workspace') or n.endswith('_supported') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_mlp_set_debug_buffer', 'pseld_mlp_supported', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections', 'pseld_stage_marker', 'pseld_gemm8_set_debug_buffer'):
                 continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn
@@ -82,13 +85,13 @@ class KernelTimer:
                 rc = _fn(*a)
                 e.record()
                 sym = self.lib.pseld_gemm_last_kernel().decode() if _n in ('pseld_gemm', 'pseld_gemm_wgrad') else None
-                self.records.append((_n, a, s, e, sym))
+                self.records.append((_n, a, s, e, sym, ops_mod._stage['name']))
                 return rc
             setattr(self.lib, n, wrapped)
 
     def detail(self):
         rows = {}
-        for n, a, s, e, _sym in self.records:
+        for n, a, s, e, _sym, _st in self.records:
             if n == 'pseld_gemm':
                 key = ('gemm', a[1], a[2], a[6], a[7], a[8], a[19], a[20])      # ta, tb, M, N, K, epi, pro
             elif n == 'pseld_gemm_wgrad':
@@ -108,7 +111,7 @@ class KernelTimer:
         (the weight-gradient entry point launches a GEMM and a slab reduction: its time is not a single kernel's)."""
         torch.cuda.synchronize()
         out = {}
-        for n, a, s, e, sym in self.records:
+        for n, a, s, e, sym, _st in self.records:
             if n != 'pseld_gemm' or not sym:
                 continue
             M, N, K, epi = a[6], a[7], a[8], a[19]
@@ -119,10 +122,19 @@ class KernelTimer:
             d[4] += ESIZE * (M * K + N * K + M * N + extra)            # + the fused epilogue operands the launch must also move
         return out
 
+    def by_stage(self):
+        """{part of the step: [ms, launches]} (ops.stage names: features, front, stage0..3, head+loss, optimizer)."""
+        torch.cuda.synchronize()
+        out = {}
+        for n, a, s, e, _sym, st in self.records:
+            d = out.setdefault(st, [0.0, 0])
+            d[0] += s.elapsed_time(e); d[1] += 1
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for n, a, s, e, _sym in self.records:
+        for n, a, s, e, _sym, _st in self.records:
             key = n
             flops = 0.0
             nbytes = 0.0
@@ -149,7 +161,7 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel family from the PMC counters. Counters cannot be read from inside
     this process: the figure is the one measured with rocprofv3 on this same command (two separate --pmc passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/."""
-    path = os.path.join(ROOT, 'profiles', 'r03_dominant_kernel_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r04_dominant_kernel_pmc.json')
     if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -513,7 +525,7 @@ def main():
                                "traffic": round(pmc['traffic_bytes_per_launch'], 1) if same else None,
                                "mfma_busy": pmc.get('mfma_busy') if same else None,
                                "rocprof_avg_launch_ms": pmc.get('rocprof_avg_launch_ms') if same else None,
-                               "pmc_source": ("profiles/r03_dominant_kernel_pmc.json (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
+                               "pmc_source": ("profiles/r04_dominant_kernel_pmc.json (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
                                               "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes over this command)") if same else None}
         if gem:
             tms, n, fl, nb, roof_ms, mfma_bound_ms = gem[0]
@@ -522,6 +534,16 @@ def main():
                                       "achieved_tflops": round(fl / (tms * 1e-3) / 1e12, 2), "achieved_gbs": round(nb / (tms * 1e-3) / 1e9, 1),
                                       "frac_shape_aware": round(roof_ms / tms, 4),
                                       "time_share_mfma_bound_shapes": round(mfma_bound_ms / tms, 4)}
+        # where the step's time is, part by part (HIP events of the instrumented one-stream steps; HBM GB per part: profiles/r04_stage_table.json,
+        # rocprofv3 --pmc passes of this command cut at stage markers by tools/pmc_stages.py)
+        st = timer.by_stage()
+        st_pmc = {}
+        sp = os.path.join(ROOT, 'profiles', 'r04_stage_table.json')
+        if args.backbone == 'htsat' and args.dtype == 'bf16' and args.clips == 32 and not args.chunks and os.path.exists(sp):
+            with open(sp) as f:
+                st_pmc = json.load(f).get('stages', {})
+        out["stage_table"] = {k: {"ms_per_step": round(v[0] / 2, 3), "launches": v[1] // 2,
+                                  "hbm_gb_per_step": st_pmc.get(k, {}).get("hbm_gb_per_step")} for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])}
         out["kernel_time_share"] = {k: {"ms_per_step": round(v[0] / 2, 3), "launches": v[1] // 2,
                                         "share": round(v[0] / total, 4)} for k, v in top[:(40 if args.gemm_detail else 10)]}
         for k, v in agg.items():

@@ -21,6 +21,10 @@ const char* pseld_last_error(void);
 int pseld_abi_version(void);
 int pseld_device_info(char* name, int n); /* returns CU count */
 
+/* Profiling aid: launches an empty kernel named stage_marker_kernel<tag> (0 <= tag < 16) on the stream, so that an in-order kernel trace can
+ * be cut into the stages of the training step (bench.py with PSELD_STAGE_MARKERS=1, tools/pmc_stages.py). */
+int pseld_stage_marker(int tag, void* stream);
+
 /* ---- K1 feature front-end ---------------------------------------------------------------------------------
  * utils/feature.py:39-56 LogmelIV_Extractor.forward, :78-91 Logmel_Extractor.forward, :93-117 intensityvector
  * (+ torchaudio 2.2.1 Spectrogram / MelScale / AmplitudeToDB semantics).
@@ -64,6 +68,18 @@ long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out);
 int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, int Mtok, int N, int K,
                      int lddy, int ldx, int lddw, int gelu_on_x, int accumulate, float* workspace,
                      long workspace_bytes, const float* rowscale, int rows_per_scale, void* stream);
+
+/* The weight gradients of several Linear layers in ONE launch (bf16): entry i is dW_i f32[N_i, K_i] = (s_i dY_i)^T X_i over Mtok_i tokens
+ * (+ dbias_i f32[N_i] = column sums of s_i dY_i when dbias[i] != NULL), s_i = rowscale[i] (DropPath factor per sample of
+ * rows_per_scale[i] tokens) or 1 - the layers of one stage of the encoder: htsat.py:118,140 (qkv, proj), model_utilities.py:166-170
+ * (fc1, fc2), htsat.py:309 (PatchMerging.reduction). Overwrites the gradients. One weight matrix alone has 4-16 output tiles and must be
+ * split ~20 ways over the tokens (one fp32 slab per workgroup, reduced afterwards); the ~25 matrices of a stage together fill the chip
+ * with ONE tile per CU: no token split, no slab, no reduction. Entries the persistent kernel does not take (small or ragged shapes) are
+ * left untouched and reported as set bits of *skipped_mask: the caller runs pseld_gemm_wgrad for those. count <= 32. */
+long pseld_gemm_wgrad_group_workspace(int count, const int* Mtok, const int* N, const int* K);
+int pseld_gemm_wgrad_group(int count, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, const int* Mtok,
+                           const int* N, const int* K, const int* lddy, const int* ldx, const float* const* rowscale,
+                           const int* rows_per_scale, float* workspace, long workspace_bytes, unsigned* skipped_mask, void* stream);
 
 /* ---- fused Swin MLP block (the HBM-bound stages: C = 96 / 192, hidden = 4C) ---------------------------------------
  * htsat.py:262-264  x = x + drop_path(mlp(norm2(x)));  model_utilities.py:159-171 Mlp (fc1 -> exact-erf GELU -> fc2),

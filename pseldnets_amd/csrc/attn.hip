@@ -1036,7 +1036,12 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     dim3 grid(slots, nhg);
     static int v2 = -1;
     if (v2 < 0) { const char* e = getenv("PSELD_ATTN_BWD_V2"); v2 = !(e && atoi(e) == 0); }
-    { const char* e = getenv("PSELD_ATTN_VARIANT"); a.variant = e ? atoi(e) : 0; }
+    {   // timing-experiment knob, read once; a result-changing value is refused unless PSELD_ALLOW_WRONG_RESULTS=1 says it is a timing run
+        static const int variant = [] { const char* e = getenv("PSELD_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+        static const bool allowed = [] { const char* e = getenv("PSELD_ALLOW_WRONG_RESULTS"); return e && e[0] == '1'; }();
+        PSELD_CHECK_ARG(variant == 0 || allowed, "window_attn_bwd: PSELD_ATTN_VARIANT=%d changes the results (timing experiments only; set PSELD_ALLOW_WRONG_RESULTS=1)", variant);
+        a.variant = variant;
+    }
     if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && v2) {
         // one wave per head, four heads per workgroup, two workgroups per CU, persistent
         int sl = (es ? atoi(es) : 512) / (heads / 4);

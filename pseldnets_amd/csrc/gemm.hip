@@ -1438,8 +1438,9 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
             d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.ldr = ldr; d.ldaux = ldaux;
             d.rows_per_scale = g.rows_per_scale; d.gelu_dual = (epi & EPI_GELU_DUAL) ? 1 : 0;
             if (pseld_gemm8_supported(d)) {
-                g_last_gemm_kernel = "gemm8_kernel";
-                return pseld_gemm8_launch(d, s);
+                const int rc8 = pseld_gemm8_launch(d, s);
+                g_last_gemm_kernel = pseld_gemm8_last_symbol();
+                return rc8;
             }
         }
     }

@@ -20,6 +20,7 @@ struct Gemm8Desc {
 // 1 when the eight-phase kernel takes the product (shape / alignment / size limits), else 0
 int pseld_gemm8_supported(const Gemm8Desc& d);
 int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream);
+const char* pseld_gemm8_last_symbol();      // instantiation of the last launch, as rocprofv3 prints it
 
 // weight gradient on the same loop (gemm8w.hip): plan returns the split count (0 = shape not taken), tile width and tokens per split
 int pseld_gemm8w_plan(int Mtok, int N, int K, int lddy, int ldx, int rows_per_scale, int has_rowscale, int max_splits, int* bn_out, int* kchunk_out);

@@ -30,10 +30,10 @@ constexpr int HALF_B = 16384;             // one half-tile image: 64 token rows 
 constexpr int BUF_B = 4 * HALF_B;         // one K-tile: dY-h0 | dY-h1 | X-h0 | X-h1
 constexpr int LDS_B = 2 * BUF_B;
 
-struct G8WArgs {
+struct G8WArgs {          // one weight matrix of the launch
     const char* A;          // dY [Mtok, lda]
     const char* B;          // X  [Mtok, ldb]
-    float* C;               // slabs: split z at C + z * slab_stride, [N_out, K_in] dense
+    float* C;               // slabs: split z at C + z * slab_stride, [N_out, K_in] dense (splits == 1: the gradient itself)
     float* colsum;          // per-split column sums of dY (bias gradient) or null; split z at colsum + z * colsum_stride
     const float* rowscale;  // DropPath factor per sample or null
     long slab_stride, colsum_stride;
@@ -42,6 +42,13 @@ struct G8WArgs {
     int kchunk;             // tokens per split (multiple of 64)
     int nx, ntile, splits;
     int rows_per_scale, nscale;
+    int pad_;
+};
+constexpr int G8W_MAXP = 32;
+struct G8WGroup {         // the weight matrices of one launch (a stage's layers): workgroup L of the launch belongs to the matrix p with
+    int count;            // first[p] <= L < first[p + 1] and is its (split, tile) pair L - first[p] in split-major order
+    int first[G8W_MAXP + 1];
+    G8WArgs p[G8W_MAXP];
 };
 
 __device__ __forceinline__ void g8w_dma(unsigned lds_dst, const void* sbase, unsigned voff) {
@@ -59,7 +66,7 @@ __device__ __forceinline__ void g8w_dma(unsigned lds_dst, const void* sbase, uns
 
 // NB = 16-column accumulator blocks per wave on the X side: 4 -> 256 x 256 tile, 3 -> 256 x 192 (X-h1 is then a [64][64] image)
 template <int NB>
-__global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WArgs g) {
+__global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WGroup grp) {
     constexpr int WN = NB * 16, BN = 4 * WN;
     constexpr int NB1 = NB - 2;
     // Just-in-time waits: a half-tile is waited for in the phase BEFORE the one that reads it, so the five youngest half-tiles stay in
@@ -72,12 +79,16 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WArgs g) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, kg = lane >> 4, q4 = l15 >> 2, p4 = l15 & 3;
 
-    // workgroup -> (tile, split): the pairs in split-major order are dealt to the XCDs in runs of 32 (one per CU), so the tiles of a
-    // split (which read the same token rows) share an L2 and no XCD gets more workgroups than it has CUs
+    // workgroup -> (matrix, split, tile): the pairs, matrix by matrix in split-major order, are dealt to the XCDs in runs of 32 (one per
+    // CU), so the tiles of a split (which read the same token rows) share an L2 and no XCD gets more workgroups than it has CUs
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int L = xcd * 32 + slot;
-    if (slot >= 32 || L >= g.ntile * g.splits) return;
-    const int z = L / g.ntile, t = L - z * g.ntile;
+    if (slot >= 32 || L >= grp.first[grp.count]) return;
+    int pi = 0;
+    while (pi + 1 < grp.count && L >= grp.first[pi + 1]) ++pi;
+    const G8WArgs& g = grp.p[pi];
+    const int Lp = L - grp.first[pi];
+    const int z = Lp / g.ntile, t = Lp - z * g.ntile;
     const int mblk = t / g.nx, nblk = t - mblk * g.nx;
     const int m0 = mblk * 256, n0 = nblk * BN;
     const int tok0 = z * g.kchunk;
@@ -317,11 +328,16 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WArgs g) {
 
 }  // namespace
 
+static bool g8w_eligible(int Mtok, int N, int K, int lddy, int ldx, int rows_per_scale, int has_rowscale) {
+    if (Mtok % 64 != 0 || Mtok < 512 || N % 8 != 0 || K % 8 != 0 || lddy % 8 != 0 || ldx % 8 != 0 || N < 128 || K < 128) return false;
+    if (has_rowscale && (rows_per_scale <= 0 || rows_per_scale % 64 != 0)) return false;
+    if ((long)64 * lddy * 2 + (long)N * 2 >= (1L << 31) || (long)64 * ldx * 2 + (long)K * 2 >= (1L << 31)) return false;
+    return true;
+}
+
 // Plan: tile width and split count for dW[N, K] over Mtok tokens; 0 when the eight-phase kernel does not take the shape.
 int pseld_gemm8w_plan(int Mtok, int N, int K, int lddy, int ldx, int rows_per_scale, int has_rowscale, int max_splits, int* bn_out, int* kchunk_out) {
-    if (Mtok % 64 != 0 || N % 8 != 0 || K % 8 != 0 || lddy % 8 != 0 || ldx % 8 != 0 || N < 128 || K < 128) return 0;
-    if (has_rowscale && (rows_per_scale <= 0 || rows_per_scale % 64 != 0)) return 0;
-    if ((long)64 * lddy * 2 + (long)N * 2 >= (1L << 31) || (long)64 * ldx * 2 + (long)K * 2 >= (1L << 31)) return 0;
+    if (!g8w_eligible(Mtok, N, K, lddy, ldx, rows_per_scale, has_rowscale)) return 0;
     const char* eb = getenv("PSELD_GEMM8W_BN");
     int bn = eb ? atoi(eb) : 0;
     if (bn != 256 && bn != 192) {
@@ -341,25 +357,134 @@ int pseld_gemm8w_plan(int Mtok, int N, int K, int lddy, int ldx, int rows_per_sc
     return splits;
 }
 
-int pseld_gemm8w_launch(const void* dY, const void* X, float* slabs, float* colsum, long slab_stride, long colsum_stride, int Mtok, int N,
-                        int K, int lddy, int ldx, int bn, int kchunk, int splits, const float* rowscale, int rows_per_scale, hipStream_t stream) {
-    G8WArgs a;
+static void g8w_fill(G8WArgs& a, const void* dY, const void* X, float* slabs, float* colsum, long slab_stride, long colsum_stride, int Mtok,
+                     int N, int K, int lddy, int ldx, int bn, int kchunk, int splits, const float* rowscale, int rows_per_scale) {
     a.A = (const char*)dY; a.B = (const char*)X; a.C = slabs; a.colsum = colsum; a.rowscale = rowscale;
     a.slab_stride = slab_stride; a.colsum_stride = colsum_stride;
     a.M = N; a.N = K; a.Mtok = Mtok; a.lda = lddy; a.ldb = ldx; a.kchunk = kchunk;
     a.nx = pseld_cdiv(K, bn); a.ntile = a.nx * pseld_cdiv(N, 256); a.splits = splits;
     a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     a.nscale = rowscale ? pseld_cdiv(Mtok, a.rows_per_scale) : 0;
-    const int nwg = 256;      // (tile, split) pairs <= 256: see the kernel's id map
+    a.pad_ = 0;
+}
+static int g8w_launch_group(const G8WGroup& grp, int bn, hipStream_t stream) {
     if (bn == 192) {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-        hipLaunchKernelGGL(gemm8w_kernel<3>, dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+        hipLaunchKernelGGL(gemm8w_kernel<3>, dim3(256), dim3(512), LDS_B, stream, grp);
     } else {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-        hipLaunchKernelGGL(gemm8w_kernel<4>, dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+        hipLaunchKernelGGL(gemm8w_kernel<4>, dim3(256), dim3(512), LDS_B, stream, grp);
     }
     PSELD_LAUNCH_CHECK("gemm8w");
+    return PSELD_OK;
+}
+
+int pseld_gemm8w_launch(const void* dY, const void* X, float* slabs, float* colsum, long slab_stride, long colsum_stride, int Mtok, int N,
+                        int K, int lddy, int ldx, int bn, int kchunk, int splits, const float* rowscale, int rows_per_scale, hipStream_t stream) {
+    static G8WGroup grp;      // (single-threaded host side, as the rest of the library)
+    grp.count = 1;
+    g8w_fill(grp.p[0], dY, X, slabs, colsum, slab_stride, colsum_stride, Mtok, N, K, lddy, ldx, bn, kchunk, splits, rowscale, rows_per_scale);
+    grp.first[0] = 0; grp.first[1] = grp.p[0].ntile * splits;
+    return g8w_launch_group(grp, bn, stream);
+}
+
+void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate, hipStream_t stream);
+
+// ---- the weight gradients of several Linear layers (a stage's qkv / proj / fc1 / fc2 of every block, its PatchMerging reduction) in ONE
+// launch. A single weight matrix has 4-16 output tiles of 256 x 192, so on its own it is split ~20 ways over the tokens to fill the chip
+// and pays one fp32 slab per workgroup (49 MB written and read back per launch: as much as its operands); together the ~25 matrices of
+// stage 2 have 252 tiles - one per CU, no token split, no slab, no reduction: every workgroup walks ALL the tokens for its tile and
+// writes the gradient itself. Matrices the eight-phase kernel does not take are reported back (return value = bit mask of skipped ones).
+extern "C" long pseld_gemm_wgrad_group_workspace(int count, const int* Mtok, const int* N, const int* K) {
+    long need = 0;
+    for (int i = 0; i < count; ++i) {
+        const int tiles = pseld_cdiv(N[i], 256) * pseld_cdiv(K[i], 256);     // (fewest tiles -> most splits)
+        int s = 256 / (tiles > 0 ? tiles : 1);
+        if (s > Mtok[i] / 512) s = Mtok[i] / 512;
+        if (s < 1) s = 1;
+        need += (long)(s + 1) * ((long)N[i] * K[i] + N[i]) * (long)sizeof(float);
+    }
+    return need;
+}
+extern "C" int pseld_gemm_wgrad_group(int count, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
+                                      const int* Mtok, const int* N, const int* K, const int* lddy, const int* ldx,
+                                      const float* const* rowscale, const int* rows_per_scale, float* workspace, long workspace_bytes,
+                                      unsigned* skipped_mask, void* stream) {
+    PSELD_CHECK_ARG(count > 0 && count <= 32 && dY && X && dW && Mtok && N && K && lddy && ldx && skipped_mask, "gemm_wgrad_group: bad arguments (count %d)", count);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned skipped = 0;
+    int idx[G8W_MAXP], n = 0;
+    for (int i = 0; i < count; ++i) {
+        PSELD_CHECK_ARG(dY[i] && X[i] && dW[i], "gemm_wgrad_group: null operand in entry %d", i);
+        const bool ok = g8w_eligible(Mtok[i], N[i], K[i], lddy[i], ldx[i], rows_per_scale ? rows_per_scale[i] : 1, rowscale && rowscale[i]) &&
+                        N[i] >= 192 && K[i] >= 192 && Mtok[i] >= 4096;
+        if (ok) idx[n++] = i; else skipped |= 1u << i;
+    }
+    *skipped_mask = skipped;
+    static G8WGroup grp;
+    int at = 0;
+    while (at < n) {
+        // the longest run of matrices whose tiles fit one resident round at one of the two tile widths; at equal reach the width with
+        // less padded work
+        int reach[2] = {at, at};
+        double work[2] = {0, 0};
+        for (int w = 0; w < 2; ++w) {
+            const int bn = w ? 256 : 192;
+            int tiles = 0, e = at;
+            while (e < n) {
+                const int i = idx[e];
+                const int t = pseld_cdiv(N[i], 256) * pseld_cdiv(K[i], bn);
+                if (tiles + t > 256) break;
+                tiles += t; work[w] += (double)t * bn * Mtok[i]; ++e;
+            }
+            reach[w] = e;
+        }
+        const int pick = reach[1] > reach[0] ? 1 : (reach[1] < reach[0] ? 0 : (work[1] < work[0] ? 1 : 0));
+        const int best_bn = pick ? 256 : 192, best_end = reach[pick];
+        if (best_end == at) { skipped |= 1u << idx[at]; ++at; continue; }      // a single matrix with more than 256 tiles
+        const int bn = best_bn;
+        int tiles = 0;
+        for (int q = at; q < best_end; ++q) tiles += pseld_cdiv(N[idx[q]], 256) * pseld_cdiv(K[idx[q]], bn);
+        int S = 256 / tiles;
+        for (int q = at; q < best_end; ++q) { const int lim = (Mtok[idx[q]] / 64) / 8; if (S > lim) S = lim; }
+        if (S < 1) S = 1;
+        long woff = 0;           // floats
+        grp.count = 0; grp.first[0] = 0;
+        bool fits = true;
+        for (int q = at; q < best_end; ++q) {
+            const int i = idx[q];
+            const int nk_all = Mtok[i] / 64, kt = pseld_cdiv(nk_all, S), sp = pseld_cdiv(nk_all, kt);
+            float* db = dbias ? dbias[i] : nullptr;
+            G8WArgs& a = grp.p[grp.count];
+            if (sp == 1) {
+                g8w_fill(a, dY[i], X[i], dW[i], db, 0, 0, Mtok[i], N[i], K[i], lddy[i], ldx[i], bn, kt * 64, 1, rowscale ? rowscale[i] : nullptr, rows_per_scale ? rows_per_scale[i] : 1);
+            } else {
+                const long per = (long)N[i] * K[i] + N[i];
+                if ((woff + (long)sp * per) * (long)sizeof(float) > workspace_bytes || !workspace) { fits = false; break; }
+                g8w_fill(a, dY[i], X[i], workspace + woff, db ? workspace + woff + (long)N[i] * K[i] : nullptr, per, per, Mtok[i], N[i], K[i], lddy[i], ldx[i], bn, kt * 64, sp,
+                         rowscale ? rowscale[i] : nullptr, rows_per_scale ? rows_per_scale[i] : 1);
+                woff += (long)sp * per;
+            }
+            grp.first[grp.count + 1] = grp.first[grp.count] + a.ntile * a.splits;
+            ++grp.count;
+        }
+        PSELD_CHECK_ARG(fits, "gemm_wgrad_group: workspace %ld bytes too small", workspace_bytes);
+        const int rc = g8w_launch_group(grp, bn, s);
+        if (rc != PSELD_OK) return rc;
+        for (int q = 0; q < grp.count; ++q) {
+            const G8WArgs& a = grp.p[q];
+            if (a.splits > 1) {
+                const int i = idx[at + q];
+                const long nk = (long)N[i] * K[i];
+                pseld_reduce_slabs(a.C, dW[i], nk, a.splits, a.slab_stride, 0, s);
+                if (a.colsum) pseld_reduce_slabs(a.colsum, dbias[i], (long)N[i], a.splits, a.colsum_stride, 0, s);
+            }
+        }
+        PSELD_LAUNCH_CHECK("gemm_wgrad_group(reduce)");
+        at = best_end;
+    }
+    *skipped_mask = skipped;
     return PSELD_OK;
 }

@@ -940,7 +940,18 @@ bool scale_ok(const float* rowscale, int rows_per_scale) { return !rowscale || (
 
 static unsigned long long* g_mlp_dbg = nullptr;
 extern "C" void pseld_mlp_set_debug_buffer(void* p) { g_mlp_dbg = (unsigned long long*)p; }
-static int mlp_variant() { const char* e = getenv("PSELD_MLP_VARIANT"); return e ? atoi(e) : 0; }
+// timing-experiment knob, read once; a result-changing value is honoured only with PSELD_ALLOW_WRONG_RESULTS=1 (else it is ignored with a
+// message on stderr: a stray environment variable must not silently change gradients)
+static int mlp_variant() {
+    static const int v = [] {
+        const char* e = getenv("PSELD_MLP_VARIANT");
+        const int x = e ? atoi(e) : 0;
+        const char* ok = getenv("PSELD_ALLOW_WRONG_RESULTS");
+        if (x != 0 && !(ok && ok[0] == '1')) { fprintf(stderr, "pseld: PSELD_MLP_VARIANT=%d ignored (changes results; set PSELD_ALLOW_WRONG_RESULTS=1 for timing runs)\n", x); return 0; }
+        return x;
+    }();
+    return v;
+}
 
 extern "C" int pseld_mlp_supported(int dtype, long M, int C, int rows_per_scale) {
     return shape_ok(dtype, M, C) && rows_per_scale > 0 && rows_per_scale % 32 == 0 ? 1 : 0;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void swin_attn_fwd_kernel(SwinArgs a) {
                 char* vcol = (char*)a.qkv + (2 * SC + head * SHD + (dl < SHD ? dl : 0)) * 2;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const unsigned off = (unsigned)toks[32 * tt + acc_row(e, h)] * (3 * SC * 2);
+                    const long off = (long)toks[32 * tt + acc_row(e, h)] * (3 * SC * 2);     // (64-bit: a saved qkv row is 3x an x row)
                     if (dl < SHD) *(bf16_t*)(vcol + off) = (bf16_t)vA[e];
                     if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows at a time: otherwise all sixteen addresses are kept live
                 }
@@ -411,7 +411,7 @@ namespace {
 int swin_launch(SwinArgs& a, int dtype, int B, int res, int C, int heads, int shift, float eps, void* stream, const char* who) {
     PSELD_CHECK_ARG(pseld_swin_attn_supported(dtype, res, C, heads), "%s: built for bf16, C = 96, 4 heads (got dtype %d C %d heads %d res %d)",
                     who, dtype, C, heads, res);
-    PSELD_CHECK_ARG(B > 0 && shift >= 0 && shift < 8 && (long)B * res * res * SRB < (1L << 32), "%s: bad B / shift, or more than 4 GB of tokens", who);
+    PSELD_CHECK_ARG(B > 0 && shift >= 0 && shift < 8 && (long)B * res * res * (3 * SC * 2) < (1L << 32), "%s: bad B / shift, or more than 4 GB of saved q|k|v rows", who);
     a.B = B; a.res = res; a.heads = heads; a.shift = shift; a.n_win_total = B * (res / 8) * (res / 8);
     a.scale = 1.0f / sqrtf((float)SHD); a.eps = eps;
     static bool attr = false;

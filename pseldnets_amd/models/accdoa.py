@@ -89,13 +89,16 @@ class HTSAT(HTSATNetBase):
         B = x.shape[0]
         dt = self.compute_dtype
         box = []
+        ops.stage('front')
         mean_rstd, scale_shift = self._bn_front(x, training, overlap=lambda: box.append(self._drop_scales(B, self.enc, x.device, training)))
         drop = box[0]
         tok, s_patch = self.enc.forward_patch(x, scale_shift, dt)
         s_layers = []
         for li in range(self.enc.nl):
+            ops.stage(f'stage{li}')
             tok, s = self.enc.forward_layer(li, tok, B, drop)
             s_layers.append(s)
+        ops.stage('head+loss')
         xn, s_fin = self.enc.forward_final(tok)
         y, s_head = self.head.forward(xn, B)
         return y, dict(feat=x, mean_rstd=mean_rstd, patch=s_patch, layers=s_layers, fin=s_fin, head=s_head, B=B)
@@ -106,15 +109,18 @@ class HTSAT(HTSATNetBase):
         dy = douts[0] if isinstance(douts, (tuple, list)) else douts
         B, dt = saved['B'], self.compute_dtype
         a = self.arena
+        ops.stage('head+loss')
         dxn = self.head.backward(dy, saved['head'], B, dt)
         dx = self.enc.backward_final(dxn, saved['fin'])
         hi = a.size
         for li in reversed(range(self.enc.nl)):
+            ops.stage(f'stage{li}')
             dx = self.enc.backward_layer(li, dx, saved['layers'][li], B)
             if on_range_done is not None and li in (3, 2):     # buckets: {stage3+norm+head}, {stage2}, {rest}
                 lo = a.offsets[self.enc.first_param_of_layer(li)][0]
                 on_range_done(lo, hi)
                 hi = lo
+        ops.stage('front')
         dw, db = self._bn_grads()
         self.enc.backward_patch(dx, saved['patch'], saved['feat'], saved['mean_rstd'], dw, db, accumulate_bn=False)
         if on_range_done is not None:

@@ -29,6 +29,23 @@ def _chk(*ts):
             raise _lib.PseldError("operands must be contiguous")
 
 
+# ---- which part of the training step is being launched (measurement aid) ------------------------------------------------------
+STAGES = ('features', 'front', 'stage0', 'stage1', 'stage2', 'stage3', 'head+loss', 'optimizer')
+_stage = {'name': 'other', 'markers': None}
+
+
+def stage(name):
+    """Names the part of the step whose kernels are launched next: bench.py's per-launch HIP events are summed per name, and with
+    PSELD_STAGE_MARKERS=1 an empty marker kernel carrying the name's index is launched too (tools/pmc_stages.py cuts rocprofv3's
+    in-order tables at them). Costs a dict store when markers are off."""
+    _stage['name'] = name
+    if _stage['markers'] is None:
+        import os
+        _stage['markers'] = os.environ.get('PSELD_STAGE_MARKERS', '0') == '1'
+    if _stage['markers'] and torch.cuda.is_available():
+        _lib.check(_lib.lib().pseld_stage_marker(STAGES.index(name) if name in STAGES else 15, _lib.stream_ptr()), "pseld_stage_marker")
+
+
 _ws_cache = {}
 
 
@@ -148,6 +165,49 @@ def linear_wgrad(dy, x, dw, dbias=None, gelu_on_x=False, accumulate=False, rowsc
     return dw
 
 
+def linear_wgrad_group(items):
+    """The weight gradients of several layers in one launch (pseld_gemm_wgrad_group; bf16): items = [(dy, x, dw, dbias | None,
+    rowscale | None, rows_per_scale), ...]. Entries the persistent kernel does not take run through linear_wgrad."""
+    import ctypes
+    todo = list(items)
+    L = _lib.lib()
+    while todo:
+        chunk, todo = todo[:32], todo[32:]
+        n = len(chunk)
+        for dy, x, dw, db, rs, rps in chunk:
+            _chk(dy, x, dw, db, rs)
+            assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and dw.shape == (dy.shape[1], x.shape[1])
+        VP, IP = ctypes.c_void_p * n, ctypes.c_int * n
+        dYp = VP(*[t[0].data_ptr() for t in chunk]); Xp = VP(*[t[1].data_ptr() for t in chunk]); dWp = VP(*[t[2].data_ptr() for t in chunk])
+        dBp = VP(*[(t[3].data_ptr() if t[3] is not None else None) for t in chunk])
+        RSp = VP(*[(t[4].data_ptr() if t[4] is not None else None) for t in chunk])
+        Mt = IP(*[t[0].shape[0] for t in chunk]); Nn = IP(*[t[0].shape[1] for t in chunk]); Kk = IP(*[t[1].shape[1] for t in chunk])
+        ldy = IP(*[t[0].stride(0) for t in chunk]); ldx = IP(*[t[1].stride(0) for t in chunk]); rps = IP(*[max(int(t[5]), 1) for t in chunk])
+        dev = chunk[0][0].device
+        ws = workspace(L.pseld_gemm_wgrad_group_workspace(n, Mt, Nn, Kk), dev)
+        skipped = ctypes.c_uint(0)
+        rc = L.pseld_gemm_wgrad_group(n, dYp, Xp, dWp, dBp, Mt, Nn, Kk, ldy, ldx, RSp, rps, _lib.ptr(ws), ws.numel() * 4, ctypes.byref(skipped),
+                                      _lib.stream_ptr())
+        _lib.check(rc, "pseld_gemm_wgrad_group")
+        for i, (dy, x, dw, db, rs, r) in enumerate(chunk):
+            if skipped.value >> i & 1:
+                linear_wgrad(dy, x, dw, dbias=db, rowscale=rs, rows_per_scale=r)
+
+
+def linear_wgrad_group_side(items):
+    """linear_wgrad_group on the device's second stream, forked from the current stream (which produced every dy)."""
+    import os
+    dev = items[0][0].device
+    st = _side.get(dev.index)
+    if st is None:
+        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1'))), 'keep': []}
+    side = st['stream']
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        linear_wgrad_group(items)
+    st['keep'].append(items)
+
+
 def colsum(x, out, accumulate=False):
     """out f32[N] (+)= sum over rows of x[M,N]."""
     _chk(x, out)
@@ -224,8 +284,9 @@ def mlp_bwd_dw_side(x, dy, *args, **kw):
 # ---------------------------------------------------------------------------------------------------------
 # fused front half of the Swin attention branch (C = 96, bf16): LayerNorm -> qkv -> window attention in one kernel
 def swin_attn_fused_supported(x, res, heads):
-    # (the kernel addresses the token rows with 32-bit byte offsets: below 4 GB of block input, i.e. 5 461 ten-second chunks at stage 0)
-    return bool(x.is_cuda and x.dim() == 2 and x.numel() * x.element_size() < (1 << 32) and
+    # (the kernel addresses token rows with 32-bit byte offsets: below 4 GB of saved q|k|v rows = 3 x the block input, i.e. 1 820 ten-second
+    #  chunks at stage 0)
+    return bool(x.is_cuda and x.dim() == 2 and 3 * x.numel() * x.element_size() < (1 << 32) and
                 _lib.lib().pseld_swin_attn_supported(dtype_code(x), res, x.shape[1], heads))
 
 

@@ -136,8 +136,11 @@ def compose(argv):
     # Hydra gives a command-line group choice precedence over the experiment's `override /group` whatever the argument order
     # (and the --config-dir path above does the same): the experiment is applied first, then the explicit group choices, then
     # the dotted overrides (`augment=default experiment=synth_maccdoa` must not end with AugMix on)
-    order = {'experiment': 0, 'model': 1, 'augment': 1, 'adapt': 1}
-    rest = sorted(rest, key=lambda a: order.get(a.partition('=')[0], 2))          # stable: equal ranks keep their order
+    #  a `model=` / `adapt=` choice SUBSTITUTES the group the experiment's defaults list would pick, and the experiment
+    # BODY (`_self_` last in its defaults) is merged over the chosen group - so the groups go first, then the experiment, then the
+    # augment choice (which must beat the experiment's `override /augment`), then the dotted overrides
+    order = {'model': 0, 'adapt': 0, 'experiment': 1, 'augment': 2}
+    rest = sorted(rest, key=lambda a: order.get(a.partition('=')[0], 3))          # stable: equal ranks keep their order
     explicit_augment = any(a.partition('=')[0] == 'augment' for a in rest)
     for arg in rest:
         key, _, val = arg.partition('=')

@@ -249,12 +249,14 @@ class FusedTrainer:
     def _step(self, batch_x, batch_target, is_features=False, hyper=None, next_x=None):
         net = self.net
         net.train()
+        ops.stage('features')
         x = self._features(batch_x) if (self.af is not None and not is_features) else batch_x
         if next_x is not None and not is_features and _PREFETCH_AT == 'start':
             self.prefetch_features(next_x)
         net._check_input(x)
         net._materialize(x.device)
         outs, saved = net._forward_impl(x.contiguous().float(), True)
+        ops.stage('head+loss')
         loss, douts, loss_dict = self._loss(outs, batch_target)
         if next_x is not None and not is_features and _PREFETCH_AT != 'start':
             self.prefetch_features(next_x)       # (A/B variant: beside the backward only; 'start' measured 0.13 ms better)
@@ -293,6 +295,7 @@ class FusedTrainer:
                     parts.append(ops.grad_norm(net.arena.grad[a:b]))
             if parts:
                 grad_norm = torch.linalg.vector_norm(torch.cat(parts)).view(1)
+        ops.stage('optimizer')
         net.fused_adamw_step(self.lr, max_norm=self.max_norm, betas=self.betas, eps=self.eps, weight_decay=self.wd,
                              grad_scale=1.0 / self.world, grad_norm=grad_norm, hyper=hyper)
         return loss_dict

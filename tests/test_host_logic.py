@@ -115,6 +115,10 @@ def test_train_config_composition_and_module_wiring():
     cp = c = compose(['experiment=synth_einv2', 'model=passt', 'model.kwargs.depth=3', 'model.decoder=gru'])
     assert (c.model.method, c.model.backbone, c.model.ps_gap, c.model.decoder) == ('einv2', 'PASST', 2, 'gru')
     assert c.model.kwargs.depth == 3 and 'spec_size' not in c.model.kwargs and c.model.loss['method'] == 'tPIT'
+    #  the experiment BODY is merged over an explicitly chosen model group, whatever the argument order
+    for args in (['model=passt', 'experiment=synth_seddoa_agg'], ['experiment=synth_seddoa_agg', 'model=passt']):
+        c = compose(args)
+        assert (c.model.backbone, c.model.method, c.model.ps_gap, c.model.loss['method']) == ('HTSAT_SEDDOA', 'einv2', 2, 'mACCDOA_pit')
     c = compose(['model=crnn', 'model.decoder=gru', 'model.num_decoder_layers=2'])
     assert (c.model.backbone, c.model.decoder, c.model.num_decoder_layers, c.model.kwargs.encoder) == ('CRNN', 'gru', 2, 'CNN12')
     net = ModelMoodule['einv2'].PASST(cp, 3, 7, pretrained_path=None, embed_dim=128, depth=3, num_heads=2)

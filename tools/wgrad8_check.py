@@ -75,3 +75,36 @@ if 'shapes' in what:
             print(f"s{li} {name:5s} wgrad dW[{N:4d},{K:4d}] over {M:6d} tokens: " + " | ".join(f"{lbl} {min(t[k]):6.1f} us {fl / min(t[k]) / 1e6:5.0f} TF" for k, lbl in
                   ((256, 'bn256'), (192, 'bn192'), (0, 'auto'), (False, 'old'))))
     print("per step (stage 2 x6 + stage 3 x2), ms: " + " | ".join(f"{lbl} {tot[k] / 1e3:.2f}" for k, lbl in ((256, 'bn256'), (192, 'bn192'), (0, 'auto'), (False, 'old'))))
+
+if 'group' in what:
+    # the 25 weight matrices of stage 2 (6 blocks x {qkv, proj, fc1, fc2} + the PatchMerging reduction) in one launch
+    torch.manual_seed(1)
+    for li, C, nblk in ((2, 384, 6), (3, 768, 2)):
+        M = int(os.environ.get('CHUNKS', '192')) * (64 >> li) ** 2
+        rps = (64 >> li) ** 2
+        items, refs = [], []
+        for b in range(nblk):
+            for name, K, N, scaled in (('qkv', C, 3 * C, False), ('proj', C, C, True), ('fc1', C, 4 * C, False), ('fc2', 4 * C, C, True)):
+                dy = torch.randn(M, N, device=dev).to(dt); x = torch.randn(M, K, device=dev).to(dt)
+                rs = ((torch.rand(M // rps, device=dev) > 0.1).float() / 0.9) if scaled else None
+                buf = torch.zeros(N * K + N, device=dev)
+                items.append((dy, x, buf[:N * K].view(N, K), buf[N * K:], rs, rps))
+        os.environ['PSELD_WGRAD8'] = '1'; os.environ['PSELD_GEMM8W_BN'] = '0'
+        ops.linear_wgrad_group(items)
+        worst = 0.0
+        for (dy, x, dw, db, rs, r) in items:
+            sc = rs.repeat_interleave(r)[:, None] if rs is not None else 1.0
+            dys = dy.float() * sc
+            e = max(((dw - dys.t() @ x.float()).norm() / (dys.t() @ x.float()).norm()).item(), ((db - dys.sum(0)).norm() / dys.sum(0).norm()).item())
+            worst = max(worst, e)
+        tg = min(timeit(lambda: ops.linear_wgrad_group(items), 5) for _ in range(3))
+
+        def single():
+            for (dy, x, dw, db, rs, r) in items: ops.linear_wgrad(dy, x, dw, dbias=db, rowscale=rs, rows_per_scale=r)
+        t1 = min(timeit(single, 5) for _ in range(3))
+        os.environ['PSELD_WGRAD8'] = '0'
+        t0 = min(timeit(single, 5) for _ in range(3))
+        os.environ['PSELD_WGRAD8'] = '1'
+        fl = sum(2.0 * d.shape[0] * d.shape[1] * x.shape[1] for d, x, *_ in items)
+        print(f"stage {li}: {len(items)} weight gradients over {M} tokens: worst rel-L2 vs fp32 {worst:.2e}{'   <-- FAIL' if worst > 3e-3 else ''}; one grouped launch {tg:7.1f} us "
+              f"({fl / tg / 1e6:5.0f} TF) | gemm8w one by one {t1:7.1f} us | ring / register-staged kernels {t0:7.1f} us")
