@@ -27,6 +27,9 @@
 // ~18 vector instructions per hidden element against 12-24 MFMA per 32x32 tile), at C = 192 by MFMA issue.
 // f32 (parity mode) instantiates the same bodies on v_mfma_f32_32x32x2_f32 with smaller tiles.
 #include "mma_frag.h"
+#ifndef MLP_GELU_TABLE
+#define MLP_GELU_TABLE 1      // bf16 kernels evaluate GELU from an LDS table (common.h: gelu_tab_*); 0 = the A&S erf everywhere (A/B build)
+#endif
 #include <stdlib.h>
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate, hipStream_t stream);
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs 
     char* ximg = smem + NBUF * WB + (threadIdx.x >> 6) * NT * XB;    // this wave's NT tiles, back to back
     float* tab = (float*)(smem + NBUF * WB + NW * NT * XB);          // gamma[C] beta[C] b2[C] b1[H]
     float* gam = tab; float* bet = tab + C; float* b2s = tab + 2 * C; float* b1s = tab + 3 * C;
+    constexpr bool GTAB = sizeof(T) == 2 && MLP_GELU_TABLE;          // bf16: GELU from the LDS table (common.h); f32 (parity mode): A&S erf
+    const f32x4* gt = (const f32x4*)(tab + 3 * C + H);
+    if constexpr (GTAB) gelu_tab_fill((f32x4*)gt, threadIdx.x, NW * 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -361,8 +367,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs 
                         if (b1 < b2) fr[0] = op_frag(sub, k0 + b1);
                         if (b1 + 1 < b2) fr[1] = op_frag(sub, k0 + b1 + 1);
                     }
-                    uu[sub & 1][2 * i] = gelu_f(uu[sub & 1][2 * i]);
-                    uu[sub & 1][2 * i + 1] = gelu_f(uu[sub & 1][2 * i + 1]);
+                    uu[sub & 1][2 * i] = GTAB ? gelu_tab_f(gt, uu[sub & 1][2 * i]) : gelu_f(uu[sub & 1][2 * i]);
+                    uu[sub & 1][2 * i + 1] = GTAB ? gelu_tab_f(gt, uu[sub & 1][2 * i + 1]) : gelu_f(uu[sub & 1][2 * i + 1]);
                     // the slice as a scheduling pipeline: its MFMAs, the operand reads of the next slice, then the GELU pair
                     if (b1 - b0 == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     if (b1 - b0 == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_fwd_kernel(MlpArgs 
                 for (int t = 0; t < NT; ++t) {
                     if (!(a.variant & 1)) {
     #pragma unroll
-                        for (int e = 0; e < 16; ++e) u[t][e] = gelu_f(u[t][e]);
+                        for (int e = 0; e < 16; ++e) u[t][e] = GTAB ? gelu_tab_f(gt, u[t][e]) : gelu_f(u[t][e]);
                     }
                     hb[t][0] = AMma<T>::from_acc(u[t], 0);
                     hb[t][1] = AMma<T>::from_acc(u[t], 1);
@@ -472,6 +478,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
     char* wbuf = smem;
     char* tiles = smem + NBUF * WB + (threadIdx.x >> 6) * NT * NREG * XB;     // tile t: Xh image, then (unless shared) its dY image
     float* b1s = (float*)(smem + NBUF * WB + NW * NT * NREG * XB);            // b1[H]
+    constexpr bool GTAB = sizeof(T) == 2 && C == 96 && MLP_GELU_TABLE;      // (C = 192: 430 against 411 us with the table)
+    const f32x4* gt = (const f32x4*)(b1s + H);
+    if constexpr (GTAB) gelu_tab_fill((f32x4*)gt, threadIdx.x, NW * 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void mlp_bwd_dx_kernel(MlpAr
             for (int t = 0; t < NT; ++t) {
                 if (!(a.variant & 1)) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * gelu_grad_shared(u[t][e]);        // dU^T
+                    for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * (GTAB ? gelu_tab_grad(gt, u[t][e]) : gelu_grad_shared(u[t][e]));        // dU^T
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) u[t][e] = dh[t][e] * u[t][e];
@@ -672,6 +681,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
     float scv[NSC];
 #pragma unroll
     for (int i = 0; i < NSC; ++i) scv[i] = a.rowscale ? a.rowscale[min(samp0 + i, samp_last)] : 1.f;
+    // (measured, tools/mlp_bench.py: the table LOSES here - 523 against 416 us at C = 96: the 16-byte entries push the 254-register loop into
+    //  spills inside the counted-vmcnt ring; it wins in the forward, 307 -> 270 us, and in dx at C = 96, 361 -> 319 us)
+    constexpr bool GTAB = false && sizeof(T) == 2 && MLP_GELU_TABLE;
+    const f32x4* gt = (const f32x4*)(smem + NST * 2 * IMG);
+    if constexpr (GTAB) { gelu_tab_fill((f32x4*)gt, tid, NW * 64); __syncthreads(); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the compiler-visible loads are retired before the DMA ring starts
 
     // sources as (split base in SGPRs) + (32-bit lane offset), recomputed per tile from a laundered lane id: hoisted out of the tile
@@ -775,12 +789,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_bwd_dw_kernel(MlpArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float hv, gv;
-                    gelu_both(u[e], hv, gv);
+                    if constexpr (GTAB) gelu_tab_both(gt, u[e], hv, gv); else gelu_both(u[e], hv, gv);
                     u[e] = hv * s_mt;                                      // s H
                     dh[e] *= gv * s_mt;                                    // dU
                     db1 += dh[e];
                     // four evaluations in flight at a time: left alone the scheduler interleaves all sixteen (~100 live temporaries)
-                    if (WPS > 1 && (e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if (WPS > 1 && (e & (GTAB ? 1 : 3)) == (GTAB ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);     // (table: two - each holds a 16-byte entry)
                 }
             } else {
 #pragma unroll
@@ -853,7 +867,7 @@ template <typename K> int set_lds(K kernel, int lds, bool& done) {
 
 template <typename T, int C, int NW, int NT, int JC, int NB, bool PIPE = false> int launch_fwd_cfg(const MlpArgs& a, hipStream_t s) {
     constexpr int ES = (int)sizeof(T), H = 4 * C;
-    constexpr int LDS = NB * 2 * JC * C * ES + NW * NT * 32 * C * ES + (3 * C + H) * 4;
+    constexpr int LDS = NB * 2 * JC * C * ES + NW * NT * 32 * C * ES + (3 * C + H) * 4 + (ES == 2 && MLP_GELU_TABLE ? GELU_TAB_BYTES : 0);
     static_assert(LDS <= 160 * 1024, "forward: LDS budget");
     auto k = mlp_fwd_kernel<T, C, NW, NT, JC, NB, PIPE>;
     static bool done = false;
@@ -873,7 +887,7 @@ template <typename T, int C> int launch_fwd(const MlpArgs& a, hipStream_t s) {
 }
 template <typename T, int C, int NW, int NT, int JC, int NB, bool SH, bool RG> int launch_dx_cfg(const MlpArgs& a, hipStream_t s) {
     constexpr int ES = (int)sizeof(T), H = 4 * C;
-    constexpr int LDS = NB * 3 * JC * C * ES + NW * NT * (SH ? 1 : 2) * 32 * C * ES + H * 4;
+    constexpr int LDS = NB * 3 * JC * C * ES + NW * NT * (SH ? 1 : 2) * 32 * C * ES + H * 4 + (ES == 2 && C == 96 && MLP_GELU_TABLE ? GELU_TAB_BYTES : 0);
     static_assert(LDS <= 160 * 1024, "dx: LDS budget");
     auto k = mlp_bwd_dx_kernel<T, C, NW, NT, JC, NB, SH, RG>;
     static bool done = false;

@@ -250,6 +250,8 @@ class SwinEncoder:
                 # deferred: the stage's weight gradients run as ONE persistent launch at the end of the stage (backward_layer) - together
                 # their output tiles fill the chip without splitting the tokens, so no fp32 slabs are written or reduced
                 grp.append((dy, x, a.g(wname), a.g(bname) if bname else None, rowscale, rows_per_scale))
+                if len(grp) >= getattr(self, '_wgroup_mats', 1 << 30):         # (PSELD_WGRAD_GROUP_MATS: flush every n matrices)
+                    self._flush_wgroup()
                 return
             if not self.lora and getattr(self, '_side_ok', False):
                 # on the second stream, beside the input-gradient / attention / LayerNorm chain (ops.linear_wgrad_side; joined at
@@ -396,6 +398,7 @@ class SwinEncoder:
         # whole stage per launch): a deferred weight gradient no longer runs beside the input-gradient kernel that reads the same dY, and
         # one chip-wide persistent launch leaves the second stream nothing to interleave
         self._wgroup_blocks = int(os.environ.get('PSELD_WGRAD_GROUP', '0'))
+        self._wgroup_mats = int(os.environ.get('PSELD_WGRAD_GROUP_MATS', '0')) or (1 << 30)
         self._wgroup = [] if (dx.dtype == torch.bfloat16 and self._wgroup_blocks > 0) else None
         self._wgroup_n = 0
         dx = self._backward_layer(li, dx, saved, B)
