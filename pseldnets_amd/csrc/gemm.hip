@@ -1570,6 +1570,7 @@ static int wgrad_ring_plan(int dtype, int Mtok, int N, int K, int gelu_on_x, int
     *splits_out = pseld_cdiv(Mtok, kchunk);
     return mt;
 }
+static int gemm8w_min_n() { const char* e = getenv("PSELD_WGRAD8_MINN"); return e ? atoi(e) : 192; }     // (A/B knob, read per call; dW[192, 768] over 196 608 tokens: 102 against 127 us)
 extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
     const int sa = wgrad_splits_for(PSELD_BF16, Mtok, N, K), sb = wgrad_splits_for(PSELD_F32, Mtok, N, K);
     int sr = 0;
@@ -1599,7 +1600,7 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr);
     PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
     // MFMA-bound weight gradients: the eight-phase kernel of gemm8w.hip (PSELD_WGRAD8=0 disables it; read per call: in-process A/B)
-    if (dtype == PSELD_BF16 && !gelu_on_x && N >= 256 && K >= 192 && Mtok >= 4096) {
+    if (dtype == PSELD_BF16 && !gelu_on_x && N >= gemm8w_min_n() && K >= 192 && Mtok >= 4096) {
         const char* e8 = getenv("PSELD_WGRAD8");
         if (!(e8 && e8[0] == '0')) {
             int bn8 = 0, kchunk8 = 0;

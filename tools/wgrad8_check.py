@@ -58,7 +58,7 @@ if 'check' in what:
 
 if 'shapes' in what:
     B = int(os.environ.get('CHUNKS', '192'))
-    tot = {256: 0.0, 192: 0.0, 0: 0.0, False: 0.0}
+    tot = {256: 0.0, 192: 0.0, 'auto': 0.0, 'old': 0.0}
     for li, C in ((2, 384), (3, 768)):
         M = B * (64 >> li) ** 2
         nblk = (2, 2, 6, 2)[li]
@@ -68,13 +68,12 @@ if 'shapes' in what:
             rs = ((torch.rand(M // rps, device=dev) > 0.1).float() / 0.9) if scaled else None
             t = {}
             for rnd in range(3):
-                for on in (256, 192, 0, False):
-                    t.setdefault(on, []).append(timeit(lambda: run(dy, x, rs, rps, on is not False, on if on else 0), 10))
+                for on in (256, 192, 'auto', 'old'):
+                    t.setdefault(on, []).append(timeit(lambda: run(dy, x, rs, rps, on != 'old', on if isinstance(on, int) else 0), 10))
             fl = 2.0 * M * N * K
             for on in t: tot[on] += min(t[on]) * nblk
-            print(f"s{li} {name:5s} wgrad dW[{N:4d},{K:4d}] over {M:6d} tokens: " + " | ".join(f"{lbl} {min(t[k]):6.1f} us {fl / min(t[k]) / 1e6:5.0f} TF" for k, lbl in
-                  ((256, 'bn256'), (192, 'bn192'), (0, 'auto'), (False, 'old'))))
-    print("per step (stage 2 x6 + stage 3 x2), ms: " + " | ".join(f"{lbl} {tot[k] / 1e3:.2f}" for k, lbl in ((256, 'bn256'), (192, 'bn192'), (0, 'auto'), (False, 'old'))))
+            print(f"s{li} {name:5s} wgrad dW[{N:4d},{K:4d}] over {M:6d} tokens: " + " | ".join(f"{lbl} {min(t[k]):6.1f} us {fl / min(t[k]) / 1e6:5.0f} TF" for k, lbl in ((256, "bn256"), (192, "bn192"), ("auto", "auto"), ("old", "old"))))
+    print("per step (stage 2 x6 + stage 3 x2), ms: " + " | ".join(f"{lbl} {tot[k] / 1e3:.2f}" for k, lbl in ((256, "bn256"), (192, "bn192"), ("auto", "auto"), ("old", "old"))))
 
 if 'group' in what:
     # the 25 weight matrices of stage 2 (6 blocks x {qkv, proj, fc1, fc2} + the PatchMerging reduction) in one launch
