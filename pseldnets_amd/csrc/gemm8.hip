@@ -30,9 +30,12 @@ typedef __attribute__((address_space(3))) void* lds_vptr8;
 constexpr int HALF_B = 16384;             // one half-tile image: 128 rows x 128 B (64 bf16 of K)
 constexpr int BUF_B = 4 * HALF_B;         // one K-tile: A-h0 | A-h1 | B-h0 | B-h1
 constexpr int RING_B = 2 * BUF_B;         // 128 KiB
-constexpr int BIAS_FLOATS = 4608;         // the product's whole bias vector (padded to the tile grid) lives in LDS
+constexpr int BIAS_FLOATS = 4672;         // the product's whole bias vector (padded to the tile grid) lives in LDS
 constexpr int LDS_B = RING_B + BIAS_FLOATS * 4;
 
+#ifndef G8_TOUCH
+#define G8_TOUCH 1
+#endif
 enum { G8_PLAIN = 0, G8_RESID = 1, G8_MULAUX = 2, G8_GELU_DUAL = 3 };   // x SCALED (DropPath factor per token row)
 
 // s_waitcnt vmcnt(0) the compiler's own wait bookkeeping sees (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15)
@@ -44,6 +47,7 @@ struct G8Args {
     int M, N, K, lda, ldb, ldc, ldr, ldaux, rows_per_scale;
     float inv_rps;
     int nx, ntiles, nk;
+    int store_m;              // rows that are stored (== M; 0 in the PSELD_GEMM8_NOSTORE timing experiment)
     unsigned long long* dbg;   // diagnostic instantiation only: s_memtime stamps per (workgroup, wave group, tile)
 };
 
@@ -60,6 +64,14 @@ __device__ __forceinline__ int div_by8(int x, int d, float rd) {
 __device__ __forceinline__ void g8_dma(unsigned lds_dst, const void* sbase, unsigned voff) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+
+// L2 "touch": 64 lanes x 4 B from 64 different 128-byte lines, dumped into a scratch corner of LDS - brings the lines into this XCD's L2
+// without a destination register (an ordinary load whose result nobody reads could land in a register the compiler has reused)
+__device__ __forceinline__ void g8_touch(unsigned lds_dst, const void* sbase, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 
@@ -93,6 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     // single wait per K-tile of the guide's template - too few for operands that come from HBM rather than L2)
     constexpr int VM_P4 = 6 + 2 * NB1, VM_P1 = 8 + NB1, VM_P2 = 8 + NB1;
     constexpr int NST = MODE == G8_GELU_DUAL ? 32 : 16;      // stores of one epilogue per wave
+    constexpr int NTOUCH = G8_TOUCH ? 2 : 0;                 // L2 touches of the next tile's A block per wave (issued in front of the epilogue)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = (float*)(smem + RING_B);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
             const long orow = (long)min(row, mlast) * g.ldc;
             const float scm = SCALED ? sc[SCALED ? mb : 0] : 1.f;
             {   // first quadrant: 8 columns
-                const bool ok = row < g.M && col0 < g.N;
+                const bool ok = row < g.store_m && col0 < g.N;
                 float v[8], x[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[k] = acc[mb][0][k]; v[4 + k] = acc[mb][1][k]; }
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
                 if (ok) *(f32x4*)(g.C + orow + c0c) = pack8f(v);
             }
             {   // second quadrant: 8 (NB = 4) or 4 (NB = 3) columns
-                const bool ok = row < g.M && col1 < g.N;
+                const bool ok = row < g.store_m && col1 < g.N;
                 float v[8], x[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[k] = acc[mb][2][k]; v[4 + k] = NB == 4 ? acc[mb][NB - 1][k] : 0.f; }
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         dmaA(1); advance();
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the B-h0 reads have left LDS: B-h0 may be refilled next phase
         // B-h1 of this K-tile has landed (read next phase); behind an epilogue its stores sit in the queue too and may stay there
-        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1 + NST) : "memory");
+        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1 + NST + NTOUCH) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1) : "memory");
         G8_BAR();
         G8_MMA(0, 0, fb0);
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         // phase 2: B-h1 fragments | B-h0 of K-tile + 2 | quadrant (m 0-63, n 32-63)
         G8_LD_B1();
         dmaB(0);
-        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2 + NST) : "memory");   // A-h1 of this K-tile has landed
+        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2 + NST + NTOUCH) : "memory");   // A-h1 of this K-tile has landed
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2) : "memory");
         G8_BAR();
         G8_MMA(0, 1, fb1);
@@ -366,6 +379,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         if (++cp_kt == g.nk) {
             unsigned long long t_loop = 0;
             if constexpr (DBG) t_loop = __builtin_amdgcn_s_memtime();
+            if constexpr (NTOUCH > 0) {
+                // The K-tiles 2 .. 5 of the NEXT tile's A block (its first two are already in flight) are pulled into this XCD's L2 now,
+                // a whole epilogue ahead of their LDS-DMA: a lone workgroup keeps <= 80 KB in flight (the ring), and at the ~4k cycles an
+                // HBM-served line takes under load that is 17 B/clk per CU, half of what the loop needs - from L2 the same ring feeds it.
+                // One 4-byte request per 128-byte line; thread = (row tid & 255, K-tile 2 + (tid >> 8) + 2 j); lines past K wrap to K-tile 0.
+                const int Tn = first + min(cp_i + 1, my_n - 1) * per;
+                const int rown = min((Tn / g.nx) * 256 + (tid & 255), g.M - 1);
+#pragma unroll
+                for (int j = 0; j < NTOUCH; ++j) {
+                    int kt = 2 + (tid >> 8) + 2 * j;
+                    kt = kt < g.nk ? kt : 0;
+                    g8_touch(lds_base + (unsigned)(RING_B + (BIAS_FLOATS - 64) * 4), g.A, (unsigned)rown * (unsigned)(g.lda * 2) + (unsigned)(kt * 128));
+                }
+            }
             epilogue(m0c, n0c);
             if constexpr (DBG) {
                 const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
@@ -435,7 +462,7 @@ int pseld_gemm8_supported(const Gemm8Desc& d) {
     if (d.K % 64 != 0 || d.K < 128 || d.M < 1 || d.N < 128 || d.N % 8 != 0) return 0;
     if (d.lda % 8 != 0 || d.ldb % 8 != 0 || d.ldc % 8 != 0 || (d.resid && d.ldr % 8 != 0) || (d.aux && d.ldaux % 8 != 0)) return 0;
     if ((long)d.M * d.lda * 2 >= (1L << 32) || (long)d.N * d.ldb * 2 >= (1L << 32) || d.M >= (1 << 24)) return 0;
-    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS) return 0;
+    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS - 64 || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS - 64) return 0;     // (the last 256 B: sink of the L2 touches)
     if ((((unsigned long)d.A | (unsigned long)d.B | (unsigned long)d.C | (unsigned long)d.C2 | (unsigned long)d.resid | (unsigned long)d.aux) & 15) != 0) return 0;
     if (d.resid && d.aux) return 0;
     if (d.gelu_dual && (d.resid || d.aux || d.rowscale || !d.C2)) return 0;
@@ -451,6 +478,7 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     a.inv_rps = 1.0f / (float)a.rows_per_scale;
     a.nk = d.K / 64;
     a.dbg = g_gemm8_dbg;
+    { const char* en = getenv("PSELD_GEMM8_NOSTORE"); a.store_m = (en && en[0] == '1') ? 0 : d.M; }     // (timing experiment: results are not written)
     // tile width: 192 when that wastes fewer columns / fills the rounds better (PSELD_GEMM8_BN=256 / 192 forces one: A/B knob)
     const char* eb = getenv("PSELD_GEMM8_BN");
     int bn = eb ? atoi(eb) : 0;
