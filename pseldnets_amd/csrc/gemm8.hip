@@ -33,8 +33,11 @@ constexpr int RING_B = 2 * BUF_B;         // 128 KiB
 constexpr int BIAS_FLOATS = 4672;         // the product's whole bias vector (padded to the tile grid) lives in LDS
 constexpr int LDS_B = RING_B + BIAS_FLOATS * 4;
 
+// G8_TOUCH=1 (build-time A/B): pull the next tile's A block into L2 a whole epilogue ahead of its LDS-DMA. Measured NOT to help (in-process
+// against the untouched 128 x 192 kernel on the same box: stage-2 qkv forward 53.0 -> 58.1 us while the old kernel read 60.8 -> 64.7, K loop
+// 3 512 -> 3 657 cycles per K-tile, epilogue +600 cycles): the short-K loop is not waiting for HBM-served A lines. Off.
 #ifndef G8_TOUCH
-#define G8_TOUCH 1
+#define G8_TOUCH 0
 #endif
 enum { G8_PLAIN = 0, G8_RESID = 1, G8_MULAUX = 2, G8_GELU_DUAL = 3 };   // x SCALED (DropPath factor per token row)
 
