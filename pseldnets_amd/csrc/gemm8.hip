@@ -8,8 +8,10 @@
 // Structure (cdna_hip_programming.md, "The 256^2 8-phase template"):
 //  * ONE workgroup of 8 waves per CU, persistent over its list of 256 x 256 output tiles; waves 2 (M) x 4 (N), 128 x 64 per wave as
 //    8 x 4 accumulator blocks of v_mfma_f32_16x16x32_bf16 computed TRANSPOSED (weight rows on the accumulator rows, tokens on the
-//    lanes), so that a lane ends up with 8 consecutive output columns of one token row: the epilogue stores 16-byte pieces straight
-//    from the accumulators (64 contiguous bytes per row and instruction) and needs neither LDS nor a barrier.
+//    lanes), and the B image -> weight row map gives a lane 16 (12) consecutive output columns of one token row. Adjacent token rows
+//    (lanes) trade halves through one DPP quad_perm, so every epilogue store / residual load instruction covers 8 rows x 128 (96)
+//    contiguous bytes - whole cache lines straight from the accumulators, no LDS, no barrier (the CU's vector-memory path is paced
+//    by the lines an instruction touches: 16 rows x 64 B per instruction measured 4.1k cycles per epilogue, 8 x 128 B 2.6k).
 //  * 128 KiB of LDS = 2 K-tiles (BK = 64) x {A-h0, A-h1, B-h0, B-h1} half-tile images of 128 rows x 128 B, filled by
 //    global_load_lds_dwordx4 (8 whole 128-byte rows per wave-instruction) with the 16-byte chunk XOR-swizzled on the SOURCE address
 //    by (row >> 1) & 7: every ds_read_b128 fragment read is bank-conflict free.
@@ -33,12 +35,6 @@ constexpr int RING_B = 2 * BUF_B;         // 128 KiB
 constexpr int BIAS_FLOATS = 4672;         // the product's whole bias vector (padded to the tile grid) lives in LDS
 constexpr int LDS_B = RING_B + BIAS_FLOATS * 4;
 
-// G8_TOUCH=1 (build-time A/B): pull the next tile's A block into L2 a whole epilogue ahead of its LDS-DMA. Measured NOT to help (in-process
-// against the untouched 128 x 192 kernel on the same box: stage-2 qkv forward 53.0 -> 58.1 us while the old kernel read 60.8 -> 64.7, K loop
-// 3 512 -> 3 657 cycles per K-tile, epilogue +600 cycles): the short-K loop is not waiting for HBM-served A lines. Off.
-#ifndef G8_TOUCH
-#define G8_TOUCH 0
-#endif
 enum { G8_PLAIN = 0, G8_RESID = 1, G8_MULAUX = 2, G8_GELU_DUAL = 3 };   // x SCALED (DropPath factor per token row)
 
 // s_waitcnt vmcnt(0) the compiler's own wait bookkeeping sees (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15)
@@ -50,7 +46,6 @@ struct G8Args {
     int M, N, K, lda, ldb, ldc, ldr, ldaux, rows_per_scale;
     float inv_rps;
     int nx, ntiles, nk;
-    int store_m;              // rows that are stored (== M; 0 in the PSELD_GEMM8_NOSTORE timing experiment)
     unsigned long long* dbg;   // diagnostic instantiation only: s_memtime stamps per (workgroup, wave group, tile)
 };
 
@@ -70,25 +65,19 @@ __device__ __forceinline__ void g8_dma(unsigned lds_dst, const void* sbase, unsi
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 
-// L2 "touch": 64 lanes x 4 B from 64 different 128-byte lines, dumped into a scratch corner of LDS - brings the lines into this XCD's L2
-// without a destination register (an ordinary load whose result nobody reads could land in a register the compiler has reused)
-__device__ __forceinline__ void g8_touch(unsigned lds_dst, const void* sbase, unsigned voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+__device__ __forceinline__ unsigned g8_pack2(float a, float b) {
+    bf16x2 t;
+    t[0] = (bf16_t)a; t[1] = (bf16_t)b;
+    return __builtin_bit_cast(unsigned, t);
 }
-
-__device__ __forceinline__ f32x4 pack8f(const float (&v)[8]) {
-    bf16x8 x;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = (bf16_t)v[k];
-    return __builtin_bit_cast(f32x4, x);
+__device__ __forceinline__ void g8_unpack2(unsigned p, float& a, float& b) {
+    const bf16x2 t = __builtin_bit_cast(bf16x2, p);
+    a = (float)t[0]; b = (float)t[1];
 }
-__device__ __forceinline__ void unpack8f(const f32x4& p, float (&v)[8]) {
-    const bf16x8 x = __builtin_bit_cast(bf16x8, p);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
-}
+// the value the neighbouring lane (lane ^ 1) holds: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ unsigned g8_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+// 16- / 12-byte pieces (PD = 4 / 3 dwords) at 4-byte aligned addresses
+template <int PD> struct G8Piece { unsigned d[PD]; };
 
 #define G8_BAR()                                  \
     do {                                          \
@@ -105,12 +94,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     constexpr int NB1 = NB - 2;                  // blocks in the second column quadrant
     // Just-in-time waits: a half-tile is waited for in the phase BEFORE the one that reads it, so the five youngest half-tiles stay in
     // flight at every wait (B-h1 is NB1 instructions per wave, the others two): every load has five phases to land (three with the
-    // single wait per K-tile of the guide's template - too few for operands that come from HBM rather than L2)
+    // single wait per K-tile of the guide's template - too few for operands that come from HBM rather than L2).
+    // Measured and NOT adopted: L2 touches of the next tile's A block a whole epilogue ahead of its LDS-DMA (stage-2 qkv forward 53.0 -> 58.1 us
+    // against 60.8 -> 64.7 for the 128 x 192 kernel in the same process, K loop 3 512 -> 3 657 cycles per K-tile); letting the stores of an
+    // epilogue stay outstanding over two more waits (no change); one extra barrier per wave group so that the two groups' epilogues run side
+    // by side instead of one after the other (no change: the epilogue is paced by the CU's vector-memory path, which the groups share).
     constexpr int VM_P4 = 6 + 2 * NB1, VM_P1 = 8 + NB1, VM_P2 = 8 + NB1;
     constexpr int NST = MODE == G8_GELU_DUAL ? 32 : 16;      // stores of one epilogue per wave
-    constexpr int NTOUCH = G8_TOUCH ? 2 : 0;                 // L2 touches of the next tile's A block per wave (issued in front of the epilogue)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = (float*)(smem + RING_B);
+    // (diagnostic instantiation) real-time stamps of the start-up pieces, and the end of K-tiles 0..7 of this workgroup's SECOND tile
+    unsigned long long r_entry = 0, r_bias = 0, r_loop = 0, kt0 = 0, kt1 = 0, kt2 = 0, kt3 = 0, kt4 = 0, kt5 = 0, kt6 = 0, kt7 = 0;
+    if constexpr (DBG) r_entry = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -127,6 +122,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 
     for (int i = tid; i < g.nx * BN; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
     __syncthreads();
+    if constexpr (DBG) r_bias = __builtin_amdgcn_s_memrealtime();
 
     // ---- fragment read addresses (buffer 0): lane reads row l15 of a 16-row block, 16-byte chunk (4 kk + q) ^ ((row >> 1) & 7) ----
     const int sw = (lane >> 1) & 7;
@@ -150,15 +146,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
                 const int tok = min(m0 + (rho >> 6) * 128 + h * 64 + (rho & 63), g.M - 1);
                 offA[h][j] = (unsigned)tok * (unsigned)(g.lda * 2) + (unsigned)(ch * 16);
             }
-            // B-h0 (and B-h1 of the 64-column wave tile): image row wc*32 + nbl*16 + i <- weight row wc*WN + 32 h + 8 (i>>2) + 4 nbl + (i&3)
-            const int nb0 = n0 + (rho >> 5) * WN + 8 * (i >> 2) + 4 * ((rho >> 4) & 1) + (i & 3);
+            // B-h0 (blocks b = nbl) and B-h1 of the 64-column wave tile (b = 2 + nbl): image row wc*32 + nbl*16 + i <- weight row
+            // wc*WN + 4 NB (i>>2) + 4 b + (i&3): accumulator row i = 4 q + k of block b is column 4 NB q + 4 b + k of the wave's strip
+            const int nb0 = n0 + (rho >> 5) * WN + 4 * NB * (i >> 2) + 4 * ((rho >> 4) & 1) + (i & 3);
             offB[0][j] = (unsigned)min(nb0, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
-            if constexpr (NB == 4) offB[1][j] = (unsigned)min(nb0 + 32, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
+            if constexpr (NB == 4) offB[1][j] = (unsigned)min(nb0 + 8, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
         }
-        if constexpr (NB == 3) {      // B-h1, one block per wave column: 64 image rows wc*16 + i <- weight row wc*48 + 32 + i; one instruction per wave
+        if constexpr (NB == 3) {      // B-h1, block b = 2 of every wave column: 64 image rows wc*16 + i <- weight row wc*48 + 12 (i>>2) + 8 + (i&3); one instruction per wave
             const int rho = wave * 8 + (lane >> 3);
             const int ch = (lane & 7) ^ ((rho >> 1) & 7);
-            offB[1][0] = (unsigned)min(n0 + (rho >> 4) * WN + 32 + (rho & 15), g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
+            const int i = rho & 15;
+            offB[1][0] = (unsigned)min(n0 + (rho >> 4) * WN + 12 * (i >> 2) + 8 + (i & 3), g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
             offB[1][1] = 0;
         }
     };
@@ -189,119 +187,110 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     f32x4 acc[8][NB];
 
     auto init_acc = [&](int n0) {
-        const float* bp = bias_s + n0 + wc * WN;
+        const float* bp = bias_s + n0 + wc * WN + 4 * NB * q;
         f32x4 b[NB];
-        b[0] = *(const f32x4*)(bp + 8 * q); b[1] = *(const f32x4*)(bp + 8 * q + 4);
-        if constexpr (NB == 4) { b[2] = *(const f32x4*)(bp + 32 + 8 * q); b[3] = *(const f32x4*)(bp + 32 + 8 * q + 4); }
-        else b[2] = *(const f32x4*)(bp + 32 + 4 * q);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(bp + 4 * nb);
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = b[nb];
     };
 
-    // lane: token row m0 + wr*128 + mb*16 + l15; columns n0 + wc*WN + 8 q + {4 nbl + k} = acc[mb][nbl][k] (first quadrant, 16 bytes) and
-    // n0 + wc*WN + 32 + 8 q + {4 nbl + k} = acc[mb][2 + nbl][k] (NB = 4) or n0 + wc*WN + 32 + 4 q + k = acc[mb][2][k] (NB = 3, 8 bytes)
+    // Lane (q, l15) holds, for token row m0 + wr*128 + 16 mb + l15, the W = 4 NB consecutive columns n0 + wc*WN + W q + (4 b + k) = acc[mb][b][k].
+    // The lanes of two adjacent token rows (l15 even / odd: "A" / "B") trade halves: A ends up with columns [W q, W q + W/2) of BOTH rows,
+    // B with [W q + W/2, W q + W) of both, so one store instruction writes the even rows of the pairs and one the odd rows - 8 rows x
+    // (WN x 2) contiguous bytes each. The residual / aux operand is loaded in the same two-row pattern and traded back before the fp32 math.
     auto epilogue = [&](int m0, int n0) {
         constexpr bool HAS_X = MODE == G8_RESID || MODE == G8_MULAUX;
-        constexpr int W1 = NB == 4 ? 8 : 4;                   // columns per lane in the second quadrant
-        const int rowb = m0 + wr * 128 + l15;
-        const int col0 = n0 + wc * WN + 8 * q, col1 = n0 + wc * WN + 32 + W1 * q;
+        constexpr int W = 4 * NB, HW = W / 2, PD = HW / 2;        // columns per lane, per piece; dwords per piece
+        typedef G8Piece<PD> piece_t;
+        const bool isB = (l15 & 1) != 0;
+        const int rown = m0 + wr * 128 + l15;                     // own token row (+ 16 mb)
+        const int r1b = rown - (isB ? 1 : 0);                      // the pair's even row (+ 16 mb); the odd one is r1 + 1
+        const int cL = n0 + wc * WN + W * q + (isB ? HW : 0);      // this lane's piece of both rows
+        const bool colok = cL < g.N;                               // (N % 8 == 0, and N % 192 == 0 where HW = 6: pieces are whole or absent)
+        const int cLc = min(cL, g.N - HW);
         const int mlast = g.M - 1;
-        const int c0c = min(col0, g.N - 8), c1c = min(col1, g.N - W1);
         const bf16_t* X = MODE == G8_RESID ? g.resid : g.aux;
         const int ldx = MODE == G8_RESID ? g.ldr : g.ldaux;
-        f32x4 xv0[HAS_X ? 8 : 1];
-        f32x4 xv1[HAS_X && NB == 4 ? 8 : 1];
-        f32x2 xw1[HAS_X && NB == 3 ? 8 : 1];
+        piece_t x1[HAS_X ? 8 : 1], x2[HAS_X ? 8 : 1];
         float sc[SCALED ? 8 : 1];
-        // every load of the epilogue is issued first, unconditionally (clamped addresses), and waited for by ONE wait the compiler
-        // knows about: no load of its own is then pending at the loop's back edge, where it would otherwise drain the LDS-DMA
-        // prefetch with a vmcnt(0) in front of the next K-tile's fragment reads
+        // The loads of the epilogue (DropPath factor, residual / aux pieces) are unconditional (clamped addresses) and all consumed inside it:
+        // no load of its own is pending at the loop's back edge, where the compiler would otherwise drain the LDS-DMA prefetch with a vmcnt(0)
+        // in front of the next K-tile's fragment reads. 192-wide tile: all of them first, ONE wait. 256-wide tile: the 64 registers of all
+        // eight row blocks do not fit beside 128 accumulators - four row blocks ahead, the compiler counts the waits.
+        constexpr int PF = (NB == 4 && HAS_X) ? 4 : 8;
+        auto load_mb = [&](int mb) {
+            if constexpr (SCALED) sc[SCALED ? mb : 0] = g.rowscale[div_by8(min(rown + mb * 16, mlast), g.rows_per_scale, g.inv_rps)];
+            if constexpr (HAS_X) {
+                x1[HAS_X ? mb : 0] = *(const piece_t*)(X + (long)min(r1b + mb * 16, mlast) * ldx + cLc);
+                x2[HAS_X ? mb : 0] = *(const piece_t*)(X + (long)min(r1b + mb * 16 + 1, mlast) * ldx + cLc);
+            }
+        };
         if constexpr (SCALED || HAS_X) {
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                const int rowc = min(rowb + mb * 16, mlast);
-                if constexpr (SCALED) sc[mb] = g.rowscale[div_by8(rowc, g.rows_per_scale, g.inv_rps)];
-                if constexpr (HAS_X) {
-                    xv0[mb] = *(const f32x4*)(X + (long)rowc * ldx + c0c);
-                    if constexpr (NB == 4) xv1[mb] = *(const f32x4*)(X + (long)rowc * ldx + c1c);
-                    else xw1[mb] = *(const f32x2*)(X + (long)rowc * ldx + c1c);
-                }
-            }
-            G8_WAIT_VM0();
+            for (int mb = 0; mb < PF; ++mb) load_mb(mb);
+            if constexpr (PF == 8) G8_WAIT_VM0();
         }
-        // v (W values): the fused options on fp32, one rounding to bf16
-        auto fuse = [&](float* v, const float* x, float scm, int W) {
-            if constexpr (MODE == G8_PLAIN) {
-                if constexpr (SCALED) for (int k = 0; k < W; ++k) v[k] *= scm;
-            } else if constexpr (MODE == G8_RESID) {
-                for (int k = 0; k < W; ++k) v[k] = SCALED ? fmaf(v[k], scm, x[k]) : v[k] + x[k];
-            } else if constexpr (MODE == G8_MULAUX) {
-                for (int k = 0; k < W; ++k) v[k] *= SCALED ? x[k] * scm : x[k];
+        // pk = the own row's W values as bf16 pairs -> the two pieces this lane stores
+        auto trade = [&](const unsigned (&pk)[W / 2], piece_t& d1, piece_t& d2) {
+#pragma unroll
+            for (int k = 0; k < PD; ++k) {
+                const unsigned got = g8_swap1(isB ? pk[k] : pk[PD + k]);        // A gives its second half, B its first
+                d1.d[k] = isB ? got : pk[k];
+                d2.d[k] = isB ? pk[PD + k] : got;
             }
         };
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
-            const int row = rowb + mb * 16;
-            const long orow = (long)min(row, mlast) * g.ldc;
-            const float scm = SCALED ? sc[SCALED ? mb : 0] : 1.f;
-            {   // first quadrant: 8 columns
-                const bool ok = row < g.store_m && col0 < g.N;
-                float v[8], x[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] = acc[mb][0][k]; v[4 + k] = acc[mb][1][k]; }
-                if constexpr (HAS_X) unpack8f(xv0[mb], x);
-                if constexpr (MODE == G8_GELU_DUAL) {
-                    float dv[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
-                        f32x2 xx = {v[k], v[k + 1]}, yy, dd;
-                        gelu_both2(xx, yy, dd);
-                        v[k] = yy[0]; v[k + 1] = yy[1]; dv[k] = dd[0]; dv[k + 1] = dd[1];
-                    }
-                    if (ok) *(f32x4*)(g.C2 + orow + c0c) = pack8f(dv);
-                } else {
-#pragma unroll
-                    for (int once = 0; once < 1; ++once) fuse(v, x, scm, 8);
-                }
-                if (ok) *(f32x4*)(g.C + orow + c0c) = pack8f(v);
+            if constexpr (PF < 8) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (mb + PF < 8) load_mb(mb + PF);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            {   // second quadrant: 8 (NB = 4) or 4 (NB = 3) columns
-                const bool ok = row < g.store_m && col1 < g.N;
-                float v[8], x[8];
+            const int r1 = r1b + mb * 16;
+            const float scm = SCALED ? sc[SCALED ? mb : 0] : 1.f;
+            unsigned pk[W / 2], pd[W / 2];
+            unsigned xo[HAS_X ? W / 2 : 1];             // the own row's residual / aux values: A loaded B's first half (x2), B loaded A's second (x1)
+            if constexpr (HAS_X) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] = acc[mb][2][k]; v[4 + k] = NB == 4 ? acc[mb][NB - 1][k] : 0.f; }
-                if constexpr (HAS_X) {
-                    if constexpr (NB == 4) unpack8f(xv1[mb], x);
-                    else {
-                        const bf16x4 xb = __builtin_bit_cast(bf16x4, xw1[mb]);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) x[k] = (float)xb[k];
-                    }
+                for (int k = 0; k < PD; ++k) {
+                    const unsigned got = g8_swap1(isB ? x1[mb].d[k] : x2[mb].d[k]);
+                    xo[k] = isB ? got : x1[mb].d[k];
+                    xo[PD + k] = isB ? x2[mb].d[k] : got;
                 }
-                float dv[8];
-                if constexpr (MODE == G8_GELU_DUAL) {
+            }
 #pragma unroll
-                    for (int k = 0; k < W1; k += 2) {
-                        f32x2 xx = {v[k], v[k + 1]}, yy, dd;
+            for (int h = 0; h < 2; ++h) {               // the fused options on fp32, one rounding to bf16; half a strip at a time (registers)
+#pragma unroll
+                for (int k = 0; k < HW; k += 2) {
+                    const int c = h * HW + k;            // column of the strip: acc[mb][c >> 2][c & 3]
+                    float v0 = acc[mb][c >> 2][c & 3], v1 = acc[mb][(c + 1) >> 2][(c + 1) & 3];
+                    if constexpr (MODE == G8_GELU_DUAL) {
+                        f32x2 xx = {v0, v1}, yy, dd;
                         gelu_both2(xx, yy, dd);
-                        v[k] = yy[0]; v[k + 1] = yy[1]; dv[k] = dd[0]; dv[k + 1] = dd[1];
+                        pk[c / 2] = g8_pack2(yy[0], yy[1]); pd[c / 2] = g8_pack2(dd[0], dd[1]);
+                    } else {
+                        float xa = 0.f, xb = 0.f;
+                        if constexpr (HAS_X) g8_unpack2(xo[c / 2], xa, xb);
+                        if constexpr (MODE == G8_PLAIN) { if constexpr (SCALED) { v0 *= scm; v1 *= scm; } }
+                        else if constexpr (MODE == G8_RESID) { v0 = SCALED ? fmaf(v0, scm, xa) : v0 + xa; v1 = SCALED ? fmaf(v1, scm, xb) : v1 + xb; }
+                        else { v0 *= SCALED ? xa * scm : xa; v1 *= SCALED ? xb * scm : xb; }
+                        pk[c / 2] = g8_pack2(v0, v1);
                     }
-                } else {
-#pragma unroll
-                    for (int once = 0; once < 1; ++once) fuse(v, x, scm, W1);
                 }
-                if constexpr (NB == 4) {
-                    if constexpr (MODE == G8_GELU_DUAL) { if (ok) *(f32x4*)(g.C2 + orow + c1c) = pack8f(dv); }
-                    if (ok) *(f32x4*)(g.C + orow + c1c) = pack8f(v);
-                } else {
-                    bf16x4 pv, pd;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { pv[k] = (bf16_t)v[k]; pd[k] = (bf16_t)dv[k]; }
-                    if constexpr (MODE == G8_GELU_DUAL) { if (ok) *(bf16x4*)(g.C2 + orow + c1c) = pd; }
-                    if (ok) *(bf16x4*)(g.C + orow + c1c) = pv;
-                }
+            }
+            piece_t d1, d2;
+            trade(pk, d1, d2);
+            const bool ok1 = colok && r1 < g.M, ok2 = colok && r1 + 1 < g.M;
+            const long o1 = (long)min(r1, mlast) * g.ldc + cLc, o2 = (long)min(r1 + 1, mlast) * g.ldc + cLc;
+            if (ok1) *(piece_t*)(g.C + o1) = d1;
+            if (ok2) *(piece_t*)(g.C + o2) = d2;
+            if constexpr (MODE == G8_GELU_DUAL) {
+                trade(pd, d1, d2);
+                if (ok1) *(piece_t*)(g.C2 + o1) = d1;
+                if (ok2) *(piece_t*)(g.C2 + o2) = d2;
             }
         }
     };
@@ -344,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 
     const int total_kt = my_n * g.nk;
     unsigned long long t_start = 0;
-    if constexpr (DBG) t_start = __builtin_amdgcn_s_memtime();
+    if constexpr (DBG) { t_start = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
     for (int s = 0; s < total_kt; ++s) {
         // phase 1: B-h0 + A-h0 fragments | A-h1 of the next K-tile | quadrant (m 0-63, n 0-31)
         G8_LD_B0();
@@ -353,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         dmaA(1); advance();
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the B-h0 reads have left LDS: B-h0 may be refilled next phase
         // B-h1 of this K-tile has landed (read next phase); behind an epilogue its stores sit in the queue too and may stay there
-        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1 + NST + NTOUCH) : "memory");
+        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1 + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1) : "memory");
         G8_BAR();
         G8_MMA(0, 0, fb0);
@@ -361,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         // phase 2: B-h1 fragments | B-h0 of K-tile + 2 | quadrant (m 0-63, n 32-63)
         G8_LD_B1();
         dmaB(0);
-        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2 + NST + NTOUCH) : "memory");   // A-h1 of this K-tile has landed
+        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2 + NST) : "memory");   // A-h1 of this K-tile has landed
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2) : "memory");
         G8_BAR();
         G8_MMA(0, 1, fb1);
@@ -379,23 +368,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         G8_MMA(1, 0, fb0);
         G8_BAR();
         ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B; rc0 ^= BUF_B; rc1 ^= BUF_B;
+        if constexpr (DBG) {
+            if (cp_i == 1) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                if (cp_kt == 0) kt0 = now; else if (cp_kt == 1) kt1 = now; else if (cp_kt == 2) kt2 = now; else if (cp_kt == 3) kt3 = now;
+                else if (cp_kt == 4) kt4 = now; else if (cp_kt == 5) kt5 = now; else if (cp_kt == 6) kt6 = now; else if (cp_kt == 7) kt7 = now;
+            }
+        }
         if (++cp_kt == g.nk) {
             unsigned long long t_loop = 0;
             if constexpr (DBG) t_loop = __builtin_amdgcn_s_memtime();
-            if constexpr (NTOUCH > 0) {
-                // The K-tiles 2 .. 5 of the NEXT tile's A block (its first two are already in flight) are pulled into this XCD's L2 now,
-                // a whole epilogue ahead of their LDS-DMA: a lone workgroup keeps <= 80 KB in flight (the ring), and at the ~4k cycles an
-                // HBM-served line takes under load that is 17 B/clk per CU, half of what the loop needs - from L2 the same ring feeds it.
-                // One 4-byte request per 128-byte line; thread = (row tid & 255, K-tile 2 + (tid >> 8) + 2 j); lines past K wrap to K-tile 0.
-                const int Tn = first + min(cp_i + 1, my_n - 1) * per;
-                const int rown = min((Tn / g.nx) * 256 + (tid & 255), g.M - 1);
-#pragma unroll
-                for (int j = 0; j < NTOUCH; ++j) {
-                    int kt = 2 + (tid >> 8) + 2 * j;
-                    kt = kt < g.nk ? kt : 0;
-                    g8_touch(lds_base + (unsigned)(RING_B + (BIAS_FLOATS - 64) * 4), g.A, (unsigned)rown * (unsigned)(g.lda * 2) + (unsigned)(kt * 128));
-                }
-            }
             epilogue(m0c, n0c);
             if constexpr (DBG) {
                 const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
@@ -416,6 +398,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     }
     if (wr == 0) G8_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the cursor's surplus DMAs must not outlive the workgroup's LDS
+    if constexpr (DBG) {
+        if ((tid & 255) == 0) {       // [wg][group]: entry, bias copy done, loop start, exit (100 MHz); then the second tile's K-tile ends (cycles)
+            unsigned long long* d = g.dbg + (long)256 * 2 * 16 * 4 + (long)(blockIdx.x * 2 + wr) * 4;
+            d[0] = r_entry; d[1] = r_bias; d[2] = r_loop; d[3] = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* e = g.dbg + (long)256 * 2 * 16 * 4 + 256 * 2 * 4 + (long)(blockIdx.x * 2 + wr) * 8;
+            e[0] = kt0; e[1] = kt1; e[2] = kt2; e[3] = kt3; e[4] = kt4; e[5] = kt5; e[6] = kt6; e[7] = kt7;
+        }
+    }
 }
 
 const char* g_gemm8_symbol = "";     // the instantiation the last launch ran, as rocprofv3 prints it (measurement aid)
@@ -465,7 +455,7 @@ int pseld_gemm8_supported(const Gemm8Desc& d) {
     if (d.K % 64 != 0 || d.K < 128 || d.M < 1 || d.N < 128 || d.N % 8 != 0) return 0;
     if (d.lda % 8 != 0 || d.ldb % 8 != 0 || d.ldc % 8 != 0 || (d.resid && d.ldr % 8 != 0) || (d.aux && d.ldaux % 8 != 0)) return 0;
     if ((long)d.M * d.lda * 2 >= (1L << 32) || (long)d.N * d.ldb * 2 >= (1L << 32) || d.M >= (1 << 24)) return 0;
-    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS - 64 || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS - 64) return 0;     // (the last 256 B: sink of the L2 touches)
+    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS) return 0;
     if ((((unsigned long)d.A | (unsigned long)d.B | (unsigned long)d.C | (unsigned long)d.C2 | (unsigned long)d.resid | (unsigned long)d.aux) & 15) != 0) return 0;
     if (d.resid && d.aux) return 0;
     if (d.gelu_dual && (d.resid || d.aux || d.rowscale || !d.C2)) return 0;
@@ -481,11 +471,11 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     a.inv_rps = 1.0f / (float)a.rows_per_scale;
     a.nk = d.K / 64;
     a.dbg = g_gemm8_dbg;
-    { const char* en = getenv("PSELD_GEMM8_NOSTORE"); a.store_m = (en && en[0] == '1') ? 0 : d.M; }     // (timing experiment: results are not written)
     // tile width: 192 when that wastes fewer columns / fills the rounds better (PSELD_GEMM8_BN=256 / 192 forces one: A/B knob)
     const char* eb = getenv("PSELD_GEMM8_BN");
     int bn = eb ? atoi(eb) : 0;
-    if (bn != 256 && bn != 192) {
+    if (d.N % 192 != 0) bn = 256;                     // (the 192 kernel's 12-byte store pieces are whole only when the strips are)
+    else if (bn != 256 && bn != 192) {
         auto cost = [&](int w) {                      // rounds x (loop cost of one tile ~ DMA bytes per K-tile)
             const long tiles = (long)pseld_cdiv(d.N, w) * pseld_cdiv(d.M, 256);
             return (double)((tiles + 255) / 256) * (256 + w);

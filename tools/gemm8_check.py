@@ -100,7 +100,7 @@ if 'square' in what:
 if 'shapes' in what:
     B = int(os.environ.get('CHUNKS', '192'))
     tot = {256: 0.0, 192: 0.0, True: 0.0, False: 0.0}
-    for li, C in ((2, 384), (3, 768)):
+    for li, C in [(l, 96 << l) for l in map(int, os.environ.get('STAGES', '2,3').split(','))]:
         M = B * (64 >> li) ** 2
         nblk = (2, 2, 6, 2)[li]
         rps = (64 >> li) ** 2

@@ -15,7 +15,7 @@ for name, M, K, N, mode in shapes:
     x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt); b = torch.randn(N, device=dev)
     extra = torch.randn(M, N, device=dev).to(dt); rps = 256
     rs = torch.rand((M + rps - 1) // rps, device=dev) + 0.5
-    dbg = torch.zeros(256 * 2 * 16 * 4, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(256 * 2 * 16 * 4 + 256 * 2 * 4 + 256 * 2 * 8, dtype=torch.int64, device=dev)
 
     def go():
         if mode == 'plain': return ops.linear_fwd(x, w, b)
@@ -23,10 +23,17 @@ for name, M, K, N, mode in shapes:
         return ops.linear_fwd(x, w, b, gelu_dual=True)
     for _ in range(5): go()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): go()
+    e1.record(); torch.cuda.synchronize(); tm = e0.elapsed_time(e1) * 100.0
     L.pseld_gemm8_set_debug_buffer(dbg.data_ptr())
     go(); torch.cuda.synchronize()
     L.pseld_gemm8_set_debug_buffer(None)
-    d = dbg.cpu().numpy().reshape(256, 2, 16, 4).astype(np.float64)
+    raw = dbg.cpu().numpy()
+    d = raw[:256 * 2 * 16 * 4].reshape(256, 2, 16, 4).astype(np.float64)
+    kk = raw[256 * 2 * 16 * 4 + 256 * 2 * 4:].reshape(256, 2, 8).astype(np.float64)
+    kr = raw[256 * 2 * 16 * 4:256 * 2 * 16 * 4 + 256 * 2 * 4].reshape(512, 4).astype(np.float64); kr = kr[kr[:, 0] > 0]
     nk = K // 64
     ntile = ((M + 255) // 256) * ((N + 255) // 256)
     out = []
@@ -35,8 +42,17 @@ for name, M, K, N, mode in shapes:
         ok = v[:, :, 2] > 0
         loop = (v[:, :, 1] - v[:, :, 0])[ok]; epi = (v[:, :, 2] - v[:, :, 1])[ok]
         out.append(f"group {grp}: K loop {np.median(loop):7.0f} cyc/tile ({np.median(loop) / nk:5.0f} per K-tile), epilogue {np.median(epi):6.0f}")
-    # whole-kernel span and clock from the first / last stamps
-    v = d.reshape(-1, 4); v = v[v[:, 2] > 0]
-    cyc = v[:, 2].max() - v[:, 0].min(); real = (v[:, 3].max() - v[:, 3].min()) / 100.0   # s_memrealtime: 100 MHz -> us
+    # second tile of every workgroup: cycles from the end of the first tile's epilogue to the end of each of its K-tiles (differences)
+    for grp in (0, 1):
+        okw = (d[:, grp, 1, 2] > 0)
+        base = d[okw, grp, 0, 2]                      # end of tile 0's epilogue
+        ends = kk[okw, grp, :min(nk, 8)]
+        prev = np.concatenate([base[:, None], ends[:, :-1]], 1)
+        print(f"   group {grp} second tile, cycles per K-tile 0..{min(nk, 8) - 1}: " + " ".join(f"{np.median(ends[:, j] - prev[:, j]):6.0f}" for j in range(min(nk, 8))))
+    # kernel-level real-time stamps (s_memrealtime, 100 MHz): first entry -> last exit, and the medians of the start-up pieces
+    t0 = kr[:, 0].min()
+    us = lambda a: a / 100.0
     print(f"{name:12s} M={M} K={K} N={N} {mode}: tiles {ntile} ({ntile / 256:.2f}/CU); " + "; ".join(out) +
-          f"; span {cyc:8.0f} cyc = {real:6.1f} us -> {cyc / max(real, 1e-9) / 1e3:.2f} GHz")
+          f"; wall first entry -> last exit {us(kr[:, 3].max() - t0):6.1f} us; entry spread {us(np.median(kr[:, 0]) - t0):5.1f} (max {us(kr[:, 0].max() - t0):5.1f}); "
+          f"bias copy {us(np.median(kr[:, 1] - kr[:, 0])):5.1f}; prologue {us(np.median(kr[:, 2] - kr[:, 1])):5.1f}; loop+epilogues {us(np.median(kr[:, 3] - kr[:, 2])):6.1f} (max {us((kr[:, 3] - kr[:, 2]).max()):6.1f}); "
+          f"event-timed {tm:6.1f} us")
