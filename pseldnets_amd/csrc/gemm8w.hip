@@ -307,14 +307,33 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WGroup grp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- slab tile: lane = n_out row m0 + wr*128 + mb*16 + l15, 4 consecutive k_in at n0 + wc*WN + nb*16 + 4 kg ----
+    // Written as they lie, an instruction stores 16 rows x 64 bytes (half cache lines; the CU's vector-memory path is paced by the lines an
+    // instruction touches, gemm8.hip). The lanes of adjacent rows (l15 even / odd) trade the blocks of a pair (nb, nb + 1): the even lane keeps
+    // block nb of both rows, the odd lane block nb + 1 - one instruction then writes 8 rows x 128 contiguous bytes.
     float* Cz = g.C + (long)z * g.slab_stride;
+    const bool odd = (l15 & 1) != 0;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
         const int row = m0 + wr * 128 + mb * 16 + l15;
+        const int re = row - (odd ? 1 : 0);                      // the pair's even row
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = n0 + wc * WN + nb * 16 + 4 * kg;
-            if (row < g.M && col < g.N) *(f32x4*)(Cz + (long)row * g.N + col) = acc[mb][nb] * s_ref;
+        for (int nb = 0; nb + 1 < NB; nb += 2) {
+            const f32x4 a0 = acc[mb][nb] * s_ref, a1 = acc[mb][nb + 1] * s_ref;
+            f32x4 d0, d1;                                        // rows re, re + 1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                        // even lane gives block nb + 1, odd lane block nb (DPP quad_perm [1, 0, 3, 2])
+                const float give = odd ? a0[k] : a1[k];
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+                d0[k] = odd ? got : a0[k];
+                d1[k] = odd ? a1[k] : got;
+            }
+            const int col = n0 + wc * WN + (nb + (odd ? 1 : 0)) * 16 + 4 * kg;
+            if (re < g.M && col < g.N) *(f32x4*)(Cz + (long)re * g.N + col) = d0;
+            if (re + 1 < g.M && col < g.N) *(f32x4*)(Cz + (long)(re + 1) * g.N + col) = d1;
+        }
+        if constexpr (NB & 1) {
+            const int col = n0 + wc * WN + (NB - 1) * 16 + 4 * kg;
+            if (row < g.M && col < g.N) *(f32x4*)(Cz + (long)row * g.N + col) = acc[mb][NB - 1] * s_ref;
         }
     }
     if (do_colsum && kg == 0) {
