@@ -380,7 +380,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         if (++cp_kt == g.nk) {
             unsigned long long t_loop = 0;
             if constexpr (DBG) t_loop = __builtin_amdgcn_s_memtime();
+            // The wave groups run one barrier apart and an epilogue has no barrier inside: left alone, group 1 sits at its last loop barrier for
+            // the whole of group 0's epilogue and group 0 at its first barrier of the next tile for the whole of group 1's. One extra barrier
+            // each - group 0 in front of its epilogue, group 1 behind its own - lets the two run side by side: their load latencies (residual /
+            // aux / DropPath factor) and GELU arithmetic overlap (GELU-pair product 120.6 -> 112.0 us; nothing for the plain store-only epilogue,
+            // which is paced by the vector-memory path the groups share).
+            if (wr == 0) G8_BAR();
             epilogue(m0c, n0c);
+            if (wr == 1) G8_BAR();
             if constexpr (DBG) {
                 const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
                 if ((tid & 255) == 0 && cp_i < 16) {
