@@ -137,7 +137,7 @@ int pseld_swin_block_attn_bwd(int dtype, const void* qkv, const float* bias_tabl
 /* Diagnostic only: when a device buffer (6 x u64 per workgroup) is installed, every pseld_gemm workgroup records
  * s_memtime stamps (start, first slice staged, K loop done, end, C tile staged, stores issued); NULL disables. */
 void pseld_gemm_set_debug_buffer(void* device_buffer);
-/* The same for the persistent eight-phase kernel (csrc/gemm8.hip: the products with K >= 384): u64 [workgroup][wave group 0/1][tile < 16][4]
+/* The same for the persistent eight-phase kernel (csrc/gemm8.hip: the products with K >= 192): u64 [workgroup][wave group 0/1][tile < 16][4]
  * = s_memtime at (tile start, K loop done, epilogue done) + s_memrealtime; a diagnostic instantiation runs while a buffer is installed. */
 void pseld_gemm8_set_debug_buffer(void* device_buffer);
 /* Measurement aid: symbol of the kernel the last pseld_gemm / pseld_gemm_wgrad call of this process launched. */

@@ -1424,12 +1424,13 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
         PSELD_LAUNCH_CHECK("gemm_skinny");
         return PSELD_OK;
     }
-    // MFMA-bound products (K >= 384: stages 2-3, merges, head): the persistent eight-phase kernel of gemm8.hip.
+    // Products with K >= 192 (stages 1-3, merges, head): the persistent eight-phase kernel of gemm8.hip (at K = 192 its whole-line epilogue
+    // is what wins: stage-1 qkv 96 -> 84 us, fc1 + GELU pair 200 -> 170 us against the 128 x 192 kernel).
     // PSELD_GEMM8=0 disables it, PSELD_GEMM8_MINK=<K> moves the threshold (both read per call: in-process A/B)
     if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && (epi & ~(EPI_BIAS | EPI_RESID | EPI_MULAUX | EPI_GELU_DUAL)) == 0) {
         const char* e8 = getenv("PSELD_GEMM8");
         const char* ek = getenv("PSELD_GEMM8_MINK");
-        const int mink = ek ? atoi(ek) : 384;
+        const int mink = ek ? atoi(ek) : 192;
         if (!(e8 && e8[0] == '0') && K >= mink) {
             Gemm8Desc d;
             d.A = A; d.B = B; d.C = C; d.C2 = (epi & EPI_GELU_DUAL) ? c2 : nullptr;

@@ -1,7 +1,7 @@
-// Persistent eight-phase bf16 GEMM for the MFMA-bound Linear layers of HTS-AT (stages 2-3, merges, head) on gfx950.
+// Persistent eight-phase bf16 GEMM for the Linear layers of HTS-AT with K >= 192 (stages 1-3, merges, head) on gfx950.
 //
 // C[M,N] = A[M,K] B[N,K]^T with the fused epilogues of pseld_gemm (include/pseld_hip.h): + bias, x DropPath factor, x aux, + residual,
-// GELU pair. Replaces, for products with K >= 384 (htsat.py:118,140 qkv / proj, model_utilities.py:166-170 fc1 / fc2, htsat.py:309
+// GELU pair. Replaces, for products with K >= 192 (htsat.py:118,140 qkv / proj, model_utilities.py:166-170 fc1 / fc2, htsat.py:309
 // PatchMerging.reduction, accdoa.py:230 head), the 128 x 192 three-workgroups-per-CU kernel of gemm.hip, whose slice loop is capped
 // by the CU's LDS-DMA rate.
 //
@@ -484,6 +484,7 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     const char* eb = getenv("PSELD_GEMM8_BN");
     int bn = eb ? atoi(eb) : 0;
     if (d.N % 192 != 0) bn = 256;                     // (the 192 kernel's 12-byte store pieces are whole only when the strips are)
+    else if (bn != 256 && bn != 192 && a.nk <= 4) bn = 256;     // short K: the epilogue dominates, and the 256 tile writes whole 128-byte lines per wave
     else if (bn != 256 && bn != 192) {
         auto cost = [&](int w) {                      // rounds x (loop cost of one tile ~ DMA bytes per K-tile)
             const long tiles = (long)pseld_cdiv(d.N, w) * pseld_cdiv(d.M, 256);
