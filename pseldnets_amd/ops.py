@@ -995,14 +995,27 @@ def conv3x3_wgrad(dY, X, dWp, B, T, F, accumulate=False):
 # Synchronised BatchNorm for the conv-stack BatchNorm2d / Conformer BatchNorm1d layers (configs/trainer/gpu.yaml:9 converts EVERY BatchNorm
 # to torch.nn.SyncBatchNorm): with a process group set (FusedTrainer, sync_bn=True) the train-mode statistics (forward: sum x, sum x^2;
 # backward: sum g xhat, sum g) are summed over the ranks between the two halves of each kernel pair, and the counts are the global ones.
-_sync_bn = {'group': None, 'world': 1, 'diag': None}
+_sync_bn = {'group': None, 'world': 1, 'diag': None, 'owner': None}
 
 
-def set_sync_bn_group(group, diag=None):
+def set_sync_bn_group(group, diag=None, owner=None):
     """group: a torch.distributed process group or None (rank-local statistics). diag: a list that receives (event, event) pairs around
-    every statistics all-reduce (trainer.enable_comm_diag)."""
+    every statistics all-reduce (trainer.enable_comm_diag). The group is process-wide state: `owner` (the FusedTrainer that sets it) makes
+    that explicit - while one owner's group is live, a DIFFERENT owner may neither replace it nor switch it off (its conv-stack statistics
+    would silently stop being synchronised); it gets a RuntimeError instead. owner=None (tests, scripts) always overrides.
+    Precondition, as for the scalar front: every rank holds the same number of rows per BatchNorm call (the reference's DistributedSampler
+    pads every rank to the same batch, src/datamodules: DataLoader under Lightning DDP) - counts are multiplied by the world size, not gathered."""
+    cur = _sync_bn['owner']
+    if owner is not None and cur is not None and cur() is not None and cur() is not owner and _sync_bn['group'] is not None and group is not _sync_bn['group']:
+        raise RuntimeError("ops.set_sync_bn_group: another FusedTrainer's sync-BatchNorm group is active in this process; "
+                           "conv-stack / Conformer BatchNorm synchronisation is process-wide state and cannot serve two different groups")
     _sync_bn['group'] = group
     _sync_bn['diag'] = diag
+    if owner is not None:
+        import weakref
+        _sync_bn['owner'] = weakref.ref(owner) if group is not None else None
+    else:
+        _sync_bn['owner'] = None
     if group is not None:
         import torch.distributed as dist
         _sync_bn['world'] = dist.get_world_size(group)

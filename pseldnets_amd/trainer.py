@@ -48,7 +48,7 @@ class FusedTrainer:
                 net.sync_bn_group = process_group
         from . import ops
         self._conv_bn_sync = process_group is not None and sync_bn
-        ops.set_sync_bn_group(process_group if self._conv_bn_sync else None)
+        ops.set_sync_bn_group(process_group if self._conv_bn_sync else None, owner=self)
         self._works, self._ranges = [], []
         # gradient all-reduce payload: 'f32' (the arena's gradients in place) or 'bf16' (each bucket is cast to bf16, summed on the wire
         # in bf16 and added back into the fp32 arena: half the bytes over xGMI; bench.py --grad-dtype, default f32)
@@ -95,7 +95,7 @@ class FusedTrainer:
         self.net.comm_diag = self.comm_diag
         if self._conv_bn_sync:
             from . import ops
-            ops.set_sync_bn_group(self.group, self.comm_diag['sync_bn'] if on else None)
+            ops.set_sync_bn_group(self.group, self.comm_diag['sync_bn'] if on else None, owner=self)
 
     def comm_report(self):
         """Averages over the steps recorded since enable_comm_diag() (call after a synchronize)."""

@@ -249,7 +249,7 @@ def _worker_crnn(rank, world, port, q, env=None):
     if os.environ.get('PSELD_TEST_NO_CONV_BN_SYNC') == '1':           # negative control: scalar front synchronised, conv stack rank-local
         from pseldnets_amd import ops
         real = ops.set_sync_bn_group
-        ops.set_sync_bn_group = lambda group, diag=None: real(None)
+        ops.set_sync_bn_group = lambda group, diag=None, owner=None: real(None)
     losses, flat, rv, n_sync, grad1 = _run_crnn(_build_crnn(dev), x, lab, dist.group.WORLD)
     q.put((rank, losses, flat.numpy(), rv.numpy(), n_sync, grad1.numpy()))
     dist.destroy_process_group()

@@ -264,3 +264,35 @@ def test_label_extraction_matches_the_reference_preprocessing(tmp_path):
         assert se[:, 3:].any() and se[:, 1:3].any()            # the fixtures exercise the B and C slots
         sed, doa = L.track_labels(rows, 5)
         assert np.array_equal(sed, g[f'mix{i}__sed_label']) and np.array_equal(doa, g[f'mix{i}__doa_label'])
+
+
+def test_sync_bn_group_is_owned(monkeypatch):
+    """ops.set_sync_bn_group is process-wide state: while one trainer's group is live another owner may neither replace it nor
+    switch it off; the same group, a dead owner, or an owner-less caller (tests, scripts) may."""
+    import gc
+    import torch.distributed as dist
+    from pseldnets_amd import ops
+    monkeypatch.setattr(dist, 'get_world_size', lambda group=None: 2)
+
+    class Owner:
+        pass
+    g1, g2, a, b = object(), object(), Owner(), Owner()
+    try:
+        ops.set_sync_bn_group(g1, owner=a)
+        assert ops._sync_bn['group'] is g1 and ops._sync_bn['world'] == 2
+        ops.set_sync_bn_group(g1, owner=b)                      # the same group: fine
+        ops.set_sync_bn_group(g1, owner=a)
+        with pytest.raises(RuntimeError):
+            ops.set_sync_bn_group(g2, owner=b)
+        with pytest.raises(RuntimeError):
+            ops.set_sync_bn_group(None, owner=b)                # would silently un-synchronise a's conv stack
+        assert ops._sync_bn['group'] is g1
+        del a
+        gc.collect()
+        ops.set_sync_bn_group(None, owner=b)                    # the owner is gone
+        assert ops._sync_bn['group'] is None and ops._sync_bn['world'] == 1
+        ops.set_sync_bn_group(g2, owner=b)
+        ops.set_sync_bn_group(None)                             # owner-less override
+        assert ops._sync_bn['group'] is None
+    finally:
+        ops.set_sync_bn_group(None)
