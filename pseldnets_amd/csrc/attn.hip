@@ -277,7 +277,18 @@ __global__ __launch_bounds__(HG * 64, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kern
     int* labels = (int*)(toks + 64);                      // [64] + [1]: "this window mixes mask regions"
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hg = blockIdx.y, wi = blockIdx.x;
+    // workgroup -> (window, head group): the head groups of a window read neighbouring 4 x head_dim x 2 byte pieces of the same q|k|v rows
+    // (192 B at head_dim 24: they share cache lines), so they must meet in ONE L2 at the same time. A (window, group) grid ran the groups a
+    // whole launch apart: FETCH_SIZE 146 MB for the 113 MB of a stage-2 qkv (8 line fetches per 6 lines of a row). 1-D grid: workgroup id ->
+    // XCD id & 7, slot id >> 3; each XCD owns a contiguous range of (window, group) pairs, group fastest.
+    const int ngrp = (a.heads + HG - 1) / HG;
+    int hg, wi;
+    {
+        const int n = a.n_win_total * ngrp, id = blockIdx.x;
+        const int Q = n >> 3, R = n & 7, xcd = id & 7;
+        const int L = xcd * Q + min(xcd, R) + (id >> 3);
+        wi = L / ngrp; hg = L - wi * ngrp;
+    }
     const int head = hg * HG + wave;
     const int heads_here = min(HG, a.heads - hg * HG);
     const int r = lane & 31, h2 = lane >> 5;
@@ -293,6 +304,8 @@ __global__ __launch_bounds__(HG * 64, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kern
         const unsigned long long diff = __ballot(lb != l0);
         if (threadIdx.x == 0) labels[64] = diff != 0ull;
     }
+    // (measured: issuing the window's LDS-DMA first and gathering the table behind it is SLOWER - 158 -> 182 / 103 -> 110 / 50.7 -> 52.1 us at
+    //  stages 0 / 1 / 2: the gather's waits then drain the DMA queue one load at a time)
     for (int i = threadIdx.x; i < heads_here * 225; i += NTHR) {
         const int hh = i / 225, idx = i - hh * 225;
         btab[hh * 225 + idx] = a.bias_table[idx * a.heads + hg * HG + hh] * LOG2E;     // scores are kept in log2 units (exp2 below)
@@ -983,7 +996,7 @@ extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bi
     a.scale = 1.0f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
     const int hgv = attn_hg(dtype);
-    dim3 grid(a.n_win_total, pseld_cdiv(heads, hgv));
+    dim3 grid((unsigned)(a.n_win_total * pseld_cdiv(heads, hgv)));
     if (dtype == PSELD_BF16) {
         if (hgv == 4) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(256), fwd_lds<bf16_t>(a.hd, 4), s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 2>), grid, dim3(128), fwd_lds<bf16_t>(a.hd, 2), s, a);
