@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+static unsigned long long* g_attn_dbg = nullptr;
+
 namespace {
 
 // heads per workgroup (= waves per workgroup): 4 or 2 for bf16 (PSELD_ATTN_HG, default 4), 2 for f32 (LDS budget)
@@ -264,6 +266,72 @@ __device__ __forceinline__ void store_tile(char* tile, int strideB, int col0, in
     }
 }
 
+// One head of one window (one wave): S^T = K Q^T, + bias (+ mask), softmax over the keys, O = P V into the head's (dead) q columns of the tile;
+// the log-sum-exp per query goes to a.lse (optional). Shared by the one-window kernel and the persistent one: same arithmetic, same bits.
+template <typename T>
+__device__ __forceinline__ void attn_fwd_head(const AttnArgs& a, char* tile, int strideB, const float* btab, const int* labels, const long* toks,
+                                              int GW, int wave, int head, int hd, int lane) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd;
+    f32x16 st[2][2];  // S^T tiles: [key tile][query tile]
+    qk_product<T>(st, tile, strideB, ck, cq, hd, lane);
+    const float* bt = btab + wave * 225;
+    float inv_l[2];
+    const float scale2 = a.scale * LOG2E;
+    const bool mixed = labels[64] != 0;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = qt * 32 + r;
+        const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
+        float m = -1e30f;
+        // key = kt*32 + (e&3) + 8*(e>>2) + 4*h2: its (y, x) = (kt*4 + (e>>2), (e&3) + 4*h2), so the table index is a
+        // per-lane base minus a compile-time constant (one address register). Scores in log2 units: s = S scale log2e + b log2e.
+        if (mixed) {
+            const int ql = labels[qi];
+            const int* labh = labels + 4 * h2;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float s = fmaf(st[kt][qt][e], scale2, btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))]);
+                    s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f * LOG2E : 0.f;
+                    st[kt][qt][e] = s;
+                    m = fmaxf(m, s);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float s = fmaf(st[kt][qt][e], scale2, btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))]);
+                    st[kt][qt][e] = s;
+                    m = fmaxf(m, s);
+                }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(st[kt][qt][e] - m);
+                st[kt][qt][e] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+        inv_l[qt] = 1.f / l;
+        if (a.lse && h2 == 0) a.lse[toks[qi] * a.heads + head] = (m + __log2f(l)) * 0.6931471805599453f;   // natural-log units
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[kt][qt][e] *= inv_l[qt];
+    }
+    f32x16 o[2];
+    xt_product<T>(o, st, tile, strideB, cv, lane);     // O[query][d] = sum_key P^T[key][query] V[key][d]
+    store_rows<T>(tile, strideB, cq, o, 1.f, hd, lane);  // into this head's (dead) q columns
+}
+
 template <typename T, int HG>
 __global__ __launch_bounds__(HG * 64, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NTHR = HG * 64;
@@ -320,67 +388,116 @@ __global__ __launch_bounds__(HG * 64, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kern
     }
     __syncthreads();   // (hipcc drains the DMA with vmcnt(0) in front of this barrier)
 
-    if (head < a.heads) {
-        const int cq = wave * hd, ck = GW + wave * hd, cv = 2 * GW + wave * hd;
-        f32x16 st[2][2];  // S^T tiles: [key tile][query tile]
-        qk_product<T>(st, tile, strideB, ck, cq, hd, lane);
-        const float* bt = btab + wave * 225;
-        float inv_l[2];
-        const float scale2 = a.scale * LOG2E;
-        const bool mixed = labels[64] != 0;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int qi = qt * 32 + r;
-            const float* btq = bt + (qi >> 3) * 15 + (qi & 7) + 112 - 4 * h2;
-            float m = -1e30f;
-            // key = kt*32 + (e&3) + 8*(e>>2) + 4*h2: its (y, x) = (kt*4 + (e>>2), (e&3) + 4*h2), so the table index is a
-            // per-lane base minus a compile-time constant (one address register). Scores in log2 units: s = S scale log2e + b log2e.
-            if (mixed) {
-                const int ql = labels[qi];
-                const int* labh = labels + 4 * h2;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float s = fmaf(st[kt][qt][e], scale2, btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))]);
-                        s -= (labh[kt * 32 + (e & 3) + 8 * (e >> 2)] != ql) ? 100.f * LOG2E : 0.f;
-                        st[kt][qt][e] = s;
-                        m = fmaxf(m, s);
-                    }
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float s = fmaf(st[kt][qt][e], scale2, btq[-((kt * 4 + (e >> 2)) * 15 + (e & 3))]);
-                        st[kt][qt][e] = s;
-                        m = fmaxf(m, s);
-                    }
-            }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(st[kt][qt][e] - m);
-                    st[kt][qt][e] = p;
-                    l += p;
-                }
-            l += __shfl_xor(l, 32, 64);
-            inv_l[qt] = 1.f / l;
-            if (a.lse && h2 == 0) a.lse[toks[qi] * a.heads + head] = (m + __log2f(l)) * 0.6931471805599453f;   // natural-log units
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) st[kt][qt][e] *= inv_l[qt];
-        }
-        f32x16 o[2];
-        xt_product<T>(o, st, tile, strideB, cv, lane);     // O[query][d] = sum_key P^T[key][query] V[key][d]
-        store_rows<T>(tile, strideB, cq, o, 1.f, hd, lane);  // into this head's (dead) q columns
-    }
+    if (head < a.heads) attn_fwd_head<T>(a, tile, strideB, btab, labels, toks, GW, wave, head, hd, lane);
     __syncthreads();
     window_copy<T, false>(tile, strideB, (T*)a.out, a.C, hg * GW, 0, heads_here * hd, toks);
+}
+
+// ---- the same forward, persistent and double-buffered (bf16, head_dim 24, heads % 4 == 0: every stage of HTS-AT) ----
+// The one-window kernel above pays two global-memory latencies per workgroup in sequence (bias-table gather, then the window's rows) with
+// nothing to compute meanwhile: 50.7 us for the 151 MB of a stage-2 launch (28 us at copy speed). Here a workgroup (4 waves = 4 heads, two
+// workgroups per CU) keeps its head group's bias table for the whole launch and walks its windows with TWO tile buffers: the rows of window
+// k + 2 are requested (LDS-DMA, inline asm: the compiler must not see them, it would drain them with vmcnt(0) at the next barrier) as soon
+// as window k has been copied out, a whole window ahead of their use; waits are counted by hand (per wave and window: 16 row DMAs, 3 output
+// stores, 2 log-sum-exp stores when lse is wanted). Raw s_barrier (__syncthreads would wait for vmcnt(0)). XCD x owns a contiguous range of
+// windows; the ngrp workgroups that hold the head groups of one window run side by side on that XCD (they share the rows' cache lines).
+constexpr int F24_STR = 3 * 96 * 2 + 16;                 // token row: q | k | v of 4 heads + pad (592 B: an odd number of 16-byte slots)
+constexpr int F24_TILE = 64 * F24_STR;
+constexpr size_t FWD24P_LDS = 2 * F24_TILE + 4 * 225 * 4 + 3 * 64 * 8 + 3 * 65 * 4;      // 81 692 B: two workgroups per CU
+
+__device__ __forceinline__ void attn_dma16(unsigned lds_dst, const void* sbase, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+#define AT_BAR()                                                  \
+    do {                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        __builtin_amdgcn_s_barrier();                             \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        asm volatile("" ::: "memory");                            \
+    } while (0)
+
+__global__ __launch_bounds__(256, 2) void attn_fwd24p_kernel(AttnArgs a) {
+    constexpr int HG = 4, HD = 24, GW = HG * HD, STR = F24_STR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* btab = (float*)(smem + 2 * F24_TILE);          // [4][225] bias x log2(e)
+    long* toks = (long*)(btab + HG * 225);                // [3][64]  (window j lives in slot j % 3)
+    int* labels = (int*)(toks + 3 * 64);                  // [3][65]
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ngrp = a.heads >> 2, wpx = 64 / ngrp;       // workgroups per head group on one XCD (grid = 512 = 8 XCDs x 64)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int hg = slot % ngrp, lg = slot / ngrp;
+    const int Q = a.n_win_total >> 3, R = a.n_win_total & 7;
+    const int w0 = xcd * Q + min(xcd, R) + lg, nwx = Q + (xcd < R ? 1 : 0);
+    const int nmine = lg < nwx ? (nwx - lg + wpx - 1) / wpx : 0;
+    if (nmine == 0) return;
+    for (int i = threadIdx.x; i < HG * 225; i += 256) {
+        const int hh = i / 225, idx = i - hh * 225;
+        btab[i] = a.bias_table[idx * a.heads + hg * HG + hh] * LOG2E;
+    }
+    const int head = hg * HG + wave;
+    const unsigned lds_base = (unsigned)(unsigned long)(lds_void_ptr_a)smem;
+    // one DMA instruction per token row: lane -> (segment q / k / v, 16-byte chunk) of the 36 live slots of a row
+    const int seg = lane / 12, kch = lane - seg * 12;
+    const unsigned voff = (unsigned)((seg * a.C + hg * GW + kch * 8) * 2);
+    const long rowB = (long)3 * a.C * 2;
+    auto set_tokens = [&](int j) {                        // wave 0: window j's token rows and mask labels into slot j % 3
+        if (threadIdx.x < 64) {
+            long tk; int lb;
+            window_token(a, w0 + j * wpx, threadIdx.x, tk, lb);
+            const int sl = j % 3;
+            toks[sl * 64 + threadIdx.x] = tk; labels[sl * 65 + threadIdx.x] = lb;
+            const int l0 = __builtin_amdgcn_readfirstlane(lb);
+            const unsigned long long diff = __ballot(lb != l0);
+            if (threadIdx.x == 0) labels[sl * 65 + 64] = diff != 0ull;
+        }
+    };
+    auto issue = [&](int j) {                             // window j's rows -> tile buffer j & 1 (toks of slot j % 3 published by a barrier)
+        // this wave's 16 rows are wave + 4 r: lane r reads its row's byte offset ONCE, the loop hands them out through v_readlane (a row
+        // at a time through LDS + readfirstlane cost 200 cycles per DMA instruction: 3.2k of a 10k-cycle window)
+        const long off = toks[(j % 3) * 64 + wave + 4 * (lane & 15)] * rowB;
+        const unsigned lo = (unsigned)off, hi = (unsigned)((unsigned long)off >> 32);
+        const unsigned dst = lds_base + (unsigned)((j & 1) * F24_TILE + wave * STR);
+        if (lane < 36) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long sb = ((unsigned long)(unsigned)__builtin_amdgcn_readlane((int)hi, r) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, r);
+                attn_dma16(dst + (unsigned)(4 * r * STR), (const char*)a.qkv + sb, voff);
+            }
+        }
+    };
+    set_tokens(0);
+    if (nmine > 1) set_tokens(1);
+    AT_BAR();
+    issue(0);
+    if (nmine > 1) issue(1);
+    const bool want_lse = a.lse != nullptr;
+    const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.x < 64;      // (diagnostic) [workgroup < 64][window < 8][8] s_memtime
+    for (int kx = 0; kx < nmine; ++kx) {
+        if (stamp && kx < 8) a.dbg[(blockIdx.x * 8 + kx) * 8 + 0] = __builtin_amdgcn_s_memtime();
+        // window kx's rows have landed. Younger in this wave's queue: the stores of window kx - 1 (3 + 2 with lse), then the 16 DMAs of kx + 1
+        if (kx + 1 >= nmine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kx == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (want_lse) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+        AT_BAR();
+        if (stamp && kx < 8) a.dbg[(blockIdx.x * 8 + kx) * 8 + 1] = __builtin_amdgcn_s_memtime();
+        if (kx + 2 < nmine) set_tokens(kx + 2);           // slot (kx + 2) % 3 = (kx - 1) % 3: window kx - 1 is finished
+        char* tile = smem + (kx & 1) * F24_TILE;
+        const long* tk = toks + (kx % 3) * 64;
+        attn_fwd_head<bf16_t>(a, tile, STR, btab, labels + (kx % 3) * 65, tk, GW, wave, head, HD, lane);
+        if (stamp && kx < 8) a.dbg[(blockIdx.x * 8 + kx) * 8 + 2] = __builtin_amdgcn_s_memtime();
+        AT_BAR();                                         // the four heads' outputs are in the tile (and the tokens of window kx + 2 in their slot)
+        if (stamp && kx < 8) a.dbg[(blockIdx.x * 8 + kx) * 8 + 3] = __builtin_amdgcn_s_memtime();
+        window_copy<bf16_t, false>(tile, STR, (bf16_t*)a.out, a.C, hg * GW, 0, GW, tk);
+        if (stamp && kx < 8) a.dbg[(blockIdx.x * 8 + kx) * 8 + 4] = __builtin_amdgcn_s_memtime();
+        AT_BAR();                                         // every wave has read its chunks of the tile: the buffer is free
+        if (kx + 2 < nmine) issue(kx + 2);
+        if (stamp && kx < 8) a.dbg[(blockIdx.x * 8 + kx) * 8 + 5] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // one 32 x 32 tile: acc = A[ta*32 + row][dims] . B[tb*32 + col][dims]^T (rows in registers, cols = lanes)
@@ -982,7 +1099,6 @@ int check_args(const char* who, int B, int res, int C, int heads, int shift) {
 
 }  // namespace
 
-static unsigned long long* g_attn_dbg = nullptr;
 extern "C" void pseld_attn_set_debug_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; }
 
 extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, float* lse, int B, int res,
@@ -997,7 +1113,14 @@ extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bi
     hipStream_t s = (hipStream_t)stream;
     const int hgv = attn_hg(dtype);
     dim3 grid((unsigned)(a.n_win_total * pseld_cdiv(heads, hgv)));
-    if (dtype == PSELD_BF16) {
+    // PSELD_ATTN_FWD_P=0: the one-window kernel for every shape (in-process A/B; both give the same bits)
+    const char* ep = getenv("PSELD_ATTN_FWD_P");
+    if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && 64 % (heads / 4) == 0 && !(ep && ep[0] == '0')) {
+        static bool attr_p = false;
+        if (!attr_p) { (void)hipFuncSetAttribute((const void*)attn_fwd24p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD24P_LDS); attr_p = true; }
+        a.dbg = g_attn_dbg;
+        hipLaunchKernelGGL(attn_fwd24p_kernel, dim3(512), dim3(256), FWD24P_LDS, s, a);
+    } else if (dtype == PSELD_BF16) {
         if (hgv == 4) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(256), fwd_lds<bf16_t>(a.hd, 4), s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 2>), grid, dim3(128), fwd_lds<bf16_t>(a.hd, 2), s, a);
     } else if (dtype == PSELD_F32) {
