@@ -157,15 +157,25 @@ class KernelTimer:
         return agg
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel family from the PMC counters. Counters cannot be read from inside
-    this process: the figure is the one measured with rocprofv3 on this same command (two separate --pmc passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/."""
-    path = os.path.join(ROOT, 'profiles', 'r04_dominant_kernel_pmc.json')
-    if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks or not os.path.exists(path):
+def pmc_traffic(args, sym=None):
+    """HBM bytes per launch of the dominant kernel from the PMC counters. Counters cannot be read from inside this process: the figure is the
+    one measured with rocprofv3 on this same command (separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
+    reduced per launch of one kernel symbol by tools/pmc_kernel.py and committed under profiles/r04_pmc/ - one file per symbol that has led
+    the step (two instantiations of the eight-phase kernel are within 2 % of each other and trade places between runs)."""
+    if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks:
         return None
-    with open(path) as f:
-        return json.load(f)
+    cands = []
+    if sym:
+        cands.append(os.path.join(ROOT, 'profiles', 'r04_pmc', 'pmc_' + ''.join(c if c.isalnum() else '_' for c in sym) + '.json'))
+    cands.append(os.path.join(ROOT, 'profiles', 'r04_dominant_kernel_pmc.json'))
+    for path in cands:
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            if sym is None or d.get('kernel') == sym:
+                d['_path'] = os.path.relpath(path, ROOT)
+                return d
+    return None
 
 
 def cpu_baseline(chunks=4, steps=3, threads=None):
@@ -508,7 +518,7 @@ def main():
             gbs = nb / (tms * 1e-3) / 1e9
             # which ceiling binds this symbol's launches: their aggregate arithmetic intensity against the ridge (peak flops / peak bytes)
             hbm = (fl / nb) < (PEAK_FLOPS * 1e12) / (PEAK_HBM_GBS * 1e9)
-            pmc = pmc_traffic(args) or {}
+            pmc = pmc_traffic(args, sym) or {}
             same = pmc.get('kernel') == sym
             out["roofline"] = {"bound": "hbm" if hbm else "mfma", "kernel": sym,
                                "measured": "kernel alone: the instrumented steps keep the weight gradients on the main stream (PSELD_WGRAD_STREAM=0)",
@@ -525,7 +535,7 @@ def main():
                                "traffic": round(pmc['traffic_bytes_per_launch'], 1) if same else None,
                                "mfma_busy": pmc.get('mfma_busy') if same else None,
                                "rocprof_avg_launch_ms": pmc.get('rocprof_avg_launch_ms') if same else None,
-                               "pmc_source": ("profiles/r04_dominant_kernel_pmc.json (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
+                               "pmc_source": (pmc.get('_path', '') + " (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
                                               "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes over this command)") if same else None}
         if gem:
             tms, n, fl, nb, roof_ms, mfma_bound_ms = gem[0]

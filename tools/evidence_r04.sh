@@ -16,6 +16,8 @@ run bench_einv2_chunks32 --backbone htsat_einv2 --chunks 32 --steps 50 --warmup 
 # same-box A/B lines of the round's kernels
 PSELD_GEMM8=0 PSELD_WGRAD8=0 run bench_n1_round3_gemms --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 PSELD_GEMM8=0 run bench_n1_gemm8_off --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
+PSELD_GEMM8_MINK=384 run bench_n1_gemm8_k384_only --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
+PSELD_ATTN_FWD_P=0 run bench_n1_attn_fwd_one_window --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 PSELD_WGRAD8=0 run bench_n1_wgrad8_off --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 PSELD_WGRAD_GROUP=99 run bench_n1_wgrad_grouped_per_stage --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 PSELD_FUSED_MLP=96,192 run bench_n1_fused_mlp_96_192 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
@@ -33,10 +35,13 @@ cd $R
 DOM=$(python3 -c "import json;print(json.load(open('gpurun_out/r04/bench_n1.json'))['roofline']['kernel'])")
 echo "dominant symbol: $DOM"
 python3 tools/pmc_kernel.py "$DOM" gpurun_out/r04/pmc_FETCH gpurun_out/r04/pmc_WRITE gpurun_out/r04/pmc_SQ_VA gpurun_out/r04/dominant_kernel_pmc.json | cut -c1-500
-for K in "gemm8_kernel<0, false, 3, false>" "gemm8_kernel<1, true, 3, false>" "gemm8_kernel<3, false, 4, false>" "gemm8w_kernel<3>" "gemm8w_kernel<4>"; do python3 tools/pmc_kernel.py "$K" gpurun_out/r04/pmc_FETCH gpurun_out/r04/pmc_WRITE gpurun_out/r04/pmc_SQ_VA "gpurun_out/r04/pmc_$(echo $K | tr -c 'a-zA-Z0-9' '_').json" | cut -c1-400; done
+for K in "gemm8_kernel<0, false, 3, false>" "gemm8_kernel<1, true, 3, false>" "gemm8_kernel<0, false, 4, false>" "gemm8_kernel<3, false, 4, false>" "gemm8_kernel<2, true, 4, false>" "gemm8w_kernel<3>" "gemm8w_kernel<4>" "attn_fwd24p_kernel" "attn_bwd24_kernel<false>"; do python3 tools/pmc_kernel.py "$K" gpurun_out/r04/pmc_FETCH gpurun_out/r04/pmc_WRITE gpurun_out/r04/pmc_SQ_VA "gpurun_out/r04/pmc_$(printf %s "$K" | tr -c 'a-zA-Z0-9' '_').json" | cut -c1-400; done
 python3 tools/pmc_stages.py gpurun_out/r04/pmc_FETCH gpurun_out/r04/pmc_WRITE 3 gpurun_out/r04/stage_table.json | tail -40
 python3 tools/pmc_feature.py gpurun_out/r04/feat_sq gpurun_out/r04/pmc_feature.json
-python3 tools/gemm8_check.py square shapes > gpurun_out/r04/gemm8_shapes.log 2>&1; tail -20 gpurun_out/r04/gemm8_shapes.log
+STAGES=1,2,3 python3 tools/gemm8_check.py square shapes > gpurun_out/r04/gemm8_shapes.log 2>&1; tail -28 gpurun_out/r04/gemm8_shapes.log
+CHUNKS=32 STAGES=1,2,3 python3 tools/gemm8_check.py shapes > gpurun_out/r04/gemm8_shapes_chunks32.log 2>&1; tail -1 gpurun_out/r04/gemm8_shapes_chunks32.log
+python3 tools/attn_fwd_ab.py > gpurun_out/r04/attn_fwd_ab.log 2>&1; grep -c True gpurun_out/r04/attn_fwd_ab.log; grep -E "us|False" gpurun_out/r04/attn_fwd_ab.log
+python3 tools/attn_fwd_stamps.py > gpurun_out/r04/attn_fwd_stamps.log 2>&1; python3 tools/attn_bench.py > gpurun_out/r04/attn_bench.log 2>&1; python3 tools/membw.py > gpurun_out/r04/membw.log 2>&1; tail -4 gpurun_out/r04/attn_bench.log gpurun_out/r04/membw.log
 python3 tools/wgrad8_check.py shapes group > gpurun_out/r04/wgrad8_shapes.log 2>&1; tail -12 gpurun_out/r04/wgrad8_shapes.log
 python3 tools/gemm8_stamps.py > gpurun_out/r04/gemm8_stamps.log 2>&1
 python3 tools/mlp_bench.py --rounds 3 > gpurun_out/r04/mlp_bench.log 2>&1; python3 tools/feature_bench.py > gpurun_out/r04/feature_bench.log 2>&1; CHUNKS=192 python3 tools/gemm_shapes.py > gpurun_out/r04/gemm_shapes.log 2>&1

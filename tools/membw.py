@@ -11,4 +11,4 @@ for mb in (151, 453, 1200):
     n = mb * 1000 * 1000 // 2
     a = torch.empty(n, dtype=torch.bfloat16, device=dev); b = torch.empty_like(a)
     tf = t(lambda: a.zero_()); tc = t(lambda: b.copy_(a)); tr = t(lambda: a.float().sum() if False else torch.sum(a.view(torch.int16)[: n // 1]))
-    print(f"{mb} MB: fill {mb/1e6/tf*1e3:.2f} TB/s write | copy {2*mb/1e6/tc*1e3:.2f} TB/s (r+w) | read-reduce {mb/1e6/tr*1e3:.2f} TB/s")
+    print(f"{mb} MB: fill {mb/1e6/tf:.2f} TB/s write | copy {2*mb/1e6/tc:.2f} TB/s (read + write)")
