@@ -96,7 +96,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     // flight at every wait (B-h1 is NB1 instructions per wave, the others two): every load has five phases to land (three with the
     // single wait per K-tile of the guide's template - too few for operands that come from HBM rather than L2).
     // Measured and NOT adopted: L2 touches of the next tile's A block a whole epilogue ahead of its LDS-DMA (stage-2 qkv forward 53.0 -> 58.1 us
-    // against 60.8 -> 64.7 for the 128 x 192 kernel in the same process, K loop 3 512 -> 3 657 cycles per K-tile); letting the stores of an
+    // against 60.8 -> 64.7 for the 128 x 192 kernel in the same process, K loop 3 512 -> 3 657 cycles per K-tile), and a touch cursor running 2 / 4
+    // K-tiles ahead of the LDS-DMA cursor through the whole stream, measured with COLD operands (tools/gemm8_check.py COLD=1: every launch reads
+    // buffers the memory-side cache has not seen, as in the step): stage 2 + 3 forward + input gradient 4.13 -> 4.45 / 4.51 ms per step; letting the stores of an
     // epilogue stay outstanding over two more waits (no change); one extra barrier per wave group so that the two groups' epilogues run side
     // by side instead of one after the other (no change: the epilogue is paced by the CU's vector-memory path, which the groups share).
     constexpr int VM_P4 = 6 + 2 * NB1, VM_P1 = 8 + NB1, VM_P2 = 8 + NB1;

@@ -110,10 +110,19 @@ if 'shapes' in what:
             x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt); b = torch.randn(N, device=dev)
             extra = torch.randn(M, N, device=dev).to(dt)
             rs = (torch.rand(M // rps, device=dev) + 0.5) if scaled else None
+            # COLD=1: every launch reads operands no earlier launch of the loop touched (the step's situation: the 256 MB memory-side cache holds
+            # nothing of a layer's input when the layer starts; the same buffers ten times in a row are served from it)
+            nrot = max(1, int(os.environ.get('COLD', '0')) * (1 + int(1.6e9 // (2 * (M * K + M * N)))))
+            xs = [x] + [x.clone() for _ in range(nrot - 1)]; es = [extra] + [extra.clone() for _ in range(nrot - 1)]
+            ctr = [0]
+
+            def one(on):
+                i = ctr[0] % nrot; ctr[0] += 1
+                return run(mode, xs[i], w, b, es[i], rs, rps, on, cat=False)
             t = {}
             for rnd in range(3):
                 for on in (256, 192, True, False):
-                    t.setdefault(on, []).append(timeit(lambda: run(mode, x, w, b, extra, rs, rps, on, cat=False), 10))
+                    t.setdefault(on, []).append(timeit(lambda: one(on), 10))
             fl = 2.0 * M * N * K
             for on in t: tot[on] += min(t[on]) * nblk
             print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: " + " | ".join(f"{lbl} {min(t[k]):6.1f} us {fl / min(t[k]) / 1e6:5.0f} TF" for k, lbl in
