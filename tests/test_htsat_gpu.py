@@ -592,6 +592,49 @@ def test_bench_size_backward_additivity(dev):
     assert tot < 2e-5 and worst[1] < 2e-4, (tot, worst)
 
 
+def test_bench_size_step_is_bit_reproducible(dev):
+    """Race screen at the BASELINE workload (full HTS-AT, bf16, 192 chunks, train mode, drop_path 0.1): forward + backward repeated on the
+    same weights, inputs and DropPath masks. Every kernel runs at its production geometry (persistent GEMMs and attention with hand-counted
+    vmcnt over LDS-DMA queues, weight gradients on the side stream); all they produce is deterministic by construction except the
+    relative-position bias-table gradients (fp32 atomics): outputs and every other gradient must not differ in a single bit
+    (tools/step_determinism.py is the long version)."""
+    from pseldnets_amd import ops
+    from pseldnets_amd.models import multi_accdoa
+    torch.manual_seed(11)
+    net = multi_accdoa.HTSAT(CFG, 170, 7, pretrained_path=None, **kw(dict(FULL, drop_path_rate=0.1)))
+    net.compute_dtype = torch.bfloat16
+    net.to(dev)
+    Bt = 192
+    gcpu = torch.Generator().manual_seed(5)
+    x = torch.randn(Bt, 7, 1001, 64, generator=gcpu).to(dev)
+    act = (torch.rand(Bt, 100, 170, generator=gcpu) < 0.02).float()
+    lab = torch.zeros(Bt, 100, 6, 4, 170)
+    lab[:, :, 0, 0] = act
+    lab[:, :, 0, 1:] = torch.nn.functional.normalize(torch.randn(Bt, 100, 3, 170, generator=gcpu), dim=2) * act.unsqueeze(2)
+    lab = lab.to(dev)
+    net._materialize(dev)
+    atomics = [n for n in net.arena.entries if 'relative_position_bias_table' in n]
+    assert atomics
+    ref = None
+    for _ in range(6):
+        torch.manual_seed(123)
+        y, saved = net._forward_impl(x, True)
+        _, dpred = ops.adpit_loss(y, lab)
+        net.zero_grad_arena()
+        net._backward_impl(saved, (dpred,))
+        torch.cuda.synchronize()
+        g = net.arena.grad.clone()
+        del saved
+        for n in atomics:
+            net.arena.view(g, n).zero_()
+        if ref is None:
+            ref = (y.clone(), g)
+            assert torch.isfinite(g).all() and g.norm().item() > 0
+        else:
+            assert torch.equal(y, ref[0]), "network output differs between identical passes"
+            assert torch.equal(g, ref[1]), "parameter gradients differ between identical passes"
+
+
 def _default_init_net(dev, dtype, seed=21):
     from pseldnets_amd.models import multi_accdoa
     torch.manual_seed(seed)
