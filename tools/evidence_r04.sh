@@ -40,6 +40,8 @@ python3 tools/pmc_stages.py gpurun_out/r04/pmc_FETCH gpurun_out/r04/pmc_WRITE 3 
 python3 tools/pmc_feature.py gpurun_out/r04/feat_sq gpurun_out/r04/pmc_feature.json
 STAGES=1,2,3 python3 tools/gemm8_check.py square shapes > gpurun_out/r04/gemm8_shapes.log 2>&1; tail -28 gpurun_out/r04/gemm8_shapes.log
 CHUNKS=32 STAGES=1,2,3 python3 tools/gemm8_check.py shapes > gpurun_out/r04/gemm8_shapes_chunks32.log 2>&1; tail -1 gpurun_out/r04/gemm8_shapes_chunks32.log
+COLD=1 STAGES=1,2,3 python3 tools/gemm8_check.py shapes > gpurun_out/r04/gemm8_shapes_cold.log 2>&1; tail -1 gpurun_out/r04/gemm8_shapes_cold.log
+python3 tools/step_determinism.py 20 > gpurun_out/r04/step_determinism.log 2>&1; tail -1 gpurun_out/r04/step_determinism.log
 python3 tools/attn_fwd_ab.py > gpurun_out/r04/attn_fwd_ab.log 2>&1; grep -c True gpurun_out/r04/attn_fwd_ab.log; grep -E "us|False" gpurun_out/r04/attn_fwd_ab.log
 python3 tools/attn_fwd_stamps.py > gpurun_out/r04/attn_fwd_stamps.log 2>&1; python3 tools/attn_bench.py > gpurun_out/r04/attn_bench.log 2>&1; python3 tools/membw.py > gpurun_out/r04/membw.log 2>&1; tail -4 gpurun_out/r04/attn_bench.log gpurun_out/r04/membw.log
 python3 tools/wgrad8_check.py shapes group > gpurun_out/r04/wgrad8_shapes.log 2>&1; tail -12 gpurun_out/r04/wgrad8_shapes.log
