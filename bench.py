@@ -472,7 +472,7 @@ def main():
         "value_at_median_step": round(clips_per_step * world / (median_ms * 1e-3), 2),
         "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1), "comm_backend": backend if world > 1 else None,
         "hip_graph": bool(use_graph and trainer._graph is not None),      # the timed steps were replays of one captured hipGraph
-        "wgrad_side_stream": os.environ.get('PSELD_WGRAD_STREAM', '1') == '1' and args.backbone.startswith('htsat'),
+        "wgrad_side_stream": ops_mod._wgrad_stream['on'] and args.backbone.startswith('htsat'),
         # every timed step issues ONE feature extraction - that of the next step's batch, on a second stream (the pipeline a loader with
         # one batch of look-ahead gives); the step itself consumes the extraction issued by its predecessor
         "feature_prefetch": bool(prefetch and args.augment == 'none'),
@@ -496,7 +496,7 @@ def main():
         # ... and on ONE stream: in the timed region the weight gradients run on a second stream beside the main chain
         # (htsat.py:_wgrad), where a kernel's duration includes the time it shares the CUs with another kernel - the per-kernel
         # roofline below is that of the kernel running alone (rocprofv3 of `PSELD_WGRAD_STREAM=0 PSELD_FEATURE_PREFETCH=0 python3 bench.py` agrees with it)
-        os.environ['PSELD_WGRAD_STREAM'] = '0'
+        ops_mod.set_wgrad_stream(False)
         prefetch = False
         trainer._prefetched = None
         for _ in range(2):

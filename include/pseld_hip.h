@@ -140,6 +140,14 @@ void pseld_gemm_set_debug_buffer(void* device_buffer);
 /* The same for the persistent eight-phase kernel (csrc/gemm8.hip: the products with K >= 192): u64 [workgroup][wave group 0/1][tile < 16][4]
  * = s_memtime at (tile start, K loop done, epilogue done) + s_memrealtime; a diagnostic instantiation runs while a buffer is installed. */
 void pseld_gemm8_set_debug_buffer(void* device_buffer);
+/* Routing knobs: the A/B switches of the measurement tools and tests (list: csrc/common.h PSELD_KNOB_LIST, e.g. "GEMM8", "WGRAD8",
+ * "ATTN_FWD_P"; the "PSELD_" prefix is optional). Every knob has a frozen default; the environment variable PSELD_<NAME> is read once per
+ * process, when the library first asks for a knob, and these two calls change one afterwards. Returns PSELD_ERR_BAD_ARG for unknown names. */
+int pseld_set_knob(const char* name, int value);
+int pseld_unset_knob(const char* name);
+/* Measurement / test aid: force the tile shape of the eight-phase kernel for the following pseld_gemm calls (rows 256 | 128, columns
+ * 256 | 192; 0 = the launch's own choice by grid fill). All four shapes sum K in the same order and give the same bits. */
+void pseld_gemm8_force_tile(int rows, int cols);
 /* Measurement aid: symbol of the kernel the last pseld_gemm / pseld_gemm_wgrad call of this process launched. */
 const char* pseld_gemm_last_kernel(void);
 

@@ -81,6 +81,14 @@ def lib():
     return _lib
 
 
+def set_knob(name, value):
+    """Routing knob of the library (include/pseld_hip.h pseld_set_knob; csrc/common.h lists them): value None = back to the frozen
+    default. The environment is read once per process, so tests and tools that switch kernels in-process go through here."""
+    L = lib()
+    rc = L.pseld_unset_knob(name.encode()) if value is None else L.pseld_set_knob(name.encode(), int(value))
+    check(rc, f"set_knob({name})")
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().pseld_last_error().decode("utf-8", "replace")

@@ -33,9 +33,7 @@ namespace {
 // heads per workgroup (= waves per workgroup): 4 or 2 for bf16 (PSELD_ATTN_HG, default 4), 2 for f32 (LDS budget)
 static int attn_hg(int dtype) {
     if (dtype != PSELD_BF16) return 2;
-    static int v = 0;
-    if (!v) { const char* e = getenv("PSELD_ATTN_HG"); v = (e && atoi(e) == 2) ? 2 : 4; }
-    return v;
+    return pseld_knob(KNOB_ATTN_HG, 4) == 2 ? 2 : 4;
 }
 
 
@@ -1114,8 +1112,7 @@ extern "C" int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bi
     const int hgv = attn_hg(dtype);
     dim3 grid((unsigned)(a.n_win_total * pseld_cdiv(heads, hgv)));
     // PSELD_ATTN_FWD_P=0: the one-window kernel for every shape (in-process A/B; both give the same bits)
-    const char* ep = getenv("PSELD_ATTN_FWD_P");
-    if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && 64 % (heads / 4) == 0 && !(ep && ep[0] == '0')) {
+    if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && 64 % (heads / 4) == 0 && pseld_knob(KNOB_ATTN_FWD_P, 1) != 0) {
         static bool attr_p = false;
         if (!attr_p) { (void)hipFuncSetAttribute((const void*)attn_fwd24p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD24P_LDS); attr_p = true; }
         a.dbg = g_attn_dbg;
@@ -1163,24 +1160,23 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     // tile per wave per workgroup) stays a small fraction of the traffic. PSELD_ATTN_HG / PSELD_ATTN_BWD_WGS: experiment knobs (tools/attn_bench.py).
     // (bf16: always two heads per workgroup since the image swizzle shortened the compute phase - with four heads, one workgroup per
     //  CU, nothing covers its window loads: stage 0 ~1 % faster, same-box A/B 493 / 488 against 486 / 483 us)
-    const int hgv = (dtype == PSELD_BF16 && !getenv("PSELD_ATTN_HG")) ? 2 : attn_hg(dtype);
+    const int hgv = (dtype == PSELD_BF16 && !pseld_knob_is_set(KNOB_ATTN_HG)) ? 2 : attn_hg(dtype);
     const int nhg = pseld_cdiv(heads, hgv);
-    const char* es = getenv("PSELD_ATTN_BWD_WGS");                  // experiment knob: total workgroups of the persistent loop
-    int slots = (es ? atoi(es) : (hgv == 4 ? 256 : 512)) / nhg;
+    const int es = pseld_knob(KNOB_ATTN_BWD_WGS, 0);               // experiment knob: total workgroups of the persistent loop
+    int slots = (es ? es : (hgv == 4 ? 256 : 512)) / nhg;
     if (slots > a.n_win_total) slots = a.n_win_total;
     if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);
-    static int v2 = -1;
-    if (v2 < 0) { const char* e = getenv("PSELD_ATTN_BWD_V2"); v2 = !(e && atoi(e) == 0); }
-    {   // timing-experiment knob, read once; a result-changing value is refused unless PSELD_ALLOW_WRONG_RESULTS=1 says it is a timing run
-        static const int variant = [] { const char* e = getenv("PSELD_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-        static const bool allowed = [] { const char* e = getenv("PSELD_ALLOW_WRONG_RESULTS"); return e && e[0] == '1'; }();
+    const int v2 = pseld_knob(KNOB_ATTN_BWD_V2, 1) != 0;
+    {   // timing-experiment knob; a result-changing value is refused unless PSELD_ALLOW_WRONG_RESULTS=1 says it is a timing run
+        const int variant = pseld_knob(KNOB_ATTN_VARIANT, 0);
+        const bool allowed = pseld_knob(KNOB_ALLOW_WRONG_RESULTS, 0) == 1;
         PSELD_CHECK_ARG(variant == 0 || allowed, "window_attn_bwd: PSELD_ATTN_VARIANT=%d changes the results (timing experiments only; set PSELD_ALLOW_WRONG_RESULTS=1)", variant);
         a.variant = variant;
     }
     if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && v2) {
         // one wave per head, four heads per workgroup, two workgroups per CU, persistent
-        int sl = (es ? atoi(es) : 512) / (heads / 4);
+        int sl = (es ? es : 512) / (heads / 4);
         if (sl > a.n_win_total) sl = a.n_win_total;
         if (sl < 1) sl = 1;
         static bool attr24 = false;

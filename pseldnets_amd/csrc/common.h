@@ -48,6 +48,24 @@ void pseld_set_error(const char* fmt, ...);
 
 static inline int pseld_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- routing knobs ---------------------------------------------------------------------------------
+// The A/B switches of the measurement tools and tests. Every knob has a FROZEN default in the code that asks for it (the routing the
+// committed numbers were measured with). The environment (PSELD_<NAME>) is read ONCE per process, at the first query of any knob
+// (runtime.hip), and pseld_set_knob() / pseld_unset_knob() change one in-process (tests, tools). No launch path calls getenv: which
+// kernel a layer gets is fixed when the library is loaded, and a query is an array read.
+#define PSELD_KNOB_LIST(X)                                                                                                            \
+    X(ATTN_HG) X(ATTN_FWD_P) X(ATTN_BWD_WGS) X(ATTN_BWD_V2) X(ATTN_VARIANT) X(ALLOW_WRONG_RESULTS) X(GRU_BWD_UNITS) X(GEMM_XCD)       \
+    X(GEMM_BIG) X(WGRAD_TILE) X(GEMM8) X(GEMM8_MINK) X(GEMM_DMA) X(GEMM_FWD_RING) X(GEMM_RING3) X(WGRAD_FILL) X(WGRAD_MINTOK)         \
+    X(WGRAD_RING) X(WGRAD8_MINN) X(WGRAD8) X(GEMM8_BN) X(GEMM8_BM) X(GEMM8W_BN) X(GEMM8W_INKERNEL_REDUCE) X(MLP_VARIANT)
+enum PseldKnob {
+#define PSELD_KNOB_ENUM(n) KNOB_##n,
+    PSELD_KNOB_LIST(PSELD_KNOB_ENUM)
+#undef PSELD_KNOB_ENUM
+    KNOB_COUNT
+};
+int pseld_knob(PseldKnob k, int dflt);       // the value the environment / pseld_set_knob gave the knob, dflt when it is unset
+bool pseld_knob_is_set(PseldKnob k);
+
 // ---- element conversion -------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -1093,7 +1093,7 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 static void gru_bwd_launch(const GruMultiArgs& m, int H, int cnt, hipStream_t s) {
     // measured: 8 units per workgroup win while the launch is short of workgroups (one or two recurrences), 32 once many recurrences
     // share it (every workgroup re-reads the [B, 3H] gate-gradient block: 12 x 128 workgroups of 8 units are slower than 12 x 32 of 32)
-    static const int forced = [] { const char* e = getenv("PSELD_GRU_BWD_UNITS"); return e ? atoi(e) : 0; }();
+    const int forced = pseld_knob(KNOB_GRU_BWD_UNITS, 0);
     const int ub = forced ? forced : (cnt <= 2 ? 8 : 32);
     if (ub == 32) hipLaunchKernelGGL(gru_step_bwd_kernel<32>, dim3(H / 32, cnt), dim3(512), 0, s, m);
     else if (ub == 16) hipLaunchKernelGGL(gru_step_bwd_kernel<16>, dim3(H / 16, cnt), dim3(512), 0, s, m);

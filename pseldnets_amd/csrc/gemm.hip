@@ -1020,8 +1020,7 @@ static int launch_gemm_fwd_ring(const GemmArgs& g, hipStream_t stream) {
 
 // PSELD_GEMM_XCD: bit 0 = swizzle forward / input-gradient launches, bit 1 = swizzle weight-gradient launches
 static int gemm_xcd_mode(bool wgrad) {
-    const char* e = getenv("PSELD_GEMM_XCD");
-    const int v = e ? atoi(e) : 3;
+    const int v = pseld_knob(KNOB_GEMM_XCD, 3);
     return wgrad ? (v >> 1) & 1 : v & 1;
 }
 
@@ -1238,9 +1237,7 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
 }
 
 static int gemm_big_tiles() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PSELD_GEMM_BIG"); v = e ? atoi(e) : 1; }
-    return v;
+    return pseld_knob(KNOB_GEMM_BIG, 1);
 }
 
 template <typename T, typename OutT, bool TA, bool TB, bool CONV = false>
@@ -1249,8 +1246,7 @@ int dispatch_tile(const GemmArgs& g, int splits, hipStream_t stream) {
     if (g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288))
         return launch_gemm<T, OutT, 4, 1, TA, TB, CONV>(g, splits, stream);
     if (sizeof(T) == 2 && TA && g.M >= 256) {
-        const char* e = getenv("PSELD_WGRAD_TILE");          // experiment knob: 22 / 42
-        const int force = e ? atoi(e) : 0;
+        const int force = pseld_knob(KNOB_WGRAD_TILE, 0);          // experiment knob: 22 / 42
         if (force == 42 || (force == 0 && gemm_big_tiles()))
             return launch_gemm<T, OutT, 4, 2, TA, TB, CONV>(g, splits, stream);   // weight gradient: 256x192, 8 waves (measured +4 %)
     }
@@ -1426,12 +1422,9 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
     }
     // Products with K >= 192 (stages 1-3, merges, head): the persistent eight-phase kernel of gemm8.hip (at K = 192 its whole-line epilogue
     // is what wins: stage-1 qkv 96 -> 84 us, fc1 + GELU pair 200 -> 170 us against the 128 x 192 kernel).
-    // PSELD_GEMM8=0 disables it, PSELD_GEMM8_MINK=<K> moves the threshold (both read per call: in-process A/B)
+    // PSELD_GEMM8=0 disables it, PSELD_GEMM8_MINK=<K> moves the threshold (knobs, common.h)
     if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && (epi & ~(EPI_BIAS | EPI_RESID | EPI_MULAUX | EPI_GELU_DUAL)) == 0) {
-        const char* e8 = getenv("PSELD_GEMM8");
-        const char* ek = getenv("PSELD_GEMM8_MINK");
-        const int mink = ek ? atoi(ek) : 192;
-        if (!(e8 && e8[0] == '0') && K >= mink) {
+        if (pseld_knob(KNOB_GEMM8, 1) != 0 && K >= pseld_knob(KNOB_GEMM8_MINK, 192)) {
             Gemm8Desc d;
             d.A = A; d.B = B; d.C = C; d.C2 = (epi & EPI_GELU_DUAL) ? c2 : nullptr;
             d.bias = (epi & EPI_BIAS) ? bias : nullptr; d.resid = (epi & EPI_RESID) ? resid : nullptr;
@@ -1446,16 +1439,15 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
         }
     }
     if (dtype == PSELD_BF16 && !trans_a && !trans_b && pro == 0 && K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0 && M >= 128) {
-        const char* e = getenv("PSELD_GEMM_DMA");
-        if (!(e && e[0] == '0')) {
+        if (pseld_knob(KNOB_GEMM_DMA, 1) != 0) {
             const bool narrow = g.N <= 96 || (g.N % 192 != 0 && g.N % 96 == 0 && g.N <= 288);
             if (narrow && K < 384) return launch_gemm_dma<4, 1>(g, s);     // 256x96 with a long K loop: gemm_kernel is faster
             if (!narrow) {
-                // long contractions: the 256 x 192 ring kernel (PSELD_GEMM_FWD_RING=<K threshold>, 0 = never; read per call for in-process A/B)
-                { const char* er = getenv("PSELD_GEMM_FWD_RING"); const int kth = er ? atoi(er) : 3072;
+                // long contractions: the 256 x 192 ring kernel (PSELD_GEMM_FWD_RING=<K threshold>, 0 = never)
+                { const int kth = pseld_knob(KNOB_GEMM_FWD_RING, 3072);
                   if (kth > 0 && K >= kth && M >= 2048) return launch_gemm_fwd_ring(g, s); }
                 // PSELD_GEMM_RING3=<K>: 3-stage ring at two workgroups per CU (4 slices in flight per CU instead of 3) for K >= <K>
-                const int ring_k = [] { const char* e = getenv("PSELD_GEMM_RING3"); return e ? atoi(e) : 0; }();
+                const int ring_k = pseld_knob(KNOB_GEMM_RING3, 0);
                 if (ring_k > 0 && K >= ring_k) return launch_gemm_dma<2, 2, 3>(g, s);
                 return launch_gemm_dma<2, 2>(g, s);
             }
@@ -1520,13 +1512,11 @@ extern "C" int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt,
 // divided by the number of output tiles, so no CU idles and there is no tail round; at least 512 tokens per split
 // keeps the fp32 slab traffic small.
 static int wgrad_fill_percent() {
-    const char* e = getenv("PSELD_WGRAD_FILL");
-    const int t = e ? atoi(e) : 100;
+    const int t = pseld_knob(KNOB_WGRAD_FILL, 100);
     return t < 10 ? 100 : t;
 }
 static int wgrad_min_tokens() {
-    const char* e = getenv("PSELD_WGRAD_MINTOK");
-    const int t = e ? atoi(e) : 512;
+    const int t = pseld_knob(KNOB_WGRAD_MINTOK, 512);
     return t < 64 ? 512 : t;
 }
 static int wgrad_splits_for(int dtype, int Mtok, int N, int K) {
@@ -1550,7 +1540,7 @@ static int wgrad_splits_for(int dtype, int Mtok, int N, int K) {
 // The ring kernel (gemm_wgrad_ring_kernel) takes the large bf16 weight gradients: returns its M-tile count in 32-row units
 // (3: 384 x 192 tile, 2: 256 x 192) and the split count, or 0 when the register-staged kernel keeps the shape.
 static int wgrad_ring_plan(int dtype, int Mtok, int N, int K, int gelu_on_x, int rows_per_scale, bool has_rowscale, int* splits_out) {
-    const int enabled = [] { const char* e = getenv("PSELD_WGRAD_RING"); return e ? atoi(e) : 1; }();   // (read per call: in-process A/B)
+    const int enabled = pseld_knob(KNOB_WGRAD_RING, 1);
     if (!enabled || dtype != PSELD_BF16 || gelu_on_x || Mtok % 32 != 0 || N % 8 != 0 || K % 8 != 0) return 0;
     if (has_rowscale && rows_per_scale % 32 != 0) return 0;
     if (N < 256 || K < 192 || (long)N * K < 384L * 384) return 0;          // small matrices: the 256x96 / 128x192 tiles waste less
@@ -1571,7 +1561,7 @@ static int wgrad_ring_plan(int dtype, int Mtok, int N, int K, int gelu_on_x, int
     *splits_out = pseld_cdiv(Mtok, kchunk);
     return mt;
 }
-static int gemm8w_min_n() { const char* e = getenv("PSELD_WGRAD8_MINN"); return e ? atoi(e) : 192; }     // (A/B knob, read per call; dW[192, 768] over 196 608 tokens: 102 against 127 us)
+static int gemm8w_min_n() { return pseld_knob(KNOB_WGRAD8_MINN, 192); }     // (dW[192, 768] over 196 608 tokens: 102 against 127 us)
 extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
     const int sa = wgrad_splits_for(PSELD_BF16, Mtok, N, K), sb = wgrad_splits_for(PSELD_F32, Mtok, N, K);
     int sr = 0;
@@ -1600,10 +1590,9 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     PSELD_CHECK_ARG(lddw == K, "gemm_wgrad: dW must be dense [N,K]");
     const long need = pseld_gemm_wgrad_workspace(Mtok, N, K, nullptr);
     PSELD_CHECK_ARG(workspace_bytes >= need, "gemm_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
-    // MFMA-bound weight gradients: the eight-phase kernel of gemm8w.hip (PSELD_WGRAD8=0 disables it; read per call: in-process A/B)
+    // MFMA-bound weight gradients: the eight-phase kernel of gemm8w.hip (PSELD_WGRAD8=0 disables it: knob, common.h)
     if (dtype == PSELD_BF16 && !gelu_on_x && N >= gemm8w_min_n() && K >= 192 && Mtok >= 4096) {
-        const char* e8 = getenv("PSELD_WGRAD8");
-        if (!(e8 && e8[0] == '0')) {
+        if (pseld_knob(KNOB_WGRAD8, 1) != 0) {
             int bn8 = 0, kchunk8 = 0;
             const long per_split = ((long)N * K + N) * (long)sizeof(float);
             const int max_splits = (int)(workspace_bytes / per_split);

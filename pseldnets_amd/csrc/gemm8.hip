@@ -24,6 +24,7 @@
 //    share an A row block run together on one L2.
 #include "gemm8.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -99,12 +100,18 @@ __device__ __forceinline__ void g8_store_nt(bf16_t* p, const G8Piece<PD>& v) {
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// NB = 16-column accumulator blocks per wave: 4 -> 256 x 256 tile (wave 128 x 64), 3 -> 256 x 192 (wave 128 x 48: the second column
-// quadrant is one block wide, B-h1 is a 64-row image, and every N of HTS-AT is a multiple of 192)
-template <int MODE, bool SCALED, int NB, bool DBG = false>
+// NB = 16-column accumulator blocks per wave: 4 -> 256-column tile (wave 128 x 64), 3 -> 192 (wave 128 x 48: the second column
+// quadrant is one block wide, B-h1 is a 64-row image, and every N of HTS-AT is a multiple of 192).
+// MBQ = 16-row accumulator blocks per wave and row quadrant: 4 -> 256-row tile (wave 128 rows), 2 -> 128-row tile (wave 64 rows, the A
+// half images are 64 rows = ONE LDS-DMA instruction per wave). Same K order per output element at every (NB, MBQ): the four tile
+// shapes give the same bits, so the launch may pick by grid fill (under-filled launches: the 32-chunk step, stage 3).
+template <int MODE, bool SCALED, int NB, int MBQ = 4, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     constexpr int WN = NB * 16, BN = 4 * WN;
     constexpr int NB1 = NB - 2;                  // blocks in the second column quadrant
+    constexpr int BM = 64 * MBQ;                 // tile rows
+    constexpr int MBN = 2 * MBQ;                 // 16-row blocks per wave
+    constexpr int MA = MBQ / 2;                  // LDS-DMA instructions per wave and A half image (32 MBQ rows, 8 per instruction and wave)
     // Just-in-time waits: a half-tile is waited for in the phase BEFORE the one that reads it, so the five youngest half-tiles stay in
     // flight at every wait (B-h1 is NB1 instructions per wave, the others two): every load has five phases to land (three with the
     // single wait per K-tile of the guide's template - too few for operands that come from HBM rather than L2).
@@ -114,8 +121,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     // buffers the memory-side cache has not seen, as in the step): stage 2 + 3 forward + input gradient 4.13 -> 4.45 / 4.51 ms per step; letting the stores of an
     // epilogue stay outstanding over two more waits (no change); one extra barrier per wave group so that the two groups' epilogues run side
     // by side instead of one after the other (no change: the epilogue is paced by the CU's vector-memory path, which the groups share).
-    constexpr int VM_P4 = 6 + 2 * NB1, VM_P1 = 8 + NB1, VM_P2 = 8 + NB1;
-    constexpr int NST = MODE == G8_GELU_DUAL ? 32 : 16;      // stores of one epilogue per wave
+    // (instructions per wave behind the awaited half-tile in the in-order queue - A halves MA, B-h0 two, B-h1 NB1:
+    //  phase 4 waits for A-h0(k+1): B-h1(k+1) A-h1(k+1) B-h0(k+2) A-h0(k+2) B-h1(k+2) stay; phase 1 for B-h1(k): A-h1(k) B-h0(k+1) A-h0(k+1)
+    //  B-h1(k+1) A-h1(k+1); phase 2 for A-h1(k): B-h0(k+1) A-h0(k+1) B-h1(k+1) A-h1(k+1) B-h0(k+2))
+    constexpr int VM_P4 = 2 + 2 * MA + 2 * NB1, VM_P1 = 2 + 3 * MA + NB1, VM_P2 = 4 + 2 * MA + NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = (float*)(smem + RING_B);
     // (diagnostic instantiation) real-time stamps of the start-up pieces, and the end of K-tiles 0..7 of this workgroup's SECOND tile
@@ -142,25 +151,31 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     // ---- fragment read addresses (buffer 0): lane reads row l15 of a 16-row block, 16-byte chunk (4 kk + q) ^ ((row >> 1) & 7) ----
     const int sw = (lane >> 1) & 7;
     const unsigned c0 = (unsigned)((q ^ sw) << 4);
-    unsigned ra0 = (unsigned)(wr * 8192 + l15 * 128) + c0, ra1 = ra0 ^ 64;
+    unsigned ra0 = (unsigned)(wr * (MBQ * 2048) + l15 * 128) + c0, ra1 = ra0 ^ 64;                          // A halves: rows wr*16 MBQ + mbl*16 + l15
     unsigned rb0 = (unsigned)(2 * HALF_B + wc * 4096 + l15 * 128) + c0, rb1 = rb0 ^ 64;                       // B-h0: rows wc*32 + nbl*16 + l15
     unsigned rc0 = (unsigned)(3 * HALF_B + wc * (NB1 * 2048) + l15 * 128) + c0, rc1 = rc0 ^ 64;               // B-h1: rows wc*(16 NB1) + nbl*16 + l15
 
     // ---- LDS-DMA source offsets of the load cursor's tile: [half][instruction] ----
-    unsigned offA[2][2], offB[2][2];
+    unsigned offA[2][MA], offB[2][2];
     auto set_tile = [&](int T) {
         const int mblk = T / g.nx, nblk = T - mblk * g.nx;
-        const int m0 = mblk * 256, n0 = nblk * BN;
+        const int m0 = mblk * BM, n0 = nblk * BN;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rho = wave * 16 + j * 8 + (lane >> 3);                  // image row this lane fills
+        for (int j = 0; j < MA; ++j) {
+            const int rho = wave * (8 * MA) + j * 8 + (lane >> 3);            // A image row this lane fills (of 32 MBQ per half)
             const int ch = (lane & 7) ^ ((rho >> 1) & 7);                     // source chunk (swizzle on the source)
-            const int i = rho & 15;
+            const int wq = rho / (16 * MBQ), within = rho - wq * (16 * MBQ);  // wave row group, row inside its half
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int tok = min(m0 + (rho >> 6) * 128 + h * 64 + (rho & 63), g.M - 1);
+                const int tok = min(m0 + wq * (32 * MBQ) + h * (16 * MBQ) + within, g.M - 1);
                 offA[h][j] = (unsigned)tok * (unsigned)(g.lda * 2) + (unsigned)(ch * 16);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rho = wave * 16 + j * 8 + (lane >> 3);                  // B image row this lane fills
+            const int ch = (lane & 7) ^ ((rho >> 1) & 7);
+            const int i = rho & 15;
             // B-h0 (blocks b = nbl) and B-h1 of the 64-column wave tile (b = 2 + nbl): image row wc*32 + nbl*16 + i <- weight row
             // wc*WN + 4 NB (i>>2) + 4 b + (i&3): accumulator row i = 4 q + k of block b is column 4 NB q + 4 b + k of the wave's strip
             const int nb0 = n0 + (rho >> 5) * WN + 4 * NB * (i >> 2) + 4 * ((rho >> 4) & 1) + (i & 3);
@@ -179,10 +194,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     const unsigned dst_w = lds_base + (unsigned)wave * 2048u;
     int ld_i = 0, ld_kt = 0;
     unsigned ld_buf = 0;
+    const unsigned dst_a = lds_base + (unsigned)wave * (unsigned)(1024 * MA);
     auto dmaA = [&](int h) {
         const char* sb = g.A + ld_kt * 128;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) g8_dma(dst_w + ld_buf + (unsigned)(h * HALF_B + j * 1024), sb, offA[h][j]);
+        for (int j = 0; j < MA; ++j) g8_dma(dst_a + ld_buf + (unsigned)(h * HALF_B + j * 1024), sb, offA[h][j]);
     };
     auto dmaB = [&](int h) {
         const char* sb = g.B + ld_kt * 128;
@@ -198,8 +214,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         }
     };
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[NB1][2];
-    f32x4 acc[8][NB];
+    bf16x8 fa[MBQ][2], fb0[2][2], fb1[NB1][2];
+    f32x4 acc[MBN][NB];
 
     auto init_acc = [&](int n0) {
         const float* bp = bias_s + n0 + wc * WN + 4 * NB * q;
@@ -207,12 +223,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(bp + 4 * nb);
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
+        for (int mb = 0; mb < MBN; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = b[nb];
     };
 
-    // Lane (q, l15) holds, for token row m0 + wr*128 + 16 mb + l15, the W = 4 NB consecutive columns n0 + wc*WN + W q + (4 b + k) = acc[mb][b][k].
+    // Lane (q, l15) holds, for token row m0 + wr*(32 MBQ) + 16 mb + l15, the W = 4 NB consecutive columns n0 + wc*WN + W q + (4 b + k) = acc[mb][b][k].
     // The lanes of two adjacent token rows (l15 even / odd: "A" / "B") trade halves: A ends up with columns [W q, W q + W/2) of BOTH rows,
     // B with [W q + W/2, W q + W) of both, so one store instruction writes the even rows of the pairs and one the odd rows - 8 rows x
     // (WN x 2) contiguous bytes each. The residual / aux operand is loaded in the same two-row pattern and traded back before the fp32 math.
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         constexpr int W = 4 * NB, HW = W / 2, PD = HW / 2;        // columns per lane, per piece; dwords per piece
         typedef G8Piece<PD> piece_t;
         const bool isB = (l15 & 1) != 0;
-        const int rown = m0 + wr * 128 + l15;                     // own token row (+ 16 mb)
+        const int rown = m0 + wr * (32 * MBQ) + l15;              // own token row (+ 16 mb)
         const int r1b = rown - (isB ? 1 : 0);                      // the pair's even row (+ 16 mb); the odd one is r1 + 1
         const int cL = n0 + wc * WN + W * q + (isB ? HW : 0);      // this lane's piece of both rows
         const bool colok = cL < g.N;                               // (N % 8 == 0, and N % 192 == 0 where HW = 6: pieces are whole or absent)
@@ -229,13 +245,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         const int mlast = g.M - 1;
         const bf16_t* X = MODE == G8_RESID ? g.resid : g.aux;
         const int ldx = MODE == G8_RESID ? g.ldr : g.ldaux;
-        piece_t x1[HAS_X ? 8 : 1], x2[HAS_X ? 8 : 1];
-        float sc[SCALED ? 8 : 1];
+        piece_t x1[HAS_X ? MBN : 1], x2[HAS_X ? MBN : 1];
+        float sc[SCALED ? MBN : 1];
         // The loads of the epilogue (DropPath factor, residual / aux pieces) are unconditional (clamped addresses) and all consumed inside it:
         // no load of its own is pending at the loop's back edge, where the compiler would otherwise drain the LDS-DMA prefetch with a vmcnt(0)
         // in front of the next K-tile's fragment reads. 192-wide tile: all of them first, ONE wait. 256-wide tile: the 64 registers of all
         // eight row blocks do not fit beside 128 accumulators - four row blocks ahead, the compiler counts the waits.
-        constexpr int PF = (NB == 4 && HAS_X) ? 4 : 8;
+        constexpr int PF = (NB == 4 && HAS_X && MBN > 4) ? 4 : MBN;
         auto load_mb = [&](int mb) {
             if constexpr (SCALED) sc[SCALED ? mb : 0] = g.rowscale[div_by8(min(rown + mb * 16, mlast), g.rows_per_scale, g.inv_rps)];
             if constexpr (HAS_X) {
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         if constexpr (SCALED || HAS_X) {
 #pragma unroll
             for (int mb = 0; mb < PF; ++mb) load_mb(mb);
-            if constexpr (PF == 8) G8_WAIT_VM0();
+            if constexpr (PF == MBN) G8_WAIT_VM0();
         }
         // pk = the own row's W values as bf16 pairs -> the two pieces this lane stores
         auto trade = [&](const unsigned (&pk)[W / 2], piece_t& d1, piece_t& d2) {
@@ -258,10 +274,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
             }
         };
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            if constexpr (PF < 8) {
+        for (int mb = 0; mb < MBN; ++mb) {
+            if constexpr (PF < MBN) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (mb + PF < 8) load_mb(mb + PF);
+                if (mb + PF < MBN) load_mb(mb + PF);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int r1 = r1b + mb * 16;
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     };
 
 #define G8_LD_A(mq)                                                                                              \
-    _Pragma("unroll") for (int mbl = 0; mbl < 4; ++mbl) {                                                        \
+    _Pragma("unroll") for (int mbl = 0; mbl < MBQ; ++mbl) {                                                      \
         fa[mbl][0] = *(const bf16x8*)(smem + ra0 + (mq) * HALF_B + mbl * 2048);                                  \
         fa[mbl][1] = *(const bf16x8*)(smem + ra1 + (mq) * HALF_B + mbl * 2048);                                  \
     }
@@ -333,16 +349,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 #define G8_MMA(mq, nq, fb)                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                               \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
-        _Pragma("unroll") for (int mbl = 0; mbl < 4; ++mbl)                                                      \
+        _Pragma("unroll") for (int mbl = 0; mbl < MBQ; ++mbl)                                                    \
             _Pragma("unroll") for (int nbl = 0; nbl < ((nq) == 0 ? 2 : NB1); ++nbl)                              \
-                acc[(mq) * 4 + mbl][(nq) * 2 + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
-                    fb[nbl][kk], fa[mbl][kk], acc[(mq) * 4 + mbl][(nq) * 2 + nbl], 0, 0, 0);                     \
+                acc[(mq) * MBQ + mbl][(nq) * 2 + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+                    fb[nbl][kk], fa[mbl][kk], acc[(mq) * MBQ + mbl][(nq) * 2 + nbl], 0, 0, 0);                   \
     __builtin_amdgcn_s_setprio(0);
 
     // ---- prologue: stream K-tile 0 complete, the first three half-tiles of K-tile 1 in flight ----
     int cp_i = 0, cp_kt = 0;
     int T = first;
-    int m0c = (T / g.nx) * 256, n0c = (T - (T / g.nx) * g.nx) * BN;
+    int m0c = (T / g.nx) * BM, n0c = (T - (T / g.nx) * g.nx) * BN;
     set_tile(first);
     dmaB(0); dmaA(0); dmaB(1); dmaA(1); advance();
     dmaB(0); dmaA(0); dmaB(1);
@@ -360,18 +376,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         __builtin_amdgcn_sched_barrier(0);
         G8_LD_A(0);
         dmaA(1); advance();
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the B-h0 reads have left LDS: B-h0 may be refilled next phase
-        // B-h1 of this K-tile has landed (read next phase); behind an epilogue its stores sit in the queue too and may stay there
-        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1 + NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MBQ) : "memory");       // the B-h0 reads (issued first) have left LDS: B-h0 may be refilled next phase
+        // B-h1 of this K-tile has landed (read next phase). Behind an epilogue its stores sit in the same in-order queue and are waited for
+        // too: a count relaxed by the epilogue's stores would be wrong for a wave whose predicated stores were all skipped (ragged M / N edge),
+        // and letting them stay outstanding measured no gain
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P1) : "memory");
         G8_BAR();
         G8_MMA(0, 0, fb0);
         G8_BAR();
         // phase 2: B-h1 fragments | B-h0 of K-tile + 2 | quadrant (m 0-63, n 32-63)
         G8_LD_B1();
         dmaB(0);
-        if (cp_kt == 0 && cp_i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2 + NST) : "memory");   // A-h1 of this K-tile has landed
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_P2) : "memory");   // A-h1 of this K-tile has landed
         G8_BAR();
         G8_MMA(0, 1, fb1);
         G8_BAR();
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
             if (++cp_i < my_n) {
                 T = first + cp_i * per;
                 const int mblk = T / g.nx;
-                m0c = mblk * 256; n0c = (T - mblk * g.nx) * BN;
+                m0c = mblk * BM; n0c = (T - mblk * g.nx) * BN;
                 init_acc(n0c);
             }
         }
@@ -436,44 +452,49 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 }
 
 const char* g_gemm8_symbol = "";     // the instantiation the last launch ran, as rocprofv3 prints it (measurement aid)
+char g_gemm8_symbuf[64];
 
-template <int MODE, bool SCALED, int NB>
+template <int MODE, bool SCALED, int NB, int MBQ>
 int launch8(const G8Args& a, int nwg, hipStream_t stream) {
-    static const char* const names[4][2][2] = {
-        {{"gemm8_kernel<0, false, 3, false>", "gemm8_kernel<0, false, 4, false>"}, {"gemm8_kernel<0, true, 3, false>", "gemm8_kernel<0, true, 4, false>"}},
-        {{"gemm8_kernel<1, false, 3, false>", "gemm8_kernel<1, false, 4, false>"}, {"gemm8_kernel<1, true, 3, false>", "gemm8_kernel<1, true, 4, false>"}},
-        {{"gemm8_kernel<2, false, 3, false>", "gemm8_kernel<2, false, 4, false>"}, {"gemm8_kernel<2, true, 3, false>", "gemm8_kernel<2, true, 4, false>"}},
-        {{"gemm8_kernel<3, false, 3, false>", "gemm8_kernel<3, false, 4, false>"}, {"gemm8_kernel<3, true, 3, false>", "gemm8_kernel<3, true, 4, false>"}}};
-    g_gemm8_symbol = names[MODE][SCALED ? 1 : 0][NB - 3];
+    snprintf(g_gemm8_symbuf, sizeof g_gemm8_symbuf, "gemm8_kernel<%d, %s, %d, %d, false>", MODE, SCALED ? "true" : "false", NB, MBQ);
+    g_gemm8_symbol = g_gemm8_symbuf;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB>), dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB, MBQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
+    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB, MBQ>), dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
     PSELD_LAUNCH_CHECK("gemm8");
     return PSELD_OK;
 }
-template <int NB>
+template <int NB, int MBQ>
 int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t stream) {
     const bool sc = d.rowscale != nullptr;
-    if (a.dbg) {          // diagnostic build of three epilogue kinds: stamps to [workgroup][wave group][tile < 16][4]
-        auto go = [&](auto kern) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
-            return PSELD_OK;
-        };
-        if (d.gelu_dual) return go(gemm8_kernel<G8_GELU_DUAL, false, NB, true>);
-        if (d.resid && sc) return go(gemm8_kernel<G8_RESID, true, NB, true>);
-        if (!d.resid && !d.aux && !sc) return go(gemm8_kernel<G8_PLAIN, false, NB, true>);
+    if constexpr (MBQ == 4) {
+        if (a.dbg) {          // diagnostic build of three epilogue kinds: stamps to [workgroup][wave group][tile < 16][4]
+            auto go = [&](auto kern) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+                hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+                return PSELD_OK;
+            };
+            if (d.gelu_dual) return go(gemm8_kernel<G8_GELU_DUAL, false, NB, 4, true>);
+            if (d.resid && sc) return go(gemm8_kernel<G8_RESID, true, NB, 4, true>);
+            if (!d.resid && !d.aux && !sc) return go(gemm8_kernel<G8_PLAIN, false, NB, 4, true>);
+        }
     }
-    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB>(a, nwg, stream);
-    if (d.resid) return sc ? launch8<G8_RESID, true, NB>(a, nwg, stream) : launch8<G8_RESID, false, NB>(a, nwg, stream);
-    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB>(a, nwg, stream) : launch8<G8_MULAUX, false, NB>(a, nwg, stream);
-    return sc ? launch8<G8_PLAIN, true, NB>(a, nwg, stream) : launch8<G8_PLAIN, false, NB>(a, nwg, stream);
+    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ>(a, nwg, stream);
+    if (d.resid) return sc ? launch8<G8_RESID, true, NB, MBQ>(a, nwg, stream) : launch8<G8_RESID, false, NB, MBQ>(a, nwg, stream);
+    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB, MBQ>(a, nwg, stream) : launch8<G8_MULAUX, false, NB, MBQ>(a, nwg, stream);
+    return sc ? launch8<G8_PLAIN, true, NB, MBQ>(a, nwg, stream) : launch8<G8_PLAIN, false, NB, MBQ>(a, nwg, stream);
 }
 
 unsigned long long* g_gemm8_dbg = nullptr;
+int g_gemm8_force_bm = 0, g_gemm8_force_bn = 0;
+// cost of a 128-row tile per staged byte against the 256-row tile's, fitted to tools/gemm8_check.py's table (stage-3 products, one
+// round of 256 x 192 against two of 128 x 192: 60.5 against 80.2 us; stage-2 N = 384, two rounds against three: 74.0 against 72.5)
+constexpr double G8_ROW128_COST = 0.93;
 }  // namespace
 
 extern "C" void pseld_gemm8_set_debug_buffer(void* p) { g_gemm8_dbg = (unsigned long long*)p; }
+// measurement aid (tools/gemm8_check.py, tests): force the tile shape of the following launches (0 = the launch's own choice)
+extern "C" void pseld_gemm8_force_tile(int bm, int bn) { g_gemm8_force_bm = bm; g_gemm8_force_bn = bn; }
 const char* pseld_gemm8_last_symbol() { return g_gemm8_symbol; }
 
 int pseld_gemm8_supported(const Gemm8Desc& d) {
@@ -498,21 +519,31 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     a.inv_rps = 1.0f / (float)a.rows_per_scale;
     a.nk = d.K / 64;
     a.dbg = g_gemm8_dbg;
-    // tile width: 192 when that wastes fewer columns / fills the rounds better (PSELD_GEMM8_BN=256 / 192 forces one: A/B knob)
-    const char* eb = getenv("PSELD_GEMM8_BN");
-    int bn = eb ? atoi(eb) : 0;
-    if (d.N % 192 != 0) bn = 256;                     // (the 192 kernel's 12-byte store pieces are whole only when the strips are)
-    else if (bn != 256 && bn != 192 && a.nk <= 4) bn = 256;     // short K: the epilogue dominates, and the 256 tile writes whole 128-byte lines per wave
-    else if (bn != 256 && bn != 192) {
-        auto cost = [&](int w) {                      // rounds x (loop cost of one tile ~ DMA bytes per K-tile)
-            const long tiles = (long)pseld_cdiv(d.N, w) * pseld_cdiv(d.M, 256);
-            return (double)((tiles + 255) / 256) * (256 + w);
-        };
-        bn = cost(192) < cost(256) ? 192 : 256;
-    }
+    // Tile shape: the cheapest of {256, 128} rows x {256, 192} columns by rounds x (bytes a workgroup stages per K-tile ~ rows + columns).
+    // 192 columns need N % 192 == 0 (12-byte store pieces are whole only when the strips are); short K (<= 4 K-tiles) takes 256 columns
+    // (the epilogue dominates and the 256 tile writes whole 128-byte lines per wave). A 128-row tile pays where the 256-row grid leaves
+    // CUs idle in its last round: the 32-chunk step (stages 1-3: 1.80 -> 1.53 ms per step for forward + input gradients,
+    // tools/gemm8_check.py CHUNKS=32) and the N = 384 products of stage 2 (384 tiles = 1.5 rounds -> 768 = 3.0: 1-3 us each on cold
+    // operands). All four shapes give the same bits, so the choice may depend on M (the batch size). PSELD_GEMM8_BN / PSELD_GEMM8_BM
+    // (knobs, common.h) and pseld_gemm8_force_tile (tools, tests) force a shape.
+    const int want_bn = g_gemm8_force_bn ? g_gemm8_force_bn : pseld_knob(KNOB_GEMM8_BN, 0);
+    const int want_bm = g_gemm8_force_bm ? g_gemm8_force_bm : pseld_knob(KNOB_GEMM8_BM, 0);
+    int bn = 0, bm = 0;
+    double best = 0;
+    for (int rows = 256; rows >= 128; rows -= 128)
+        for (int w = 256; w >= 192; w -= 64) {
+            if (w == 192 && d.N % 192 != 0) continue;
+            if (want_bm == 128 || want_bm == 256) { if (rows != want_bm) continue; }
+            if (want_bn == 192 || want_bn == 256) { if (w != want_bn && !(w == 256 && d.N % 192 != 0)) continue; }
+            else if (w == 192 && a.nk <= 4) continue;
+            const long tiles = (long)pseld_cdiv(d.N, w) * pseld_cdiv(d.M, rows);
+            const double c = (double)((tiles + 255) / 256) * (rows + w) * (rows == 128 ? G8_ROW128_COST : 1.0);
+            if (bn == 0 || c < best) { best = c; bn = w; bm = rows; }
+        }
     a.nx = pseld_cdiv(d.N, bn);
-    a.ntiles = a.nx * pseld_cdiv(d.M, 256);
+    a.ntiles = a.nx * pseld_cdiv(d.M, bm);
     int nwg = (a.ntiles + 7) / 8 * 8;
     if (nwg > 256) nwg = 256;
-    return bn == 192 ? launch8_mode<3>(d, a, nwg, stream) : launch8_mode<4>(d, a, nwg, stream);
+    if (bm == 128) return bn == 192 ? launch8_mode<3, 2>(d, a, nwg, stream) : launch8_mode<4, 2>(d, a, nwg, stream);
+    return bn == 192 ? launch8_mode<3, 4>(d, a, nwg, stream) : launch8_mode<4, 4>(d, a, nwg, stream);
 }

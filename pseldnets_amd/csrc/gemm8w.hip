@@ -357,8 +357,7 @@ static bool g8w_eligible(int Mtok, int N, int K, int lddy, int ldx, int rows_per
 // Plan: tile width and split count for dW[N, K] over Mtok tokens; 0 when the eight-phase kernel does not take the shape.
 int pseld_gemm8w_plan(int Mtok, int N, int K, int lddy, int ldx, int rows_per_scale, int has_rowscale, int max_splits, int* bn_out, int* kchunk_out) {
     if (!g8w_eligible(Mtok, N, K, lddy, ldx, rows_per_scale, has_rowscale)) return 0;
-    const char* eb = getenv("PSELD_GEMM8W_BN");
-    int bn = eb ? atoi(eb) : 0;
+    int bn = pseld_knob(KNOB_GEMM8W_BN, 0);
     if (bn != 256 && bn != 192) {
         auto pad = [&](int w) { return (double)pseld_cdiv(K, w) * w; };
         bn = pad(192) < pad(256) ? 192 : 256;

@@ -957,14 +957,13 @@ extern "C" void pseld_mlp_set_debug_buffer(void* p) { g_mlp_dbg = (unsigned long
 // timing-experiment knob, read once; a result-changing value is honoured only with PSELD_ALLOW_WRONG_RESULTS=1 (else it is ignored with a
 // message on stderr: a stray environment variable must not silently change gradients)
 static int mlp_variant() {
-    static const int v = [] {
-        const char* e = getenv("PSELD_MLP_VARIANT");
-        const int x = e ? atoi(e) : 0;
-        const char* ok = getenv("PSELD_ALLOW_WRONG_RESULTS");
-        if (x != 0 && !(ok && ok[0] == '1')) { fprintf(stderr, "pseld: PSELD_MLP_VARIANT=%d ignored (changes results; set PSELD_ALLOW_WRONG_RESULTS=1 for timing runs)\n", x); return 0; }
-        return x;
-    }();
-    return v;
+    const int x = pseld_knob(KNOB_MLP_VARIANT, 0);
+    if (x != 0 && pseld_knob(KNOB_ALLOW_WRONG_RESULTS, 0) != 1) {
+        static bool told = false;
+        if (!told) { fprintf(stderr, "pseld: PSELD_MLP_VARIANT=%d ignored (changes results; set PSELD_ALLOW_WRONG_RESULTS=1 for timing runs)\n", x); told = true; }
+        return 0;
+    }
+    return x;
 }
 
 extern "C" int pseld_mlp_supported(int dtype, long M, int C, int rows_per_scale) {

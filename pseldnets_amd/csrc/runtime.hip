@@ -15,6 +15,52 @@ extern "C" const char* pseld_last_error(void) { return g_err; }
 
 extern "C" int pseld_abi_version(void) { return 1; }
 
+// ---- routing knobs (common.h): one pass over the environment per process, then array reads ----
+#include <stdlib.h>
+namespace {
+struct KnobState { bool set[KNOB_COUNT]; int val[KNOB_COUNT]; };
+const char* const g_knob_names[KNOB_COUNT] = {
+#define PSELD_KNOB_NAME(n) #n,
+    PSELD_KNOB_LIST(PSELD_KNOB_NAME)
+#undef PSELD_KNOB_NAME
+};
+KnobState& knobs() {
+    static KnobState st = [] {
+        KnobState k;
+        for (int i = 0; i < KNOB_COUNT; ++i) {
+            char name[64];
+            snprintf(name, sizeof name, "PSELD_%s", g_knob_names[i]);
+            const char* e = getenv(name);
+            k.set[i] = e != nullptr && e[0] != 0;
+            k.val[i] = k.set[i] ? atoi(e) : 0;
+        }
+        return k;
+    }();
+    return st;
+}
+int knob_index(const char* name) {
+    if (!name) return -1;
+    if (strncmp(name, "PSELD_", 6) == 0) name += 6;
+    for (int i = 0; i < KNOB_COUNT; ++i) if (strcmp(name, g_knob_names[i]) == 0) return i;
+    return -1;
+}
+}  // namespace
+int pseld_knob(PseldKnob k, int dflt) { const KnobState& st = knobs(); return st.set[k] ? st.val[k] : dflt; }
+bool pseld_knob_is_set(PseldKnob k) { return knobs().set[k]; }
+extern "C" int pseld_set_knob(const char* name, int value) {
+    const int i = knob_index(name);
+    PSELD_CHECK_ARG(i >= 0, "set_knob: unknown knob '%s'", name ? name : "(null)");
+    KnobState& st = knobs();
+    st.set[i] = true; st.val[i] = value;
+    return PSELD_OK;
+}
+extern "C" int pseld_unset_knob(const char* name) {
+    const int i = knob_index(name);
+    PSELD_CHECK_ARG(i >= 0, "unset_knob: unknown knob '%s'", name ? name : "(null)");
+    knobs().set[i] = false;
+    return PSELD_OK;
+}
+
 // Fills name (<= n bytes) with the gcnArchName of the current device; returns the CU count or <0.
 extern "C" int pseld_device_info(char* name, int n) {
     int dev = 0;

@@ -31,6 +31,13 @@ FUSED_ATTN = os.environ.get('PSELD_FUSED_ATTN', '1') != '0'
 # row (C = 96 / 192, bf16): one launch instead of GEMM + LayerNorm backward. PSELD_FUSED_LNBWD=0: two launches.
 FUSED_LNBWD = os.environ.get('PSELD_FUSED_LNBWD', '1') != '0'
 FUSED_ATTN_TAIL = os.environ.get('PSELD_FUSED_ATTN', '1') != 'front'      # 'front': stop in front of proj (A/B of the fused tail)
+# A/B knobs of the backward pass, read once at import (nothing in a step reads the environment):
+LN_DEFER = os.environ.get('PSELD_LN_DEFER', '1') == '1'            # one reduction per stage for the LayerNorms' d(gamma) / d(beta) partials
+# PSELD_WGRAD_GROUP=<blocks per launch> (0, the default: every weight gradient its own launch; 99: the whole stage at once),
+# PSELD_WGRAD_GROUP_MATS=<n>: flush every n matrices
+WGRAD_GROUP_BLOCKS = int(os.environ.get('PSELD_WGRAD_GROUP', '0'))
+WGRAD_GROUP_MATS = int(os.environ.get('PSELD_WGRAD_GROUP_MATS', '0')) or (1 << 30)
+MLP_DW_FIRST = os.environ.get('PSELD_MLP_DW_FIRST', '1') == '1'
 _inference = [False]      # set by the no-grad forward (seld_net._run): nothing is saved for a backward pass
 
 
@@ -388,17 +395,16 @@ class SwinEncoder:
         rpb = self._rpb_state(dx.device)
         if li == self.nl - 1:
             rpb['acc'].zero_()                # the backward starts at the last stage: every block's accumulator, one launch
-        if os.environ.get('PSELD_LN_DEFER', '1') != '1':
+        if not LN_DEFER:
             self._defer = None                                       # (A/B knob: every LayerNorm reduces its own partials)
         elif getattr(self, '_defer', None) is None or self._defer.buf.device != dx.device:
             self._defer = ops.DeferredReductions(dx.device)      # d(gamma) / d(beta) partials of the stage's LayerNorms: one reduction
-        # PSELD_WGRAD_GROUP=<blocks per launch> (0, the default: every weight gradient its own launch; 99: the whole stage at once).
-        # The grouped launch is 16-29 % faster than its members one by one in isolation (tools/wgrad8_check.py group: no token split, no
+        # WGRAD_GROUP_BLOCKS (PSELD_WGRAD_GROUP). The grouped launch is 16-29 % faster than its members one by one in isolation (tools/wgrad8_check.py group: no token split, no
         # fp32 slabs) and SLOWER inside the step (same box, 30 steps: 18.74 ms ungrouped, 19.25 / 19.00 / 19.06 ms with 1 / 2 blocks / the
         # whole stage per launch): a deferred weight gradient no longer runs beside the input-gradient kernel that reads the same dY, and
         # one chip-wide persistent launch leaves the second stream nothing to interleave
-        self._wgroup_blocks = int(os.environ.get('PSELD_WGRAD_GROUP', '0'))
-        self._wgroup_mats = int(os.environ.get('PSELD_WGRAD_GROUP_MATS', '0')) or (1 << 30)
+        self._wgroup_blocks = WGRAD_GROUP_BLOCKS
+        self._wgroup_mats = WGRAD_GROUP_MATS
         self._wgroup = [] if (dx.dtype == torch.bfloat16 and self._wgroup_blocks > 0) else None
         self._wgroup_n = 0
         dx = self._backward_layer(li, dx, saved, B)
@@ -463,7 +469,7 @@ class SwinEncoder:
                 # the weight-gradient kernel is forked onto the second stream BEFORE dx is launched: the earlier the side chain of the
                 # block starts the better (A/B PSELD_MLP_DW_FIRST=0 - fork behind dx, so that dw runs beside the HBM-bound kernels that
                 # follow instead of beside the equally VALU-bound dx - measured 21.33 against 20.99 ms per step)
-                dw_first = os.environ.get('PSELD_MLP_DW_FIRST', '1') == '1'
+                dw_first = MLP_DW_FIRST
                 if not dw_first:
                     dxh2 = ops.mlp_bwd_dx(s['xh2'], dx, w1, a.p(b + 'mlp.fc1.bias'), w2t, w1t, rowscale=s['s2'], rows_per_scale=L)
                 if getattr(self, '_side_ok', False):

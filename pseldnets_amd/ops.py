@@ -118,12 +118,25 @@ def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resi
 _side = {}           # device index -> {'stream', 'keep'}
 
 
+def _env_int(name, dflt):
+    import os
+    return int(os.environ.get(name, dflt))
+
+
+# second-stream weight gradients: read once at import; ops.set_wgrad_stream() switches in-process (bench.py's one-stream instrumented steps)
+_wgrad_stream = {'on': _env_int('PSELD_WGRAD_STREAM', '1') == 1, 'min_chunks': _env_int('PSELD_WGRAD_STREAM_MIN_CHUNKS', '64'),
+                 'prio': _env_int('PSELD_WGRAD_STREAM_PRIO', '-1')}
+
+
+def set_wgrad_stream(on):
+    _wgrad_stream['on'] = bool(on)
+
+
 def wgrad_side_enabled(device, n_chunks):
     """The second stream pays from ~64 chunks per step on (measured: at the reference's batch of 32 the ~50 forks per step cost more
     host time than the overlap returns); never while a hipGraph is being captured. PSELD_WGRAD_STREAM=0 disables it."""
-    import os
-    return (device.type == 'cuda' and os.environ.get('PSELD_WGRAD_STREAM', '1') == '1' and
-            n_chunks >= int(os.environ.get('PSELD_WGRAD_STREAM_MIN_CHUNKS', '64')) and not torch.cuda.is_current_stream_capturing())
+    return (device.type == 'cuda' and _wgrad_stream['on'] and n_chunks >= _wgrad_stream['min_chunks']
+            and not torch.cuda.is_current_stream_capturing())
 
 
 def linear_wgrad_side(dy, x, dw, **kw):
@@ -132,7 +145,7 @@ def linear_wgrad_side(dy, x, dw, **kw):
     dev = dy.device
     st = _side.get(dev.index)
     if st is None:
-        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1'))), 'keep': []}
+        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=_wgrad_stream['prio']), 'keep': []}
     side = st['stream']
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -200,7 +213,7 @@ def linear_wgrad_group_side(items):
     dev = items[0][0].device
     st = _side.get(dev.index)
     if st is None:
-        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1'))), 'keep': []}
+        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=_wgrad_stream['prio']), 'keep': []}
     side = st['stream']
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -273,7 +286,7 @@ def mlp_bwd_dw_side(x, dy, *args, **kw):
     dev = dy.device
     st = _side.get(dev.index)
     if st is None:
-        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=int(os.environ.get('PSELD_WGRAD_STREAM_PRIO', '-1'))), 'keep': []}
+        st = _side[dev.index] = {'stream': torch.cuda.Stream(device=dev, priority=_wgrad_stream['prio']), 'keep': []}
     side = st['stream']
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):

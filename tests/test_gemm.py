@@ -28,6 +28,15 @@ def _check(name, got, ref, dtype, denom=None):
 SHAPES = [(256, 96, 96), (300, 288, 96), (1000, 192, 384), (512, 1536, 4608), (130, 48, 112), (4096, 768, 3072)]
 
 
+
+@pytest.fixture
+def wgrad_ring_all():
+    """WGRAD_RING = 2: the ring weight-gradient kernel takes every eligible shape, however short its token range."""
+    from pseldnets_amd import _lib
+    _lib.set_knob('WGRAD_RING', 2)
+    yield
+    _lib.set_knob('WGRAD_RING', None)
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_linear_fwd(dev, dtype, M, N, K):
@@ -79,9 +88,8 @@ def test_linear_dgrad_gelu_grad(dev, dtype):
 @pytest.mark.parametrize("M,N,K", [(4096, 96, 96), (8192, 288, 96), (4096, 384, 1536), (2048, 1536, 4608), (1024, 48, 112),
                                    # the LDS-DMA ring kernel's shapes (bf16): whole 384 x 192 tiles, ragged columns / rows, the 256-row tile
                                    (6144, 1152, 384), (2080, 768, 360), (1536, 600, 384), (3200, 512, 768)])
-def test_linear_wgrad(dev, dtype, M, N, K, monkeypatch):
+def test_linear_wgrad(dev, dtype, M, N, K, wgrad_ring_all):
     from pseldnets_amd import ops
-    monkeypatch.setenv('PSELD_WGRAD_RING', '2')      # the ring kernel takes every eligible shape, however short its token range
     dy, x = _mk((M, N), dtype, 8, 0.1), _mk((M, K), dtype, 9)
     dw = torch.empty(N, K, dtype=torch.float32, device=dev)
     dbf = torch.empty(N, dtype=torch.float32, device=dev)
@@ -127,11 +135,10 @@ def test_fc1_dual_gelu_epilogue_and_mul_dgrad(dev, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows_per_scale,N,K", [(64, 384, 384), (256, 1536, 384), (96, 768, 192)])
-def test_droppath_factor_in_the_large_weight_gradients(dev, dtype, rows_per_scale, N, K, monkeypatch):
+def test_droppath_factor_in_the_large_weight_gradients(dev, dtype, rows_per_scale, N, K, wgrad_ring_all):
     """The same at the sizes the LDS-DMA ring weight-gradient kernel takes (bf16): slices of dropped samples are skipped, kept
     samples' dY fragments are scaled; the fused bias gradient sees the scaled rows; accumulate adds onto the old dW."""
     from pseldnets_amd import ops
-    monkeypatch.setenv('PSELD_WGRAD_RING', '2')
     nsamp = 24
     M = nsamp * rows_per_scale
     dy, h = _mk((M, N), dtype, 1, 0.2), _mk((M, K), dtype, 2)

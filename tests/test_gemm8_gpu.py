@@ -1,12 +1,10 @@
 """Eight-phase persistent GEMMs (csrc/gemm8.hip forward / input gradient, csrc/gemm8w.hip weight gradient, bf16) against a float64
 matmul of the same bf16-rounded operands, through the C ABI (pseld_gemm / pseld_gemm_wgrad / pseld_gemm_wgrad_group route the shapes
-here to the new kernels; the PSELD_GEMM8 / PSELD_WGRAD8 knobs pick the kernel under test). Every fused epilogue, both tile widths
+here to the new kernels; the GEMM8 / WGRAD8 knobs pick the kernel under test). Every fused epilogue, both tile widths
 (256 x 256 and 256 x 192), ragged rows / columns, DropPath factors incl. dropped samples and non-uniform factors, bias gradients, the
 grouped launch, run-to-run bit identity (a race in the counted-vmcnt pipeline shows up as rare wrong tiles) and bit-exact
-batch independence. Tolerances: one bf16 rounding of an fp32-accumulated result (rel 8e-3 of the largest output, rel-L2 2.5e-3);
+batch independence; the four tile shapes (256 | 128 rows x 256 | 192 columns, pseld_gemm8_force_tile) give the same bits. Tolerances: one bf16 rounding of an fp32-accumulated result (rel 8e-3 of the largest output, rel-L2 2.5e-3);
 fp32 weight gradients rel-L2 1e-4."""
-import os
-
 import pytest
 import torch
 
@@ -15,17 +13,22 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _knobs():
-    keep = {k: os.environ.get(k) for k in ('PSELD_GEMM8', 'PSELD_GEMM8_MINK', 'PSELD_GEMM8_BN', 'PSELD_WGRAD8', 'PSELD_GEMM8W_BN')}
-    os.environ['PSELD_GEMM8'] = '1'; os.environ['PSELD_GEMM8_MINK'] = '128'; os.environ['PSELD_WGRAD8'] = '1'
+    from pseldnets_amd import _lib
+    _lib.set_knob('GEMM8', 1); _lib.set_knob('GEMM8_MINK', 128); _lib.set_knob('WGRAD8', 1)
     yield
-    for k, v in keep.items():
-        if v is None: os.environ.pop(k, None)
-        else: os.environ[k] = v
+    for k in ('GEMM8', 'GEMM8_MINK', 'WGRAD8', 'GEMM8W_BN'):
+        _lib.set_knob(k, None)
+    _lib.lib().pseld_gemm8_force_tile(0, 0)
 
 
 def _kernel():
     from pseldnets_amd import _lib
     return _lib.lib().pseld_gemm_last_kernel().decode()
+
+
+def _tile(rows, bn):
+    from pseldnets_amd import _lib
+    _lib.lib().pseld_gemm8_force_tile(rows, bn)
 
 
 def _mk(shape, seed, scale=1.0, dtype=torch.bfloat16):
@@ -54,11 +57,12 @@ def _run(dev, mode, x, w, b, extra, rs, rps):
     return ops.linear_dgrad(d(x), d(w.t().contiguous()), rowscale=d(rs), rows_per_scale=rps, mul=d(extra), wt=d(w))
 
 
+@pytest.mark.parametrize("rows", [256, 128])
 @pytest.mark.parametrize("bn", [256, 192])
 @pytest.mark.parametrize("mode,scaled", [('plain', False), ('plain', True), ('resid', False), ('resid', True), ('gelu', False), ('mulaux', False), ('mulaux', True)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 1152, 384), (777, 200, 192), (2048, 768, 1536), (3000, 4096, 256)])
-def test_forward_products_and_fused_epilogues(dev, bn, mode, scaled, M, N, K):
-    os.environ['PSELD_GEMM8_BN'] = str(bn)
+def test_forward_products_and_fused_epilogues(dev, rows, bn, mode, scaled, M, N, K):
+    _tile(rows, bn)
     x, w, b = _mk((M, K), 1), _mk((N, K), 2, 0.05), _mk((N,), 3, dtype=torch.float32)
     extra = _mk((M, N), 4)
     rps = 64
@@ -69,25 +73,50 @@ def test_forward_products_and_fused_epilogues(dev, bn, mode, scaled, M, N, K):
     ref = _ref(mode, x, w, None if mode == 'mulaux' else b, extra, rs, rps)
     rel = ((y - ref).abs().max() / ref.abs().max()).item()
     l2 = ((y - ref).norm() / ref.norm()).item()
-    print(f"{mode} scaled={scaled} bn={bn} {M}x{N}x{K}: max rel {rel:.2e} rel-L2 {l2:.2e}")
+    print(f"{mode} scaled={scaled} tile {rows}x{bn} {M}x{N}x{K}: max rel {rel:.2e} rel-L2 {l2:.2e}")
     assert rel < 8e-3 and l2 < 2.5e-3
 
 
 def test_repeated_launches_are_bit_identical_and_rows_do_not_depend_on_the_batch(dev):
     """A staged buffer read before its LDS-DMA has landed shows up as rare wrong tiles that come and go (guide: place reads by the
-    vmcnt / barrier count, never by clean runs - so: many runs, two shapes, both widths); a row's result must not depend on which tile
-    of which launch computed it."""
+    vmcnt / barrier count, never by clean runs - so: many runs, several shapes, every tile shape); a row's result must not depend on
+    which tile of which launch computed it, nor on the tile shape. The shapes cover what the bench runs and round 4's test did not
+    (ADVICE r4): SEVERAL tiles per workgroup together with a ragged N edge (196 608 x 576 x 192 = stage-1 qkv, plain epilogue: the
+    waves of the last column tile store nothing) or a ragged M edge (50 000 rows), plain and GELU-pair epilogues."""
+    from pseldnets_amd import ops, _lib
+    for (M, N, K, gelu) in ((49152, 1536, 384, False), (12288, 768, 3072, False), (196608, 576, 192, False), (50000, 1152, 384, False),
+                            (50000, 1536, 384, True)):
+        x, w, b = _mk((M, K), 7).to(dev), _mk((N, K), 8, 0.05).to(dev), _mk((N,), 9, dtype=torch.float32).to(dev)
+        fwd = (lambda xx: torch.cat(ops.linear_fwd(xx, w, b, gelu_dual=True), 1)) if gelu else (lambda xx: ops.linear_fwd(xx, w, b))
+        first = None
+        for rows in (256, 128):
+            for bn in (256, 192):
+                if bn == 192 and N % 192: continue
+                _tile(rows, bn)
+                y = fwd(x).clone()
+                assert _kernel().startswith('gemm8_kernel<') and _kernel().endswith(f"{3 if bn == 192 else 4}, {rows // 64}, false>"), _kernel()
+                for _ in range(20):
+                    assert torch.equal(y, fwd(x)), (M, N, K, rows, bn)
+                lo, hi = 256 * 5 + 13, 256 * 9 + 100                      # a ragged slice of the rows through the same kernel
+                assert torch.equal(fwd(x[lo:hi].contiguous()), y[lo:hi])
+                if first is None: first = y
+                else: assert torch.equal(first, y), f"tile {rows}x{bn} differs from 256x256 at {M}x{N}x{K}"
+        # against the 128 x 192 kernels of gemm.hip (another K order: one bf16 rounding apart)
+        _lib.set_knob('GEMM8', 0)
+        y0 = fwd(x).float()
+        _lib.set_knob('GEMM8', 1)
+        assert not _kernel().startswith('gemm8_kernel<')
+        assert ((first.float() - y0).norm() / y0.norm()).item() < 2.5e-3
+
+
+def test_tile_choice_follows_the_grid_fill(dev):
+    """The launch's own choice: 128-row tiles where the 256-row grid leaves CUs idle (the 32-chunk step, stage 3), 256-row tiles on full grids."""
     from pseldnets_amd import ops
-    for bn in (256, 192):
-        os.environ['PSELD_GEMM8_BN'] = str(bn)
-        for (M, N, K) in ((49152, 1536, 384), (12288, 768, 3072)):
-            x, w, b = _mk((M, K), 7).to(dev), _mk((N, K), 8, 0.05).to(dev), _mk((N,), 9, dtype=torch.float32).to(dev)
-            y = ops.linear_fwd(x, w, b).clone()
-            assert _kernel().startswith('gemm8_kernel<')
-            for _ in range(20):
-                assert torch.equal(y, ops.linear_fwd(x, w, b))
-            lo, hi = 256 * 5 + 13, 256 * 9 + 100                      # a ragged slice of the rows through the same kernel
-            assert torch.equal(ops.linear_fwd(x[lo:hi].contiguous(), w, b), y[lo:hi])
+    _tile(0, 0)
+    for (M, N, K, rows) in ((2048, 768, 768, 128), (8192, 384, 1536, 128), (196608, 768, 192, 256), (49152, 1536, 384, 256)):
+        x, w = _mk((M, K), 1).to(dev), _mk((N, K), 2, 0.05).to(dev)
+        ops.linear_fwd(x, w, None)
+        assert _kernel().startswith('gemm8_kernel<') and f", {rows // 64}, false>" in _kernel(), (M, N, K, _kernel())
 
 
 @pytest.mark.parametrize("bn", [256, 192])
@@ -95,7 +124,8 @@ def test_repeated_launches_are_bit_identical_and_rows_do_not_depend_on_the_batch
 @pytest.mark.parametrize("M,N,K", [(4096, 256, 192), (12288, 1152, 384), (8192, 1000, 392), (16384, 384, 1536), (4096, 2304, 768)])
 def test_weight_gradient(dev, bn, mode, M, N, K):
     from pseldnets_amd import ops
-    os.environ['PSELD_GEMM8W_BN'] = str(bn)
+    from pseldnets_amd import _lib
+    _lib.set_knob('GEMM8W_BN', bn)
     dy, x = _mk((M, N), 11), _mk((M, K), 12)
     rps, rs = 64, None
     g = torch.Generator().manual_seed(13)

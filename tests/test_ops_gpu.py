@@ -150,22 +150,19 @@ def test_window_attention(dev, dtype, B, res, C, heads, shift):
 @pytest.mark.parametrize("B,res,C,heads,shift", [(5, 16, 384, 16, 4), (3, 8, 768, 32, 0), (7, 32, 192, 8, 4), (2, 64, 96, 4, 0), (11, 16, 384, 16, 0)])
 def test_persistent_attention_forward_equals_the_one_window_kernel(dev, B, res, C, heads, shift):
     """attn_fwd24p_kernel (bf16, head_dim 24: persistent, double-buffered, hand-counted LDS-DMA waits) must give the bits of attn_fwd_kernel
-    (PSELD_ATTN_FWD_P=0) - window counts that are not multiples of 8 or of the workgroups per head group included - run to run."""
-    import os
-    from pseldnets_amd import ops
+    (knob ATTN_FWD_P = 0) - window counts that are not multiples of 8 or of the workgroups per head group included - run to run."""
+    from pseldnets_amd import ops, _lib
     qkv = rnd((B * res * res, 3 * C), 11, torch.bfloat16).to(dev)
     table = (0.5 * rnd((225, heads), 12)).to(dev)
-    keep = os.environ.get('PSELD_ATTN_FWD_P')
     try:
-        os.environ['PSELD_ATTN_FWD_P'] = '0'
+        _lib.set_knob('ATTN_FWD_P', 0)
         o0, l0 = ops.window_attn_fwd(qkv, table, B, res, heads, shift)
-        os.environ['PSELD_ATTN_FWD_P'] = '1'
+        _lib.set_knob('ATTN_FWD_P', 1)
         for _ in range(5):
             o1, l1 = ops.window_attn_fwd(qkv, table, B, res, heads, shift)
             assert torch.equal(o0, o1) and torch.equal(l0, l1)
     finally:
-        if keep is None: os.environ.pop('PSELD_ATTN_FWD_P', None)
-        else: os.environ['PSELD_ATTN_FWD_P'] = keep
+        _lib.set_knob('ATTN_FWD_P', None)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

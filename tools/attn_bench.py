@@ -3,7 +3,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pseldnets_amd import ops
+from pseldnets_amd import ops, _lib
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 
 
@@ -36,7 +36,7 @@ for li, (C, heads) in enumerate(((96, 4), (192, 8), (384, 16), (768, 32))):
         out.append(f"bwd[skip={m}] {tb:6.1f}")
     os.environ['PSELD_ATTN_SKIP'] = '0'
     for w in wgs:
-        os.environ['PSELD_ATTN_BWD_WGS'] = w
+        _lib.set_knob('ATTN_BWD_WGS', int(w))
         out.append(f"bwd[wgs={w}] {timeit(lambda: ops.window_attn_bwd(qkv, bt, ao, lse, dout, dbt, B, res, heads, shift)):6.1f}")
     os.environ.pop('PSELD_ATTN_BWD_WGS', None)
     print('  '.join(out) + f"  (bwd floor {7 * u:5.1f})")

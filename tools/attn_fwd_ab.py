@@ -3,7 +3,7 @@ bit equality of out / lse on the four HTS-AT stages (shifted and not), then the 
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pseldnets_amd import ops
+from pseldnets_amd import ops, _lib
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 
 
@@ -25,7 +25,7 @@ for B in (192, 7, 1):
         for shift in ((0, 4) if res > 8 else (0,)):
             outs = {}
             for p in ('0', '1'):
-                os.environ['PSELD_ATTN_FWD_P'] = p
+                _lib.set_knob('ATTN_FWD_P', int(p))
                 o, l = ops.window_attn_fwd(qkv, bt, B, res, heads, shift)
                 o2, l2 = ops.window_attn_fwd(qkv, bt, B, res, heads, shift)
                 assert torch.equal(o, o2) and torch.equal(l, l2), "run-to-run mismatch"
@@ -36,7 +36,7 @@ for B in (192, 7, 1):
                 t = {}
                 for rnd in range(3):
                     for p in ('0', '1'):
-                        os.environ['PSELD_ATTN_FWD_P'] = p
+                        _lib.set_knob('ATTN_FWD_P', int(p))
                         t.setdefault(p, []).append(timeit(lambda: ops.window_attn_fwd(qkv, bt, B, res, heads, shift)))
                 line += f"   one-window {min(t['0']):6.1f} us | persistent {min(t['1']):6.1f} us"
             print(line)

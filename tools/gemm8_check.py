@@ -4,7 +4,8 @@ stage-2 / stage-3 products of the 192-chunk HTS-AT step.   python tools/gemm8_ch
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pseldnets_amd import ops
+from pseldnets_amd import ops, _lib
+L = _lib.lib()
 
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 what = sys.argv[1:] or ['check', 'square', 'shapes']
@@ -22,10 +23,12 @@ def timeit(fn, n=10):
 _wt = {}
 
 
-def run(mode, x, w, b, extra, rs, rps, on, cat=True):
-    os.environ['PSELD_GEMM8'] = '1' if on else '0'
-    if on: os.environ['PSELD_GEMM8_BN'] = str(on if on in (192, 256) else 0)
-    os.environ['PSELD_GEMM8_MINK'] = '128'
+def run(mode, x, w, b, extra, rs, rps, on, cat=True, rows=0):
+    """on: False = the 128 x 192 kernels of gemm.hip; True = the eight-phase kernel, its own tile choice; 256 / 192 = that tile width;
+    rows: 0 = own choice, 256 / 128 = that tile height"""
+    _lib.set_knob('GEMM8', 1 if on else 0)
+    L.pseld_gemm8_force_tile(rows, on if on in (192, 256) else 0)
+    _lib.set_knob('GEMM8_MINK', 128)
     if mode == 'plain': return ops.linear_fwd(x, w, b, rowscale=rs, rows_per_scale=rps)
     if mode == 'resid': return ops.linear_fwd(x, w, b, resid=extra, rowscale=rs, rows_per_scale=rps)
     if mode == 'gelu':
@@ -56,7 +59,7 @@ if 'check' in what:
     for (M, N, K) in ((256, 256, 128), (512, 384, 384), (1000, 1152, 384), (4096, 1536, 384), (777, 200, 192), (2048, 768, 3072),
                       (12288, 2304, 768), (3000, 4096, 256)):
         for mode in ('plain', 'resid', 'gelu', 'mulaux'):
-          for bn in (256, 192):
+          for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128)):
             for scaled in (False, True):
                 if mode == 'gelu' and scaled: continue
                 x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
@@ -64,7 +67,10 @@ if 'check' in what:
                 extra = torch.randn(M, N, device=dev).to(dt)
                 rps = 64
                 rs = (torch.rand((M + rps - 1) // rps, device=dev) + 0.5) if scaled else None
-                y8 = run(mode, x, w, b, extra, rs, rps, bn).float()
+                y8 = run(mode, x, w, b, extra, rs, rps, bn, rows=rows).float()
+                if rows == 128:       # the four tile shapes sum K in the same order: same bits
+                    same = torch.equal(y8, run(mode, x, w, b, extra, rs, rps, bn, rows=256).float())
+                    if not same: print(f"M={M} N={N} K={K} {mode} bn={bn}: 128-row tile differs from the 256-row tile   <-- FAIL")
                 y0 = run(mode, x, w, b, extra, rs, rps, False).float()
                 r = ref(mode, x, w, b, extra, rs, rps)
                 den = r.abs().max().item()
@@ -72,15 +78,15 @@ if 'check' in what:
                 l8 = ((y8 - r).norm() / r.norm()).item(); l0 = ((y0 - r).norm() / r.norm()).item()
                 flag = '' if (e8 <= max(2 * e0, 8e-3) and l8 <= max(1.5 * l0, 3e-3)) else '   <-- FAIL'
                 worst = max(worst, l8)
-                print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} bn={bn} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
+                print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} bn={bn} rows={rows} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
     # race screen: the same product many times must give bit-identical results
     x = torch.randn(49152, 384, device=dev).to(dt); w = (torch.randn(1536, 384, device=dev) * 0.05).to(dt); b = torch.randn(1536, device=dev)
-    for bn in (256, 192):
-        y = run('plain', x, w, b, None, None, 1, bn).clone()
+    for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128)):
+        y = run('plain', x, w, b, None, None, 1, bn, rows=rows).clone()
         bad = 0
         for _ in range(30):
-            bad += int(not torch.equal(y, run('plain', x, w, b, None, None, 1, bn)))
-        print(f"race screen (30 repeats, 49152x1536x384, bn={bn}): mismatching repeats =", bad)
+            bad += int(not torch.equal(y, run('plain', x, w, b, None, None, 1, bn, rows=rows)))
+        print(f"race screen (30 repeats, 49152x1536x384, bn={bn} rows={rows}): mismatching repeats =", bad)
 
 if 'square' in what:
     for n in (4096, 8192):
@@ -89,8 +95,8 @@ if 'square' in what:
         res = {}
         for rnd in range(3):
             for on in (256, 192, False):
-                os.environ['PSELD_GEMM8'] = '1' if on else '0'
-                os.environ['PSELD_GEMM8_BN'] = str(on) if on else '0'
+                _lib.set_knob('GEMM8', 1 if on else 0)
+                L.pseld_gemm8_force_tile(256, on if on else 0)
                 res.setdefault(on, []).append(timeit(lambda: ops.linear_fwd(a, bm, None, out=out), 20))
         lib = timeit(lambda: torch.matmul(a, bm.t(), out=out), 20)
         fl = 2.0 * n ** 3
@@ -99,7 +105,8 @@ if 'square' in what:
 
 if 'shapes' in what:
     B = int(os.environ.get('CHUNKS', '192'))
-    tot = {256: 0.0, 192: 0.0, True: 0.0, False: 0.0}
+    VARS = (((256, 256), 'r256c256'), ((192, 256), 'r256c192'), ((256, 128), 'r128c256'), ((192, 128), 'r128c192'), ((True, 0), 'auto'), ((False, 0), 'old'))
+    tot = {k: 0.0 for k, _ in VARS}
     for li, C in [(l, 96 << l) for l in map(int, os.environ.get('STAGES', '2,3').split(','))]:
         M = B * (64 >> li) ** 2
         nblk = (2, 2, 6, 2)[li]
@@ -116,15 +123,16 @@ if 'shapes' in what:
             xs = [x] + [x.clone() for _ in range(nrot - 1)]; es = [extra] + [extra.clone() for _ in range(nrot - 1)]
             ctr = [0]
 
-            def one(on):
+            def one(v):
                 i = ctr[0] % nrot; ctr[0] += 1
-                return run(mode, xs[i], w, b, es[i], rs, rps, on, cat=False)
+                return run(mode, xs[i], w, b, es[i], rs, rps, v[0], cat=False, rows=v[1])
             t = {}
             for rnd in range(3):
-                for on in (256, 192, True, False):
-                    t.setdefault(on, []).append(timeit(lambda: one(on), 10))
+                for v, _ in VARS:
+                    t.setdefault(v, []).append(timeit(lambda: one(v), 10))
             fl = 2.0 * M * N * K
-            for on in t: tot[on] += min(t[on]) * nblk
-            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: " + " | ".join(f"{lbl} {min(t[k]):6.1f} us {fl / min(t[k]) / 1e6:5.0f} TF" for k, lbl in
-                  ((256, 'bn256'), (192, 'bn192'), (True, 'auto'), (False, 'old'))))
-    print("per step (stage 2 x6 + stage 3 x2, fwd + dgrad), ms: " + " | ".join(f"{lbl} {tot[k] / 1e3:.2f}" for k, lbl in ((256, 'bn256'), (192, 'bn192'), (True, 'auto'), (False, 'old'))))
+            for v in t: tot[v] += min(t[v]) * nblk
+            best = min((min(t[v]), lbl) for v, lbl in VARS[:4])[1]
+            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: " + " | ".join(f"{lbl} {min(t[v]):6.1f}" for v, lbl in VARS) + f" us | auto {fl / min(t[(True, 0)]) / 1e6:5.0f} TF | best {best}")
+    print("per step (blocks x (fwd + dgrad)), ms: " + " | ".join(f"{lbl} {tot[v] / 1e3:.2f}" for v, lbl in VARS))
+L.pseld_gemm8_force_tile(0, 0)

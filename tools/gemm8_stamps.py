@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pseldnets_amd import ops, _lib
 
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-os.environ['PSELD_GEMM8'] = '1'; os.environ['PSELD_GEMM8_MINK'] = '128'
+_lib.set_knob('GEMM8', 1); _lib.set_knob('GEMM8_MINK', 128)
 L = _lib.lib()
 shapes = [('s2 qkv fwd', 49152, 384, 1152, 'plain'), ('s2 proj fwd', 49152, 384, 384, 'resid'), ('s2 fc1 fwd', 49152, 384, 1536, 'gelu'),
           ('s2 fc2 fwd', 49152, 1536, 384, 'resid'), ('s3 fc1 dgrad', 12288, 3072, 768, 'plain'), ('4096^3', 4096, 4096, 4096, 'plain')]

@@ -3,7 +3,7 @@ MFMA-bound shapes.  python tools/gemm_feeders.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pseldnets_amd import ops
+from pseldnets_amd import ops, _lib
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 
 
@@ -23,7 +23,7 @@ for M, N, K in SHAPES:
     x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.02).to(dt)
     line = f"M={M:7d} N={N:6d} K={K:6d}:"
     for mode in ('1', '0'):
-        os.environ['PSELD_GEMM_DMA'] = mode
+        _lib.set_knob('GEMM_DMA', int(mode))
         t = timeit(lambda: ops.linear_fwd(x, w))
         line += f"  [dma={mode}] {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.0f} TF/s"
     print(line, flush=True)

@@ -4,7 +4,7 @@ stage-2 / stage-3 weight gradients of the 192-chunk HTS-AT step.   python tools/
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pseldnets_amd import ops
+from pseldnets_amd import ops, _lib
 
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 what = sys.argv[1:] or ['check', 'shapes']
@@ -20,8 +20,8 @@ def timeit(fn, n=10):
 
 
 def run(dy, x, rs, rps, on, bn=0):
-    os.environ['PSELD_WGRAD8'] = '1' if on else '0'
-    os.environ['PSELD_GEMM8W_BN'] = str(bn)
+    _lib.set_knob('WGRAD8', 1 if on else 0)
+    _lib.set_knob('GEMM8W_BN', bn)
     N, K = dy.shape[1], x.shape[1]
     buf = torch.empty(N * K + N, device=dev)
     dw, db = buf[:N * K].view(N, K), buf[N * K:]
@@ -88,7 +88,7 @@ if 'group' in what:
                 rs = ((torch.rand(M // rps, device=dev) > 0.1).float() / 0.9) if scaled else None
                 buf = torch.zeros(N * K + N, device=dev)
                 items.append((dy, x, buf[:N * K].view(N, K), buf[N * K:], rs, rps))
-        os.environ['PSELD_WGRAD8'] = '1'; os.environ['PSELD_GEMM8W_BN'] = '0'
+        _lib.set_knob('WGRAD8', 1); _lib.set_knob('GEMM8W_BN', 0)
         ops.linear_wgrad_group(items)
         worst = 0.0
         for (dy, x, dw, db, rs, r) in items:
@@ -101,9 +101,9 @@ if 'group' in what:
         def single():
             for (dy, x, dw, db, rs, r) in items: ops.linear_wgrad(dy, x, dw, dbias=db, rowscale=rs, rows_per_scale=r)
         t1 = min(timeit(single, 5) for _ in range(3))
-        os.environ['PSELD_WGRAD8'] = '0'
+        _lib.set_knob('WGRAD8', 0)
         t0 = min(timeit(single, 5) for _ in range(3))
-        os.environ['PSELD_WGRAD8'] = '1'
+        _lib.set_knob('WGRAD8', 1)
         fl = sum(2.0 * d.shape[0] * d.shape[1] * x.shape[1] for d, x, *_ in items)
         print(f"stage {li}: {len(items)} weight gradients over {M} tokens: worst rel-L2 vs fp32 {worst:.2e}{'   <-- FAIL' if worst > 3e-3 else ''}; one grouped launch {tg:7.1f} us "
               f"({fl / tg / 1e6:5.0f} TF) | gemm8w one by one {t1:7.1f} us | ring / register-staged kernels {t0:7.1f} us")
