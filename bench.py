@@ -72,7 +72,9 @@ class KernelTimer:
 
     def install(self, names):
         for n in names:
-            if n.endswith('_workspace') or n.endswith('_supported') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_mlp_set_debug_buffer', 'pseld_mlp_supported', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections', 'pseld_stage_marker', 'pseld_gemm8_set_debug_buffer'):
+            if n.endswith('_workspace') or n.endswith('_supported') or n in ('pseld_last_error', 'pseld_gemm_set_debug_buffer', 'pseld_attn_set_debug_buffer', 'pseld_mlp_set_debug_buffer', 'pseld_mlp_supported', 'pseld_passt_grid_t', 'pseld_gemm_last_kernel', 'pseld_adamw_bias_corrections', 'pseld_stage_marker', 'pseld_gemm8_set_debug_buffer', 'pseld_set_knob', 'pseld_unset_knob',
+                                                                          'pseld_gemm8_force_tile', 'pseld_gemm_wgrad_timing', 'pseld_gemm_wgrad_timing_count', 'pseld_gemm_wgrad_timing_read',
+                                                                          'pseld_gemm_wgrad_timing_symbol'):
                 continue                                   # host-only queries: nothing is launched
             fn = getattr(self.lib, n)
             self._orig[n] = fn
@@ -81,17 +83,20 @@ class KernelTimer:
                 if not self.on:
                     return _fn(*a)
                 s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+                widx = self.lib.pseld_gemm_wgrad_timing_count() if _n == 'pseld_gemm_wgrad' else -1
                 s.record()
                 rc = _fn(*a)
                 e.record()
                 sym = self.lib.pseld_gemm_last_kernel().decode() if _n in ('pseld_gemm', 'pseld_gemm_wgrad') else None
-                self.records.append((_n, a, s, e, sym, ops_mod._stage['name']))
+                if widx >= 0 and self.lib.pseld_gemm_wgrad_timing_count() != widx + 1:
+                    widx = -1                                  # (the library did not stamp this call: timing off)
+                self.records.append((_n, a, s, e, sym, ops_mod._stage['name'], widx))
                 return rc
             setattr(self.lib, n, wrapped)
 
     def detail(self):
         rows = {}
-        for n, a, s, e, _sym, _st in self.records:
+        for n, a, s, e, _sym, _st, _w in self.records:
             if n == 'pseld_gemm':
                 key = ('gemm', a[1], a[2], a[6], a[7], a[8], a[19], a[20])      # ta, tb, M, N, K, epi, pro
             elif n == 'pseld_gemm_wgrad':
@@ -107,26 +112,39 @@ class KernelTimer:
                   f"{t / c * 1e3:7.1f} us each, {fl / (t / c * 1e-3) / 1e12:6.0f} TF/s, {t / 2:7.3f} ms/step", file=sys.stderr)
 
     def by_symbol(self):
-        """{kernel symbol: [ms, launches, flops, algorithmic bytes]} over the forward / input-gradient launches of pseld_gemm
-        (the weight-gradient entry point launches a GEMM and a slab reduction: its time is not a single kernel's)."""
+        """{kernel symbol: [ms, launches, flops, algorithmic bytes, bytes incl. fused operands]} over EVERY GEMM launch of the step: the forward /
+        input-gradient launches of pseld_gemm (HIP events around the call = the kernel) and the weight-gradient kernels of
+        pseld_gemm_wgrad, whose call also launches a slab reduction: there the library's own event pair around the GEMM kernel alone
+        (pseld_gemm_wgrad_timing) is read."""
         torch.cuda.synchronize()
         out = {}
-        for n, a, s, e, sym, _st in self.records:
-            if n != 'pseld_gemm' or not sym:
+        for n, a, s, e, sym, _st, widx in self.records:
+            if not sym:
                 continue
-            M, N, K, epi = a[6], a[7], a[8], a[19]
-            extra = M * N * ((1 if epi & 2 else 0) + (1 if epi & (4 | 32) else 0) + (1 if epi & 16 else 0))   # resid / aux rows read, second GELU output written
+            if n == 'pseld_gemm':
+                M, N, K, epi = a[6], a[7], a[8], a[19]
+                extra = M * N * ((1 if epi & 2 else 0) + (1 if epi & (4 | 32) else 0) + (1 if epi & 16 else 0))   # resid / aux rows read, second GELU output written
+                ms, fl = s.elapsed_time(e), 2.0 * M * N * K
+                nb = ESIZE * (M * K + N * K + M * N)                      # operands + result once (SURVEY 8d / DESIGN 4 definition)
+                nb2 = ESIZE * (M * K + N * K + M * N + extra)              # + the fused epilogue operands the launch must also move
+            elif n == 'pseld_gemm_wgrad' and widx >= 0:
+                Mtok, N, K = a[5], a[6], a[7]
+                ms, fl = self.lib.pseld_gemm_wgrad_timing_read(widx), 2.0 * Mtok * N * K
+                if ms < 0:
+                    continue
+                nb = ESIZE * (Mtok * N + Mtok * K) + 4.0 * N * K           # both operands + the fp32 gradient once
+                nb2 = nb
+            else:
+                continue
             d = out.setdefault(sym, [0.0, 0, 0.0, 0.0, 0.0])
-            d[0] += s.elapsed_time(e); d[1] += 1; d[2] += 2.0 * M * N * K
-            d[3] += ESIZE * (M * K + N * K + M * N)                    # operands + result once (SURVEY 8d / DESIGN 4 definition)
-            d[4] += ESIZE * (M * K + N * K + M * N + extra)            # + the fused epilogue operands the launch must also move
+            d[0] += ms; d[1] += 1; d[2] += fl; d[3] += nb; d[4] += nb2
         return out
 
     def by_stage(self):
         """{part of the step: [ms, launches]} (ops.stage names: features, front, stage0..3, head+loss, optimizer)."""
         torch.cuda.synchronize()
         out = {}
-        for n, a, s, e, _sym, st in self.records:
+        for n, a, s, e, _sym, st, _w in self.records:
             d = out.setdefault(st, [0.0, 0])
             d[0] += s.elapsed_time(e); d[1] += 1
         return out
@@ -134,7 +152,7 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for n, a, s, e, _sym, _st in self.records:
+        for n, a, s, e, _sym, _st, _w in self.records:
             key = n
             flops = 0.0
             nbytes = 0.0
@@ -160,14 +178,14 @@ class KernelTimer:
 def pmc_traffic(args, sym=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters. Counters cannot be read from inside this process: the figure is the
     one measured with rocprofv3 on this same command (separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
-    reduced per launch of one kernel symbol by tools/pmc_kernel.py and committed under profiles/r04_pmc/ - one file per symbol that has led
+    reduced per launch of one kernel symbol by tools/pmc_kernel.py and committed under profiles/r05_pmc/ - one file per symbol that has led
     the step (two instantiations of the eight-phase kernel are within 2 % of each other and trade places between runs)."""
     if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks:
         return None
     cands = []
     if sym:
-        cands.append(os.path.join(ROOT, 'profiles', 'r04_pmc', 'pmc_' + ''.join(c if c.isalnum() else '_' for c in sym) + '.json'))
-    cands.append(os.path.join(ROOT, 'profiles', 'r04_dominant_kernel_pmc.json'))
+        cands.append(os.path.join(ROOT, 'profiles', 'r05_pmc', 'pmc_' + ''.join(c if c.isalnum() else '_' for c in sym) + '.json'))
+    cands.append(os.path.join(ROOT, 'profiles', 'r05_dominant_kernel_pmc.json'))
     for path in cands:
         if os.path.exists(path):
             with open(path) as f:
@@ -492,6 +510,7 @@ def main():
         # rank runs them: a training step contains the gradient all-reduce, so rank 0 cannot step alone.
         if timer is not None:
             timer.on = True
+            lib.pseld_gemm_wgrad_timing(1)           # the weight-gradient GEMM kernels alone (their call also launches the slab reduction)
         trainer.use_graph = False                             # the instrumented steps launch kernel by kernel
         # ... and on ONE stream: in the timed region the weight gradients run on a second stream beside the main chain
         # (htsat.py:_wgrad), where a kernel's duration includes the time it shares the CUs with another kernel - the per-kernel
@@ -507,6 +526,7 @@ def main():
         if args.gemm_detail:
             timer.detail()
         timer.on = False
+        lib.pseld_gemm_wgrad_timing(0)
         total = sum(v[0] for v in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1][0])
         gem = [v for k, v in agg.items() if k.startswith('gemm_kernel(fwd')]
@@ -536,7 +556,11 @@ def main():
                                "mfma_busy": pmc.get('mfma_busy') if same else None,
                                "rocprof_avg_launch_ms": pmc.get('rocprof_avg_launch_ms') if same else None,
                                "pmc_source": (pmc.get('_path', '') + " (static: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes over this command)") if same else None}
+                                              "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes over this command)") if same else None,
+                               # the ranking the dominant symbol was picked from: every GEMM kernel symbol of the step, weight gradients included
+                               "ranked_symbols": [{"kernel": k, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[1] // 2,
+                                                   "tflops": round(v[2] / (v[0] * 1e-3) / 1e12, 1), "algorithmic_gbs": round(v[3] / (v[0] * 1e-3) / 1e9, 1)}
+                                                  for k, v in sorted(syms.items(), key=lambda kv: -kv[1][0])[:6]]}
         if gem:
             tms, n, fl, nb, roof_ms, mfma_bound_ms = gem[0]
             out["roofline_family"] = {"kernel": "every pseld_gemm forward + input-gradient launch (all tile variants)",
@@ -548,7 +572,9 @@ def main():
         # rocprofv3 --pmc passes of this command cut at stage markers by tools/pmc_stages.py)
         st = timer.by_stage()
         st_pmc = {}
-        sp = os.path.join(ROOT, 'profiles', 'r04_stage_table.json')
+        sp = os.path.join(ROOT, 'profiles', 'r05_stage_table.json')
+        if not os.path.exists(sp):
+            sp = os.path.join(ROOT, 'profiles', 'r04_stage_table.json')
         if args.backbone == 'htsat' and args.dtype == 'bf16' and args.clips == 32 and not args.chunks and os.path.exists(sp):
             with open(sp) as f:
                 st_pmc = json.load(f).get('stages', {})

@@ -1561,6 +1561,38 @@ static int wgrad_ring_plan(int dtype, int Mtok, int N, int K, int gelu_on_x, int
     *splits_out = pseld_cdiv(Mtok, kchunk);
     return mt;
 }
+// ---- measurement aid: the weight-gradient entry point launches a GEMM kernel AND a slab reduction, so HIP events around the call do not
+// time one kernel. With pseld_gemm_wgrad_timing(1) every pseld_gemm_wgrad call brackets its GEMM kernel alone with two library-owned
+// events; pseld_gemm_wgrad_timing_read(i) returns the i-th call's kernel time in ms (bench.py: the per-symbol roofline over ALL symbols).
+#include <vector>
+namespace {
+struct WgradStamp { hipEvent_t a, b; const char* sym; };
+std::vector<WgradStamp> g_wgrad_stamps;
+size_t g_wgrad_stamp_n = 0;
+bool g_wgrad_timing = false;
+inline WgradStamp* wgrad_stamp_begin(hipStream_t s) {
+    if (!g_wgrad_timing) return nullptr;
+    if (g_wgrad_stamp_n == g_wgrad_stamps.size()) {
+        WgradStamp w{};
+        if (hipEventCreate(&w.a) != hipSuccess || hipEventCreate(&w.b) != hipSuccess) return nullptr;
+        g_wgrad_stamps.push_back(w);
+    }
+    WgradStamp* w = &g_wgrad_stamps[g_wgrad_stamp_n++];
+    (void)hipEventRecord(w->a, s);
+    return w;
+}
+inline void wgrad_stamp_end(WgradStamp* w, hipStream_t s, const char* sym) { if (w) { (void)hipEventRecord(w->b, s); w->sym = sym; } }
+}  // namespace
+extern "C" int pseld_gemm_wgrad_timing(int enable) { g_wgrad_timing = enable != 0; g_wgrad_stamp_n = 0; return PSELD_OK; }
+extern "C" int pseld_gemm_wgrad_timing_count(void) { return (int)g_wgrad_stamp_n; }
+extern "C" float pseld_gemm_wgrad_timing_read(int i) {
+    if (i < 0 || (size_t)i >= g_wgrad_stamp_n) return -1.f;
+    float ms = -1.f;
+    if (hipEventSynchronize(g_wgrad_stamps[i].b) != hipSuccess || hipEventElapsedTime(&ms, g_wgrad_stamps[i].a, g_wgrad_stamps[i].b) != hipSuccess) return -1.f;
+    return ms;
+}
+extern "C" const char* pseld_gemm_wgrad_timing_symbol(int i) { return (i < 0 || (size_t)i >= g_wgrad_stamp_n || !g_wgrad_stamps[i].sym) ? "" : g_wgrad_stamps[i].sym; }
+
 static int gemm8w_min_n() { return pseld_knob(KNOB_WGRAD8_MINN, 192); }     // (dW[192, 768] over 196 608 tokens: 102 against 127 us)
 extern "C" long pseld_gemm_wgrad_workspace(int Mtok, int N, int K, int* splits_out) {
     const int sa = wgrad_splits_for(PSELD_BF16, Mtok, N, K), sb = wgrad_splits_for(PSELD_F32, Mtok, N, K);
@@ -1601,9 +1633,11 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
                 const bool fused = dbias && dbias == dW + (long)N * K;
                 const long stride = fused ? (long)N * K + N : (long)N * K;
                 float* cs = fused ? workspace + (long)N * K : (dbias ? workspace + (long)s8 * N * K : nullptr);
-                g_last_gemm_kernel = "gemm8w_kernel";
+                g_last_gemm_kernel = bn8 == 192 ? "gemm8w_kernel<3>" : "gemm8w_kernel<4>";
+                WgradStamp* st8 = wgrad_stamp_begin((hipStream_t)stream);
                 const int rc8 = pseld_gemm8w_launch(dY, X, workspace, cs, stride, fused ? stride : (long)N, Mtok, N, K, lddy, ldx, bn8, kchunk8, s8,
                                                     rowscale, rows_per_scale > 0 ? rows_per_scale : 1, (hipStream_t)stream);
+                wgrad_stamp_end(st8, (hipStream_t)stream, g_last_gemm_kernel);
                 if (rc8 != PSELD_OK) return rc8;
                 const long n8 = (long)N * K;
                 if (fused) pseld_reduce_slabs(workspace, dW, n8 + N, s8, stride, accumulate, (hipStream_t)stream);
@@ -1639,11 +1673,13 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
     else { g.colsum = dbias ? workspace + (long)splits * N * K : nullptr; g.colsum_stride = N; }
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    WgradStamp* st = wgrad_stamp_begin(s);
     if (ring_mt == 3) rc = launch_wgrad_ring<3, 3>(g, splits, s);
     else if (ring_mt == 2) rc = launch_wgrad_ring<2, 3>(g, splits, s);
     else if (dtype == PSELD_BF16) rc = dispatch_tile<bf16_t, float, true, true>(g, splits, s);
     else if (dtype == PSELD_F32) rc = dispatch_tile<float, float, true, true>(g, splits, s);
     else { pseld_set_error("gemm_wgrad: unknown dtype %d", dtype); return PSELD_ERR_BAD_ARG; }
+    wgrad_stamp_end(st, s, g_last_gemm_kernel);
     if (rc != PSELD_OK) return rc;
     const long n = (long)N * K;
     if (fused_bias) {

@@ -487,9 +487,11 @@ int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t strea
 
 unsigned long long* g_gemm8_dbg = nullptr;
 int g_gemm8_force_bm = 0, g_gemm8_force_bn = 0;
-// cost of a 128-row tile per staged byte against the 256-row tile's, fitted to tools/gemm8_check.py's table (stage-3 products, one
-// round of 256 x 192 against two of 128 x 192: 60.5 against 80.2 us; stage-2 N = 384, two rounds against three: 74.0 against 72.5)
-constexpr double G8_ROW128_COST = 0.93;
+// cost of a 128-row tile per staged byte against the 256-row tile's. Isolated, on cold operands, the stage-2 N = 384 products (two rounds
+// of 256 x 192 or three of 128 x 192) say 0.93 (74.0 against 72.5 us); inside the step that choice LOSES (three alternating same-box
+// runs: 18.67 / 18.72 / 18.75 ms against 18.57 / 18.50 with 256 rows there), and the stage-3 products (one round against two: 60.5
+// against 80.2 us) and the whole 32-chunk table (1.80 -> 1.53 ms) are indifferent between 0.93 and 1: so 1
+constexpr double G8_ROW128_COST = 1.0;
 }  // namespace
 
 extern "C" void pseld_gemm8_set_debug_buffer(void* p) { g_gemm8_dbg = (unsigned long long*)p; }
@@ -523,8 +525,7 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     // 192 columns need N % 192 == 0 (12-byte store pieces are whole only when the strips are); short K (<= 4 K-tiles) takes 256 columns
     // (the epilogue dominates and the 256 tile writes whole 128-byte lines per wave). A 128-row tile pays where the 256-row grid leaves
     // CUs idle in its last round: the 32-chunk step (stages 1-3: 1.80 -> 1.53 ms per step for forward + input gradients,
-    // tools/gemm8_check.py CHUNKS=32) and the N = 384 products of stage 2 (384 tiles = 1.5 rounds -> 768 = 3.0: 1-3 us each on cold
-    // operands). All four shapes give the same bits, so the choice may depend on M (the batch size). PSELD_GEMM8_BN / PSELD_GEMM8_BM
+    // tools/gemm8_check.py CHUNKS=32; the step 6.66 -> 6.30 ms). All four shapes give the same bits, so the choice may depend on M (the batch size). PSELD_GEMM8_BN / PSELD_GEMM8_BM
     // (knobs, common.h) and pseld_gemm8_force_tile (tools, tests) force a shape.
     const int want_bn = g_gemm8_force_bn ? g_gemm8_force_bn : pseld_knob(KNOB_GEMM8_BN, 0);
     const int want_bm = g_gemm8_force_bm ? g_gemm8_force_bm : pseld_knob(KNOB_GEMM8_BM, 0);

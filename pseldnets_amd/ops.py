@@ -128,8 +128,13 @@ _wgrad_stream = {'on': _env_int('PSELD_WGRAD_STREAM', '1') == 1, 'min_chunks': _
                  'prio': _env_int('PSELD_WGRAD_STREAM_PRIO', '-1')}
 
 
-def set_wgrad_stream(on):
-    _wgrad_stream['on'] = bool(on)
+def set_wgrad_stream(on=None, min_chunks=None):
+    """In-process switch of the second-stream weight gradients (bench.py's one-stream instrumented steps; tests that force the path at
+    a small batch): on = True / False, min_chunks = smallest batch that takes the second stream. None leaves a setting as it is."""
+    if on is not None:
+        _wgrad_stream['on'] = bool(on)
+    if min_chunks is not None:
+        _wgrad_stream['min_chunks'] = int(min_chunks)
 
 
 def wgrad_side_enabled(device, n_chunks):

@@ -50,6 +50,9 @@ def _run(net, x, lab, group, steps=2):
 def _worker(rank, world, port, q, env=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     os.environ.update(env or {})
+    if env and 'PSELD_WGRAD_STREAM_MIN_CHUNKS' in env:      # (ops reads its environment once, at import: switch in-process)
+        from pseldnets_amd import ops
+        ops.set_wgrad_stream(on=env.get('PSELD_WGRAD_STREAM', '1') == '1', min_chunks=int(env['PSELD_WGRAD_STREAM_MIN_CHUNKS']))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda:0')
     x = oh.formula_features(4)[2 * rank: 2 * rank + 2].contiguous().to(dev)
@@ -99,20 +102,16 @@ def test_two_ranks_with_side_stream_wgrads_and_deferred_reductions(dev):
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    from pseldnets_amd import ops
+    keep = dict(ops._wgrad_stream)
+    ops.set_wgrad_stream(on=True, min_chunks=1)
     try:
-        from pseldnets_amd import ops
         assert ops.wgrad_side_enabled(dev, 2)                              # the path under test is really on at this batch
         x = oh.formula_features(4).to(dev)
         lab = synth.formula_adpit_label(4, 100, 3).to(dev)
         losses1, flat1, rm1 = _run(_build(dev), x, lab, None)
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        ops.set_wgrad_stream(on=keep['on'], min_chunks=keep['min_chunks'])
     for step in range(2):
         mean2 = 0.5 * (res[0][1][step] + res[1][1][step])
         assert abs(mean2 - losses1[step]) < 2e-4 * abs(losses1[step]), (step, mean2, losses1[step])
@@ -242,6 +241,9 @@ def _worker_crnn(rank, world, port, q, env=None):
     from oracle import crnn as oc
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     os.environ.update(env or {})
+    if env and 'PSELD_WGRAD_STREAM_MIN_CHUNKS' in env:      # (ops reads its environment once, at import: switch in-process)
+        from pseldnets_amd import ops
+        ops.set_wgrad_stream(on=env.get('PSELD_WGRAD_STREAM', '1') == '1', min_chunks=int(env['PSELD_WGRAD_STREAM_MIN_CHUNKS']))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda:0')
     x = oc.random_features(4, seed=1)[2 * rank: 2 * rank + 2].contiguous().to(dev)
