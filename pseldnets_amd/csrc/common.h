@@ -202,7 +202,7 @@ __device__ __forceinline__ float gelu_grad_shared(float x) {
 }
 // ---- GELU and its derivative from an LDS table with linear interpolation (the fused MLP kernels in bf16 mode; f32 parity mode keeps the
 // A&S erf). 512 entries of 16 bytes over [-8, 8): {gelu(x0), gelu(x1) - gelu(x0), gelu'(x0), gelu'(x1) - gelu'(x0)}, x1 = x0 + 1/32;
-// |error| <= 1.2e-4 for both (h^2 / 8 max|f''|), a thirtieth of the bf16 spacing at 1 the results are rounded to. One ds_read_b128 + 2 FMA
+// |error| <= 6e-5 for both (h^2 / 16 max|f''|, every chord shifted by half its midpoint gap), a sixtieth of the bf16 spacing at 1 the results are rounded to. One ds_read_b128 + 2 FMA
 // + index arithmetic per element against 1 v_rcp + 1 v_exp + ~12 FMA-class instructions (tools/experiments/gelu_table.hip: 59 against 85
 // cycles per wave for the pair); beyond +8 the identity / 1, below -8 the table's first entry (0 / 0 to 1e-14).
 constexpr int GELU_TAB_N = 512;
@@ -210,10 +210,15 @@ constexpr int GELU_TAB_BYTES = GELU_TAB_N * 16;
 __device__ __forceinline__ void gelu_tab_fill(f32x4* tab, int tid, int nthreads) {
     for (int i = tid; i < GELU_TAB_N; i += nthreads) {
         const float x0 = (float)(i - GELU_TAB_N / 2) * (1.0f / 32.0f), x1 = x0 + (1.0f / 32.0f);
-        float g0, d0, g1, d1;
+        float g0, d0, g1, d1, gm, dm;
         gelu_both(x0, g0, d0);
         gelu_both(x1, g1, d1);
-        tab[i] = f32x4{g0, g1 - g0, d0, d1 - d0};
+        gelu_both(x0 + (1.0f / 64.0f), gm, dm);
+        // the chord of a convex (concave) piece lies above (below) the function, by at most its gap at the midpoint: each interval's chord is
+        // lowered by half that gap, so the error is centred (+-6e-5 instead of one-sided 1.2e-4: no systematic bias against the erf
+        // evaluation the weight-gradient kernel recomputes the hidden activations with)
+        const float eg = 0.5f * (0.5f * (g0 + g1) - gm), ed = 0.5f * (0.5f * (d0 + d1) - dm);
+        tab[i] = f32x4{g0 - eg, g1 - g0, d0 - ed, d1 - d0};
     }
 }
 __device__ __forceinline__ f32x4 gelu_tab_entry(const f32x4* tab, float x, float& fr) {

@@ -1633,7 +1633,7 @@ extern "C" int pseld_gemm_wgrad(int dtype, const void* dY, const void* X, float*
                 const bool fused = dbias && dbias == dW + (long)N * K;
                 const long stride = fused ? (long)N * K + N : (long)N * K;
                 float* cs = fused ? workspace + (long)N * K : (dbias ? workspace + (long)s8 * N * K : nullptr);
-                g_last_gemm_kernel = bn8 == 192 ? "gemm8w_kernel<3>" : "gemm8w_kernel<4>";
+                g_last_gemm_kernel = bn8 == 192 ? "gemm8w_kernel<3, (anonymous namespace)::G8WOne>" : "gemm8w_kernel<4, (anonymous namespace)::G8WOne>";   // as rocprofv3 prints them
                 WgradStamp* st8 = wgrad_stamp_begin((hipStream_t)stream);
                 const int rc8 = pseld_gemm8w_launch(dY, X, workspace, cs, stride, fused ? stride : (long)N, Mtok, N, K, lddy, ldx, bn8, kchunk8, s8,
                                                     rowscale, rows_per_scale > 0 ? rows_per_scale : 1, (hipStream_t)stream);

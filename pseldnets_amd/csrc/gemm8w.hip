@@ -45,6 +45,7 @@ struct G8WArgs {          // one weight matrix of the launch
     int pad_;
 };
 constexpr int G8W_MAXP = 32;
+struct G8WOne { G8WArgs p; };      // a single matrix: 104 bytes of kernel arguments instead of the group's 3.5 KB
 struct G8WGroup {         // the weight matrices of one launch (a stage's layers): workgroup L of the launch belongs to the matrix p with
     int count;            // first[p] <= L < first[p + 1] and is its (split, tile) pair L - first[p] in split-major order
     int first[G8W_MAXP + 1];
@@ -65,8 +66,9 @@ __device__ __forceinline__ void g8w_dma(unsigned lds_dst, const void* sbase, uns
     } while (0)
 
 // NB = 16-column accumulator blocks per wave on the X side: 4 -> 256 x 256 tile, 3 -> 256 x 192 (X-h1 is then a [64][64] image)
-template <int NB>
-__global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WGroup grp) {
+template <int NB, typename P = G8WOne>
+__global__ __launch_bounds__(512, 2) void gemm8w_kernel(const P grp) {
+    constexpr bool ONE = __is_same(P, G8WOne);
     constexpr int WN = NB * 16, BN = 4 * WN;
     constexpr int NB1 = NB - 2;
     // Just-in-time waits: a half-tile is waited for in the phase BEFORE the one that reads it, so the five youngest half-tiles stay in
@@ -83,11 +85,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const G8WGroup grp) {
     // CU), so the tiles of a split (which read the same token rows) share an L2 and no XCD gets more workgroups than it has CUs
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int L = xcd * 32 + slot;
-    if (slot >= 32 || L >= grp.first[grp.count]) return;
-    int pi = 0;
-    while (pi + 1 < grp.count && L >= grp.first[pi + 1]) ++pi;
-    const G8WArgs& g = grp.p[pi];
-    const int Lp = L - grp.first[pi];
+    int pi = 0, Lp = L;
+    if constexpr (ONE) {
+        if (slot >= 32 || L >= grp.p.ntile * grp.p.splits) return;
+    } else {
+        if (slot >= 32 || L >= grp.first[grp.count]) return;
+        while (pi + 1 < grp.count && L >= grp.first[pi + 1]) ++pi;
+        Lp = L - grp.first[pi];
+    }
+    const G8WArgs& g = [&]() -> const G8WArgs& { if constexpr (ONE) return grp.p; else return grp.p[pi]; }();
     const int z = Lp / g.ntile, t = Lp - z * g.ntile;
     const int mblk = t / g.nx, nblk = t - mblk * g.nx;
     const int m0 = mblk * 256, n0 = nblk * BN;
@@ -385,15 +391,16 @@ static void g8w_fill(G8WArgs& a, const void* dY, const void* X, float* slabs, fl
     a.nscale = rowscale ? pseld_cdiv(Mtok, a.rows_per_scale) : 0;
     a.pad_ = 0;
 }
-static int g8w_launch_group(const G8WGroup& grp, int bn, hipStream_t stream) {
+template <typename P>
+static int g8w_launch_group(const P& grp, int bn, hipStream_t stream) {
     if (bn == 192) {
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-        hipLaunchKernelGGL(gemm8w_kernel<3>, dim3(256), dim3(512), LDS_B, stream, grp);
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8w_kernel<3, P>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
+        hipLaunchKernelGGL((gemm8w_kernel<3, P>), dim3(256), dim3(512), LDS_B, stream, grp);
     } else {
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-        hipLaunchKernelGGL(gemm8w_kernel<4>, dim3(256), dim3(512), LDS_B, stream, grp);
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8w_kernel<4, P>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
+        hipLaunchKernelGGL((gemm8w_kernel<4, P>), dim3(256), dim3(512), LDS_B, stream, grp);
     }
     PSELD_LAUNCH_CHECK("gemm8w");
     return PSELD_OK;
@@ -401,11 +408,9 @@ static int g8w_launch_group(const G8WGroup& grp, int bn, hipStream_t stream) {
 
 int pseld_gemm8w_launch(const void* dY, const void* X, float* slabs, float* colsum, long slab_stride, long colsum_stride, int Mtok, int N,
                         int K, int lddy, int ldx, int bn, int kchunk, int splits, const float* rowscale, int rows_per_scale, hipStream_t stream) {
-    static G8WGroup grp;      // (single-threaded host side, as the rest of the library)
-    grp.count = 1;
-    g8w_fill(grp.p[0], dY, X, slabs, colsum, slab_stride, colsum_stride, Mtok, N, K, lddy, ldx, bn, kchunk, splits, rowscale, rows_per_scale);
-    grp.first[0] = 0; grp.first[1] = grp.p[0].ntile * splits;
-    return g8w_launch_group(grp, bn, stream);
+    G8WOne one;
+    g8w_fill(one.p, dY, X, slabs, colsum, slab_stride, colsum_stride, Mtok, N, K, lddy, ldx, bn, kchunk, splits, rowscale, rows_per_scale);
+    return g8w_launch_group(one, bn, stream);
 }
 
 void pseld_reduce_slabs(const float* slabs, float* out, long n, int splits, long slab_stride, int accumulate, hipStream_t stream);
@@ -436,8 +441,9 @@ extern "C" int pseld_gemm_wgrad_group(int count, const void* const* dY, const vo
     int idx[G8W_MAXP], n = 0;
     for (int i = 0; i < count; ++i) {
         PSELD_CHECK_ARG(dY[i] && X[i] && dW[i], "gemm_wgrad_group: null operand in entry %d", i);
+        // (a matrix that ends up with one split is written as 16-byte pieces straight into dW: the slot must be 16-byte aligned)
         const bool ok = g8w_eligible(Mtok[i], N[i], K[i], lddy[i], ldx[i], rows_per_scale ? rows_per_scale[i] : 1, rowscale && rowscale[i]) &&
-                        N[i] >= 192 && K[i] >= 192 && Mtok[i] >= 4096;
+                        N[i] >= 192 && K[i] >= 192 && Mtok[i] >= 4096 && ((unsigned long)dW[i] & 15) == 0;
         if (ok) idx[n++] = i; else skipped |= 1u << i;
     }
     *skipped_mask = skipped;

@@ -5,8 +5,9 @@
 The reference reads a float32 slice per chunk from FLAC/WAV files through soundfile in DataLoader workers; at the MI355X
 step rate (≈ 7 500 ten-second chunks/s per GPU) that is ≈ 29 GB/s of fp32 audio per GPU. Here the clips are decoded ONCE
 to 16-bit PCM and kept in HBM (STARSS23 dev: 5 GB); a training batch is cut, padded and converted by one kernel launch
-from a table of index rows. HDF5 / FLAC readers are not rebuilt (h5py / soundfile are absent from this image); a RIFF PCM16
-reader is included for WAV clips.
+from a table of index rows. The index CSV of `extract_index` is written and read here (write_index_csv / read_index_csv, pinned to
+rows the reference's own function wrote: tests/golden/index.npz). HDF5 / FLAC containers are not read (h5py / soundfile are absent from this
+image, so no reference-written file of either kind can exist here to pin a reader against); a RIFF PCM16 reader is included for WAV clips.
 """
 import struct
 
@@ -33,6 +34,40 @@ def segment_index(x_len, chunklen, hoplen, last_frame_always_paddding=False):
     else:
         idx.append((x_len - chunklen, x_len)); pad.append((0, 0))
     return idx, pad
+
+
+def write_index_csv(path, recordings, chunklen, hoplen, last_frame_always_paddding=False):
+    """The index file of preproc/preprocess.py:430-479 (`extract_index`, data_type 'wav'): one row `recording path,begin,end,pad_before,
+    pad_after` per chunk, recordings in the given order (the reference sorts its glob). recordings: [(path, frames), ...]; chunklen /
+    hoplen in samples. The reference writes the train file with the short-remainder rule and the test file with
+    last_frame_always_paddding=True (:433)."""
+    with open(path, 'w') as f:
+        for rec, frames in recordings:
+            idx, pad = segment_index(int(frames), chunklen, hoplen, last_frame_always_paddding)
+            for (b, e), (pb, pa) in zip(idx, pad):
+                f.write(f'{rec},{b},{e},{pb},{pa}\n')
+
+
+def read_index_csv(path):
+    """Rows of an index file as data/components/data.py:38-45 reads them: [(recording path, begin, end, pad_before, pad_after), ...]
+    (the four integers are the LAST four comma-separated fields: a path may itself contain commas)."""
+    rows = []
+    with open(path) as f:
+        for ln, line in enumerate(f, 1):
+            line = line.rstrip('\n')
+            if not line:
+                continue
+            parts = line.rsplit(',', 4)
+            if len(parts) != 5:
+                raise ValueError(f'{path}:{ln}: expected `path,begin,end,pad_before,pad_after`, got {line!r}')
+            try:
+                b, e, pb, pa = (int(v) for v in parts[1:])
+            except ValueError:
+                raise ValueError(f'{path}:{ln}: non-integer index field in {line!r}') from None
+            if b < 0 or e < b or pb < 0 or pa < 0:
+                raise ValueError(f'{path}:{ln}: inconsistent index row {line!r}')
+            rows.append((parts[0], b, e, pb, pa))
+    return rows
 
 
 def read_wav_pcm16(path):
@@ -180,7 +215,7 @@ class DeviceSELDDataset:
     method: 'multi_accdoa' | 'accdoa' | 'einv2'; metas: {recording name: path of its DCASE metadata CSV}."""
 
     def __init__(self, store, metas, method, num_classes, sample_rate=24000, chunklen_sec=10, hoplen_sec=10, label_res=0.1, max_ov=3,
-                 mono_adapter=False, rng=None):
+                 mono_adapter=False, rng=None, index_csv=None):
         from .. import inference
         self.mono_adapter, self.rng = mono_adapter, rng          # cfg.adapt.method == 'mono_adapter' (data.py:109-111,169-171,223-225)
         from . import labels as L
@@ -189,7 +224,19 @@ class DeviceSELDDataset:
         self.ppp = int(sample_rate * label_res)                       # points_per_predictions
         self.frames = int(chunklen_sec / label_res)
         self.max_ov = max_ov
-        self.rows = store.index_rows(self.chunk_len, int(hoplen_sec * sample_rate))
+        if index_csv is not None:
+            # the reference's own index file (read_index_csv): its rows name recordings by path; the store knows them by that path or by
+            # its file name (an index written on another machine carries that machine's directories)
+            import os
+            by_base = {os.path.basename(n): n for n in store.names}
+            self.rows = []
+            for rec, b, e, pb, pa in read_index_csv(index_csv):
+                name = rec if rec in store.names else by_base.get(os.path.basename(rec))
+                if name is None:
+                    raise KeyError(f'{index_csv}: recording {rec!r} is not in the clip store')
+                self.rows.append((name, b, e, pb, pa))
+        else:
+            self.rows = store.index_rows(self.chunk_len, int(hoplen_sec * sample_rate))
         dev = store.device
         self.labels = {}
         for name in store.names:

@@ -1013,32 +1013,38 @@ def conv3x3_wgrad(dY, X, dWp, B, T, F, accumulate=False):
 # Synchronised BatchNorm for the conv-stack BatchNorm2d / Conformer BatchNorm1d layers (configs/trainer/gpu.yaml:9 converts EVERY BatchNorm
 # to torch.nn.SyncBatchNorm): with a process group set (FusedTrainer, sync_bn=True) the train-mode statistics (forward: sum x, sum x^2;
 # backward: sum g xhat, sum g) are summed over the ranks between the two halves of each kernel pair, and the counts are the global ones.
-_sync_bn = {'group': None, 'world': 1, 'diag': None, 'owner': None}
+_sync_bn = {'group': None, 'world': 1, 'diag': None}
 
 
-def set_sync_bn_group(group, diag=None, owner=None):
+def set_sync_bn_group(group, diag=None):
     """group: a torch.distributed process group or None (rank-local statistics). diag: a list that receives (event, event) pairs around
-    every statistics all-reduce (trainer.enable_comm_diag). The group is process-wide state: `owner` (the FusedTrainer that sets it) makes
-    that explicit - while one owner's group is live, a DIFFERENT owner may neither replace it nor switch it off (its conv-stack statistics
-    would silently stop being synchronised); it gets a RuntimeError instead. owner=None (tests, scripts) always overrides.
+    every statistics all-reduce (trainer.enable_comm_diag). This is the state the conv-stack / Conformer BatchNorm kernels read while they
+    run; a FusedTrainer does not leave it set: it wraps each of its steps in sync_bn_scope(), so trainers with different groups (or none:
+    an eval / teacher model beside a data-parallel one) coexist in one process (round 4 raised RuntimeError for the second one).
     Precondition, as for the scalar front: every rank holds the same number of rows per BatchNorm call (the reference's DistributedSampler
     pads every rank to the same batch, src/datamodules: DataLoader under Lightning DDP) - counts are multiplied by the world size, not gathered."""
-    cur = _sync_bn['owner']
-    if owner is not None and cur is not None and cur() is not None and cur() is not owner and _sync_bn['group'] is not None and group is not _sync_bn['group']:
-        raise RuntimeError("ops.set_sync_bn_group: another FusedTrainer's sync-BatchNorm group is active in this process; "
-                           "conv-stack / Conformer BatchNorm synchronisation is process-wide state and cannot serve two different groups")
     _sync_bn['group'] = group
     _sync_bn['diag'] = diag
-    if owner is not None:
-        import weakref
-        _sync_bn['owner'] = weakref.ref(owner) if group is not None else None
-    else:
-        _sync_bn['owner'] = None
     if group is not None:
         import torch.distributed as dist
         _sync_bn['world'] = dist.get_world_size(group)
     else:
         _sync_bn['world'] = 1
+
+
+class sync_bn_scope:
+    """with ops.sync_bn_scope(group, diag): ... - the BatchNorm statistics of the kernels launched inside are summed over `group`
+    (None: rank-local); the previous state comes back on exit."""
+
+    def __init__(self, group, diag=None):
+        self.group, self.diag = group, diag
+
+    def __enter__(self):
+        self.prev = dict(_sync_bn)
+        set_sync_bn_group(self.group, self.diag)
+
+    def __exit__(self, *exc):
+        _sync_bn.update(self.prev)
 
 
 def _sync_bn_allreduce(sums):

@@ -58,19 +58,25 @@ AUGMENT_GROUPS = {
     'default': {},
     'augmix': {'type': ['specaug', 'crop', 'freqshift', 'rotate', 'trackmix', 'wavmix'], 'AugMix': True},
 }
-EXPERIMENTS = {
-    'synth_maccdoa': {},
-    'synth_accdoa': {'model': {'method': 'accdoa', 'loss': {'_target_': 'loss.accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'}}},
-    # configs/experiment/synth_einv2.yaml over configs/loss/einv2_pit.yaml (its augment override is chosen with augment=augmix here)
+EXPERIMENTS = {      # configs/experiment/synth_*.yaml bodies over their `override /loss:` file (trainer.max_epochs stays this entry's own: synthetic loop)
+    'synth_maccdoa': {'model': {'batch_size': 32, 'optimizer': {'kwargs': {'lr': 1e-4}}, 'lr_scheduler': {'kwargs': {'step_size': 20}}}},
+    'synth_accdoa': {'model': {'method': 'accdoa', 'batch_size': 40, 'loss': {'_target_': 'loss.accdoa.Losses', 'loss_fn': 'mse', 'loss_type': 'loss_all'},
+                               'optimizer': {'kwargs': {'lr': 1e-4}}, 'lr_scheduler': {'kwargs': {'step_size': 20}}}},
     # configs/experiment/synth_einv2_agg.yaml (einv2.HTSAT) / synth_seddoa_agg.yaml (model.backbone=HTSAT_SEDDOA) over
     # configs/loss/einv2_pit_agg.yaml
-    'synth_einv2_agg': {'model': {'method': 'einv2', 'loss': {'_target_': 'loss.einv2.Losses_agg_pit', 'loss_fn': 'mse', 'loss_type': 'loss_all',
-                                                           'loss_alpha': 0., 'method': 'mACCDOA_pit'}}},
-    'synth_seddoa_agg': {'model': {'method': 'einv2', 'backbone': 'HTSAT_SEDDOA',
+    'synth_einv2_agg': {'model': {'method': 'einv2', 'batch_size': 17, 'thresh_unify': 10,
+                                  'loss': {'_target_': 'loss.einv2.Losses_agg_pit', 'loss_fn': 'mse', 'loss_type': 'loss_all',
+                                           'loss_alpha': 0., 'method': 'mACCDOA_pit'},
+                                  'optimizer': {'method': 'AdamW', 'kwargs': {'lr': 5e-5}}, 'lr_scheduler': {'kwargs': {'step_size': 6}}}},
+    'synth_seddoa_agg': {'model': {'method': 'einv2', 'backbone': 'HTSAT_SEDDOA', 'batch_size': 40, 'thresh_unify': 10,
                                    'loss': {'_target_': 'loss.einv2.Losses_agg_pit', 'loss_fn': 'mse', 'loss_type': 'loss_all',
-                                            'loss_alpha': 0., 'method': 'mACCDOA_pit'}}},
-    'synth_einv2': {'model': {'method': 'einv2', 'loss': {'_target_': 'loss.einv2.Losses_pit', 'loss_fn': {'sed': 'bce', 'doa': 'mse'},
-                                                       'loss_type': 'loss_all', 'method': 'tPIT', 'loss_beta': 0.5}}},
+                                            'loss_alpha': 0., 'method': 'mACCDOA_pit'},
+                                   'optimizer': {'method': 'AdamW', 'kwargs': {'lr': 1e-4}}, 'lr_scheduler': {'kwargs': {'step_size': 10}}}},
+    # configs/experiment/synth_einv2.yaml:7-13 over configs/loss/einv2_pit.yaml
+    'synth_einv2': {'model': {'method': 'einv2', 'batch_size': 17,
+                              'loss': {'_target_': 'loss.einv2.Losses_pit', 'loss_fn': {'sed': 'bce', 'doa': 'mse'},
+                                       'loss_type': 'loss_all', 'method': 'tPIT', 'loss_beta': 0.5},
+                              'optimizer': {'method': 'AdamW', 'kwargs': {'lr': 5e-5}}, 'lr_scheduler': {'kwargs': {'step_size': 6}}}},
 }
 
 

@@ -46,9 +46,8 @@ class FusedTrainer:
                 # seld_net._bn_front, the conv-stack BatchNorm2d / Conformer BatchNorm1d layers in ops.bn2d_stats / ops.bn_relu_bwd
                 # (statistics summed over the ranks between the two halves of each kernel pair)
                 net.sync_bn_group = process_group
-        from . import ops
+        # the conv-stack / Conformer BatchNorm kernels read their group from ops' state: set for the duration of each step (_step)
         self._conv_bn_sync = process_group is not None and sync_bn
-        ops.set_sync_bn_group(process_group if self._conv_bn_sync else None, owner=self)
         self._works, self._ranges = [], []
         # gradient all-reduce payload: 'f32' (the arena's gradients in place) or 'bf16' (each bucket is cast to bf16, summed on the wire
         # in bf16 and added back into the fp32 arena: half the bytes over xGMI; bench.py --grad-dtype, default f32)
@@ -93,9 +92,6 @@ class FusedTrainer:
         compute stream stalled, `issue -> complete` per bucket an upper bound of the collective's own duration (bench.py, world > 1)."""
         self.comm_diag = {'buckets': [], 'sync_bn': []} if on else None
         self.net.comm_diag = self.comm_diag
-        if self._conv_bn_sync:
-            from . import ops
-            ops.set_sync_bn_group(self.group, self.comm_diag['sync_bn'] if on else None, owner=self)
 
     def comm_report(self):
         """Averages over the steps recorded since enable_comm_diag() (call after a synchronize)."""
@@ -247,6 +243,11 @@ class FusedTrainer:
         return g['out']
 
     def _step(self, batch_x, batch_target, is_features=False, hyper=None, next_x=None):
+        with ops.sync_bn_scope(self.group if self._conv_bn_sync else None,
+                               self.comm_diag['sync_bn'] if (self._conv_bn_sync and self.comm_diag is not None) else None):
+            return self._step_impl(batch_x, batch_target, is_features, hyper, next_x)
+
+    def _step_impl(self, batch_x, batch_target, is_features=False, hyper=None, next_x=None):
         net = self.net
         net.train()
         ops.stage('features')

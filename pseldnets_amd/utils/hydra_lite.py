@@ -28,6 +28,27 @@ class ConfigError(ValueError):
     pass
 
 
+class _Loader(yaml.SafeLoader):
+    """PyYAML's YAML-1.1 float rule needs a '.', so `lr: 5e-5` (configs/experiment/synth_einv2.yaml:11) loads as the STRING '5e-5';
+    OmegaConf - what Hydra loads its files with - registers the YAML-1.2 float pattern, and the reference's optimizer receives a
+    float. Same pattern here (omegaconf's documented resolver: digits with optional fraction and exponent, .inf, .nan)."""
+
+
+_Loader.add_implicit_resolver(
+    'tag:yaml.org,2002:float',
+    re.compile(r"""^(?:[-+]?(?:[0-9][0-9_]*)\.[0-9_]*(?:[eE][-+]?[0-9]+)?
+                    |[-+]?(?:[0-9][0-9_]*)(?:[eE][-+]?[0-9]+)
+                    |\.[0-9_]+(?:[eE][-+][0-9]+)?
+                    |[-+]?[0-9][0-9_]*(?::[0-5]?[0-9])+\.[0-9_]*
+                    |[-+]?\.(?:inf|Inf|INF)
+                    |\.(?:nan|NaN|NAN))$""", re.X),
+    list('-+0123456789.'))
+
+
+def _yaml_load(text):
+    return yaml.load(text, Loader=_Loader)
+
+
 class AttrDict(dict):
     """dict with attribute access (cfg.model.method), as the reference's code reads its DictConfig."""
 
@@ -95,7 +116,7 @@ def _load(path):
     with open(path) as f:
         text = f.read()
     is_global = bool(re.search(r'^\s*#\s*@package\s+_global_\s*$', text, flags=re.M))
-    data = yaml.safe_load(text) or {}
+    data = _yaml_load(text) or {}
     if not isinstance(data, dict):
         raise ConfigError(f'{path}: a config file must hold a mapping')
     return data, is_global
@@ -254,7 +275,7 @@ def _resolve_tree(cfg, node):
 
 def _parse_scalar(text):
     try:
-        return yaml.safe_load(text)
+        return _yaml_load(text)
     except yaml.YAMLError:
         return text
 

@@ -1154,8 +1154,46 @@ def gen_labels():
     save('labels.npz', **out)
 
 
+def gen_index():
+    """preproc/preprocess.py:430-479 extract_index (data_type 'wav': the `path,begin,end,pad_before,pad_after` rows of the
+    `{dataset}_{chunk}sChunklen_{hop}sHoplen_{train,test}.csv` files data/components/data.py reads) run unbound with a stand-in `self`
+    and a stand-in soundfile.info (soundfile is absent): the rows it writes for recordings of seeded lengths - shorter than a chunk,
+    an exact multiple of the hop, remainders below / above half a chunk. Stored as arrays (recording number, begin, end, pad_before,
+    pad_after): the fixture holds no path text of the build container."""
+    import tempfile
+    import types
+    from pathlib import Path
+    lengths = [240000 * 6, 100000, 240000 * 2 + 50000, 240000 * 3 + 130000, 240000, 1440000 + 119999, 1440000 + 120000]
+    frames = {}
+    R._mod('h5py')
+    R._mod('soundfile', info=lambda path: types.SimpleNamespace(frames=frames[Path(path).name]))
+    for name in [m for m in list(sys.modules) if m.startswith('preproc')]:
+        del sys.modules[name]
+    from preproc.preprocess import Preprocess
+    out = {'lengths': np.array(lengths, dtype=np.int64)}
+    with tempfile.TemporaryDirectory() as td:
+        foa = Path(td) / 'foa'; foa.mkdir()
+        for i, n in enumerate(lengths):
+            (foa / f'rec{i:02d}.flac').touch(); frames[f'rec{i:02d}.flac'] = n
+        csvs = [Path(td) / 'idx' / 'synth_train.csv', Path(td) / 'idx' / 'synth_test.csv']
+        for tag, (cl, hl, tcl, thl) in {'a': (10, 10, 10, 10), 'b': (4, 2, 10, 5)}.items():
+            fake = types.SimpleNamespace(train_chunklen_sec=cl, train_hoplen_sec=hl, test_chunklen_sec=tcl, test_hoplen_sec=thl, fs=24000,
+                                         indexes_path_list=csvs, data_type='wav', data_dir={'foa': foa}, wav_format='.flac',
+                                         cfg=R.AttrDict(dataset='synth'))
+            Preprocess.extract_index(fake)
+            for split, path in zip(('train', 'test'), csvs):
+                rows = []
+                for line in path.read_text().splitlines():
+                    name, b, e, pb, pa = line.rsplit(',', 4)
+                    assert name.startswith(str(foa))                      # the reference writes the absolute path of the recording
+                    rows.append([int(Path(name).stem[3:]), int(b), int(e), int(pb), int(pa)])
+                out[f'{tag}_{split}'] = np.array(rows, dtype=np.int64)
+            out[f'{tag}_cfg'] = np.array([cl, hl, tcl, thl], dtype=np.int64)
+    save('index.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'conformer_full', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt', 'labels']
+    which = sys.argv[1:] or ['feature', 'tiny', 'full', 'losses', 'optim', 'sampler', 'passt', 'crnn', 'conformer', 'conformer_full', 'augment', 'decode', 'adapter', 'lora', 'data', 'metrics', 'gru', 'transformer', 'einv2_passt', 'einv2_crnn', 'epoch_end', 'spatial', 'ckpt', 'labels', 'index']
     if 'feature' in which: gen_feature()
     if 'tiny' in which: gen_htsat_tiny()
     if 'full' in which: gen_htsat_full()
@@ -1180,3 +1218,4 @@ if __name__ == '__main__':
     if 'spatial' in which: gen_spatial()
     if 'ckpt' in which: gen_ckpt()
     if 'labels' in which: gen_labels()
+    if 'index' in which: gen_index()

@@ -178,6 +178,32 @@ def test_bench_two_ranks_terminates_and_reports(dev):
     assert out['comm']['allreduce_bytes'] > 0 and len(out['comm']['buckets']) == 3 and 'sync_bn_exposed_ms' in out['comm']
 
 
+@pytest.mark.parametrize("backbone", ['htsat', 'crnn'])
+def test_bench_four_ranks_the_drivers_scale_launch(dev, backbone):
+    """The driver's SCALE launch line at N = 4 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 4 ...`), the four ranks sharing cuda:0 over gloo: the first real multi-GPU run
+    must not die on the rendezvous, the bucket order, the deferred waits or the sync-BN collectives. Rank 0 prints one JSON line with
+    four ranks' worth of clips, three gradient buckets covering the arena once, and the sync-BN wait accounted; `crnn` exercises the
+    conv-stack / Conformer BatchNorm collectives (25 per step) the HTS-AT path does not have."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSELD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+           '--master-port', str(29531 + (backbone == 'crnn')), os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1',
+           '--chunks', '2', '--backbone', backbone, '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 4 and out['rccl_ranks'] == 4 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['config']['global_chunks'] == 8 and out['config']['sync_batchnorm'] is True and out['config']['parallelism'] == 'dp4'
+    assert out['comm']['allreduce_bytes'] > 0 and len(out['comm']['buckets']) >= 1 and out['comm']['sync_bn_exposed_ms'] >= 0
+    assert abs(out['loss']) < 1e6 and out['loss'] == out['loss']
+
+
 def test_bench_starts_its_own_ranks_without_a_launcher(dev):
     """`python bench.py --gpus 2` with no torchrun around it: the parent (which never touches a GPU) starts two child ranks,
     relays rank 0's single JSON line and exits 0; the line reports 2 ranks, sync-BN on (the reference's DDP recipe,
@@ -251,7 +277,7 @@ def _worker_crnn(rank, world, port, q, env=None):
     if os.environ.get('PSELD_TEST_NO_CONV_BN_SYNC') == '1':           # negative control: scalar front synchronised, conv stack rank-local
         from pseldnets_amd import ops
         real = ops.set_sync_bn_group
-        ops.set_sync_bn_group = lambda group, diag=None, owner=None: real(None)
+        ops.set_sync_bn_group = lambda group, diag=None: real(None)
     losses, flat, rv, n_sync, grad1 = _run_crnn(_build_crnn(dev), x, lab, dist.group.WORLD)
     q.put((rank, losses, flat.numpy(), rv.numpy(), n_sync, grad1.numpy()))
     dist.destroy_process_group()

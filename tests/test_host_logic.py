@@ -266,33 +266,67 @@ def test_label_extraction_matches_the_reference_preprocessing(tmp_path):
         assert np.array_equal(sed, g[f'mix{i}__sed_label']) and np.array_equal(doa, g[f'mix{i}__doa_label'])
 
 
-def test_sync_bn_group_is_owned(monkeypatch):
-    """ops.set_sync_bn_group is process-wide state: while one trainer's group is live another owner may neither replace it nor
-    switch it off; the same group, a dead owner, or an owner-less caller (tests, scripts) may."""
-    import gc
+def test_index_csv_matches_the_rows_the_reference_writes(tmp_path):
+    """data/ingest.py write_index_csv / read_index_csv against the rows preproc/preprocess.py:430-479 extract_index wrote for recordings of
+    the same lengths (tests/golden/index.npz, generated by importing the reference with a stand-in soundfile.info): train file (short
+    remainders re-use the clip's tail) and test file (last chunk always padded), chunk = hop and chunk > hop."""
+    from pseldnets_amd.data import ingest
+    g = np.load(os.path.join(G, 'index.npz'))
+    recs = [(f'/data/somewhere/foa/rec{i:02d}.flac', int(n)) for i, n in enumerate(g['lengths'])]
+    for tag in ('a', 'b'):
+        cl, hl, tcl, thl = (int(v) for v in g[f'{tag}_cfg'])
+        for split, (c, h, pad_last) in (('train', (cl, hl, False)), ('test', (tcl, thl, True))):
+            path = tmp_path / f'{tag}_{split}.csv'
+            ingest.write_index_csv(path, recs, c * 24000, h * 24000, pad_last)
+            rows = ingest.read_index_csv(path)
+            want = g[f'{tag}_{split}']
+            assert len(rows) == len(want), (tag, split, len(rows), len(want))
+            for r, w in zip(rows, want):
+                assert r[0] == recs[int(w[0])][0] and tuple(r[1:]) == tuple(int(v) for v in w[1:]), (tag, split, r, w)
+            assert all(pb + (e - b) + pa == c * 24000 for _, b, e, pb, pa in rows)        # every row is one whole chunk
+    # a path with commas keeps its commas; malformed rows are refused with their line number
+    p = tmp_path / 'odd.csv'
+    p.write_text('/data/a,b/rec.flac,0,240000,0,0\n\n/x.flac,240000,300000,0,180000\n')
+    assert ingest.read_index_csv(p) == [('/data/a,b/rec.flac', 0, 240000, 0, 0), ('/x.flac', 240000, 300000, 0, 180000)]
+    for bad in ('/x.flac,0,10\n', '/x.flac,0,ten,0,0\n', '/x.flac,10,5,0,0\n'):
+        p.write_text(bad)
+        with pytest.raises(ValueError, match=r'odd\.csv:1'):
+            ingest.read_index_csv(p)
+
+
+def test_sync_bn_scope_nests_and_restores(monkeypatch):
+    """The sync-BatchNorm group is state the conv-stack kernels read while they run; a FusedTrainer sets it for the duration of each
+    step (ops.sync_bn_scope) instead of owning it for its lifetime (round 4: a second trainer with another group - or none: an eval /
+    teacher model beside a data-parallel one - raised RuntimeError): scopes nest, restore on exit and on exceptions."""
     import torch.distributed as dist
     from pseldnets_amd import ops
+    monkeypatch.setattr(dist, 'get_world_size', lambda group=None: 2 if group == 'g1' else 4)
+    assert ops._sync_bn['group'] is None and ops._sync_bn['world'] == 1
+    diag = []
+    with ops.sync_bn_scope('g1', diag):
+        assert ops._sync_bn['group'] == 'g1' and ops._sync_bn['world'] == 2 and ops._sync_bn['diag'] is diag
+        with ops.sync_bn_scope(None):                               # a trainer without a group stepping in between
+            assert ops._sync_bn['group'] is None and ops._sync_bn['world'] == 1 and ops._sync_bn['diag'] is None
+        with ops.sync_bn_scope('g2'):
+            assert ops._sync_bn['group'] == 'g2' and ops._sync_bn['world'] == 4
+        assert ops._sync_bn['group'] == 'g1' and ops._sync_bn['world'] == 2 and ops._sync_bn['diag'] is diag
+        with pytest.raises(ValueError):
+            with ops.sync_bn_scope('g2'):
+                raise ValueError('step failed')
+        assert ops._sync_bn['group'] == 'g1'
+    assert ops._sync_bn['group'] is None and ops._sync_bn['world'] == 1 and ops._sync_bn['diag'] is None
+
+
+def test_two_trainers_with_different_groups_can_be_built(monkeypatch):
+    """FusedTrainer.__init__ touches no process-wide sync-BN state: a second trainer (no group) is built while the first one's
+    'group' exists, and neither construction changes ops' state."""
+    import torch.distributed as dist
+    from pseldnets_amd import ops
+    from pseldnets_amd.trainer import FusedTrainer
     monkeypatch.setattr(dist, 'get_world_size', lambda group=None: 2)
 
-    class Owner:
-        pass
-    g1, g2, a, b = object(), object(), Owner(), Owner()
-    try:
-        ops.set_sync_bn_group(g1, owner=a)
-        assert ops._sync_bn['group'] is g1 and ops._sync_bn['world'] == 2
-        ops.set_sync_bn_group(g1, owner=b)                      # the same group: fine
-        ops.set_sync_bn_group(g1, owner=a)
-        with pytest.raises(RuntimeError):
-            ops.set_sync_bn_group(g2, owner=b)
-        with pytest.raises(RuntimeError):
-            ops.set_sync_bn_group(None, owner=b)                # would silently un-synchronise a's conv stack
-        assert ops._sync_bn['group'] is g1
-        del a
-        gc.collect()
-        ops.set_sync_bn_group(None, owner=b)                    # the owner is gone
-        assert ops._sync_bn['group'] is None and ops._sync_bn['world'] == 1
-        ops.set_sync_bn_group(g2, owner=b)
-        ops.set_sync_bn_group(None)                             # owner-less override
-        assert ops._sync_bn['group'] is None
-    finally:
-        ops.set_sync_bn_group(None)
+    class Net:
+        sync_bn_group = None
+    a = FusedTrainer(Net(), None, 'adpit', process_group='g1', sync_bn=True)
+    b = FusedTrainer(Net(), None, 'adpit')
+    assert a._conv_bn_sync and not b._conv_bn_sync and ops._sync_bn['group'] is None

@@ -133,6 +133,26 @@ def test_device_dataset_batches_equal_the_reference_getitem(dev, tmp_path, metho
         assert got['ov'][n] == ov and got['filename'][n] == name
 
 
+def test_device_dataset_from_a_reference_format_index_file(dev, tmp_path):
+    """DeviceSELDDataset(index_csv=...): rows come from an index file in the reference's format (preprocess.py:430-479) written on
+    ANOTHER machine (other directories: recordings are matched by file name); same batches as the dataset's own index."""
+    import os
+    from pseldnets_amd.data import ingest
+    from pseldnets_amd.data.ingest import DeviceSELDDataset
+    store, metas, _ = _make_split(tmp_path, dev)
+    own = DeviceSELDDataset(store, metas, 'multi_accdoa', 5)
+    recs = [('/mnt/elsewhere/foa_dev/' + os.path.basename(n), store.lengths[i]) for n, i in store.names.items()]
+    csv = tmp_path / 'synth_10sChunklen_10sHoplen_train.csv'
+    ingest.write_index_csv(csv, recs, 240000, 240000)
+    ds = DeviceSELDDataset(store, metas, 'multi_accdoa', 5, index_csv=csv)
+    assert ds.rows == own.rows
+    a, b = ds.batch(range(len(ds))), own.batch(range(len(own)))
+    assert torch.equal(a['data'], b['data']) and torch.equal(a['adpit_label'], b['adpit_label']) and a['ov'] == b['ov']
+    csv.write_text('/mnt/elsewhere/unknown.flac,0,240000,0,0\n')
+    with pytest.raises(KeyError):
+        DeviceSELDDataset(store, metas, 'multi_accdoa', 5, index_csv=csv)
+
+
 def test_train_entry_point_on_recordings(dev, tmp_path, capsys):
     """`python -m pseldnets_amd.train data.wav_dir=...`: WAV recordings + metadata CSVs -> HBM split -> the reference's sampler ->
     device-assembled batches -> fused training steps (3 batches per epoch: 6 index rows + the sampler's wrap-around batch); the
