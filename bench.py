@@ -312,6 +312,10 @@ def main():
     ap.add_argument('--grad-dtype', default='f32', choices=['f32', 'bf16'],
                     help='payload of the gradient all-reduce (N > 1): f32 = the arena in place (138 MB), bf16 = cast buckets (69 MB), '
                          'summed on the wire in bf16 and accumulated back into the fp32 arena')
+    ap.add_argument('--comm', default='torch', choices=['torch', 'rccl', 'rccl_direct'],
+                    help="gradient all-reduce (N > 1): torch = torch.distributed.all_reduce on the RCCL process group (default); rccl = this build's "
+                         "own RCCL layer (include/pseld_comm.h), ncclAllReduce; rccl_direct = the same layer, grouped point-to-point reduce-scatter + "
+                         "all-gather to all peers at once (S / W bytes per xGMI link per phase instead of a ring's 2 (W-1)/W S over one link)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-detail', action='store_true', help='per-shape GEMM launch table on stderr')
@@ -395,7 +399,8 @@ def main():
     use_graph = group is None and args.adapt == 'none' and args.warmup >= 2 and \
         args.graph == 'on'
     trainer = FusedTrainer(net, get_afextractor(cfg).to(device), 'tpit' if einv2_mode else 'adpit', lr=1e-4, max_norm=1.0,
-                           process_group=group, sync_bn=sync_bn, use_graph=use_graph, graph_warmup=min(3, args.warmup - 1))
+                           process_group=group, sync_bn=sync_bn, use_graph=use_graph, graph_warmup=min(3, args.warmup - 1),
+                           comm=args.comm if backend == 'nccl' else 'torch')
     trainer.grad_dtype = args.grad_dtype
     clips_per_step = n_chunks / CHUNKS_PER_CLIP
     if einv2_mode:     # track-wise labels: track 0 carries the ADPIT A0 events, tracks 1-2 silent
@@ -489,6 +494,7 @@ def main():
         "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(step_ms[0], 3), "ms_per_step_p90": round(step_ms[int(0.9 * (len(step_ms) - 1))], 3),
         "value_at_median_step": round(clips_per_step * world / (median_ms * 1e-3), 2),
         "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1), "comm_backend": backend if world > 1 else None,
+        "comm_allreduce": trainer.comm_kind if group is not None else None,
         "hip_graph": bool(use_graph and trainer._graph is not None),      # the timed steps were replays of one captured hipGraph
         "wgrad_side_stream": ops_mod._wgrad_stream['on'] and args.backbone.startswith('htsat'),
         # every timed step issues ONE feature extraction - that of the next step's batch, on a second stream (the pipeline a loader with

@@ -151,8 +151,8 @@ void pseld_gemm8_force_tile(int rows, int cols);
 /* Measurement aid: symbol of the kernel the last pseld_gemm / pseld_gemm_wgrad call of this process launched. */
 const char* pseld_gemm_last_kernel(void);
 /* Measurement aid: pseld_gemm_wgrad launches a GEMM kernel and a slab reduction, so events around the call do not time one kernel.
- * After pseld_gemm_wgrad_timing(1) every call brackets its GEMM kernel alone with two library-owned HIP events (0 switches it off;
- * both reset the record count); _count = calls recorded, _read(i) = the i-th call's kernel time in ms (synchronises on its end event;
+ * After pseld_gemm_wgrad_timing(1) every call brackets its GEMM kernel alone with two library-owned HIP events (switching on resets the
+ * record count, 0 switches it off and keeps the records readable); _count = calls recorded, _read(i) = the i-th call's kernel time in ms (synchronises on its end event;
  * < 0 on error), _symbol(i) = the kernel symbol it launched. bench.py ranks ALL kernel symbols of the step with it. */
 int pseld_gemm_wgrad_timing(int enable);
 int pseld_gemm_wgrad_timing_count(void);

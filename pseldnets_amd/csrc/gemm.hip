@@ -1583,7 +1583,7 @@ inline WgradStamp* wgrad_stamp_begin(hipStream_t s) {
 }
 inline void wgrad_stamp_end(WgradStamp* w, hipStream_t s, const char* sym) { if (w) { (void)hipEventRecord(w->b, s); w->sym = sym; } }
 }  // namespace
-extern "C" int pseld_gemm_wgrad_timing(int enable) { g_wgrad_timing = enable != 0; g_wgrad_stamp_n = 0; return PSELD_OK; }
+extern "C" int pseld_gemm_wgrad_timing(int enable) { g_wgrad_timing = enable != 0; if (enable) g_wgrad_stamp_n = 0; return PSELD_OK; }     // (switching off keeps the records readable)
 extern "C" int pseld_gemm_wgrad_timing_count(void) { return (int)g_wgrad_stamp_n; }
 extern "C" float pseld_gemm_wgrad_timing_read(int i) {
     if (i < 0 || (size_t)i >= g_wgrad_stamp_n) return -1.f;

@@ -30,7 +30,7 @@ class FusedTrainer:
 
     def __init__(self, net, af_extractor, loss_kind='adpit', lr=1e-4, max_norm=1.0, weight_decay=0.01,
                  betas=(0.9, 0.999), eps=1e-8, step_size=20, gamma=0.1, process_group=None, sync_bn=False,
-                 loss_beta=0.5, agg_weights=(1.0, 0.0), agg_l1=False, use_graph=False, graph_warmup=3):
+                 loss_beta=0.5, agg_weights=(1.0, 0.0), agg_l1=False, use_graph=False, graph_warmup=3, comm='torch'):
         self.net, self.af, self.loss_kind = net, af_extractor, loss_kind
         self.base_lr, self.max_norm, self.wd, self.betas, self.eps = lr, max_norm, weight_decay, betas, eps
         self.step_size, self.gamma, self.epoch = step_size, gamma, 0
@@ -46,6 +46,15 @@ class FusedTrainer:
                 # seld_net._bn_front, the conv-stack BatchNorm2d / Conformer BatchNorm1d layers in ops.bn2d_stats / ops.bn_relu_bwd
                 # (statistics summed over the ranks between the two halves of each kernel pair)
                 net.sync_bn_group = process_group
+        # gradient all-reduce: 'torch' = torch.distributed.all_reduce on the group's own backend (RCCL under 'nccl'; gloo in the CPU-side
+        # tests); 'rccl' / 'rccl_direct' = this build's own RCCL layer (pseldnets_amd/comm.py, include/pseld_comm.h: pseld_comm_init /
+        # allreduce_bucket / finalize; 'rccl_direct' = point-to-point reduce-scatter + all-gather over every xGMI link at once)
+        self.comm_kind, self._rccl = comm, None
+        if comm not in ('torch', 'rccl', 'rccl_direct'):
+            raise ValueError(f"comm={comm!r}: 'torch', 'rccl' or 'rccl_direct'")
+        if comm != 'torch' and process_group is not None:
+            from .comm import RcclComm
+            self._rccl = RcclComm(process_group, torch.device('cuda', torch.cuda.current_device()), comm)
         # the conv-stack / Conformer BatchNorm kernels read their group from ops' state: set for the duration of each step (_step)
         self._conv_bn_sync = process_group is not None and sync_bn
         self._works, self._ranges = [], []
@@ -80,11 +89,12 @@ class FusedTrainer:
         if self.comm_diag is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()                                              # bucket issued (on the compute stream, behind the kernels that produced it)
+        reduce = self._rccl.allreduce_ if self._rccl is not None else (lambda t: dist.all_reduce(t, group=self.group, async_op=True))
         if self.grad_dtype == 'bf16':
             buf = g.to(torch.bfloat16)                               # (plumbing: a cast, not arithmetic of the model)
-            self._works.append((dist.all_reduce(buf, group=self.group, async_op=True), buf, g, ev))
+            self._works.append((reduce(buf), buf, g, ev))
         else:
-            self._works.append((dist.all_reduce(g, group=self.group, async_op=True), None, g, ev))
+            self._works.append((reduce(g), None, g, ev))
         self._ranges.append((a, b))
 
     def enable_comm_diag(self, on=True):
