@@ -27,6 +27,7 @@ class FusedTrainer:
     comm_diag = None
     grad_dtype = 'f32'
     _conv_bn_sync = False
+    comm_kind, _rccl = 'torch', None
 
     def __init__(self, net, af_extractor, loss_kind='adpit', lr=1e-4, max_norm=1.0, weight_decay=0.01,
                  betas=(0.9, 0.999), eps=1e-8, step_size=20, gamma=0.1, process_group=None, sync_bn=False,
