@@ -63,6 +63,11 @@ class _EventWork:
         torch.cuda.current_stream().wait_event(self.event)
 
 
+class _NoWork:
+    def wait(self):
+        pass
+
+
 class RcclComm:
     def __init__(self, group, device, algo='rccl_direct'):
         import torch.distributed as dist
@@ -88,6 +93,8 @@ class RcclComm:
         compute stream has enqueued so far; returns an object whose wait() makes the compute stream wait for the result."""
         if not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("allreduce_: contiguous f32 / bf16 tensors only")
+        if self.world == 1:
+            return _NoWork()                                # the identity: no stream hand-off, no events
         L = lib()
         es = t.element_size()
         need = L.pseld_comm_scratch_bytes(self.handle, t.numel(), es, self.algo)

@@ -45,6 +45,19 @@ def short(name):
     return name.strip()
 
 
+def family(name):
+    """Tile-shape variants of one kernel are one ledger row: gemm8_kernel<MODE, SCALED, *>, gemm8w_kernel<*>, ln_fwd / ln_bwd."""
+    m = re.match(r'gemm8_kernel<(\d), (true|false),', name)
+    if m:
+        return f'gemm8_kernel<{m.group(1)}, {m.group(2)}, *>'
+    if name.startswith('gemm8w_kernel<'):
+        return 'gemm8w_kernel<*>'
+    for k in ('ln_fwd_kernel', 'ln_bwd_kernel', 'reduce_slabs'):
+        if name.startswith(k):
+            return k + ('*' if k == 'reduce_slabs' else '')
+    return name
+
+
 def staged(rs):
     rs.sort(key=lambda r: int(r['Dispatch_Id']))
     cur = 'other'
@@ -60,7 +73,7 @@ def counter(d, cname):
     acc = {}
     rs = [r for r in rows(d, '*counter_collection.csv') if r['Counter_Name'] == cname or 'stage_marker_kernel' in r['Kernel_Name']]
     for st, r in staged(rs):
-        k = (st, short(r['Kernel_Name']))
+        k = (st, family(short(r['Kernel_Name'])) if st in DEPTH else short(r['Kernel_Name']))
         acc[k] = acc.get(k, 0.0) + float(r['Counter_Value'])
     return acc
 
@@ -68,7 +81,7 @@ def counter(d, cname):
 fetch, write = counter(fdir, 'FETCH_SIZE'), counter(wdir, 'WRITE_SIZE')
 t, n = {}, {}
 for st, r in staged(rows(wdir, '*kernel_trace.csv')):
-    k = (st, short(r['Kernel_Name']))
+    k = (st, family(short(r['Kernel_Name'])) if st in DEPTH else short(r['Kernel_Name']))
     t[k] = t.get(k, 0.0) + (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6
     n[k] = n.get(k, 0) + 1
 
