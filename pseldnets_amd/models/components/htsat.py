@@ -37,6 +37,7 @@ LN_DEFER = os.environ.get('PSELD_LN_DEFER', '1') == '1'            # one reducti
 # PSELD_WGRAD_GROUP_MATS=<n>: flush every n matrices
 WGRAD_GROUP_BLOCKS = int(os.environ.get('PSELD_WGRAD_GROUP', '0'))
 WGRAD_GROUP_MATS = int(os.environ.get('PSELD_WGRAD_GROUP_MATS', '0')) or (1 << 30)
+WGRAD_GROUP_STAGES = tuple(int(v) for v in os.environ.get('PSELD_WGRAD_GROUP_STAGES', '0,1,2,3').split(',') if v.strip())   # stages that group
 MLP_DW_FIRST = os.environ.get('PSELD_MLP_DW_FIRST', '1') == '1'
 _inference = [False]      # set by the no-grad forward (seld_net._run): nothing is saved for a backward pass
 
@@ -405,7 +406,7 @@ class SwinEncoder:
         # one chip-wide persistent launch leaves the second stream nothing to interleave
         self._wgroup_blocks = WGRAD_GROUP_BLOCKS
         self._wgroup_mats = WGRAD_GROUP_MATS
-        self._wgroup = [] if (dx.dtype == torch.bfloat16 and self._wgroup_blocks > 0) else None
+        self._wgroup = [] if (dx.dtype == torch.bfloat16 and self._wgroup_blocks > 0 and li in WGRAD_GROUP_STAGES) else None
         self._wgroup_n = 0
         dx = self._backward_layer(li, dx, saved, B)
         self._flush_wgroup()

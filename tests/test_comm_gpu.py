@@ -73,7 +73,9 @@ def test_single_rank_communicator_and_trainer_step(dev):
         if tr._rccl is not None:
             tr._rccl.close()
         return losses, net.arena.flat.detach().cpu().clone()
-    l0, f0 = run(None, 'torch')
+    l0, f0 = run(None, 'torch')                    # no group: the clipping norm is taken over the whole arena at once
+    lg, fg = run(group, 'torch')                   # one-rank group: the bucketed path (norm from per-bucket parts: another fp32 summation order)
+    assert l0 == lg and ((f0 - fg).norm() / f0.norm()).item() < 1e-6
     for kind in ('rccl', 'rccl_direct'):
         l1, f1 = run(group, kind)
-        assert l0 == l1 and torch.equal(f0, f1), kind
+        assert lg == l1 and torch.equal(fg, f1), kind   # the same bucketed path, another transport: the same bits
