@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float* __restrict__ 
         for (int k = 0; k < 4; ++k) mean[k] = sums[2 * (c * 64 + 4 * fq + k)] / count;
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    // row -> (sample, frame) through the reciprocal (exact after one fix-up step for rows < 2^24; a 64-bit division per load cost more
+    // than the load: 64 us for the 57 MB of a 32-chunk batch, latency of the division chain, not of memory)
+    const float rT = 1.0f / (float)T;
     for (long r0 = rbeg + rr; r0 < rend; r0 += 64) {
         f32x4 v[4];
         bool live[4];
@@ -256,9 +259,12 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float* __restrict__ 
         for (int u = 0; u < 4; ++u) {
             const long r = r0 + 16 * u;
             live[u] = r < rend;
-            const long rc = live[u] ? r : rbeg;
-            const long b = rc / T, t = rc - b * T;
-            v[u] = *(const f32x4*)(feat + ((b * Cin + c) * T + t) * 64 + 4 * fq);
+            const int rc = (int)(live[u] ? r : rbeg);
+            int b = (int)((float)rc * rT);
+            int t = rc - b * T;
+            b += (t >= T) - (t < 0);
+            t = rc - b * T;
+            v[u] = *(const f32x4*)(feat + (((long)b * Cin + c) * T + t) * 64 + 4 * fq);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -675,6 +681,7 @@ extern "C" int pseld_bn_scalar_stats(const float* feat, float* sums, int B, int 
     PSELD_CHECK_ARG(feat && sums && workspace, "bn_scalar_stats: null pointer");
     PSELD_CHECK_ARG(F == 64, "bn_scalar_stats: mel_bins must be 64 (got %d)", F);
     PSELD_CHECK_ARG(workspace_bytes >= pseld_bn_scalar_workspace(B, Cin, T), "bn_scalar_stats: workspace too small");
+    PSELD_CHECK_ARG((long)B * T < (1L << 24), "bn_scalar_stats: B * T = %ld rows: the row -> (sample, frame) map is exact below 2^24", (long)B * T);
     hipStream_t s = (hipStream_t)stream;
     const int nb = pseld_cdiv((long)B * T, BN_ROWS);
     const int n = Cin * F;
