@@ -105,9 +105,16 @@ __device__ __forceinline__ void g8_store_nt(bf16_t* p, const G8Piece<PD>& v) {
 // MBQ = 16-row accumulator blocks per wave and row quadrant: 4 -> 256-row tile (wave 128 rows), 2 -> 128-row tile (wave 64 rows, the A
 // half images are 64 rows = ONE LDS-DMA instruction per wave). Same K order per output element at every (NB, MBQ): the four tile
 // shapes give the same bits, so the launch may pick by grid fill (under-filled launches: the 32-chunk step, stage 3).
-template <int MODE, bool SCALED, int NB, int MBQ = 4, bool DBG = false>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
+// PACK (built for NB = 3, MBQ = 2: the 128 x 192 tile): the four half-tile images are packed to their real sizes (8 + 8 + 16 + 8 KB per K-tile,
+// 80 KB for the ring) and the bias comes from global memory instead of an LDS copy, so that TWO workgroups fit a CU (16 waves, <= 128
+// registers each): twice the LDS-DMA bytes in flight per CU and a second workgroup's phases under every barrier of the first.
+template <int MODE, bool SCALED, int NB, int MBQ = 4, bool DBG = false, bool PACK = false>
+__global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g) {
     constexpr int WN = NB * 16, BN = 4 * WN;
+    constexpr int OFF_A1 = PACK ? 32 * MBQ * 128 : HALF_B;                   // A-h1 image (A-h0 at 0)
+    constexpr int OFF_B0 = PACK ? 2 * OFF_A1 : 2 * HALF_B;
+    constexpr int OFF_B1 = PACK ? OFF_B0 + HALF_B : 3 * HALF_B;
+    constexpr int BUF = PACK ? OFF_B1 + (NB - 2) * 8192 : BUF_B;             // one K-tile
     constexpr int NB1 = NB - 2;                  // blocks in the second column quadrant
     constexpr int BM = 64 * MBQ;                 // tile rows
     constexpr int MBN = 2 * MBQ;                 // 16-row blocks per wave
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     //  B-h1(k+1) A-h1(k+1); phase 2 for A-h1(k): B-h0(k+1) A-h0(k+1) B-h1(k+1) A-h1(k+1) B-h0(k+2))
     constexpr int VM_P4 = 2 + 2 * MA + 2 * NB1, VM_P1 = 2 + 3 * MA + NB1, VM_P2 = 4 + 2 * MA + NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* bias_s = (float*)(smem + RING_B);
+    float* bias_s = (float*)(smem + RING_B);      // (not PACK)
     // (diagnostic instantiation) real-time stamps of the start-up pieces, and the end of K-tiles 0..7 of this workgroup's SECOND tile
     unsigned long long r_entry = 0, r_bias = 0, r_loop = 0, kt0 = 0, kt1 = 0, kt2 = 0, kt3 = 0, kt4 = 0, kt5 = 0, kt6 = 0, kt7 = 0;
     if constexpr (DBG) r_entry = __builtin_amdgcn_s_memrealtime();
@@ -144,16 +151,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     const int my_n = (chunkn - slot + per - 1) / per;
     const int first = chunk0 + slot;
 
-    for (int i = tid; i < g.nx * BN; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
-    __syncthreads();
+    if constexpr (!PACK) {
+        for (int i = tid; i < g.nx * BN; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
+        __syncthreads();
+    }
     if constexpr (DBG) r_bias = __builtin_amdgcn_s_memrealtime();
 
     // ---- fragment read addresses (buffer 0): lane reads row l15 of a 16-row block, 16-byte chunk (4 kk + q) ^ ((row >> 1) & 7) ----
     const int sw = (lane >> 1) & 7;
     const unsigned c0 = (unsigned)((q ^ sw) << 4);
     unsigned ra0 = (unsigned)(wr * (MBQ * 2048) + l15 * 128) + c0, ra1 = ra0 ^ 64;                          // A halves: rows wr*16 MBQ + mbl*16 + l15
-    unsigned rb0 = (unsigned)(2 * HALF_B + wc * 4096 + l15 * 128) + c0, rb1 = rb0 ^ 64;                       // B-h0: rows wc*32 + nbl*16 + l15
-    unsigned rc0 = (unsigned)(3 * HALF_B + wc * (NB1 * 2048) + l15 * 128) + c0, rc1 = rc0 ^ 64;               // B-h1: rows wc*(16 NB1) + nbl*16 + l15
+    unsigned rb0 = (unsigned)(OFF_B0 + wc * 4096 + l15 * 128) + c0, rb1 = rb0 ^ 64;                       // B-h0: rows wc*32 + nbl*16 + l15
+    unsigned rc0 = (unsigned)(OFF_B1 + wc * (NB1 * 2048) + l15 * 128) + c0, rc1 = rc0 ^ 64;               // B-h1: rows wc*(16 NB1) + nbl*16 + l15
 
     // ---- LDS-DMA source offsets of the load cursor's tile: [half][instruction] ----
     unsigned offA[2][MA], offB[2][2];
@@ -198,16 +207,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     auto dmaA = [&](int h) {
         const char* sb = g.A + ld_kt * 128;
 #pragma unroll
-        for (int j = 0; j < MA; ++j) g8_dma(dst_a + ld_buf + (unsigned)(h * HALF_B + j * 1024), sb, offA[h][j]);
+        for (int j = 0; j < MA; ++j) g8_dma(dst_a + ld_buf + (unsigned)(h * OFF_A1 + j * 1024), sb, offA[h][j]);
     };
     auto dmaB = [&](int h) {
         const char* sb = g.B + ld_kt * 128;
-        if (NB == 3 && h == 1) { g8_dma(lds_base + (unsigned)wave * 1024u + ld_buf + (unsigned)(3 * HALF_B), sb, offB[1][0]); return; }
+        if (NB == 3 && h == 1) { g8_dma(lds_base + (unsigned)wave * 1024u + ld_buf + (unsigned)OFF_B1, sb, offB[1][0]); return; }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) g8_dma(dst_w + ld_buf + (unsigned)((2 + h) * HALF_B + j * 1024), sb, offB[h][j]);
+        for (int j = 0; j < 2; ++j) g8_dma(dst_w + ld_buf + (unsigned)((h ? OFF_B1 : OFF_B0) + j * 1024), sb, offB[h][j]);
     };
     auto advance = [&]() {       // past the end of the list the cursor re-reads the last tile (nobody reads those images): the
-        ld_buf ^= BUF_B;         // vmcnt distance stays constant in the tail
+        ld_buf = (unsigned)BUF - ld_buf;         // vmcnt distance stays constant in the tail
         if (++ld_kt == g.nk) {
             ld_kt = 0;
             if (ld_i + 1 < my_n) { ++ld_i; set_tile(first + ld_i * per); }
@@ -218,10 +227,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     f32x4 acc[MBN][NB];
 
     auto init_acc = [&](int n0) {
-        const float* bp = bias_s + n0 + wc * WN + 4 * NB * q;
         f32x4 b[NB];
+        if constexpr (PACK) {          // no LDS copy of the bias: this lane's 4 NB values straight from global memory (N % BN == 0 for the packed tile)
+            const float* bp = g.bias + n0 + wc * WN + 4 * NB * q;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(bp + 4 * nb);
+            for (int nb = 0; nb < NB; ++nb) b[nb] = g.bias ? *(const f32x4*)(bp + 4 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const float* bp = bias_s + n0 + wc * WN + 4 * NB * q;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(bp + 4 * nb);
+        }
 #pragma unroll
         for (int mb = 0; mb < MBN; ++mb)
 #pragma unroll
@@ -333,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 
 #define G8_LD_A(mq)                                                                                              \
     _Pragma("unroll") for (int mbl = 0; mbl < MBQ; ++mbl) {                                                      \
-        fa[mbl][0] = *(const bf16x8*)(smem + ra0 + (mq) * HALF_B + mbl * 2048);                                  \
-        fa[mbl][1] = *(const bf16x8*)(smem + ra1 + (mq) * HALF_B + mbl * 2048);                                  \
+        fa[mbl][0] = *(const bf16x8*)(smem + ra0 + (mq) * OFF_A1 + mbl * 2048);                                  \
+        fa[mbl][1] = *(const bf16x8*)(smem + ra1 + (mq) * OFF_A1 + mbl * 2048);                                  \
     }
 #define G8_LD_B0()                                                                                               \
     _Pragma("unroll") for (int nbl = 0; nbl < 2; ++nbl) {                                                        \
@@ -368,6 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     if (wr == 1) G8_BAR();                       // the stagger: waves 4-7 run one barrier behind waves 0-3
 
     const int total_kt = my_n * g.nk;
+    unsigned rdelta = (unsigned)BUF;             // (PACK) the read addresses alternate between the two K-tile buffers by +- BUF
     unsigned long long t_start = 0;
     if constexpr (DBG) { t_start = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
     for (int s = 0; s < total_kt; ++s) {
@@ -403,7 +419,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
         G8_BAR();
         G8_MMA(1, 0, fb0);
         G8_BAR();
-        ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B; rc0 ^= BUF_B; rc1 ^= BUF_B;
+        if constexpr (PACK) { ra0 += rdelta; ra1 += rdelta; rb0 += rdelta; rb1 += rdelta; rc0 += rdelta; rc1 += rdelta; rdelta = 0u - rdelta; }
+        else { ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B; rc0 ^= BUF_B; rc1 ^= BUF_B; }
         if constexpr (DBG) {
             if (cp_i == 1) {
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -454,17 +471,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
 const char* g_gemm8_symbol = "";     // the instantiation the last launch ran, as rocprofv3 prints it (measurement aid)
 char g_gemm8_symbuf[64];
 
-template <int MODE, bool SCALED, int NB, int MBQ>
+constexpr int LDS_PACK_B = 2 * (2 * 32 * 2 * 128 + HALF_B + 8192);      // NB = 3, MBQ = 2 packed: 2 x 40 KB = half a CU's LDS
+template <int MODE, bool SCALED, int NB, int MBQ, bool PACK = false>
 int launch8(const G8Args& a, int nwg, hipStream_t stream) {
-    snprintf(g_gemm8_symbuf, sizeof g_gemm8_symbuf, "gemm8_kernel<%d, %s, %d, %d, false>", MODE, SCALED ? "true" : "false", NB, MBQ);
+    snprintf(g_gemm8_symbuf, sizeof g_gemm8_symbuf, "gemm8_kernel<%d, %s, %d, %d, false%s>", MODE, SCALED ? "true" : "false", NB, MBQ, PACK ? ", true" : "");
     g_gemm8_symbol = g_gemm8_symbuf;
+    constexpr int lds = PACK ? LDS_PACK_B : LDS_B;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB, MBQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr = true; }
-    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB, MBQ>), dim3((unsigned)nwg), dim3(512), LDS_B, stream, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB, MBQ, false, PACK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB, MBQ, false, PACK>), dim3((unsigned)nwg), dim3(512), lds, stream, a);
     PSELD_LAUNCH_CHECK("gemm8");
     return PSELD_OK;
 }
-template <int NB, int MBQ>
+template <int NB, int MBQ, bool PACK = false>
 int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t stream) {
     const bool sc = d.rowscale != nullptr;
     if constexpr (MBQ == 4) {
@@ -479,10 +498,10 @@ int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t strea
             if (!d.resid && !d.aux && !sc) return go(gemm8_kernel<G8_PLAIN, false, NB, 4, true>);
         }
     }
-    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ>(a, nwg, stream);
-    if (d.resid) return sc ? launch8<G8_RESID, true, NB, MBQ>(a, nwg, stream) : launch8<G8_RESID, false, NB, MBQ>(a, nwg, stream);
-    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB, MBQ>(a, nwg, stream) : launch8<G8_MULAUX, false, NB, MBQ>(a, nwg, stream);
-    return sc ? launch8<G8_PLAIN, true, NB, MBQ>(a, nwg, stream) : launch8<G8_PLAIN, false, NB, MBQ>(a, nwg, stream);
+    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ, PACK>(a, nwg, stream);
+    if (d.resid) return sc ? launch8<G8_RESID, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_RESID, false, NB, MBQ, PACK>(a, nwg, stream);
+    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_MULAUX, false, NB, MBQ, PACK>(a, nwg, stream);
+    return sc ? launch8<G8_PLAIN, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_PLAIN, false, NB, MBQ, PACK>(a, nwg, stream);
 }
 
 unsigned long long* g_gemm8_dbg = nullptr;
@@ -529,6 +548,18 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     // (knobs, common.h) and pseld_gemm8_force_tile (tools, tests) force a shape.
     const int want_bn = g_gemm8_force_bn ? g_gemm8_force_bn : pseld_knob(KNOB_GEMM8_BN, 0);
     const int want_bm = g_gemm8_force_bm ? g_gemm8_force_bm : pseld_knob(KNOB_GEMM8_BM, 0);
+    // rows = 64: the 128 x 192 tile packed for two workgroups per CU. Forced (force_tile / knob GEMM8_BM = 64), or chosen (knob GEMM8_PACK,
+    // A/B) for narrow outputs (N <= 384: one or two column tiles, the A operand dominates the traffic) with at least one full round of 512
+    bool pack = want_bm == 64;
+    if (!pack && want_bm == 0 && want_bn == 0 && pseld_knob(KNOB_GEMM8_PACK, 0) != 0 && d.N <= 384 && a.nk > 4 &&
+        (long)(d.N / 192) * pseld_cdiv(d.M, 128) >= 512) pack = true;
+    if (pack && d.N % 192 == 0 && (((unsigned long)d.bias) & 15) == 0) {
+        a.nx = d.N / 192;
+        a.ntiles = a.nx * pseld_cdiv(d.M, 128);
+        int nwg2 = (a.ntiles + 7) / 8 * 8;
+        if (nwg2 > 512) nwg2 = 512;
+        return launch8_mode<3, 2, true>(d, a, nwg2, stream);
+    }
     int bn = 0, bm = 0;
     double best = 0;
     for (int rows = 256; rows >= 128; rows -= 128)
