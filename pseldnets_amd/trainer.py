@@ -80,6 +80,35 @@ class FusedTrainer:
     def end_epoch(self):
         self.epoch += 1
 
+    # -- save / resume (the reference: Lightning's ModelCheckpoint + `ckpt_path` resume, configs/train.yaml:32-33: weights, optimiser
+    #    state, scheduler epoch) --------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """Everything a resumed run needs to continue bit for bit: the network's state dict (reference key names: weights, BatchNorm
+        running statistics), AdamW's first / second moments per parameter (same key names), its step count, the StepLR epoch."""
+        net = self.net
+        net._materialize(next(net.parameters()).device)
+        a = net.arena
+        a.ensure_opt_state()
+        moments = {n: (a.view(a.m, n).detach().clone(), a.view(a.v, n).detach().clone()) for n in a.entries}
+        return {'model': {k: v.detach().clone() for k, v in net.state_dict().items()},
+                'optimizer': {'exp_avg': {n: mv[0] for n, mv in moments.items()}, 'exp_avg_sq': {n: mv[1] for n, mv in moments.items()}, 'step': int(a.step)},
+                'lr_scheduler': {'epoch': int(self.epoch), 'base_lr': self.base_lr, 'step_size': self.step_size, 'gamma': self.gamma}}
+
+    def load_state_dict(self, state):
+        net = self.net
+        net.load_state_dict(state['model'])
+        net._materialize(next(net.parameters()).device)      # (the arena of a network that has not stepped yet is built here)
+        a = net.arena
+        a.ensure_opt_state()
+        opt = state['optimizer']
+        for n in a.entries:
+            a.view(a.m, n).copy_(opt['exp_avg'][n])
+            a.view(a.v, n).copy_(opt['exp_avg_sq'][n])
+        a.step = int(opt['step'])
+        self.epoch = int(state['lr_scheduler']['epoch'])
+        self._graph = None                      # a captured step holds the old hyper-parameters' device copy: re-capture
+        self._eager_steps = 0
+
     # -- gradient buckets ----------------------------------------------------------------------------------------
     def _reduce_range(self, a, b):
         if self.group is None or b <= a:

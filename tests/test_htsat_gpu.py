@@ -692,6 +692,56 @@ def test_einv2_bench_size_batch_independence_and_bit_reproducibility(dev):
             assert torch.equal(g, ref[2]), "EINV2 parameter gradients differ between identical passes"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainer_state_dict_resumes(dev, dtype, tmp_path):
+    """Save / resume (the reference resumes through Lightning's `ckpt_path`, configs/train.yaml:32-33: weights, optimiser state,
+    scheduler epoch): after 2 steps + end_epoch, FusedTrainer.state_dict() goes through torch.save / torch.load into a FRESH network and
+    trainer. The restored state is the saved one bit for bit (weights, both AdamW moments, step count, epoch / learning rate, BatchNorm
+    running statistics); two more steps of the resumed and of the uninterrupted trainer then agree to the run-to-run noise of the step
+    (fp32 atomics in the bias-table gradients, amplified by AdamW's normalisation to at most lr per weight and step), while a resume
+    that dropped the optimiser state lands somewhere else."""
+    from pseldnets_amd.models import multi_accdoa
+    from pseldnets_amd.trainer import FusedTrainer
+    x = oh.formula_features(2).to(dev)
+    lab = {'adpit_label': synth.formula_adpit_label(2, 100, 3).to(dev)}
+    lr = 1e-3
+
+    def fresh():
+        net, _ = build_net(multi_accdoa.HTSAT, 'multi_accdoa', 3, dict(TINY, drop_path_rate=0.0), dev)
+        net.compute_dtype = dtype
+        return net, FusedTrainer(net, None, 'adpit', lr=lr, step_size=1, gamma=0.5)
+    net_b, tr_b = fresh()
+    for _ in range(2):
+        tr_b.training_step(x.clone(), lab, is_features=True)
+    tr_b.end_epoch()
+    torch.save(tr_b.state_dict(), tmp_path / 'ckpt.pt')
+    net_c, tr_c = fresh()                                   # fresh weights, fresh moments, step 0, epoch 0
+    tr_c.load_state_dict(torch.load(tmp_path / 'ckpt.pt', map_location=dev))
+    assert tr_c.epoch == 1 and net_c.arena.step == 2 and abs(tr_c.lr - 0.5 * lr) < 1e-12
+    for buf in ('flat', 'm', 'v'):
+        assert torch.equal(getattr(net_b.arena, buf), getattr(net_c.arena, buf)), buf
+    sb, sc = net_b.state_dict(), net_c.state_dict()
+    assert set(sb) == set(sc) and all(torch.equal(sb[k], sc[k]) for k in sb)
+    ref = net_b.arena.flat.clone()
+    lb = [tr_b.training_step(x.clone(), lab, is_features=True)['loss_all'].item() for _ in range(2)]
+    lc = [tr_c.training_step(x.clone(), lab, is_features=True)['loss_all'].item() for _ in range(2)]
+    torch.cuda.synchronize()
+    assert all(abs(p - q) <= 2e-3 * abs(p) for p, q in zip(lb, lc)), (lb, lc)
+    moved = (net_b.arena.flat - ref).abs().max().item()
+    assert (net_b.arena.flat - net_c.arena.flat).abs().max().item() <= 2 * 0.5 * lr * 1.01 and moved > 0
+    # negative control: weights restored, optimiser state and step count dropped -> bias corrections and moments restart, the update differs
+    net_d, tr_d = fresh()
+    net_d.load_state_dict(torch.load(tmp_path / 'ckpt.pt', map_location=dev)['model'])
+    tr_d.epoch = 1
+    for _ in range(2):
+        tr_d.training_step(x.clone(), lab, is_features=True)
+    torch.cuda.synchronize()
+    good = ((net_b.arena.flat - net_c.arena.flat).norm() / (net_b.arena.flat - ref).norm()).item()
+    bad = ((net_b.arena.flat - net_d.arena.flat).norm() / (net_b.arena.flat - ref).norm()).item()
+    print(f'resume: update difference / update size {good:.3e} (resumed) against {bad:.3e} (optimiser state dropped)')
+    assert good < 0.25 * bad
+
+
 def _default_init_net(dev, dtype, seed=21):
     from pseldnets_amd.models import multi_accdoa
     torch.manual_seed(seed)
