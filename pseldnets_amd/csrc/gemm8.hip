@@ -81,6 +81,7 @@ __device__ __forceinline__ unsigned g8_swap1(unsigned v) { return (unsigned)__bu
 template <int PD> struct G8Piece { unsigned d[PD]; };
 template <int PD>
 __device__ __forceinline__ void g8_store_nt(bf16_t* p, const G8Piece<PD>& v) {
+    static_assert(PD == 4 || PD == 3, "non-temporal pieces exist for the 256- and 192-column tiles");
     if constexpr (PD == 4) {
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         __builtin_nontemporal_store(u32x4_t{v.d[0], v.d[1], v.d[2], v.d[3]}, (u32x4_t*)p);
@@ -111,11 +112,18 @@ __device__ __forceinline__ void g8_store_nt(bf16_t* p, const G8Piece<PD>& v) {
 template <int MODE, bool SCALED, int NB, int MBQ = 4, bool DBG = false, bool PACK = false>
 __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g) {
     constexpr int WN = NB * 16, BN = 4 * WN;
-    constexpr int OFF_A1 = PACK ? 32 * MBQ * 128 : HALF_B;                   // A-h1 image (A-h0 at 0)
-    constexpr int OFF_B0 = PACK ? 2 * OFF_A1 : 2 * HALF_B;
-    constexpr int OFF_B1 = PACK ? OFF_B0 + HALF_B : 3 * HALF_B;
-    constexpr int BUF = PACK ? OFF_B1 + (NB - 2) * 8192 : BUF_B;             // one K-tile
-    constexpr int NB1 = NB - 2;                  // blocks in the second column quadrant
+    // NB = 6 ("WIDE", MBQ = 2 only): the 128 x 384 tile - a tile spans the whole row of a C = 384 layer (stage 2 of HTS-AT), the A operand
+    // is staged once per row block instead of once per column tile, and row-wise epilogues (LayerNorm) become possible. Column quadrants
+    // of 3 + 3 blocks; images packed: A-h0 8 | A-h1 8 | B-h0 24 | B-h1 24 KB = the same 64 KB per K-tile.
+    constexpr bool WIDE = NB == 6;
+    static_assert(!WIDE || MBQ == 2, "the 384-column tile is built for 128 rows");
+    constexpr int NB0 = WIDE ? 3 : 2;            // blocks in the first column quadrant = LDS-DMA instructions per wave of B-h0 (64 NB0 rows)
+    constexpr int NB1 = NB - NB0;                // ... in the second = instructions per wave of B-h1
+    constexpr int OFF_A1 = (PACK || WIDE) ? 32 * MBQ * 128 : HALF_B;        // A-h1 image (A-h0 at 0)
+    constexpr int OFF_B0 = (PACK || WIDE) ? 2 * OFF_A1 : 2 * HALF_B;
+    constexpr int OFF_B1 = (PACK || WIDE) ? OFF_B0 + NB0 * 8192 : 3 * HALF_B;
+    constexpr int BUF = (PACK || WIDE) ? OFF_B1 + NB1 * 8192 : BUF_B;       // one K-tile
+    static_assert(PACK || BUF == BUF_B, "the unpacked ring toggles its buffers by XOR");
     constexpr int BM = 64 * MBQ;                 // tile rows
     constexpr int MBN = 2 * MBQ;                 // 16-row blocks per wave
     constexpr int MA = MBQ / 2;                  // LDS-DMA instructions per wave and A half image (32 MBQ rows, 8 per instruction and wave)
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     // (instructions per wave behind the awaited half-tile in the in-order queue - A halves MA, B-h0 two, B-h1 NB1:
     //  phase 4 waits for A-h0(k+1): B-h1(k+1) A-h1(k+1) B-h0(k+2) A-h0(k+2) B-h1(k+2) stay; phase 1 for B-h1(k): A-h1(k) B-h0(k+1) A-h0(k+1)
     //  B-h1(k+1) A-h1(k+1); phase 2 for A-h1(k): B-h0(k+1) A-h0(k+1) B-h1(k+1) A-h1(k+1) B-h0(k+2))
-    constexpr int VM_P4 = 2 + 2 * MA + 2 * NB1, VM_P1 = 2 + 3 * MA + NB1, VM_P2 = 4 + 2 * MA + NB1;
+    constexpr int VM_P4 = 2 * NB1 + 2 * MA + NB0, VM_P1 = 3 * MA + NB0 + NB1, VM_P2 = 2 * NB0 + 2 * MA + NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = (float*)(smem + RING_B);      // (not PACK)
     // (diagnostic instantiation) real-time stamps of the start-up pieces, and the end of K-tiles 0..7 of this workgroup's SECOND tile
@@ -161,11 +169,11 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     const int sw = (lane >> 1) & 7;
     const unsigned c0 = (unsigned)((q ^ sw) << 4);
     unsigned ra0 = (unsigned)(wr * (MBQ * 2048) + l15 * 128) + c0, ra1 = ra0 ^ 64;                          // A halves: rows wr*16 MBQ + mbl*16 + l15
-    unsigned rb0 = (unsigned)(OFF_B0 + wc * 4096 + l15 * 128) + c0, rb1 = rb0 ^ 64;                       // B-h0: rows wc*32 + nbl*16 + l15
+    unsigned rb0 = (unsigned)(OFF_B0 + wc * (NB0 * 2048) + l15 * 128) + c0, rb1 = rb0 ^ 64;               // B-h0: rows wc*(16 NB0) + nbl*16 + l15
     unsigned rc0 = (unsigned)(OFF_B1 + wc * (NB1 * 2048) + l15 * 128) + c0, rc1 = rc0 ^ 64;               // B-h1: rows wc*(16 NB1) + nbl*16 + l15
 
     // ---- LDS-DMA source offsets of the load cursor's tile: [half][instruction] ----
-    unsigned offA[2][MA], offB[2][2];
+    unsigned offA[2][MA], offB[2][NB0];
     auto set_tile = [&](int T) {
         const int mblk = T / g.nx, nblk = T - mblk * g.nx;
         const int m0 = mblk * BM, n0 = nblk * BN;
@@ -180,27 +188,24 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
                 offA[h][j] = (unsigned)tok * (unsigned)(g.lda * 2) + (unsigned)(ch * 16);
             }
         }
+        // B-h0 (blocks b = nbl < NB0) and B-h1 (b = NB0 + nbl) of a wave's WN-column strip: image row wc*(16 NBh) + nbl*16 + i <- weight row
+        // wc*WN + 4 NB (i>>2) + 4 b + (i&3): accumulator row i = 4 q + k of block b is column 4 NB q + 4 b + k of the strip. A half image is
+        // 64 NBh rows = NBh instructions per wave (8 rows each); instruction (wave, j) fills rows (wave NBh + j) 8 .. + 7
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rho = wave * 16 + j * 8 + (lane >> 3);                  // B image row this lane fills
-            const int ch = (lane & 7) ^ ((rho >> 1) & 7);
-            const int i = rho & 15;
-            // B-h0 (blocks b = nbl) and B-h1 of the 64-column wave tile (b = 2 + nbl): image row wc*32 + nbl*16 + i <- weight row
-            // wc*WN + 4 NB (i>>2) + 4 b + (i&3): accumulator row i = 4 q + k of block b is column 4 NB q + 4 b + k of the wave's strip
-            const int nb0 = n0 + (rho >> 5) * WN + 4 * NB * (i >> 2) + 4 * ((rho >> 4) & 1) + (i & 3);
-            offB[0][j] = (unsigned)min(nb0, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
-            if constexpr (NB == 4) offB[1][j] = (unsigned)min(nb0 + 8, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
-        }
-        if constexpr (NB == 3) {      // B-h1, block b = 2 of every wave column: 64 image rows wc*16 + i <- weight row wc*48 + 12 (i>>2) + 8 + (i&3); one instruction per wave
-            const int rho = wave * 8 + (lane >> 3);
-            const int ch = (lane & 7) ^ ((rho >> 1) & 7);
-            const int i = rho & 15;
-            offB[1][0] = (unsigned)min(n0 + (rho >> 4) * WN + 12 * (i >> 2) + 8 + (i & 3), g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
-            offB[1][1] = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int NBH = h ? NB1 : NB0;
+#pragma unroll
+            for (int j = 0; j < (h ? NB1 : NB0); ++j) {
+                const int rho = (wave * NBH + j) * 8 + (lane >> 3);
+                const int ch = (lane & 7) ^ ((rho >> 1) & 7);
+                const int wcc = rho / (16 * NBH), within = rho - wcc * (16 * NBH);
+                const int nbl = within >> 4, i = within & 15;
+                const int row = n0 + wcc * WN + 4 * NB * (i >> 2) + 4 * ((h ? NB0 : 0) + nbl) + (i & 3);
+                offB[h][j] = (unsigned)min(row, g.N - 1) * (unsigned)(g.ldb * 2) + (unsigned)(ch * 16);
+            }
         }
     };
     const unsigned lds_base = (unsigned)(unsigned long)(lds_vptr8)smem;
-    const unsigned dst_w = lds_base + (unsigned)wave * 2048u;
     int ld_i = 0, ld_kt = 0;
     unsigned ld_buf = 0;
     const unsigned dst_a = lds_base + (unsigned)wave * (unsigned)(1024 * MA);
@@ -211,9 +216,13 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     };
     auto dmaB = [&](int h) {
         const char* sb = g.B + ld_kt * 128;
-        if (NB == 3 && h == 1) { g8_dma(lds_base + (unsigned)wave * 1024u + ld_buf + (unsigned)OFF_B1, sb, offB[1][0]); return; }
+        if (h == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) g8_dma(dst_w + ld_buf + (unsigned)((h ? OFF_B1 : OFF_B0) + j * 1024), sb, offB[h][j]);
+            for (int j = 0; j < NB0; ++j) g8_dma(lds_base + ld_buf + (unsigned)(OFF_B0 + (wave * NB0 + j) * 1024), sb, offB[0][j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB1; ++j) g8_dma(lds_base + ld_buf + (unsigned)(OFF_B1 + (wave * NB1 + j) * 1024), sb, offB[1][j]);
+        }
     };
     auto advance = [&]() {       // past the end of the list the cursor re-reads the last tile (nobody reads those images): the
         ld_buf = (unsigned)BUF - ld_buf;         // vmcnt distance stays constant in the tail
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
         }
     };
 
-    bf16x8 fa[MBQ][2], fb0[2][2], fb1[NB1][2];
+    bf16x8 fa[MBQ][2], fb0[NB0][2], fb1[NB1][2];
     f32x4 acc[MBN][NB];
 
     auto init_acc = [&](int n0) {
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
         fa[mbl][1] = *(const bf16x8*)(smem + ra1 + (mq) * OFF_A1 + mbl * 2048);                                  \
     }
 #define G8_LD_B0()                                                                                               \
-    _Pragma("unroll") for (int nbl = 0; nbl < 2; ++nbl) {                                                        \
+    _Pragma("unroll") for (int nbl = 0; nbl < NB0; ++nbl) {                                                      \
         fb0[nbl][0] = *(const bf16x8*)(smem + rb0 + nbl * 2048);                                                 \
         fb0[nbl][1] = *(const bf16x8*)(smem + rb1 + nbl * 2048);                                                 \
     }
@@ -365,9 +374,9 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     __builtin_amdgcn_s_setprio(1);                                                                               \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
         _Pragma("unroll") for (int mbl = 0; mbl < MBQ; ++mbl)                                                    \
-            _Pragma("unroll") for (int nbl = 0; nbl < ((nq) == 0 ? 2 : NB1); ++nbl)                              \
-                acc[(mq) * MBQ + mbl][(nq) * 2 + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
-                    fb[nbl][kk], fa[mbl][kk], acc[(mq) * MBQ + mbl][(nq) * 2 + nbl], 0, 0, 0);                   \
+            _Pragma("unroll") for (int nbl = 0; nbl < ((nq) == 0 ? NB0 : NB1); ++nbl)                            \
+                acc[(mq) * MBQ + mbl][(nq) * NB0 + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(               \
+                    fb[nbl][kk], fa[mbl][kk], acc[(mq) * MBQ + mbl][(nq) * NB0 + nbl], 0, 0, 0);                 \
     __builtin_amdgcn_s_setprio(0);
 
     // ---- prologue: stream K-tile 0 complete, the first three half-tiles of K-tile 1 in flight ----
@@ -498,7 +507,9 @@ int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t strea
             if (!d.resid && !d.aux && !sc) return go(gemm8_kernel<G8_PLAIN, false, NB, 4, true>);
         }
     }
-    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ, PACK>(a, nwg, stream);
+    if constexpr (NB != 6) {
+        if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ, PACK>(a, nwg, stream);
+    }
     if (d.resid) return sc ? launch8<G8_RESID, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_RESID, false, NB, MBQ, PACK>(a, nwg, stream);
     if (d.aux) return sc ? launch8<G8_MULAUX, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_MULAUX, false, NB, MBQ, PACK>(a, nwg, stream);
     return sc ? launch8<G8_PLAIN, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_PLAIN, false, NB, MBQ, PACK>(a, nwg, stream);
@@ -524,7 +535,7 @@ int pseld_gemm8_supported(const Gemm8Desc& d) {
     if (d.K % 64 != 0 || d.K < 128 || d.M < 1 || d.N < 128 || d.N % 8 != 0) return 0;
     if (d.lda % 8 != 0 || d.ldb % 8 != 0 || d.ldc % 8 != 0 || (d.resid && d.ldr % 8 != 0) || (d.aux && d.ldaux % 8 != 0)) return 0;
     if ((long)d.M * d.lda * 2 >= (1L << 32) || (long)d.N * d.ldb * 2 >= (1L << 32) || d.M >= (1 << 24)) return 0;
-    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS) return 0;
+    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS || pseld_cdiv(d.N, 384) * 384 > BIAS_FLOATS) return 0;
     if ((((unsigned long)d.A | (unsigned long)d.B | (unsigned long)d.C | (unsigned long)d.C2 | (unsigned long)d.resid | (unsigned long)d.aux) & 15) != 0) return 0;
     if (d.resid && d.aux) return 0;
     if (d.gelu_dual && (d.resid || d.aux || d.rowscale || !d.C2)) return 0;
@@ -559,6 +570,14 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
         int nwg2 = (a.ntiles + 7) / 8 * 8;
         if (nwg2 > 512) nwg2 = 512;
         return launch8_mode<3, 2, true>(d, a, nwg2, stream);
+    }
+    // columns = 384 (force / knob): the 128 x 384 row-spanning tile (no GELU-pair epilogue; N a multiple of 96: whole 24-byte store pieces)
+    if (want_bn == 384 && d.N % 96 == 0 && !d.gelu_dual) {
+        a.nx = pseld_cdiv(d.N, 384);
+        a.ntiles = a.nx * pseld_cdiv(d.M, 128);
+        int nwg6 = (a.ntiles + 7) / 8 * 8;
+        if (nwg6 > 256) nwg6 = 256;
+        return launch8_mode<6, 2>(d, a, nwg6, stream);
     }
     int bn = 0, bm = 0;
     double best = 0;

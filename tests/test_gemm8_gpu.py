@@ -92,12 +92,13 @@ def test_repeated_launches_are_bit_identical_and_rows_do_not_depend_on_the_batch
         fwd = (lambda xx: torch.cat(ops.linear_fwd(xx, w, b, gelu_dual=True), 1)) if gelu else (lambda xx: ops.linear_fwd(xx, w, b))
         first = None
         for rows in (256, 128, 64):                    # 64 = the 128 x 192 tile packed for two workgroups per CU (bias from global memory)
-            for bn in (256, 192):
+            for bn in (256, 192, 384):                 # 384 = the 128 x 384 row-spanning tile (no GELU-pair epilogue)
                 if bn == 192 and N % 192: continue
                 if rows == 64 and (bn != 192 or N % 192): continue
+                if bn == 384 and (rows != 128 or N % 96 or gelu): continue
                 _tile(rows, bn)
                 y = fwd(x).clone()
-                want = f"{3 if bn == 192 else 4}, {rows // 64}, false>" if rows != 64 else "3, 2, false, true>"
+                want = "6, 2, false>" if bn == 384 else (f"{3 if bn == 192 else 4}, {rows // 64}, false>" if rows != 64 else "3, 2, false, true>")
                 assert _kernel().startswith('gemm8_kernel<') and _kernel().endswith(want), _kernel()
                 for _ in range(20):
                     assert torch.equal(y, fwd(x)), (M, N, K, rows, bn)
