@@ -12,10 +12,12 @@
 // reference never exist in memory.
 //
 // Roofline: the HBM floor (5.634 MB algorithmic bytes per 10 s chunk: 3.84 MB in + 1.794 MB out -> 0.2 ms per 192 chunks) is NOT
-// what binds this kernel: it is VALU-issue-bound. rocprofv3 --pmc (profiles/r02_pmc_feature.json): 3 590 vector instructions per
-// frame (two 1024-point register FFTs in packed fp32, inter-stage twiddles, spectrum split, compact mel) = 690 M wave-instructions
-// per 192 chunks, SQ_ACTIVE_INST_VALU = 81 % of the kernel's wave-cycles (2 waves per SIMD, 4 cycles per wave64 instruction),
-// 1.2x the algorithmic bytes fetched. Getting closer to the HBM floor means fewer instructions per frame, not better memory access.
+// what binds this kernel. Rounds 1-4 it was VALU-issue-bound (3 590, then 1 993 vector instructions per frame; profiles/r02_pmc_feature.json,
+// r04 / r05_pmc_feature.json). Round 5: the complex arithmetic is written in packed-fp32 instructions with operand selects (below) - the frame
+// loop's 1 455 static vector instructions became 829 - and the workgroups are persistent (tables built once per CU): 1.22 -> 0.88 ms per 192
+// chunks. What is left is latency: 2 waves per SIMD (150 KB of LDS per workgroup = one workgroup per CU) walk a chain of four LDS exchanges
+// per frame; neither the VALU (~0.40 ms of issue) nor the LDS pipe (~0.43 ms incl. bank conflicts) is saturated. Inside the step the kernel
+// is NOT hidden by the second stream it runs on: with the features cached the step is 0.9 ms shorter (tools/experiments/feature_cost.py).
 #include "common.h"
 
 namespace {
@@ -35,13 +37,10 @@ struct FeatArgs {
     const int* mel_off;  // [n_mels] offset of the filter's weights in mel_w
     const float* mel_w;  // [nnz]
     long L;
-    int T, hop, n_ch, n_out, n_mels, nnz, with_iv;
+    int T, hop, n_ch, n_out, n_mels, nnz, with_iv, nb;
     float amin, iv_eps;
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
 
 // Register FFT. A 1024-point complex FFT is a 32 x 32 Cooley-Tukey split run by 32 lanes that each hold 32 points:
 //   x[t + 32 m] (m = 0..31) -> 32-point DFT over m in registers -> twiddle W_1024^(t k1) -> ONE transpose through LDS
@@ -55,59 +54,98 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 constexpr int EX_LD = 33;                  // transpose row stride (elements): lane k1' reads row k1' conflict-free
 constexpr int FFT_LDS = 32 * EX_LD;        // elements per FFT region (also holds the 1024-point spectrum afterwards)
 constexpr int WAVES2 = 8;                  // waves (= frames in flight) per workgroup
-constexpr int FPB2 = 32;                   // frames per workgroup (the 14 KB of tables are re-read per workgroup: amortised over 4 frames per wave)
+constexpr int FPB2 = 64;                   // frames per work item (a persistent workgroup walks the (chunk, 64-frame block) items round-robin)
 constexpr int V2_WAVE_BYTES = 2 * FFT_LDS * 8;
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }      // a * (-i)
-
-// forward 4-point DFT, in place
-__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
-    const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = mul_mi(csub(x1, x3));
-    x0 = cadd(a0, a2); x1 = cadd(a1, a3); x2 = csub(a0, a2); x3 = csub(a1, a3);
+// Complex arithmetic on packed fp32 (round 5). A complex number is one 64-bit register pair; v_pk_add / v_pk_mul / v_pk_fma_f32 pick, per
+// result half, which half of each source they read (op_sel / op_sel_hi) and whether it is negated (neg_lo / neg_hi) - so a multiplication by
+// -i, a conjugate, a broadcast of the real part are operand modifiers, not instructions. Written as inline asm: the compiler's own packing
+// of the scalar formulation spent 466 of the frame loop's 1 455 vector instructions on v_mov (pairing unrelated scalars).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PSELD_PK2(name, op, mods)                                                                                  \
+    __device__ __forceinline__ f32x2 name(f32x2 a, f32x2 b) { f32x2 d; asm(op " %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b)); return d; }
+PSELD_PK2(cadd, "v_pk_add_f32", "")                                                          // a + b
+PSELD_PK2(csub, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]")                               // a - b
+PSELD_PK2(cadd_mi, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")            // a + (-i) b = (a.x + b.y, a.y - b.x)
+PSELD_PK2(csub_mi, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")            // a - (-i) b = (a.x - b.y, a.y + b.x)
+PSELD_PK2(pmul, "v_pk_mul_f32", "")                                                          // (a.x b.x, a.y b.y)
+PSELD_PK2(pmul_lo, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[1,0]")                          // a * b.x
+PSELD_PK2(pmul_hi, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1]")                          // a * b.y
+#undef PSELD_PK2
+__device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 pfma_lo(f32x2 a, f32x2 b, f32x2 c) {      // a * b.x + c
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 pfma_hi(f32x2 a, f32x2 b, f32x2 c) {      // a * b.y + c
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// c + r a / c - r a, r = (R, R) in scalar registers
+__device__ __forceinline__ f32x2 pfma_s(f32x2 a, f32x2 r, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(r), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 pfnma_s(f32x2 a, f32x2 r, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(r), "v"(c)); return d; }
+// complex product v w = (v.x w.x - v.y w.y, v.x w.y + v.y w.x): two instructions; w in vector or in scalar registers
+__device__ __forceinline__ f32x2 cmul(f32x2 v, f32x2 w) {
+    f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(v), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(v), "v"(w), "v"(t));
+    return r;
 }
-// forward 8-point DFT: in a[0..7] (natural), out X[k] (natural) written to o[0..7]
-__device__ __forceinline__ void dft8(const float2 (&a)[8], float2 (&o)[8]) {
-    float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
-    float2 q0 = a[1], q1 = a[3], q2 = a[5], q3 = a[7];
+__device__ __forceinline__ f32x2 cmul_s(f32x2 v, f32x2 w) {
+    f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(v), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(v), "s"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ f32x2 mul_mi(f32x2 a) {                          // a * (-i) = (a.y, -a.x)
+    const f32x2 c = {1.f, -1.f};
+    f32x2 d; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "s"(c)); return d;
+}
+
+// forward 4-point DFT, in place (8 packed additions: the -i of the odd butterfly is an operand select)
+__device__ __forceinline__ void dft4(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3) {
+    const f32x2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = csub(x1, x3);
+    x0 = cadd(a0, a2); x2 = csub(a0, a2); x1 = cadd_mi(a1, a3); x3 = csub_mi(a1, a3);
+}
+// forward 8-point DFT: in a[0..7] (natural), out X[k] (natural) written to o[0..7] (26 packed instructions)
+__device__ __forceinline__ void dft8(const f32x2 (&a)[8], f32x2 (&o)[8]) {
+    f32x2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+    f32x2 q0 = a[1], q1 = a[3], q2 = a[5], q3 = a[7];
     dft4(e0, e1, e2, e3);
     dft4(q0, q1, q2, q3);
-    constexpr float R = 0.70710678118654752f;
-    const float2 t1 = make_float2((q1.x + q1.y) * R, (q1.y - q1.x) * R);      // q1 * (1 - i)/sqrt2
-    const float2 t2 = mul_mi(q2);                                              // q2 * (-i)
-    const float2 t3 = make_float2((q3.y - q3.x) * R, -(q3.x + q3.y) * R);     // q3 * (-1 - i)/sqrt2
+    const f32x2 RR = {0.70710678118654752f, 0.70710678118654752f};
+    const f32x2 s1 = cadd_mi(q1, q1);            // (q1.x + q1.y, q1.y - q1.x):  q1 (1 - i) / sqrt2 = R s1
+    const f32x2 s3 = csub_mi(q3, q3);            // (q3.x - q3.y, q3.y + q3.x):  q3 (-1 - i) / sqrt2 = -R s3
     o[0] = cadd(e0, q0); o[4] = csub(e0, q0);
-    o[1] = cadd(e1, t1); o[5] = csub(e1, t1);
-    o[2] = cadd(e2, t2); o[6] = csub(e2, t2);
-    o[3] = cadd(e3, t3); o[7] = csub(e3, t3);
+    o[1] = pfma_s(s1, RR, e1); o[5] = pfnma_s(s1, RR, e1);
+    o[2] = cadd_mi(e2, q2); o[6] = csub_mi(e2, q2);          // q2 (-i)
+    o[3] = pfnma_s(s3, RR, e3); o[7] = pfma_s(s3, RR, e3);
 }
 // exp(-2 pi i j / 32), j = n2 * k1 <= 21
-__device__ __forceinline__ float2 w32(int j) {
+__device__ __forceinline__ constexpr float w32c(int j) {
     constexpr float C[22] = {1.f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f,
                              0.f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f,
                              -0.98078528f, -1.f, -0.98078528f, -0.923879533f, -0.831469612f, -0.707106781f, -0.555570233f};
+    return C[j];
+}
+__device__ __forceinline__ constexpr float w32s(int j) {
     constexpr float S[22] = {0.f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f,
                              -0.98078528f, -1.f, -0.98078528f, -0.923879533f, -0.831469612f, -0.707106781f, -0.555570233f,
                              -0.382683432f, -0.195090322f, 0.f, 0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f};
-    return make_float2(C[j], S[j]);
+    return S[j];
 }
 // forward 32-point DFT in registers (32 = 4 x 8: n = 8 n1 + n2, k = k1 + 4 k2). In place: natural order in, and
 // X[k] is left in slot fslot(k) = 8 (k & 3) + (k >> 2) — a compile-time renaming instead of a 32-register copy.
 __device__ __forceinline__ constexpr int fslot(int k) { return 8 * (k & 3) + (k >> 2); }
-__device__ __forceinline__ void fft32(float2 (&x)[32]) {
+__device__ __forceinline__ void fft32(f32x2 (&x)[32]) {
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) dft4(x[n2], x[8 + n2], x[16 + n2], x[24 + n2]);     // x[8 k1 + n2] = y[n2][k1]
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) {
-        float2 a[8], r[8];
+        f32x2 a[8], r[8];
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) {
-            const float2 v = x[8 * k1 + n2];
+            const f32x2 v = x[8 * k1 + n2];
             const int j = n2 * k1;
             if (j == 0) a[n2] = v;
             else if (j == 8) a[n2] = mul_mi(v);
-            else a[n2] = cmul(v, w32(j));
+            else { const f32x2 w = {w32c(j), w32s(j)}; a[n2] = cmul_s(v, w); }
         }
         dft8(a, r);
 #pragma unroll
@@ -129,24 +167,25 @@ __device__ __forceinline__ void fft32(float2 (&x)[32]) {
 //    of all 16 filters of its pass: 26 iterations of 25 instructions), the runs of one filter meet by two lane shuffles;
 //  * the next frame's samples are requested before the split / mel phase of the current one.
 constexpr int MEL_CAP = 12;                // bins per run
+constexpr int CAP_LD = (MEL_CAP + 1) & ~1;     // weights per run in the LDS table (pairs)
 constexpr int VBINS = 528;                 // bins per value plane (513 + the overhang of a zero-weighted run tail)
 constexpr int VI_OFF = VBINS * 16;         // byte offset of the IV plane inside a wave's region (2 * 8448 = 16896 = 2 * FFT_LDS * 8)
 static_assert(2 * VBINS * 16 == 2 * FFT_LDS * 8, "value planes must overlay the two spectrum regions exactly");
 
 __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* tws = (float2*)smem;                      // [32 k1][32 t]: W_1024^(t k1)
+    f32x2* tws = (f32x2*)smem;                        // [32 k1][32 t]: W_1024^(t k1)
     int* sched = (int*)(tws + 32 * 32);               // [128 runs][2]: {k0 | band << 16 | first << 24 | following runs << 25, weight offset | n << 16}
     int* sched_ok = sched + 256;                      // [4]
     float* mws = (float*)(sched_ok + 4);              // [128 runs][12]: zero-padded weights of each run
-    float* wins = mws + 128 * MEL_CAP;                // [32 t][36]: window[t + 32 m], rows padded to 144 B (conflict-free ds_read_b128)
+    float* wins = mws + 128 * CAP_LD;                // [32 t][36]: window[t + 32 m], rows padded to 144 B (conflict-free ds_read_b128)
     char* wave_base = (char*)(wins + 32 * 36);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* region = wave_base + wave * V2_WAVE_BYTES;
-    float2* spec = (float2*)region;                   // [2 pairs][FFT_LDS]: transpose buffer, then the spectrum, then the value planes
+    f32x2* spec = (f32x2*)region;                     // [2 pairs][FFT_LDS]: transpose buffer, then the spectrum, then the value planes
 
     const int pr = lane >> 5, t = lane & 31;
-    for (int n = tid; n < 32 * 32; n += WAVES2 * 64) tws[n] = a.twid[((n & 31) * (n >> 5)) & (NFFT - 1)];
+    for (int n = tid; n < 32 * 32; n += WAVES2 * 64) { const float2 w = a.twid[((n & 31) * (n >> 5)) & (NFFT - 1)]; tws[n] = f32x2{w.x, w.y}; }
     for (int n = tid; n < 256; n += WAVES2 * 64) sched[n] = 0;
     for (int n = tid; n < NFFT; n += WAVES2 * 64) wins[(n & 31) * 36 + (n >> 5)] = a.window[n];
     __syncthreads();
@@ -186,63 +225,69 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
         const int e0 = sched[2 * (p * 64 + lane)];
         mk0[p] = e0 & 0xffff; mband[p] = (e0 >> 16) & 0xff; mfirst[p] = (e0 >> 24) & 1; mfollow[p] = (e0 >> 25) & 15;
     }
-    for (int n = tid; n < 128 * MEL_CAP; n += WAVES2 * 64) {
-        const int r = n / MEL_CAP, i = n - r * MEL_CAP, e1 = sched[2 * r + 1];
+    for (int n = tid; n < 128 * CAP_LD; n += WAVES2 * 64) {
+        const int r = n / CAP_LD, i = n - r * CAP_LD, e1 = sched[2 * r + 1];
         mws[n] = (fast_mel && i < (e1 >> 16)) ? a.mel_w[(e1 & 0xffff) + i] : 0.f;
     }
     __syncthreads();
 
-    const int b = blockIdx.y;
+    // Persistent workgroups (round 5): the 14 KB of tables above are built once per workgroup, not once per 32 frames (the prologue - the
+    // table gathers, wave 0's serial run schedule, three barriers - was 12 % of the kernel); a workgroup then walks the (chunk, 32-frame block)
+    // items round-robin. No barrier below this line: the eight waves drift apart freely.
     const int c0 = 2 * pr, c1 = 2 * pr + 1;
     const bool has0 = c0 < a.n_ch, has1 = c1 < a.n_ch;
+    const int nfb = (a.T + FPB2 - 1) / FPB2;
+  for (int item = blockIdx.x; item < nfb * a.nb; item += gridDim.x) {
+    const int b = item / nfb;
     const float* wv = a.wave + (long)b * a.n_ch * a.L;
     const float* w0 = wv + (long)(has0 ? c0 : 0) * a.L;
     const float* w1 = wv + (long)(has1 ? c1 : 0) * a.L;
     const float k0f = has0 ? 1.f : 0.f, k1f = has1 ? 1.f : 0.f;   // missing channels: load channel 0, scale by zero
-    float2* ex = spec + pr * FFT_LDS;
-    const float2* sp0 = spec;
-    const float2* sp1 = spec + FFT_LDS;
+    f32x2* ex = spec + pr * FFT_LDS;
+    const f32x2* sp0 = spec;
+    const f32x2* sp1 = spec + FFT_LDS;
     const float eps4 = 4.f * a.iv_eps;
 
     auto interior = [&](int frame) { const long s0 = (long)frame * a.hop - NFFT / 2; return s0 >= 0 && s0 + NFFT <= a.L; };
-    auto load_interior = [&](int frame, float2 (&x)[32]) {        // 64 loads at immediate offsets from two base pointers
+    auto load_interior = [&](int frame, f32x2 (&x)[32]) {        // 64 loads at immediate offsets from two base pointers
         const long s0 = (long)frame * a.hop - NFFT / 2;
         const float* p0 = w0 + s0 + t;
         const float* p1 = w1 + s0 + t;
 #pragma unroll
-        for (int m = 0; m < 32; ++m) x[m] = make_float2(p0[32 * m], p1[32 * m]);
+        for (int m = 0; m < 32; ++m) x[m] = f32x2{p0[32 * m], p1[32 * m]};
     };
     // the 6 frames of a chunk that reach over its ends (reflect padding): a ROLLED loop stages the samples in the wave's (idle)
     // transpose buffer - unrolled, the 64 reflected 64-bit addresses cost the whole kernel 80 registers
-    auto load_edge = [&](int frame, float2 (&x)[32]) {
+    auto load_edge = [&](int frame, f32x2 (&x)[32]) {
         const long s0 = (long)frame * a.hop - NFFT / 2;
 #pragma unroll 1
         for (int m = 0; m < 32; ++m) {
             long sx = s0 + t + 32 * m;
             if (sx < 0) sx = -sx;
             if (sx >= a.L) sx = 2 * (a.L - 1) - sx;
-            ex[m * 32 + t] = make_float2(w0[sx], w1[sx]);
+            ex[m * 32 + t] = f32x2{w0[sx], w1[sx]};
         }
 #pragma unroll
         for (int m = 0; m < 32; ++m) x[m] = ex[m * 32 + t];
     };
 
-    const int frame0 = blockIdx.x * FPB2;
-    float2 xr[32];
+    const int frame0 = (item - b * nfb) * FPB2;
+    f32x2 xr[32];
     if (frame0 + wave < a.T) { if (interior(frame0 + wave)) load_interior(frame0 + wave, xr); else load_edge(frame0 + wave, xr); }
     for (int f = wave; f < FPB2; f += WAVES2) {
         const int frame = frame0 + f;
         if (frame >= a.T) break;                                   // uniform across the wave
-        float2 x[32];
+        f32x2 x[32];
 #pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) {
-            const f32x4 wn = *(const f32x4*)(wins + t * 36 + 4 * m4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[4 * m4 + i] = make_float2(xr[4 * m4 + i].x * wn[i], xr[4 * m4 + i].y * wn[i]);
+        for (int m2 = 0; m2 < 16; ++m2) {
+            const f32x2 wn = *(const f32x2*)(wins + t * 36 + 2 * m2);      // window[t + 32 m], m = 2 m2, 2 m2 + 1
+            x[2 * m2] = pmul_lo(xr[2 * m2], wn);
+            x[2 * m2 + 1] = pmul_hi(xr[2 * m2 + 1], wn);
         }
         if (a.n_ch < 4) {
+            const f32x2 kf = {k0f, k1f};
 #pragma unroll
-            for (int m = 0; m < 32; ++m) x[m] = make_float2(x[m].x * k0f, x[m].y * k1f);
+            for (int m = 0; m < 32; ++m) x[m] = pmul(x[m], kf);
         }
         fft32(x);                                                  // slot fslot(k1) = sum_m x[t + 32 m] W_32^(m k1)
 #pragma unroll
@@ -258,7 +303,7 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
         for (int k2 = 0; k2 < 32; ++k2) ex[t + 32 * k2] = x[fslot(k2)];   // natural-order spectrum over the transpose buffer
         asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
         // ---- split the packed spectra, power + intensity per bin: ALL reads, then the value planes over the same region ----
-        float2 z0[9], zn0[9], z1[9], zn1[9];
+        f32x2 z0[9], zn0[9], z1[9], zn1[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int k = min(lane + 64 * j, NBIN - 1), kn = (NFFT - k) & (NFFT - 1);
@@ -269,18 +314,28 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int k = lane + 64 * j;
-            // ch0 = a / 2, ch1 = b / (2i), ch2 = c / 2, ch3 = d / (2i)  with  a = z + conj(zn), b = z - conj(zn)
-            const float ax = z0[j].x + zn0[j].x, ay = z0[j].y - zn0[j].y, bx = z0[j].x - zn0[j].x, by = z0[j].y + zn0[j].y;
-            const float cx = z1[j].x + zn1[j].x, cy = z1[j].y - zn1[j].y, dx = z1[j].x - zn1[j].x, dy = z1[j].y + zn1[j].y;
-            f32x4 pw = {fmaf(ax, ax, ay * ay), fmaf(bx, bx, by * by), fmaf(cx, cx, cy * cy), fmaf(dx, dx, dy * dy)};   // 4 x power
+            // ch0 = a / 2, ch1 = b / (2i), ch2 = c / 2, ch3 = d / (2i)  with  a = z + conj(zn), b = z - conj(zn). Packed as the pairs the products
+            // below want: X = (ax, bx), Y = (ay, by), P = (cx, dy), Q = (cy, dx) - four instructions
+            f32x2 X, Y, P, Q, t, pw01, pw23;
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(X) : "v"(z0[j]), "v"(zn0[j]));       // (z.x + zn.x, z.x - zn.x)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[0,1]" : "=v"(Y) : "v"(z0[j]), "v"(zn0[j]));       // (z.y - zn.y, z.y + zn.y)
+            P = cadd(z1[j], zn1[j]);                                                                                              // (z.x + zn.x, z.y + zn.y)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Q) : "v"(z1[j]), "v"(zn1[j]));   // (z.y - zn.y, z.x - zn.x)
+            pw01 = pfma(Y, Y, pmul(X, X));                                   // 4 x power of channels 0, 1
+            pw23 = pfma(Q, Q, pmul(P, P));                                   // (cx^2 + cy^2, dy^2 + dx^2): channels 2, 3
             f32x4 iv = {0.f, 0.f, 0.f, 0.f};
             if (a.with_iv) {
-                const float i1 = fmaf(ax, by, -ay * bx), i2 = fmaf(ax, cx, ay * cy), i3 = fmaf(ax, dy, -ay * dx);            // 4 x intensity
-                const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(i1, i1, fmaf(i2, i2, i3 * i3))) + eps4);
-                iv[0] = i1 * inv; iv[1] = i2 * inv; iv[2] = i3 * inv;
+                // 4 x intensity: i1 = ax by - ay bx, (i2, i3) = (ax cx + ay cy, ax dy - ay dx) = ax P + ay (Q.x, -Q.y)
+                f32x2 i23;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(X), "v"(P));
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(i23) : "v"(Y), "v"(Q), "v"(t));
+                const float i1 = fmaf(X[0], Y[1], -Y[0] * X[1]);
+                const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(i1, i1, fmaf(i23[0], i23[0], i23[1] * i23[1]))) + eps4);
+                iv[0] = i1 * inv; iv[1] = i23[0] * inv; iv[2] = i23[1] * inv;
             }
             if (k < NBIN) {
-                *(f32x4*)(region + k * 16) = pw;
+                *(f32x2*)(region + k * 16) = pw01;
+                *(f32x2*)(region + k * 16 + 8) = pw23;
                 *(f32x4*)(region + VI_OFF + k * 16) = iv;
             }
         }
@@ -292,19 +347,22 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
         if (fast_mel) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const char* vp = region + mk0[p] * 16;
-                f32x4 w4[MEL_CAP / 4];
+                f32x2 w2[CAP_LD / 2];
 #pragma unroll
-                for (int i = 0; i < MEL_CAP / 4; ++i) w4[i] = *(const f32x4*)(mws + (p * 64 + lane) * MEL_CAP + 4 * i);
+                for (int i = 0; i < CAP_LD / 2; ++i) w2[i] = *(const f32x2*)(mws + (p * 64 + lane) * CAP_LD + 2 * i);
+                f32x2 a01 = {0.f, 0.f}, a23 = a01, a45 = a01;
+                float a6 = 0.f;
 #pragma unroll
-                for (int i = 0; i < MEL_CAP; ++i) {
-                    const f32x4 P = *(const f32x4*)(vp + i * 16);
-                    const f32x4 I = *(const f32x4*)(vp + VI_OFF + i * 16);
-                    const float w = w4[i >> 2][i & 3];
-                    acc[0] = fmaf(P[0], w, acc[0]); acc[1] = fmaf(P[1], w, acc[1]); acc[2] = fmaf(P[2], w, acc[2]); acc[3] = fmaf(P[3], w, acc[3]);
-                    acc[4] = fmaf(I[0], w, acc[4]); acc[5] = fmaf(I[1], w, acc[5]); acc[6] = fmaf(I[2], w, acc[6]);
+                for (int i = 0; i < MEL_CAP; ++i) {                 // a bin's seven values times its weight: three packed FMAs + one
+                    const f32x2 P01 = *(const f32x2*)(vp + i * 16), P23 = *(const f32x2*)(vp + i * 16 + 8);
+                    const f32x2 I01 = *(const f32x2*)(vp + VI_OFF + i * 16);
+                    const float I2 = *(const float*)(vp + VI_OFF + i * 16 + 8);
+                    if (i & 1) { a01 = pfma_hi(P01, w2[i >> 1], a01); a23 = pfma_hi(P23, w2[i >> 1], a23); a45 = pfma_hi(I01, w2[i >> 1], a45); }
+                    else { a01 = pfma_lo(P01, w2[i >> 1], a01); a23 = pfma_lo(P23, w2[i >> 1], a23); a45 = pfma_lo(I01, w2[i >> 1], a45); }
+                    a6 = fmaf(I2, w2[i >> 1][i & 1], a6);
                 }
+                float acc[7] = {a01[0], a01[1], a23[0], a23[1], a45[0], a45[1], a6};
                 // the runs of one filter sit on consecutive lanes: run r collects the runs behind it (up to 7)
 #pragma unroll
                 for (int o = 1; o <= 4; o <<= 1) {
@@ -371,6 +429,7 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
         if (more && !more_in) load_edge(frame + WAVES2, xr);     // (the region is idle again)
         asm volatile("" ::: "memory");   // (lanes exchange data through LDS: the compiler must keep the order it can prove irrelevant for ONE lane)
     }
+  }
 }
 
 }  // namespace
@@ -391,12 +450,19 @@ extern "C" int pseld_logmel_iv_fwd(const float* wave, float* feat, int B, int n_
     a.wave = wave; a.feat = feat; a.window = window; a.twid = (const float2*)twiddle;
     a.mel_lo = mel_lo; a.mel_cnt = mel_cnt; a.mel_off = mel_off; a.mel_w = mel_w;
     a.L = L; a.T = (int)(1 + L / hop); a.hop = hop; a.n_ch = n_ch; a.n_out = n_ch + (with_iv ? 3 : 0);
-    a.n_mels = n_mels; a.nnz = nnz; a.with_iv = with_iv; a.amin = amin; a.iv_eps = iv_eps;
-    const size_t lds = 32 * 32 * sizeof(float2) + 256 * sizeof(int) + 4 * sizeof(int) + 128 * MEL_CAP * sizeof(float) + 32 * 36 * sizeof(float) +
+    a.n_mels = n_mels; a.nnz = nnz; a.with_iv = with_iv; a.amin = amin; a.iv_eps = iv_eps; a.nb = B;
+    const size_t lds = 32 * 32 * sizeof(float2) + 256 * sizeof(int) + 4 * sizeof(int) + 128 * CAP_LD * sizeof(float) + 32 * 36 * sizeof(float) +
                        (size_t)WAVES2 * V2_WAVE_BYTES;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)logmel_iv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    dim3 grid(pseld_cdiv(a.T, FPB2), B, 1);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t pr;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    const long items = (long)pseld_cdiv(a.T, FPB2) * B;          // one workgroup per CU (150 KB of LDS), walking the items round-robin
+    PSELD_CHECK_ARG(items < (1L << 31), "logmel_iv_fwd: B x T too large");
+    dim3 grid((unsigned)(items < n_cu ? items : n_cu), 1, 1);
     hipLaunchKernelGGL(logmel_iv_kernel, grid, dim3(WAVES2 * 64), lds, (hipStream_t)stream, a);
     PSELD_LAUNCH_CHECK("logmel_iv_fwd");
     return PSELD_OK;

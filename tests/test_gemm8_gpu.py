@@ -57,13 +57,15 @@ def _run(dev, mode, x, w, b, extra, rs, rps):
     return ops.linear_dgrad(d(x), d(w.t().contiguous()), rowscale=d(rs), rows_per_scale=rps, mul=d(extra), wt=d(w))
 
 
-@pytest.mark.parametrize("rows", [256, 128, 64])
-@pytest.mark.parametrize("bn", [256, 192])
+_SHAPES = [(256, 256, 128), (1000, 1152, 384), (777, 200, 192), (2048, 768, 1536), (3000, 4096, 256)]
+# (rows 64 = the 128 x 192 tile packed for two workgroups per CU: 192 columns, N a multiple of 192)
+_TILES = [(rows, bn, shp) for rows in (256, 128, 64) for bn in (256, 192) for shp in _SHAPES if rows != 64 or (bn == 192 and shp[1] % 192 == 0)]
+
+
+@pytest.mark.parametrize("rows,bn,shape", _TILES)
 @pytest.mark.parametrize("mode,scaled", [('plain', False), ('plain', True), ('resid', False), ('resid', True), ('gelu', False), ('mulaux', False), ('mulaux', True)])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 1152, 384), (777, 200, 192), (2048, 768, 1536), (3000, 4096, 256)])
-def test_forward_products_and_fused_epilogues(dev, rows, bn, mode, scaled, M, N, K):
-    if rows == 64 and (bn != 192 or N % 192):
-        pytest.skip("rows 64 = the packed two-per-CU variant of the 128 x 192 tile only")
+def test_forward_products_and_fused_epilogues(dev, rows, bn, mode, scaled, shape):
+    M, N, K = shape
     _tile(rows, bn)
     x, w, b = _mk((M, K), 1), _mk((N, K), 2, 0.05), _mk((N,), 3, dtype=torch.float32)
     extra = _mk((M, N), 4)
