@@ -33,9 +33,14 @@ FUSED_LNBWD = os.environ.get('PSELD_FUSED_LNBWD', '1') != '0'
 FUSED_ATTN_TAIL = os.environ.get('PSELD_FUSED_ATTN', '1') != 'front'      # 'front': stop in front of proj (A/B of the fused tail)
 # A/B knobs of the backward pass, read once at import (nothing in a step reads the environment):
 LN_DEFER = os.environ.get('PSELD_LN_DEFER', '1') == '1'            # one reduction per stage for the LayerNorms' d(gamma) / d(beta) partials
-# PSELD_WGRAD_GROUP=<blocks per launch> (0, the default: every weight gradient its own launch; 99: the whole stage at once),
+# PSELD_WGRAD_GROUP=<blocks per launch> (0: every weight gradient its own launch; 99: the whole stage at once; unset: by the batch, below),
 # PSELD_WGRAD_GROUP_MATS=<n>: flush every n matrices
-WGRAD_GROUP_BLOCKS = int(os.environ.get('PSELD_WGRAD_GROUP', '0'))
+WGRAD_GROUP_BLOCKS = int(os.environ.get('PSELD_WGRAD_GROUP', '-1'))
+# Unset: a stage's weight gradients run as ONE launch when the step holds at most this many chunks. The split-K slabs of a single launch are
+# 256 workgroups x one fp32 tile whatever the batch: at the reference's 32 chunks (synth_maccdoa.yaml:8) they are 3x the operand bytes, and the
+# grouped launch (all tiles of the stage, no token split, no slabs, no reduction launches) wins - 6.22 -> 5.70 ms per step; 64 chunks 7.80 ->
+# 7.68; from 96 chunks on the deferral costs more than the slabs (10.31 -> 10.35; 192 chunks: docs/EXPERIMENTS.md)
+WGRAD_GROUP_AUTO_MAX_CHUNKS = 64
 WGRAD_GROUP_MATS = int(os.environ.get('PSELD_WGRAD_GROUP_MATS', '0')) or (1 << 30)
 WGRAD_GROUP_STAGES = tuple(int(v) for v in os.environ.get('PSELD_WGRAD_GROUP_STAGES', '0,1,2,3').split(',') if v.strip())   # stages that group
 MLP_DW_FIRST = os.environ.get('PSELD_MLP_DW_FIRST', '1') == '1'
@@ -405,10 +410,10 @@ class SwinEncoder:
         elif getattr(self, '_defer', None) is None or self._defer.buf.device != dx.device:
             self._defer = ops.DeferredReductions(dx.device)      # d(gamma) / d(beta) partials of the stage's LayerNorms: one reduction
         # WGRAD_GROUP_BLOCKS (PSELD_WGRAD_GROUP). The grouped launch is 16-29 % faster than its members one by one in isolation (tools/wgrad8_check.py group: no token split, no
-        # fp32 slabs) and SLOWER inside the step (same box, 30 steps: 18.74 ms ungrouped, 19.25 / 19.00 / 19.06 ms with 1 / 2 blocks / the
+        # fp32 slabs) and SLOWER inside the 192-chunk step (same box, 30 steps: 18.74 ms ungrouped, 19.25 / 19.00 / 19.06 ms with 1 / 2 blocks / the
         # whole stage per launch): a deferred weight gradient no longer runs beside the input-gradient kernel that reads the same dY, and
-        # one chip-wide persistent launch leaves the second stream nothing to interleave
-        self._wgroup_blocks = WGRAD_GROUP_BLOCKS
+        # one chip-wide persistent launch leaves the second stream nothing to interleave. Small batches are the other way round (top of the file)
+        self._wgroup_blocks = WGRAD_GROUP_BLOCKS if WGRAD_GROUP_BLOCKS >= 0 else (99 if B <= WGRAD_GROUP_AUTO_MAX_CHUNKS else 0)
         self._wgroup_mats = WGRAD_GROUP_MATS
         self._wgroup = [] if (dx.dtype == torch.bfloat16 and self._wgroup_blocks > 0 and li in WGRAD_GROUP_STAGES) else None
         self._wgroup_n = 0
