@@ -666,37 +666,70 @@ extern "C" int pseld_adamw_step_dev(float* p, const float* g, float* m, float* v
 // Batched transpose of the 2-D bf16 weights of a parameter arena: tensor t = [rows, cols] at element offset off (same
 // offset in src and dst) becomes [cols, rows]. desc = {off, rows, cols, first_tile} per tensor (longs), 32x32 tiles.
 // The input-gradient GEMMs read these copies so that dX = dY W is a k-contiguous product like the forward.
+// One workgroup walks tiles grid-stride: the descriptor table sits in LDS (a tile's tensor is found by one pass of the threads over it - the
+// per-tile binary search in global memory was seven dependent loads, most of the old kernel's 75 us per step), and element PAIRS move where the
+// tensor allows it (even rows / cols / offset: 4-byte loads along a row, 4-byte stores of two rows' values along a transposed row).
+constexpr int TB_MAX_DESC = 512;
 __global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                              const long* __restrict__ desc, int n_desc) {
+                                                              const long* __restrict__ desc, int n_desc, long total_tiles) {
     __shared__ bf16_t tile[32][34];
-    int lo = 0, hi = n_desc - 1;                         // last tensor whose first_tile <= blockIdx.x
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (desc[4 * mid + 3] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const long off = desc[4 * lo], rows = desc[4 * lo + 1], cols = desc[4 * lo + 2];
-    const long t = (long)blockIdx.x - desc[4 * lo + 3];
-    const long tiles_c = (cols + 31) / 32;
-    const long r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long r = r0 + ty + 8 * i, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[off + r * cols + c];
-    }
+    __shared__ long sdesc[TB_MAX_DESC * 4];
+    __shared__ int which;
+    for (int i = threadIdx.x; i < 4 * n_desc; i += 256) sdesc[i] = desc[i];
     __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (long tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        for (int d = threadIdx.x; d < n_desc; d += 256) {
+            const long f0 = sdesc[4 * d + 3], f1 = d + 1 < n_desc ? sdesc[4 * d + 7] : total_tiles;
+            if (f0 <= tl && tl < f1) which = d;
+        }
+        __syncthreads();
+        const int lo = which;
+        const long off = sdesc[4 * lo], rows = sdesc[4 * lo + 1], cols = sdesc[4 * lo + 2];
+        const long t = tl - sdesc[4 * lo + 3];
+        const long tiles_c = (cols + 31) / 32;
+        const long r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+        if (((rows | cols | off) & 1) == 0) {
+            const int px = threadIdx.x & 15, py = threadIdx.x >> 4;      // 16 pairs x 16
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long c = c0 + ty + 8 * i, r = r0 + tx;
-        if (r < rows && c < cols) dst[off + c * rows + r] = tile[tx][ty + 8 * i];
+            for (int i = 0; i < 2; ++i) {
+                const long r = r0 + py + 16 * i, c = c0 + 2 * px;
+                if (r < rows && c < cols) *(unsigned*)&tile[py + 16 * i][2 * px] = *(const unsigned*)(src + off + r * cols + c);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long c = c0 + py + 16 * i, r = r0 + 2 * px;
+                if (r < rows && c < cols) {
+                    const unsigned lo16 = __builtin_bit_cast(unsigned short, tile[2 * px][py + 16 * i]);
+                    const unsigned hi16 = __builtin_bit_cast(unsigned short, tile[2 * px + 1][py + 16 * i]);
+                    *(unsigned*)(dst + off + c * rows + r) = lo16 | (hi16 << 16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long r = r0 + ty + 8 * i, c = c0 + tx;
+                if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[off + r * cols + c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long c = c0 + ty + 8 * i, r = r0 + tx;
+                if (r < rows && c < cols) dst[off + c * rows + r] = tile[tx][ty + 8 * i];
+            }
+        }
+        __syncthreads();                                   // the tile and `which` are free again
     }
 }
 
 extern "C" int pseld_transpose_batch_bf16(const void* src, void* dst, const long* desc, int n_desc, long total_tiles,
                                           void* stream) {
     PSELD_CHECK_ARG(src && dst && desc && n_desc > 0 && total_tiles > 0, "transpose_batch_bf16: bad arguments");
-    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
-                       (bf16_t*)dst, desc, n_desc);
+    PSELD_CHECK_ARG(n_desc <= TB_MAX_DESC, "transpose_batch_bf16: %d tensors (at most %d per call)", n_desc, TB_MAX_DESC);
+    const long grid = total_tiles < 256 * 16 ? total_tiles : 256 * 16;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (bf16_t*)dst, desc, n_desc, total_tiles);
     PSELD_LAUNCH_CHECK("transpose_batch_bf16");
     return PSELD_OK;
 }
