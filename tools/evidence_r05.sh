@@ -20,6 +20,11 @@ run bench_n1_clips16 --clips 16 --steps 30 --warmup 5 --no-cpu-baseline --no-ker
 PSELD_GEMM8_BM=256 run bench_n1_rows256 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 PSELD_GEMM8_BM=256 run bench_n1_chunks32_rows256 --chunks 32 --steps 100 --warmup 10 --no-cpu-baseline --no-kernel-timing
 run bench_n1_again --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
+PSELD_WGRAD_GROUP=0 run bench_n1_chunks32_ungrouped --chunks 32 --steps 100 --warmup 10 --no-cpu-baseline --no-kernel-timing
+PSELD_WGRAD_GROUP=0 run bench_n1_chunks64_ungrouped --chunks 64 --steps 100 --warmup 10 --no-cpu-baseline --no-kernel-timing
+run bench_n1_chunks64 --chunks 64 --steps 100 --warmup 10 --no-cpu-baseline --no-kernel-timing
+PSELD_LNBWD384=1 PSELD_RESIDLN384=1 run bench_n1_ln384_epilogues --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
+timeout 600 python3 $R/tools/experiments/feature_cost.py --steps 20 --warmup 5 --no-kernel-timing 2> $O/feature_cost.err | tail -1 > $O/feature_cost_cached_features.json; echo "feature_cost $(python3 -c "import json;d=json.load(open('$O/feature_cost_cached_features.json'));print(d['value'],d['ms_per_step'])" 2>&1)"
 PSELD_BENCH_FORCE_GROUP=1 run bench_n1_rccl_group1 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 PSELD_BENCH_FORCE_GROUP=1 run bench_n1_rccl_group1_direct --comm rccl_direct --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 # kernel stats: everything on one stream (what the per-kernel roofline is measured on), as timed, and the 32-chunk step
@@ -45,6 +50,7 @@ COLD=1 STAGES=2,3 python3 tools/gemm8_check.py shapes > $O/gemm8_shapes_cold.log
 python3 tools/wgrad8_check.py shapes > $O/wgrad8_shapes.log 2>&1; tail -1 $O/wgrad8_shapes.log
 python3 tools/step_determinism.py 20 > $O/step_determinism.log 2>&1; tail -1 $O/step_determinism.log
 python3 tools/attn_bench.py > $O/attn_bench.log 2>&1; tail -3 $O/attn_bench.log
+python3 tools/ln384_check.py > $O/ln384_check.log 2>&1; grep launches $O/ln384_check.log
 python3 tools/mlp_bench.py --rounds 3 > $O/mlp_bench.log 2>&1; python3 tools/feature_bench.py > $O/feature_bench.log 2>&1
 tail -2 $O/mlp_bench.log $O/feature_bench.log
 ls $O | wc -l
