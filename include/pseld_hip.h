@@ -525,7 +525,7 @@ int pseld_adamw_step_dev(float* p, const float* g, float* m, float* v, void* sha
                          float weight_decay, void* stream);
 int pseld_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 /* Transposed bf16 copies of the arena's 2-D weights, for the input-gradient GEMMs (dX = dY W as a k-contiguous product):
- * desc = n_desc x {element offset, rows, cols, first 32x32 tile} (device longs), dst[off + c*rows + r] = src[off + r*cols + c]. */
+ * desc = n_desc x {element offset, rows, cols, first 32x32 tile} (device longs, n_desc <= 512), dst[off + c*rows + r] = src[off + r*cols + c]. */
 int pseld_transpose_batch_bf16(const void* src, void* dst, const long* desc, int n_desc, long total_tiles, void* stream);
 
 #ifdef __cplusplus

@@ -38,7 +38,7 @@ cd $R
 DOM=$(python3 -c "import json;print(json.load(open('gpurun_out/r05/bench_n1.json'))['roofline']['kernel'])")
 echo "dominant symbol: $DOM"
 python3 tools/pmc_kernel.py "$DOM" $O/pmc_FETCH $O/pmc_WRITE $O/pmc_SQ_VA $O/dominant_kernel_pmc.json | cut -c1-500
-for K in "gemm8w_kernel<3, (anonymous namespace)::G8WOne>" "gemm8w_kernel<4, (anonymous namespace)::G8WOne>" "gemm8_kernel<0, false, 3, 4, false>" "gemm8_kernel<1, true, 3, 4, false>" "gemm8_kernel<0, false, 4, 4, false>" "gemm8_kernel<3, false, 4, 4, false>" "gemm8_kernel<2, true, 4, 4, false>" "attn_fwd24p_kernel" "attn_bwd24_kernel<false>"; do python3 tools/pmc_kernel.py "$K" $O/pmc_FETCH $O/pmc_WRITE $O/pmc_SQ_VA "$O/pmc_$(printf %s "$K" | tr -c 'a-zA-Z0-9' '_').json" | cut -c1-300; done
+for K in "gemm8w_kernel<3, (anonymous namespace)::G8WOne>" "gemm8w_kernel<4, (anonymous namespace)::G8WOne>" "gemm8_kernel<0, false, 3, 4, false" "gemm8_kernel<1, true, 3, 4, false" "gemm8_kernel<0, false, 4, 4, false" "gemm8_kernel<3, false, 4, 4, false" "gemm8_kernel<2, true, 4, 4, false" "attn_fwd24p_kernel" "attn_bwd24_kernel<false>"; do python3 tools/pmc_kernel.py "$K" $O/pmc_FETCH $O/pmc_WRITE $O/pmc_SQ_VA "$O/pmc_$(printf %s "$K" | sed 's/false$/false>/' | tr -c 'a-zA-Z0-9' '_').json" | cut -c1-300; done
 python3 tools/pmc_stages.py $O/pmc_FETCH $O/pmc_WRITE 3 $O/stage_table.json | tail -12
 python3 tools/pmc_ledger.py $O/pmc_FETCH $O/pmc_WRITE 3 $O/ledger.json > $O/ledger.txt 2>&1; grep "^==" $O/ledger.txt
 python3 tools/pmc_feature.py $O/feat_sq $O/pmc_feature.json | tail -3
