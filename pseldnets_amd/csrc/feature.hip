@@ -161,7 +161,7 @@ __device__ __forceinline__ void fft32(f32x2 (&x)[32]) {
 //    order), then writes the seven per-bin values as two dense planes VP[k] = (P0..P3), VI[k] = (I1..I3, -) indexed by the bin - no
 //    mirrored in-place slots, no per-bin pointer selects; raw v_sqrt / v_rcp instead of the IEEE sequences, the factors 1/2 of the
 //    real / imaginary split folded into one 1/4 on the mel sums and into the IV epsilon;
-//  * mel projection: the 998 (filter, bin) weights are cut into runs of <= 12 consecutive bins of one filter (115 runs for the
+//  * mel projection: the 998 (filter, bin) weights are cut into runs of <= MEL_CAP consecutive bins of one filter (115 runs at 12, 124 at 11 for the
 //    64-mel HTK bank); a lane owns one run per pass (2 passes), its 12 weights live in registers across the frame loop, a bin's
 //    seven values arrive as two ds_read_b128 (was: five dependent LDS reads per weight, the widest filter setting the trip count
 //    of all 16 filters of its pass: 26 iterations of 25 instructions), the runs of one filter meet by two lane shuffles;
@@ -334,8 +334,7 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
                 iv[0] = i1 * inv; iv[1] = i23[0] * inv; iv[2] = i23[1] * inv;
             }
             if (k < NBIN) {
-                *(f32x2*)(region + k * 16) = pw01;
-                *(f32x2*)(region + k * 16 + 8) = pw23;
+                *(f32x4*)(region + k * 16) = __builtin_shufflevector(pw01, pw23, 0, 1, 2, 3);     // one 16-byte write per plane: conflict-free
                 *(f32x4*)(region + VI_OFF + k * 16) = iv;
             }
         }
@@ -355,9 +354,10 @@ __global__ __launch_bounds__(WAVES2 * 64) void logmel_iv_kernel(FeatArgs a) {
                 float a6 = 0.f;
 #pragma unroll
                 for (int i = 0; i < MEL_CAP; ++i) {                 // a bin's seven values times its weight: three packed FMAs + one
-                    const f32x2 P01 = *(const f32x2*)(vp + i * 16), P23 = *(const f32x2*)(vp + i * 16 + 8);
-                    const f32x2 I01 = *(const f32x2*)(vp + VI_OFF + i * 16);
-                    const float I2 = *(const float*)(vp + VI_OFF + i * 16 + 8);
+                    const f32x4 P = *(const f32x4*)(vp + i * 16), I = *(const f32x4*)(vp + VI_OFF + i * 16);
+                    const f32x2 P01 = __builtin_shufflevector(P, P, 0, 1), P23 = __builtin_shufflevector(P, P, 2, 3);
+                    const f32x2 I01 = __builtin_shufflevector(I, I, 0, 1);
+                    const float I2 = I[2];
                     if (i & 1) { a01 = pfma_hi(P01, w2[i >> 1], a01); a23 = pfma_hi(P23, w2[i >> 1], a23); a45 = pfma_hi(I01, w2[i >> 1], a45); }
                     else { a01 = pfma_lo(P01, w2[i >> 1], a01); a23 = pfma_lo(P23, w2[i >> 1], a23); a45 = pfma_lo(I01, w2[i >> 1], a45); }
                     a6 = fmaf(I2, w2[i >> 1][i & 1], a6);
