@@ -49,7 +49,6 @@ struct AttnArgs {
     unsigned long long* dbg;  // diagnostic: s_memtime stamps of workgroup 0's first windows
     int B, res, C, heads, hd, shift;
     int n_win_total;          // B * (res/8)^2
-    int variant;              // timing experiments (PSELD_ATTN_VARIANT): results are wrong when set
     const void* wproj_t;      // attn_bwd24_kernel<true>: [C, C] = attn.proj.weight^T; dout is then d(x_mid), the gradient of the projection's OUTPUT
     const float* rowscale;    // ... and the DropPath factor per sample (or null)
     float scale;
@@ -945,8 +944,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
                     // (the key-side fragments are re-read per tile rather than kept across the query tiles: 24 registers)
                     const bool live = 16 * kk + 8 * h2 < HD;
                     const bf16x8 kr = M::keep_if(M::ld_row(tile + (kt * 32 + pr) * STR + (ck + 16 * kk + 8 * h2) * 2), live);
-                    const bf16x8 vr = M::keep_if(M::ld_row(tile + (kt * 32 + pr) * STR + (cv + 16 * kk + 8 * h2) * 2), live);
-                    const bf16x8 qr = M::keep_if(M::ld_row(tile + (qt * 32 + pr) * STR + (cq + 16 * kk + 8 * h2) * 2), live);
+                    // (one masked operand per product is enough: the other side's dead dims 24-31 are the NEXT head's or segment's finite bf16
+                    //  values, times zero. q and v run into live segments; dO may run into the row's uninitialised pad, so it keeps the mask)
+                    const bf16x8 vr = M::ld_row(tile + (kt * 32 + pr) * STR + (cv + 16 * kk + 8 * h2) * 2);
+                    const bf16x8 qr = M::ld_row(tile + (qt * 32 + pr) * STR + (cq + 16 * kk + 8 * h2) * 2);
                     const bf16x8 dor = M::keep_if(M::ld_row(tile + (qt * 32 + pr) * STR + (cdo + 16 * kk + 8 * h2) * 2), live);
                     M::mma(kr, qr, pt);                   // S^T[key][query]: row i <-> key swap23(i), lane <-> query swap23(lane)
                     M::mma(vr, dor, dpt);                 // dP^T
@@ -984,12 +985,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
                 f32x16 pq, sq;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { pq[e] = 0.f; sq[e] = 0.f; }
-                if (!(a.variant & 2)) {
                 M::mma(pf0, idf[0], pq); M::mma(pf1, idf[1], pq);
                 M::mma(sf0, idf[0], sq); M::mma(sf1, idf[1], sq);
-                }
                 // dV^T[d][key] += dO^T P, dK^T[d][key] += Q^T dS (contraction over the query rows)
-                if (!(a.variant & 4))
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     M::mma(ld_colp(qt * 32 + 16 * s, cdo, lane), M::from_acc(pq, s), dvT);
@@ -1015,7 +1013,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
         if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 2] = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (stamp && it < 8) { a.dbg[(blockIdx.x * 8 + it) * 8 + 3] = __builtin_amdgcn_s_memtime(); a.dbg[(blockIdx.x * 8 + it) * 8 + 4] = a.dbg[(blockIdx.x * 8 + it) * 8 + 3]; }
-        if (!(a.variant & 8))
         for (int sel = 0; sel < 3; ++sel)
             window_copy<bf16_t, false>(tile, STR, (bf16_t*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, GW, toks);
         if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 5] = __builtin_amdgcn_s_memtime();
@@ -1168,12 +1165,6 @@ extern "C" int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bi
     if (slots < 1) slots = 1;
     dim3 grid(slots, nhg);
     const int v2 = pseld_knob(KNOB_ATTN_BWD_V2, 1) != 0;
-    {   // timing-experiment knob; a result-changing value is refused unless PSELD_ALLOW_WRONG_RESULTS=1 says it is a timing run
-        const int variant = pseld_knob(KNOB_ATTN_VARIANT, 0);
-        const bool allowed = pseld_knob(KNOB_ALLOW_WRONG_RESULTS, 0) == 1;
-        PSELD_CHECK_ARG(variant == 0 || allowed, "window_attn_bwd: PSELD_ATTN_VARIANT=%d changes the results (timing experiments only; set PSELD_ALLOW_WRONG_RESULTS=1)", variant);
-        a.variant = variant;
-    }
     if (dtype == PSELD_BF16 && a.hd == 24 && heads % 4 == 0 && v2) {
         // one wave per head, four heads per workgroup, two workgroups per CU, persistent
         int sl = (es ? es : 512) / (heads / 4);
