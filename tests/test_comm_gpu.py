@@ -11,6 +11,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope='module', autouse=True)
+def _leave_no_group_behind():
+    """The module's gloo group is torn down at its end: the single-rank RCCL tests of test_htsat_gpu.py need to create their own."""
+    yield
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def _group():
     import torch.distributed as dist
     if not dist.is_initialized():
