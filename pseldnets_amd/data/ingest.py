@@ -212,10 +212,12 @@ class DeviceSELDDataset:
     files (or, for EINV2, the track-wise arrays), the index rows of `extract_index`. `batch(indices)` returns what the
     reference's DataLoader would collate for those rows — {'filename', 'data' f32 [B,4,L], '<method> label' [B,100,...], 'ov'} —
     with ONE chunk-cutting launch and one label-synthesis launch for the whole batch.
-    method: 'multi_accdoa' | 'accdoa' | 'einv2'; metas: {recording name: path of its DCASE metadata CSV}."""
+    method: 'multi_accdoa' | 'accdoa' | 'einv2'; metas: {recording name: path of its DCASE metadata CSV} - or label_h5: the label
+    file the reference's preprocessing wrote for the method (`.../adpit/<type>/<dataset>.h5`, `accdoa/...`, `track/...`:
+    preprocess.py:63-65), read through data/hdf5_lite.py by recording stem exactly as data/data.py:92-96, 159-161, 220-224 do."""
 
     def __init__(self, store, metas, method, num_classes, sample_rate=24000, chunklen_sec=10, hoplen_sec=10, label_res=0.1, max_ov=3,
-                 mono_adapter=False, rng=None, index_csv=None):
+                 mono_adapter=False, rng=None, index_csv=None, label_h5=None):
         from .. import inference
         self.mono_adapter, self.rng = mono_adapter, rng          # cfg.adapt.method == 'mono_adapter' (data.py:109-111,169-171,223-225)
         from . import labels as L
@@ -239,7 +241,19 @@ class DeviceSELDDataset:
             self.rows = store.index_rows(self.chunk_len, int(hoplen_sec * sample_rate))
         dev = store.device
         self.labels = {}
-        for name in store.names:
+        if label_h5 is not None:
+            import os
+            from . import hdf5_lite
+            with hdf5_lite.File(label_h5) as hf:
+                for name in store.names:
+                    fn = os.path.splitext(os.path.basename(name))[0]
+                    if method == 'einv2':
+                        arrs = (hf[f'{fn}/sed_label'][...], hf[f'{fn}/doa_label'][...].astype('float32'))
+                    else:
+                        grp = 'adpit' if method == 'multi_accdoa' else 'accdoa'
+                        arrs = tuple(hf[f'{fn}/{grp}/{k}'][...] for k in ('se', 'azi', 'ele'))
+                    self.labels[name] = tuple(torch.from_numpy(a).to(dev) for a in arrs)
+        for name in (store.names if label_h5 is None else ()):
             if method == 'einv2':
                 sed, doa = L.track_labels(L.read_meta_rows(metas[name]), num_classes, max_ov)
                 self.labels[name] = (torch.from_numpy(sed).to(dev), torch.from_numpy(doa).to(dev))

@@ -1,7 +1,8 @@
 """Label extraction from DCASE metadata — host-side mirror of the reference's offline preprocessing
-(`preproc/preprocess.py`: extract_track_label :80-133, extract_accdoa_label :176-212, extract_adpit_label :346-461), without
-the HDF5 container (h5py is absent from this image): the functions return the arrays the reference stores as
-`{fn}/accdoa/{se,azi,ele}`, `{fn}/adpit/{se,azi,ele}` and `{fn}/{sed_label,doa_label}`; `data/ingest.py:polar_labels` turns the
+(`preproc/preprocess.py`: extract_track_label :80-133, extract_accdoa_label :176-212, extract_adpit_label :346-461): the functions
+return the arrays the reference stores as `{fn}/accdoa/{se,azi,ele}`, `{fn}/adpit/{se,azi,ele}` and `{fn}/{sed_label,doa_label}` in its
+HDF5 label files (those files themselves are read by `data/hdf5_lite.py`, `DeviceSELDDataset(label_h5=...)`; h5py is absent from this
+image, so nothing here writes the container); `data/ingest.py:polar_labels` turns the
 (se, azi, ele) triples into the float training labels on the device. Plain numpy: this is preprocessing, not the hot path."""
 import numpy as np
 

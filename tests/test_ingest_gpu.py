@@ -76,14 +76,14 @@ def test_generate_spatial_samples_vs_reference(dev, method):
     assert torch.equal(res2[0], res[0])
 
 
-def _make_split(tmp_path, dev, seeds=(31, 32, 33)):
+def _make_split(tmp_path, dev, seeds=(31, 32, 33), frames_of=lambda i: 60 + 85 * i):
     """WAV recordings + DCASE metadata on disk -> DeviceClipStore; recording i is exactly as long as its metadata says."""
     from pseldnets_amd.data.ingest import DeviceClipStore
     from tests.golden.meta_inputs import meta_rows, write_meta
     rng = np.random.default_rng(5)
     store, metas, pcms = DeviceClipStore(dev, 4), {}, {}
     for i, seed in enumerate(seeds):
-        rows = meta_rows(seed, num_frames=60 + 85 * i)             # 6 s, 14.5 s, 23 s
+        rows = meta_rows(seed, num_frames=frames_of(i))            # 6 s, 14.5 s, 23 s
         frames = rows[-1][0] + 1
         pcm = (rng.standard_normal((frames * 2400, 4)) * 3000).astype(np.int16)
         wav, meta = tmp_path / f'mix{i}.wav', tmp_path / f'mix{i}.csv'
@@ -193,3 +193,23 @@ def test_device_dataset_mono_adapter(dev, tmp_path, method):
         assert torch.allclose(mono['accdoa_label'], want[1][:, :, 5:])
     assert torch.equal(mono['data'], want[0]) and mono['ov'] == plain['ov'] == ['1']
     assert not torch.equal(mono['data'][:, 1], plain['data'][:, 1]) and torch.equal(mono['data'][:, 0], plain['data'][:, 0])
+
+
+@pytest.mark.parametrize("method,fname", [('multi_accdoa', 'adpit.h5'), ('accdoa', 'accdoa.h5'), ('einv2', 'track.h5')])
+def test_device_dataset_labels_from_the_reference_hdf5_label_files(dev, tmp_path, method, fname):
+    """DeviceSELDDataset(label_h5=...): the labels come out of the HDF5 file the reference's preprocessing writes for the method
+    (preprocess.py:63-65, 88-129, 197-209, 449-459; read back by recording stem as data/data.py:92-96, 159-161, 220-224 do) instead of
+    being re-derived from the metadata CSVs. tests/golden/hdf5/*.h5 hold the reference's own arrays for the seeded recordings mix0 /
+    mix1 (written by libhdf5: tests/golden/make_hdf5_golden.py): same batches as the metadata route, every key."""
+    import os
+    from pseldnets_amd.data.ingest import DeviceSELDDataset
+    h5 = os.path.join(os.path.dirname(__file__), 'golden', 'hdf5', fname)
+    store, metas, _ = _make_split(tmp_path, dev, seeds=(31, 32), frames_of=lambda i: 60)
+    a = DeviceSELDDataset(store, metas, method, 5)
+    b = DeviceSELDDataset(store, None, method, 5, label_h5=h5)
+    assert len(a) == len(b) == 2
+    ga, gb = a.batch(range(2)), b.batch(range(2))
+    assert ga.keys() == gb.keys() and ga['ov'] == gb['ov'] and ga['filename'] == gb['filename']
+    for k in ga:
+        if torch.is_tensor(ga[k]):
+            assert torch.equal(ga[k], gb[k]), k
