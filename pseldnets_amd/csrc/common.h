@@ -201,24 +201,37 @@ __device__ __forceinline__ float gelu_grad_shared(float x) {
     return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 // ---- GELU and its derivative from an LDS table with linear interpolation (the fused MLP kernels in bf16 mode; f32 parity mode keeps the
-// A&S erf). 512 entries of 16 bytes over [-8, 8): {gelu(x0), gelu(x1) - gelu(x0), gelu'(x0), gelu'(x1) - gelu'(x0)}, x1 = x0 + 1/32;
-// |error| <= 6e-5 for both (h^2 / 16 max|f''|, every chord shifted by half its midpoint gap), a sixtieth of the bf16 spacing at 1 the results are rounded to. One ds_read_b128 + 2 FMA
-// + index arithmetic per element against 1 v_rcp + 1 v_exp + ~12 FMA-class instructions (tools/experiments/gelu_table.hip: 59 against 85
-// cycles per wave for the pair); beyond +8 the identity / 1, below -8 the table's first entry (0 / 0 to 1e-14).
+// A&S erf). 512 entries of 16 bytes over [-8, 8): {Phi(x0), Phi(x1) - Phi(x0), gelu'(x0), gelu'(x1) - gelu'(x0)}, x1 = x0 + 1/32, Phi the
+// normal CDF: gelu(x) = x Phi(x). Both tabulated functions are CONSTANT outside the table (0 / 0 below -8, 1 / 1 above +8 to 1e-14), so the
+// clamped index is all the range handling there is - round 5: the table used to hold gelu itself, which needs a compare + select for
+// x >= 8 per element; two vector instructions less in the forward and dx kernels' inner loops. |error| <= 1.5e-5 |x| for gelu (h^2 / 16
+// max|Phi''| = 1.5e-5, every chord shifted by half its midpoint gap: centred, no systematic bias against the erf evaluation) and 6e-5 for
+// gelu', a sixtieth of the bf16 spacing at 1 the results are rounded to. One ds_read_b128 + 2-3 FMA-class + index arithmetic per element
+// against 1 v_rcp + 1 v_exp + ~12 FMA-class instructions (tools/experiments/gelu_table.hip: 59 against 85 cycles per wave for the pair).
 constexpr int GELU_TAB_N = 512;
 constexpr int GELU_TAB_BYTES = GELU_TAB_N * 16;
 __device__ __forceinline__ void gelu_tab_fill(f32x4* tab, int tid, int nthreads) {
+    auto phi_d = [](float x, float& phi, float& d) {          // Phi(x) and gelu'(x) = Phi + x pdf: gelu_both's A&S evaluation, the CDF kept
+        const float ax = fabsf(x) * 0.70710678118654752f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+        float p = fmaf(1.061405429f, t, -1.453152027f);
+        p = fmaf(p, t, 1.421413741f);
+        p = fmaf(p, t, -0.284496736f);
+        p = fmaf(p, t, 0.254829592f);
+        const float e = __expf(-ax * ax);
+        phi = 0.5f * (1.0f + copysignf(1.0f - p * t * e, x));
+        d = phi + x * 0.3989422804014327f * e;
+    };
     for (int i = tid; i < GELU_TAB_N; i += nthreads) {
         const float x0 = (float)(i - GELU_TAB_N / 2) * (1.0f / 32.0f), x1 = x0 + (1.0f / 32.0f);
-        float g0, d0, g1, d1, gm, dm;
-        gelu_both(x0, g0, d0);
-        gelu_both(x1, g1, d1);
-        gelu_both(x0 + (1.0f / 64.0f), gm, dm);
+        float p0, d0, p1, d1, pm, dm;
+        phi_d(x0, p0, d0);
+        phi_d(x1, p1, d1);
+        phi_d(x0 + (1.0f / 64.0f), pm, dm);
         // the chord of a convex (concave) piece lies above (below) the function, by at most its gap at the midpoint: each interval's chord is
-        // lowered by half that gap, so the error is centred (+-6e-5 instead of one-sided 1.2e-4: no systematic bias against the erf
-        // evaluation the weight-gradient kernel recomputes the hidden activations with)
-        const float eg = 0.5f * (0.5f * (g0 + g1) - gm), ed = 0.5f * (0.5f * (d0 + d1) - dm);
-        tab[i] = f32x4{g0 - eg, g1 - g0, d0 - ed, d1 - d0};
+        // lowered by half that gap, so the error is centred
+        const float ep = 0.5f * (0.5f * (p0 + p1) - pm), ed = 0.5f * (0.5f * (d0 + d1) - dm);
+        tab[i] = f32x4{p0 - ep, p1 - p0, d0 - ed, d1 - d0};
     }
 }
 __device__ __forceinline__ f32x4 gelu_tab_entry(const f32x4* tab, float x, float& fr) {
@@ -229,19 +242,18 @@ __device__ __forceinline__ f32x4 gelu_tab_entry(const f32x4* tab, float x, float
 __device__ __forceinline__ float gelu_tab_f(const f32x4* tab, float x) {
     float fr;
     const f32x4 e = gelu_tab_entry(tab, x, fr);
-    return x >= 8.0f ? x : fmaf(e[1], fr, e[0]);
+    return x * fmaf(e[1], fr, e[0]);
 }
 __device__ __forceinline__ float gelu_tab_grad(const f32x4* tab, float x) {
     float fr;
     const f32x4 e = gelu_tab_entry(tab, x, fr);
-    return x >= 8.0f ? 1.0f : fmaf(e[3], fr, e[2]);
+    return fmaf(e[3], fr, e[2]);
 }
 __device__ __forceinline__ void gelu_tab_both(const f32x4* tab, float x, float& y, float& dy) {
     float fr;
     const f32x4 e = gelu_tab_entry(tab, x, fr);
-    const bool big = x >= 8.0f;
-    y = big ? x : fmaf(e[1], fr, e[0]);
-    dy = big ? 1.0f : fmaf(e[3], fr, e[2]);
+    y = x * fmaf(e[1], fr, e[0]);
+    dy = fmaf(e[3], fr, e[2]);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
