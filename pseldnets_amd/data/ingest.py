@@ -119,6 +119,24 @@ class DeviceClipStore:
             raise ValueError(f'{path}: sample rate {rate} Hz, expected cfg.data.sample_rate = {sample_rate} Hz (no resampler on this path)')
         self.add_clip(str(path), pcm)
 
+    def add_flac(self, path, sample_rate=None):
+        """A FLAC recording (the reference's synthetic datasets: data/components/data.py:81; read there by soundfile). Decoded on the host
+        by libpseld_host.so (data/flac.py: frame CRCs and the stream's MD5 signature checked); 16-bit streams only - the store holds
+        PCM16, and `sf.read(dtype='float32')` of a 16-bit stream is exactly int16 / 32768, the scaling the chunk kernel applies."""
+        from . import flac
+        with open(path, 'rb') as f:
+            data = f.read()
+        pcm, info = flac.decode_flac(data)
+        if info['bits_per_sample'] != 16:
+            raise NotImplementedError(f"{path}: {info['bits_per_sample']}-bit FLAC (the clip store holds 16-bit PCM)")
+        if sample_rate is not None and int(info['sample_rate']) != int(sample_rate):
+            raise ValueError(f"{path}: sample rate {info['sample_rate']} Hz, expected cfg.data.sample_rate = {sample_rate} Hz (no resampler on this path)")
+        self.add_clip(str(path), pcm.astype(np.int16))
+
+    def add_audio(self, path, sample_rate=None):
+        """By extension: .flac -> add_flac, anything else -> add_wav (RIFF PCM16)."""
+        return self.add_flac(path, sample_rate) if str(path).lower().endswith('.flac') else self.add_wav(path, sample_rate)
+
     def finalize(self):
         if self.pcm is None:
             _lib.require_gpu()
@@ -231,9 +249,10 @@ class DeviceSELDDataset:
             # its file name (an index written on another machine carries that machine's directories)
             import os
             by_base = {os.path.basename(n): n for n in store.names}
+            by_stem = {os.path.splitext(os.path.basename(n))[0]: n for n in store.names}      # (.wav rows, .flac recordings: data/components/data.py:81)
             self.rows = []
             for rec, b, e, pb, pa in read_index_csv(index_csv):
-                name = rec if rec in store.names else by_base.get(os.path.basename(rec))
+                name = rec if rec in store.names else by_base.get(os.path.basename(rec), by_stem.get(os.path.splitext(os.path.basename(rec))[0]))
                 if name is None:
                     raise KeyError(f'{index_csv}: recording {rec!r} is not in the clip store')
                 self.rows.append((name, b, e, pb, pa))

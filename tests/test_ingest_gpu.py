@@ -213,3 +213,36 @@ def test_device_dataset_labels_from_the_reference_hdf5_label_files(dev, tmp_path
     for k in ga:
         if torch.is_tensor(ga[k]):
             assert torch.equal(ga[k], gb[k]), k
+
+
+def test_clip_store_takes_flac_recordings(dev, tmp_path):
+    """DeviceClipStore.add_audio on .flac files (the reference's synthetic datasets, data/components/data.py:81; `sf.read` there): the same
+    PCM16 in HBM as from the .wav of the same samples, chunks bit-equal; an index file that names the .wav finds the .flac recording."""
+    from pseldnets_amd.data import ingest
+    from tests import flac_testenc as E
+    rng = np.random.default_rng(11)
+    a, b = ingest.DeviceClipStore(dev, 4), ingest.DeviceClipStore(dev, 4)
+    for i, n in enumerate((240000 + 1234, 90000)):
+        t = np.arange(n)[:, None]
+        pcm = (8000 * np.sin(2 * np.pi * (0.01 + 0.003 * np.arange(4)[None]) * t) + rng.standard_normal((n, 4)) * 300).astype(np.int16)
+        wav, fl = tmp_path / f'rec{i}.wav', tmp_path / f'rec{i}.flac'
+        with wave.open(str(wav), 'wb') as w:
+            w.setnchannels(4); w.setsampwidth(2); w.setframerate(24000); w.writeframes(pcm.tobytes())
+        fl.write_bytes(E.encode(pcm, 24000, 16, 4096, ('fixed2', 'lpc8p12s9', 'fixed1', 'lpc4p12s9'), 3))
+        a.add_audio(wav, 24000); b.add_audio(fl, 24000)
+    a.finalize(); b.finalize()
+    assert torch.equal(a.pcm, b.pcm) and a.lengths == b.lengths
+    ra, rb = a.index_rows(240000, 240000), b.index_rows(240000, 240000)
+    assert torch.equal(a.chunks(ra, 240000), b.chunks(rb, 240000))
+    with pytest.raises(ValueError, match='sample rate'):
+        ingest.DeviceClipStore(dev, 4).add_audio(tmp_path / 'rec0.flac', 16000)
+    idx = tmp_path / 'idx.csv'
+    ingest.write_index_csv(idx, [(str(tmp_path / 'rec0.wav'), a.lengths[0]), (str(tmp_path / 'rec1.wav'), a.lengths[1])], 240000, 240000)
+    metas = {}
+    from tests.golden.meta_inputs import meta_rows, write_meta
+    for i, name in enumerate(b.names):
+        m = tmp_path / f'rec{i}.csv'
+        write_meta(m, meta_rows(40 + i, num_frames=b.lengths[i] // 2400))
+        metas[name] = m
+    ds = ingest.DeviceSELDDataset(b, metas, 'multi_accdoa', 5, index_csv=str(idx))
+    assert [r[0] for r in ds.rows] == [str(tmp_path / 'rec0.flac')] * 2 + [str(tmp_path / 'rec1.flac')]
