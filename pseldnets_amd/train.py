@@ -245,13 +245,18 @@ def main(argv=None):
         from .data.components.sampler import UserDistributedBatchSampler
         from .data.ingest import DeviceClipStore, DeviceSELDDataset
         store = DeviceClipStore(device, 4)
-        wavs = sorted(Path(cfg.data.wav_dir).glob('*.wav'))
+        # recordings: *.wav (RIFF PCM16) and *.flac (the reference's synthetic datasets, data/components/data.py:81); labels: the DCASE
+        # metadata CSVs beside them (data.meta_dir), or the HDF5 label file the reference's preprocessing wrote (data.label_h5:
+        # .../{adpit,accdoa,track}/<type>/<dataset>.h5); rows: the dataset's own index, or the reference's index CSV (data.index_csv)
+        wavs = sorted(list(Path(cfg.data.wav_dir).glob('*.wav')) + list(Path(cfg.data.wav_dir).glob('*.flac')))
         for w in wavs:
-            store.add_wav(w, sample_rate=cfg.data.sample_rate)
-        metas = {str(w): Path(cfg.data.get('meta_dir') or cfg.data.wav_dir) / (w.stem + '.csv') for w in wavs}
+            store.add_audio(w, sample_rate=cfg.data.sample_rate)
+        label_h5 = cfg.data.get('label_h5')
+        metas = None if label_h5 else {str(w): Path(cfg.data.get('meta_dir') or cfg.data.wav_dir) / (w.stem + '.csv') for w in wavs}
         ds = DeviceSELDDataset(store, metas, cfg.model.method, cfg.data.num_classes, cfg.data.sample_rate, cfg.data.train_chunklen_sec,
                                cfg.data.get('train_hoplen_sec', cfg.data.train_chunklen_sec),
-                               mono_adapter=(cfg.adapt or {}).get('method') == 'mono_adapter')
+                               mono_adapter=(cfg.adapt or {}).get('method') == 'mono_adapter',
+                               index_csv=cfg.data.get('index_csv'), label_h5=label_h5)
         sampler = UserDistributedBatchSampler(len(ds), cfg.model.batch_size, seed=cfg.seed)
         batches, n_batches = iter(sampler), min(n_batches, len(sampler)) if n_batches else len(sampler)
     for epoch in range(cfg.trainer.max_epochs):

@@ -246,3 +246,22 @@ def test_clip_store_takes_flac_recordings(dev, tmp_path):
         metas[name] = m
     ds = ingest.DeviceSELDDataset(b, metas, 'multi_accdoa', 5, index_csv=str(idx))
     assert [r[0] for r in ds.rows] == [str(tmp_path / 'rec0.flac')] * 2 + [str(tmp_path / 'rec1.flac')]
+
+
+def test_train_entry_point_on_flac_recordings_with_the_reference_label_file(dev, tmp_path, capsys):
+    """`python -m pseldnets_amd.train data.wav_dir=<dir of .flac> data.label_h5=<adpit.h5>`: FLAC recordings (test encoder) + the HDF5
+    label file (libhdf5-written fixture holding the reference's arrays for mix0 / mix1) -> the same training loop; finite losses."""
+    import os
+    from pseldnets_amd import train
+    from tests import flac_testenc as E
+    rng = np.random.default_rng(3)
+    for i in range(2):
+        pcm = (rng.standard_normal((60 * 2400, 4)) * 3000).astype(np.int16)          # 6 s, as long as the fixture's 60 label frames
+        (tmp_path / f'mix{i}.flac').write_bytes(E.encode(pcm, 24000, 16, 4096, ('fixed2',), 2))
+    h5 = os.path.join(os.path.dirname(__file__), 'golden', 'hdf5', 'adpit.h5')
+    train.main(['experiment=synth_maccdoa', f'data.wav_dir={tmp_path}', f'data.label_h5={h5}', 'data.num_classes=5', 'model.batch_size=2', 'model.kwargs.embed_dim=48',
+                'model.kwargs.depths=[2,2,2,2]', 'model.kwargs.num_heads=[2,4,8,16]', 'model.kwargs.drop_path_rate=0.0', 'trainer.max_epochs=2',
+                'trainer.limit_train_batches=2', 'model.optimizer.kwargs.lr=0.001'])
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('epoch')]
+    losses = [float(ln.split('loss_all')[1].split()[0]) for ln in lines]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and all(0.0 < v < 5.0 for v in losses), lines
