@@ -213,6 +213,15 @@ int launch_ln(const LnArgs& a, bool bwd, int rows_per_block, int nblocks, hipStr
             hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, MERGE>), dim3(nblocks), dim3(256), lds, s, a, rows_per_block); \
         }                                                                                                       \
     } while (0)
+    // widths that are 24 x a power of two (every HTS-AT stage: 96 / 192 / 384 / 768, PaSST's 768): G = C / 24 lanes x 3 vectors of 8 cover the
+    // row exactly - the power-of-two groups below leave a quarter of their lanes without a vector at these widths. Round 5 (tools/ln_shapes.py,
+    // same box): forward 70 / 35.5 / 19.8 / 11.7 -> 63 / 31.4 / 17.9 / 10.5 us at stages 0-3, PaSST 76.5 -> 68; backward 167 -> 150 us at PaSST's
+    // 115 584 rows, unchanged at stages 0-2, 27.8 -> 29.6 at stage 3 (12 288 rows of 768: stays on 64 lanes); the step 17.71 -> 17.58 ms.
+    // Knob LN_EXACT = 0: the old mapping (A/B).
+    const int g24 = a.C % 24 == 0 ? a.C / 24 : 0;
+    if (pseld_knob(KNOB_LN_EXACT, 1) != 0 && (g24 == 4 || g24 == 8 || g24 == 16 || g24 == 32) && !(bwd && g24 == 32 && a.M < 65536)) {
+        if (g24 == 4) LN_CASE(4, 3); else if (g24 == 8) LN_CASE(8, 3); else if (g24 == 16) LN_CASE(16, 3); else LN_CASE(32, 3);
+    } else
     if (a.C <= 128) LN_CASE(16, 1);
     else if (a.C <= 256) LN_CASE(32, 1);
     else if (a.C <= 512) LN_CASE(64, 1);
