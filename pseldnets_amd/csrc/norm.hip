@@ -234,11 +234,13 @@ int launch_ln(const LnArgs& a, bool bwd, int rows_per_block, int nblocks, hipStr
     return PSELD_OK;
 }
 
-// rows per workgroup of the backward: each row group walks its rows serially (load -> two reductions -> store is one
-// dependent chain per row), so small inputs need MANY short workgroups to keep loads in flight; the cap bounds the
-// dgamma/dbeta partial slabs the reduction has to read
+// rows per workgroup of the backward: each row group walks its rows serially (load -> two reductions -> store is one dependent chain per
+// row), and every workgroup ends with the same fixed work (its d(gamma) / d(beta) sums through LDS, one partial row written). Alone, fewer
+// and longer workgroups win (tools/ln_shapes.py with a grid knob, round 5: 256 workgroups 130 / 64.7 / 37.3 us at stages 0-2 against 132 /
+// 68.2 / 42.2 with 1024); INSIDE the step they lose (17.72 / 17.75 -> 17.88 / 17.86 ms, alternating on one box): the weight gradients of
+// the second stream hold CUs, and a grid of exactly one long workgroup per CU waits for them. 1024 it stays.
 constexpr int LN_BWD_MAX_BLOCKS = 1024;
-static inline int ln_bwd_rows(long M) { long r = (M + LN_BWD_MAX_BLOCKS - 1) / LN_BWD_MAX_BLOCKS; if (r < 16) r = 16; return (int)r; }
+static inline int ln_bwd_rows(long M, int) { long r = (M + LN_BWD_MAX_BLOCKS - 1) / LN_BWD_MAX_BLOCKS; if (r < 16) r = 16; return (int)r; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Scalar BatchNorm statistics: sums[c][f][0..1] = (sum x, sum x^2) over (b, t) of feat[B, Cin, T, F]
@@ -640,7 +642,7 @@ extern "C" int pseld_layernorm_fwd(int dtype, const void* x, const float* gamma,
 }
 
 extern "C" long pseld_layernorm_bwd_workspace(long M, int C) {
-    return (long)pseld_cdiv(M, ln_bwd_rows(M)) * 2 * C * (long)sizeof(float);
+    return (long)pseld_cdiv(M, ln_bwd_rows(M, C)) * 2 * C * (long)sizeof(float);
 }
 
 // dx = LN'(dy) (+ dres); dgamma/dbeta (fp32, overwritten or accumulated). In merge mode x/dx use the un-merged
@@ -654,7 +656,7 @@ extern "C" int pseld_layernorm_bwd(int dtype, const void* dy, const void* x, con
     PSELD_CHECK_ARG(workspace_bytes >= pseld_layernorm_bwd_workspace(M, C), "layernorm_bwd: workspace too small");
     LnArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy; a.dx = dx; a.dres = dres; a.gamma = gamma; a.partial = workspace; a.M = M; a.C = C; a.res = merge_res; a.eps = eps;
-    const int rows = ln_bwd_rows(M);
+    const int rows = ln_bwd_rows(M, C);
     const int nb = pseld_cdiv(M, rows);
     hipStream_t s = (hipStream_t)stream;
     int rc;
