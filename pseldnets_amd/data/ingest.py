@@ -6,8 +6,8 @@ The reference reads a float32 slice per chunk from FLAC/WAV files through soundf
 step rate (≈ 7 500 ten-second chunks/s per GPU) that is ≈ 29 GB/s of fp32 audio per GPU. Here the clips are decoded ONCE
 to 16-bit PCM and kept in HBM (STARSS23 dev: 5 GB); a training batch is cut, padded and converted by one kernel launch
 from a table of index rows. The index CSV of `extract_index` is written and read here (write_index_csv / read_index_csv, pinned to
-rows the reference's own function wrote: tests/golden/index.npz). HDF5 / FLAC containers are not read (h5py / soundfile are absent from this
-image, so no reference-written file of either kind can exist here to pin a reader against); a RIFF PCM16 reader is included for WAV clips.
+rows the reference's own function wrote: tests/golden/index.npz). Recordings come from RIFF PCM16 WAV (read_wav_pcm16) or FLAC (data/flac.py:
+own decoder); labels from the DCASE metadata CSVs (data/labels.py) or from the reference's HDF5 label files (data/hdf5_lite.py: own reader).
 """
 import struct
 
