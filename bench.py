@@ -488,7 +488,7 @@ def main():
                                + f"170 classes, {'tPIT' if einv2_mode else 'ADPIT'}, clip 1.0, AdamW, "
                                f"{'dropout 0.1' if args.backbone.startswith('crnn') else 'drop_path 0.0' if args.backbone.startswith('passt') else 'drop_path 0.1'}, BN train mode, {'AugMix augmentations (x3 chunks through the network)' if args.augment == 'augmix' else 'no augmentation'}",
                    "global_clips": round(clips_per_step * world, 3), "global_chunks": n_chunks * world, "parallelism": f"dp{world}",
-                   "sync_batchnorm": bool(sync_bn)},
+                   "sync_batchnorm": bool(sync_bn), "comm": args.comm},
         "loss": round(loss_val, 6),
         # per-step HIP-event durations on rank 0's launch stream (median over >= 100 steps when --steps >= 100)
         "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(step_ms[0], 3), "ms_per_step_p90": round(step_ms[int(0.9 * (len(step_ms) - 1))], 3),

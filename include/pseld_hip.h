@@ -159,6 +159,27 @@ int pseld_unset_knob(const char* name);
 /* Measurement / test aid: force the tile shape of the eight-phase kernel for the following pseld_gemm calls (rows 256 | 128, columns
  * 256 | 192; 0 = the launch's own choice by grid fill). All four shapes sum K in the same order and give the same bits. */
 void pseld_gemm8_force_tile(int rows, int cols);
+/* The same for the row-panel-stationary kernel (csrc/gemm8p.hip: K = 192 / 384, the A rows of a 64 mb-row panel in registers, the weights
+ * streamed through LDS; replaces htsat.py:118,140 qkv / proj and model_utilities.py:166-170 fc1 with their K <= 384 input gradients at
+ * bench-size batches): mb = 16-row blocks per wave (2 | 3 at K = 384, 3 | 4 at K = 192; 0 = own choice), stag = -1 own choice | 0 | 1
+ * (second wave of every SIMD runs its epilogue one tile late). Every shape gives the bits of the eight-phase kernel. */
+void pseld_gemm8p_force(int mb, int stag);
+/* Diagnostic only: while a device buffer (u64 [workgroup][wave group 0/1][10]) is installed, the unstaggered 192-row launches of the plain,
+ * GELU-pair and scaled-aux epilogues run a stamped instantiation: cycle sums of (A panel load, vmcnt wait, barrier, LDS-DMA issue, matrix
+ * part, epilogue), the workgroup's lifetime and its tile count. NULL disables. */
+void pseld_gemm8p_set_debug_buffer(void* device_buffer);
+/* Fused MLP forward of a C = 192 / 384 block (csrc/mlp8f.hip; reference: model_utilities.py:159-171 Mlp.forward with the block's DropPath +
+ * shortcut, htsat.py:262-264): y[M, C] = resid + s[m / rows_per_scale] (gelu(xn W1^T + b1) W2^T + b2), and the two tensors the backward pass
+ * reads, h = gelu(.) and g = gelu'(.) [M, H = 4 C]. bf16 operands (xn = the LayerNorm output, W1 [H, C], W2 [C, H], row-major, 16-byte
+ * aligned), fp32 biases / DropPath factors (rowscale may be NULL). One launch; the bits of pseld_gemm(fc1, GELU pair) + pseld_gemm(fc2,
+ * residual). _force(mb): 16-row blocks per wave (panel = 64 mb rows; 0 = own choice), measurement aid. _set_debug_buffer: while a device
+ * buffer (u64 [workgroup][wave][12]) is installed a stamped instantiation runs (cycle sums of the loop's phases). */
+int pseld_mlp_panel_fwd_supported(int dtype, int M, int C, int H);
+int pseld_mlp_panel_fwd(int dtype, const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid,
+                        const float* rowscale, int rows_per_scale, void* y, void* h, void* g, int M, int C, int H, int ldx, int ldr,
+                        int ldy, int ldh, void* stream);
+void pseld_mlp_panel_force(int mb);
+void pseld_mlp_panel_set_debug_buffer(void* device_buffer);
 /* Measurement aid: symbol of the kernel the last pseld_gemm / pseld_gemm_wgrad call of this process launched. */
 const char* pseld_gemm_last_kernel(void);
 /* Measurement aid: pseld_gemm_wgrad launches a GEMM kernel and a slab reduction, so events around the call do not time one kernel.

@@ -85,8 +85,23 @@ class RcclComm:
         with torch.cuda.device(self.device):
             _check(L.pseld_comm_init(box[0], self.rank, self.world, ctypes.byref(handle)), "pseld_comm_init")
         self.handle = handle
-        self.stream = torch.cuda.Stream(device=self.device)
+        # The communication stream exists only where there is something to communicate (world size 1 returns before any stream hand-off).
+        # (Measured, round 6: whether this stream exists or not makes no difference to the one-rank step - 19.54 / 19.63 ms with it, 19.51 /
+        # 19.63 without, profiles/r06_comm_world1.txt; what a second communicator costs there is looked for elsewhere)
+        self.stream = torch.cuda.Stream(device=self.device) if (self.world > 1 or os.environ.get('PSELD_COMM_IDLE_STREAM') == '1') else None
         self._scratch = None
+
+    def reserve(self, numel, elem_size):
+        """Size the DIRECT algorithm's scratch once, for the largest bucket, before the first bucket is issued. The buffer is allocated
+        WITH THE COMMUNICATION STREAM CURRENT, so the caching allocator ties it to that stream: when it is replaced or freed, its memory
+        is handed out again only in that stream's order - never to compute-stream tensors while a receive or the rank-order sum may still
+        be running on it."""
+        if self.world == 1:
+            return
+        need = lib().pseld_comm_scratch_bytes(self.handle, int(numel), int(elem_size), self.algo)
+        if need > 0 and (self._scratch is None or self._scratch.numel() < need):
+            with torch.cuda.stream(self.stream):
+                self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
 
     def allreduce_(self, t):
         """In-place sum of the contiguous f32 / bf16 tensor t over the ranks: issued on the communication stream behind everything the
@@ -98,14 +113,14 @@ class RcclComm:
         L = lib()
         es = t.element_size()
         need = L.pseld_comm_scratch_bytes(self.handle, t.numel(), es, self.algo)
-        if need > 0 and (self._scratch is None or self._scratch.numel() < need):
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.reserve(t.numel(), es)                         # (a no-op once the largest bucket has been seen or reserved)
         ready = torch.cuda.Event()
         ready.record()                                      # compute stream: the bucket's gradients are final
         self.stream.wait_event(ready)
         with torch.cuda.stream(self.stream):
             _check(L.pseld_comm_allreduce_bucket(self.handle, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1, self.algo,
-                                                 self._scratch.data_ptr() if need > 0 else None, need, self.stream.cuda_stream),
+                                                 self._scratch.data_ptr() if need > 0 else None, self._scratch.numel() if need > 0 else 0,
+                                                 self.stream.cuda_stream),
                    "pseld_comm_allreduce_bucket")
             done = torch.cuda.Event()
             done.record(self.stream)

@@ -23,7 +23,19 @@ void set_err(const char* fmt, ...) {
 #define COMM_CHECK_ARG(cond, ...) do { if (!(cond)) { set_err(__VA_ARGS__); return -1; } } while (0)
 #define COMM_NCCL(call, what) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { set_err("%s: %s", what, ncclGetErrorString(r__)); return -3; } } while (0)
 
-struct Comm { ncclComm_t nccl; int rank, world; };
+struct Comm { ncclComm_t nccl; int rank, world; bool aborted; };
+
+// An error between the two phases of the DIRECT algorithm (or inside one of its ncclGroups) leaves the peers, which have entered the phase,
+// waiting for this rank for ever: close the open group, abort the communicator (the peers' pending operations then fail instead of hanging)
+// and report. Every later call on the communicator fails at once; the caller is expected to exit non-zero so that the launcher tears the
+// job down.
+static int comm_fatal(Comm* c, bool in_group, const char* what, const char* why) {
+    set_err("%s: %s (communicator aborted)", what, why);
+    if (in_group) (void)ncclGroupEnd();
+    if (!c->aborted) { c->aborted = true; (void)ncclCommAbort(c->nccl); }
+    return -3;
+}
+#define COMM_NCCL_FATAL(c, in_group, call, what) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) return comm_fatal(c, in_group, what, ncclGetErrorString(r__)); } while (0)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
@@ -74,7 +86,7 @@ extern "C" int pseld_comm_init(const void* idb, int rank, int world, void** comm
     COMM_CHECK_ARG(idb && comm_out && world >= 1 && rank >= 0 && rank < world, "comm_init: bad arguments (rank %d of %d)", rank, world);
     ncclUniqueId id;
     memcpy(&id, idb, sizeof id);
-    Comm* c = new Comm{nullptr, rank, world};
+    Comm* c = new Comm{nullptr, rank, world, false};
     ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
     if (r != ncclSuccess) { set_err("ncclCommInitRank(rank %d of %d): %s", rank, world, ncclGetErrorString(r)); delete c; return -3; }
     *comm_out = c;
@@ -108,6 +120,7 @@ extern "C" int pseld_comm_allreduce_bucket(void* comm, void* buf, long count, in
     Comm* c = (Comm*)comm;
     hipStream_t s = (hipStream_t)stream;
     if (c->world == 1 || count == 0) return 0;
+    COMM_CHECK_ARG(!c->aborted, "comm_allreduce_bucket: the communicator was aborted by an earlier error");
     const ncclDataType_t dt = dtype == 0 ? ncclFloat32 : ncclBfloat16;
     const int es = dtype == 0 ? 4 : 2;
     if (algo == PSELD_COMM_ALGO_RCCL) {
@@ -131,29 +144,30 @@ extern "C" int pseld_comm_allreduce_bucket(void* comm, void* buf, long count, in
     char* sc = (char*)scratch;
     const int me = c->rank;
     // phase 1 (reduce-scatter): my copy of chunk p -> rank p; rank r's copy of chunk `me` -> scratch slot of r
-    COMM_NCCL(ncclGroupStart(), "ncclGroupStart");
+    COMM_NCCL_FATAL(c, false, ncclGroupStart(), "ncclGroupStart");
     for (int p = 0; p < c->world; ++p) {
         if (p == me) continue;
-        if (len[p] > 0) COMM_NCCL(ncclSend(b + off[p] * es, (size_t)len[p], dt, p, c->nccl, s), "ncclSend(reduce-scatter)");
-        if (len[me] > 0) COMM_NCCL(ncclRecv(sc + (long)(p < me ? p : p - 1) * stride * es, (size_t)len[me], dt, p, c->nccl, s), "ncclRecv(reduce-scatter)");
+        if (len[p] > 0) COMM_NCCL_FATAL(c, true, ncclSend(b + off[p] * es, (size_t)len[p], dt, p, c->nccl, s), "ncclSend(reduce-scatter)");
+        if (len[me] > 0) COMM_NCCL_FATAL(c, true, ncclRecv(sc + (long)(p < me ? p : p - 1) * stride * es, (size_t)len[me], dt, p, c->nccl, s), "ncclRecv(reduce-scatter)");
     }
-    COMM_NCCL(ncclGroupEnd(), "ncclGroupEnd");
+    COMM_NCCL_FATAL(c, false, ncclGroupEnd(), "ncclGroupEnd(reduce-scatter)");
     if (len[me] > 0) {
         // (count % 8 == 0 and the stride is a multiple of 8: every chunk is whole 16-byte pieces)
         const long n16 = len[me] * es / 16;
         const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
         if (dtype == 0) hipLaunchKernelGGL(sum_in_rank_order<f4>, dim3(blocks), dim3(256), 0, s, (f4*)(b + off[me] * es), (const f4*)sc, n16, stride * es / 16, me, c->world);
         else hipLaunchKernelGGL(sum_in_rank_order<bf16x8v>, dim3(blocks), dim3(256), 0, s, (bf16x8v*)(b + off[me] * es), (const bf16x8v*)sc, n16, stride * es / 16, me, c->world);
-        if (hipGetLastError() != hipSuccess) { set_err("comm_allreduce_bucket: sum kernel launch failed"); return -3; }
+        // (the peers are already on their way into phase 2: a rank that stops here must not leave them waiting)
+        if (hipGetLastError() != hipSuccess) return comm_fatal(c, false, "comm_allreduce_bucket", "sum kernel launch failed");
     }
     // phase 2 (all-gather): my reduced chunk -> every peer; theirs arrive in place
-    COMM_NCCL(ncclGroupStart(), "ncclGroupStart");
+    COMM_NCCL_FATAL(c, false, ncclGroupStart(), "ncclGroupStart");
     for (int p = 0; p < c->world; ++p) {
         if (p == me) continue;
-        if (len[me] > 0) COMM_NCCL(ncclSend(b + off[me] * es, (size_t)len[me], dt, p, c->nccl, s), "ncclSend(all-gather)");
-        if (len[p] > 0) COMM_NCCL(ncclRecv(b + off[p] * es, (size_t)len[p], dt, p, c->nccl, s), "ncclRecv(all-gather)");
+        if (len[me] > 0) COMM_NCCL_FATAL(c, true, ncclSend(b + off[me] * es, (size_t)len[me], dt, p, c->nccl, s), "ncclSend(all-gather)");
+        if (len[p] > 0) COMM_NCCL_FATAL(c, true, ncclRecv(b + off[p] * es, (size_t)len[p], dt, p, c->nccl, s), "ncclRecv(all-gather)");
     }
-    COMM_NCCL(ncclGroupEnd(), "ncclGroupEnd");
+    COMM_NCCL_FATAL(c, false, ncclGroupEnd(), "ncclGroupEnd(all-gather)");
     return 0;
 }
 
@@ -175,7 +189,7 @@ extern "C" int pseld_comm_sum_in_rank_order(void* own, const void* scratch, long
 extern "C" int pseld_comm_finalize(void* comm) {
     if (!comm) return 0;
     Comm* c = (Comm*)comm;
-    ncclResult_t r = ncclCommDestroy(c->nccl);
+    ncclResult_t r = c->aborted ? ncclSuccess : ncclCommDestroy(c->nccl);      // (ncclCommAbort has already released an aborted one)
     delete c;
     if (r != ncclSuccess) { set_err("ncclCommDestroy: %s", ncclGetErrorString(r)); return -3; }
     return 0;

@@ -1431,6 +1431,17 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
             d.aux = (epi & EPI_MULAUX) ? aux : nullptr; d.rowscale = rowscale;
             d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.ldr = ldr; d.ldaux = ldaux;
             d.rows_per_scale = g.rows_per_scale; d.gelu_dual = (epi & EPI_GELU_DUAL) ? 1 : 0;
+            // K = 192 / 384 on enough rows to fill the chip with 192-row panels: the row-panel-stationary kernel (gemm8p.hip; same bits, so the
+            // choice may depend on M). OFF by default (knob GEMM8P = 1 switches it on, GEMM8P_MINM moves the row threshold, GEMM8P_MODES / _K
+            // pick epilogue kinds / K): isolated on cold operands it takes 12 % off the stage-2 qkv and fc1 products (47.6 against 53.8 us, 93.6
+            // against 107.0) and loses on the residual / aux epilogues; inside the step every routing measured 18.51-18.73 ms against
+            // 18.46-18.58 without it (profiles/r06_gemm8p_ab.txt) - the A rows are read once, but the per-tile time is then bound by the matrix
+            // pipe and the exposed A-panel load (stamps: docs/EXPERIMENTS.md, round 6)
+            if (pseld_knob(KNOB_GEMM8P, 0) != 0 && M >= pseld_knob(KNOB_GEMM8P_MINM, 36864) && pseld_gemm8p_supported(d) && pseld_gemm8p_wanted(d)) {
+                const int rcp = pseld_gemm8p_launch(d, s);
+                g_last_gemm_kernel = pseld_gemm8p_last_symbol();
+                return rcp;
+            }
             if (pseld_gemm8_supported(d)) {
                 const int rc8 = pseld_gemm8_launch(d, s);
                 g_last_gemm_kernel = pseld_gemm8_last_symbol();

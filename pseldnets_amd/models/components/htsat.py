@@ -19,6 +19,24 @@ import torch
 from ... import ops
 
 GELU_DUAL = os.environ.get('PSELD_GELU_DUAL', '1') != '0'
+# Fused MLP forward of the C = 192 / 384 blocks (csrc/mlp8f.hip, one launch, the bits of the two launches): PSELD_MLP_PANEL = 0 (off) | 192 |
+# 384 | 1 (both). Read once at import (no getenv in a launch path). Round 6, measured: C = 192 (eight waves x 32 rows) 225 against 261-273 us
+# per block isolated and 17.62 against 17.72 ms in the step (three alternating same-box runs each, profiles/r06_mlp_panel_ab.txt): ON;
+# C = 384 (four waves, 512 registers) 204 against 176 us - one wave per SIMD serialises matrix part, GELU and LDS-DMA issue - and +0.3 ms
+# in the step: OFF. docs/EXPERIMENTS.md, round 6.
+_MLP_PANEL = os.environ.get('PSELD_MLP_PANEL', '192')
+
+
+_MLP_PANEL_MB = int(os.environ.get('PSELD_MLP_PANEL_MB', '0'))      # (A/B aid: panel geometry, pseld_mlp_panel_force)
+_mlp_panel_forced = [False]
+
+
+def _mlp_panel(C, M):
+    if _MLP_PANEL_MB and not _mlp_panel_forced[0]:
+        from ... import _lib
+        _lib.lib().pseld_mlp_panel_force(_MLP_PANEL_MB)
+        _mlp_panel_forced[0] = True
+    return M >= 36864 and (_MLP_PANEL == '1' or _MLP_PANEL == str(C))
 # Fused MLP blocks (csrc/mlp.hip: LN2 -> fc1 -> GELU -> fc2 -> DropPath + residual in one kernel, backward by recompute).
 # PSELD_FUSED_MLP: comma-separated channel widths that take the fused kernels ('' = none). Default: C = 96 (stage 0 of HTS-AT),
 # where the layer-wise chain is HBM-bound and the fused one measures faster; at C = 192 the recompute costs more than the traffic
@@ -372,7 +390,15 @@ class SwinEncoder:
             xh2 = xh2_pre if xh2_pre is not None else ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
             if self.mlp_adapter:
                 xs, ad['mlp'] = self._adapter_fwd(xh2, b + 'mlp.adapter.')          # xs = adapter(x) (model_utilities.py:160-170)
-            if GELU_DUAL:
+            if GELU_DUAL and _mlp_panel(C, x_mid.shape[0]) and ops.mlp_panel_fwd_supported(xh2, 4 * C) and not self.lora:
+                # fc1 -> GELU pair -> fc2 -> DropPath + shortcut in ONE launch (csrc/mlp8f.hip): the bits of the two launches below, h never re-read
+                x_out, hact, gact = ops.mlp_panel_fwd(xh2, self._w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), self._w(b + 'mlp.fc2.weight', dtype),
+                                                      a.p(b + 'mlp.fc2.bias'), x_mid, rowscale=s2, rows_per_scale=L)
+                if self.mlp_adapter:
+                    x_out = ops.add(x_out, ops.rowscale(xs, s2, L * C) if s2 is not None else xs)
+                saved_blocks.append(dict(x_in=x, xh1=xh1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, xh2=xh2, h=hact, g=gact, s1=s1,
+                                         s2=s2, shift=shift, ad=ad))
+            elif GELU_DUAL:
                 # fc1 epilogue emits h = gelu(u) and g = gelu'(u): erf is evaluated once per element, not in fc2/dW2/dU
                 hact, gact = ops.linear_fwd(xh2, self._w(b + 'mlp.fc1.weight', dtype), a.p(b + 'mlp.fc1.bias'), gelu_dual=True)
                 x_out = ops.linear_fwd(hact, self._w(b + 'mlp.fc2.weight', dtype), a.p(b + 'mlp.fc2.bias'), resid=x_mid,

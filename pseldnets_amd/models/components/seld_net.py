@@ -156,13 +156,21 @@ class HTSATNetBase(nn.Module):
         if training:
             group = self.sync_bn_group
             centered = group is None
+            ops.host_mark('bn: in')
+            import os as _os
+            if _os.environ.get('PSELD_BN_DROP_FIRST') == '1' and overlap is not None:     # (diagnostic A/B: which call stalls the host)
+                overlap(); overlap = None
+                ops.host_mark('bn: DropPath factors drawn FIRST')
             sums = ops.bn_scalar_stats(feat, centered=centered)
+            ops.host_mark('bn: statistics launched')
             if group is not None:
                 import torch.distributed as dist
                 work = dist.all_reduce(sums[:2 * n], group=group, async_op=True)
                 count *= dist.get_world_size(group)
+                ops.host_mark('bn: all-reduce issued')
         if overlap is not None:
             overlap()
+            ops.host_mark('bn: DropPath factors drawn')
         if work is not None:
             diag = getattr(self, 'comm_diag', None)               # trainer.comm_diag: events around the wait = the time the compute stream stalled
             if diag is not None:
@@ -173,6 +181,7 @@ class HTSATNetBase(nn.Module):
                 diag['sync_bn'].append((e0, e1))
             else:
                 work.wait()
+            ops.host_mark('bn: waited')
         mean_rstd, scale_shift = ops.bn_scalar_finalize(sums, count, centered, w, b, self._rm.view(-1), self._rv.view(-1),
                                                        self._nbt, training, self.bn_momentum, self.bn_eps)
         return mean_rstd, scale_shift

@@ -42,8 +42,20 @@ def stage(name):
     if _stage['markers'] is None:
         import os
         _stage['markers'] = os.environ.get('PSELD_STAGE_MARKERS', '0') == '1'
+        _stage['host_trace'] = [] if os.environ.get('PSELD_HOST_TRACE', '0') == '1' else None
+    if _stage.get('host_trace') is not None:          # diagnostic: when the HOST thread reaches each part of the step (tools/host_trace.py)
+        import time
+        _stage['host_trace'].append((name, time.perf_counter()))
     if _stage['markers'] and torch.cuda.is_available():
         _lib.check(_lib.lib().pseld_stage_marker(STAGES.index(name) if name in STAGES else 15, _lib.stream_ptr()), "pseld_stage_marker")
+
+
+def host_mark(name):
+    """Diagnostic (PSELD_HOST_TRACE=1): a finer host-side time mark inside a part of the step; free otherwise."""
+    tr = _stage.get('host_trace')
+    if tr is not None:
+        import time
+        tr.append(('.' + name, time.perf_counter()))
 
 
 _ws_cache = {}
@@ -80,6 +92,29 @@ def linear_fwd(x, w, bias=None, resid=None, rowscale=None, rows_per_scale=1, gel
                                None, 0, epi, PRO_GELU_A if gelu_in else PRO_NONE, _lib.ptr(out2), _lib.stream_ptr())
     _lib.check(rc, "pseld_gemm(fwd)")
     return (out, out2) if gelu_dual else out
+
+
+def mlp_panel_fwd_supported(xn, hidden):
+    return xn.is_cuda and xn.dtype == torch.bfloat16 and bool(_lib.lib().pseld_mlp_panel_fwd_supported(dtype_code(xn), xn.shape[0], xn.shape[1], hidden))
+
+
+def mlp_panel_fwd(xn, w1, b1, w2, b2, resid, rowscale=None, rows_per_scale=1):
+    """(y, h, g): y = resid + s (gelu(xn w1^T + b1) w2^T + b2), h = gelu(.), g = gelu'(.) in ONE launch (csrc/mlp8f.hip; C = 192 / 384, bf16):
+    the bits of linear_fwd(xn, w1, b1, gelu_dual=True) followed by linear_fwd(h, w2, b2, resid=resid, rowscale=...)."""
+    _chk(w1, b1, w2, b2, resid, rowscale)
+    M, C = xn.shape
+    H = w1.shape[0]
+    assert w1.shape == (H, C) and w2.shape == (C, H) and resid.shape == (M, C) and w1.is_contiguous() and w2.is_contiguous()
+    if xn.stride(1) != 1 or resid.stride(1) != 1:
+        raise _lib.PseldError("mlp_panel_fwd: unit stride along the columns")
+    y = torch.empty((M, C), dtype=xn.dtype, device=xn.device)
+    h = torch.empty((M, H), dtype=xn.dtype, device=xn.device)
+    g = torch.empty_like(h)
+    rc = _lib.lib().pseld_mlp_panel_fwd(dtype_code(xn), _lib.ptr(xn), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(resid),
+                                        _lib.ptr(rowscale), rows_per_scale, _lib.ptr(y), _lib.ptr(h), _lib.ptr(g), M, C, H, xn.stride(0),
+                                        resid.stride(0), y.stride(0), h.stride(0), _lib.stream_ptr())
+    _lib.check(rc, "pseld_mlp_panel_fwd")
+    return y, h, g
 
 
 def linear_dgrad(dy, w, rowscale=None, rows_per_scale=1, gelu_grad_of=None, resid=None, out=None, mul=None, wt=None):

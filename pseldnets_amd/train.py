@@ -259,7 +259,53 @@ def main(argv=None):
                                index_csv=cfg.data.get('index_csv'), label_h5=label_h5)
         sampler = UserDistributedBatchSampler(len(ds), cfg.model.batch_size, seed=cfg.seed)
         batches, n_batches = iter(sampler), min(n_batches, len(sampler)) if n_batches else len(sampler)
-    for epoch in range(cfg.trainer.max_epochs):
+    # -- save / resume: the counterpart of Lightning's ModelCheckpoint + `ckpt_path=...` (reference: configs/train.yaml:32-33,
+    #    configs/callbacks/default.yaml, src/train.py:49-50 `trainer.fit(..., ckpt_path=cfg.get("ckpt_path"))`). Rank 0 writes
+    #    <paths.output_dir>/checkpoints/last.ckpt at the end of every epoch (and epoch_NNN.ckpt every `trainer.save_every_n_epochs`);
+    #    `ckpt_path=FILE` makes every rank load it before the loop: weights, AdamW moments + step, StepLR epoch, and the data order -
+    #    the sampler's pointer / permutation / RandomState and the synthetic generator's state, so a resumed run draws the batches the
+    #    uninterrupted run would have drawn.
+    out_dir = (cfg.get('paths') or {}).get('output_dir') or cfg.get('output_dir') or os.path.join(os.getcwd(), 'outputs')
+    ckpt_dir = os.path.join(out_dir, 'checkpoints')
+    first_epoch = 0
+    if cfg.get('ckpt_path'):
+        state = torch.load(cfg.ckpt_path, map_location=device, weights_only=False)
+        trainer.load_state_dict(state['trainer'])
+        first_epoch = int(state['epoch']) + 1
+        per_rank = state['data'][rank] if rank < len(state['data']) else None
+        if per_rank is not None:
+            gen.set_state(per_rank['generator'].cpu())
+            torch.set_rng_state(per_rank['torch_rng'].cpu())                   # DropPath / dropout / augmentation draws continue where they stopped
+            torch.cuda.set_rng_state(per_rank['cuda_rng'].cpu(), device)
+            if batches is not None and per_rank.get('sampler') is not None:
+                sampler.pointer, sampler.indices = int(per_rank['sampler']['pointer']), per_rank['sampler']['indices'].copy()
+                if sampler.shuffle:
+                    sampler.random_state.set_state(per_rank['sampler']['random_state'])
+        if rank == 0:
+            print(f"resumed from {cfg.ckpt_path}: epoch {first_epoch}, optimiser step {state['trainer']['optimizer']['step']}")
+
+    def save_checkpoint(epoch):
+        data = {'generator': gen.get_state(), 'torch_rng': torch.get_rng_state(), 'cuda_rng': torch.cuda.get_rng_state(device),
+                'sampler': None if batches is None else {'pointer': sampler.pointer, 'indices': sampler.indices.copy(),
+                                                         'random_state': sampler.random_state.get_state() if sampler.shuffle else None}}
+        if world > 1:                          # every rank's data-order state travels to rank 0 (small host objects)
+            import torch.distributed as dist
+            gathered = [None] * world
+            dist.all_gather_object(gathered, data)
+        else:
+            gathered = [data]
+        if rank != 0:
+            return
+        os.makedirs(ckpt_dir, exist_ok=True)
+        state = {'epoch': epoch, 'trainer': trainer.state_dict(), 'data': gathered, 'world': world}
+        tmp = os.path.join(ckpt_dir, 'last.ckpt.tmp')
+        torch.save(state, tmp)
+        os.replace(tmp, os.path.join(ckpt_dir, 'last.ckpt'))           # (never a half-written last.ckpt)
+        every = int(cfg.trainer.get('save_every_n_epochs', 0) or 0)
+        if every and (epoch + 1) % every == 0:
+            torch.save(state, os.path.join(ckpt_dir, f'epoch_{epoch:03d}.ckpt'))
+
+    for epoch in range(first_epoch, cfg.trainer.max_epochs):
         t0 = time.perf_counter()
         draw = lambda: ds.batch(next(batches)) if batches is not None else synthetic_batch(cfg, cfg.model.method, device, gen)
         nxt = draw()
@@ -271,6 +317,8 @@ def main(argv=None):
             print(f"epoch {epoch}: loss_all {loss['loss_all'].item():.5f}  lr {trainer.lr:.2e}  "
                   f"{n_batches * cfg.model.batch_size * world / (time.perf_counter() - t0):.1f} chunks/s")
         trainer.end_epoch()
+        if cfg.trainer.get('enable_checkpointing', True):
+            save_checkpoint(epoch)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -119,6 +119,10 @@ class FusedTrainer:
         if self.comm_diag is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()                                              # bucket issued (on the compute stream, behind the kernels that produced it)
+        if self._rccl is not None:
+            # scratch of the direct algorithm: sized ONCE for the whole arena (an upper bound of every bucket), before the first bucket is
+            # issued - never re-allocated while the communication stream may still be receiving into it
+            self._rccl.reserve(self.net.arena.grad.numel(), 4)
         reduce = self._rccl.allreduce_ if self._rccl is not None else (lambda t: dist.all_reduce(t, group=self.group, async_op=True))
         if self.grad_dtype == 'bf16':
             buf = g.to(torch.bfloat16)                               # (plumbing: a cast, not arithmetic of the model)
@@ -313,7 +317,10 @@ class FusedTrainer:
             net._backward_impl(saved, douts)
             idx = self._trainable_index()
             buf = net.arena.grad.index_select(0, idx)
-            dist.all_reduce(buf, group=self.group)
+            if getattr(self, '_rccl', None) is not None:
+                self._rccl.allreduce_(buf).wait()          # the transport that was asked for (comm='rccl' | 'rccl_direct'), VERDICT r5 item 7 i
+            else:
+                dist.all_reduce(buf, group=self.group)
             net.arena.grad.index_copy_(0, idx, buf)
         else:
             # buckets are issued back to front while earlier layers are still in backward (RCCL's own stream); each is waited for

@@ -187,13 +187,35 @@ def test_full_size_forward_vs_golden(dev, kind, dtype, gate):
     ['experiment=synth_einv2_agg', 'model=passt', 'model.kwargs.embed_dim=128', 'model.kwargs.depth=2', 'model.kwargs.num_heads=2',
      'model.loss.method=both', 'model.loss.loss_alpha=0.5'],
 ])
-def test_train_entry_point_runs_the_einv2_networks(dev, argv, capsys):
+def test_train_entry_point_runs_the_einv2_networks(dev, argv, capsys, tmp_path):
     """`python -m pseldnets_amd.train experiment=synth_einv2 model=...`: the module wiring (registry, tPIT loss, fused step)
     end to end on synthetic batches; the loss must be finite and fall over 12 steps at lr 1e-3."""
     from pseldnets_amd import train
     train.main(argv + ['model.batch_size=4', 'data.num_classes=5', 'trainer.limit_train_batches=6', 'trainer.max_epochs=2',
-                       'model.optimizer.kwargs.lr=0.001'])
+                       'model.optimizer.kwargs.lr=0.001', f'paths.output_dir={tmp_path}'])
     lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('epoch')]
     losses = [float(ln.split('loss_all')[1].split()[0]) for ln in lines]
     print(lines)
     assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0]
+    assert (tmp_path / 'checkpoints' / 'last.ckpt').exists()
+
+
+def test_train_entry_point_saves_and_resumes(dev, capsys, tmp_path):
+    """The train entry writes <paths.output_dir>/checkpoints/last.ckpt at every epoch end and `ckpt_path=FILE` resumes from it (the
+    reference: Lightning's ModelCheckpoint + src/train.py:49-50 `ckpt_path`): a run stopped after epoch 0 and resumed prints for epoch 1
+    exactly what the uninterrupted two-epoch run printed - weights, AdamW moments + step, StepLR epoch, the data generator and the
+    DropPath random streams all continue where they stopped."""
+    from pseldnets_amd import train
+    argv = ['experiment=synth_maccdoa', 'model.kwargs.embed_dim=48', 'model.kwargs.depths=[2,2,2,2]', 'model.kwargs.num_heads=[2,4,8,16]',
+            'model.batch_size=4', 'data.num_classes=5', 'trainer.limit_train_batches=5', 'model.optimizer.kwargs.lr=0.001', 'augment=default']
+    ep = lambda out: [ln.split('  lr')[0] for ln in out.splitlines() if ln.startswith('epoch')]
+    train.main(argv + ['trainer.max_epochs=2', f'paths.output_dir={tmp_path / "a"}'])
+    whole = ep(capsys.readouterr().out)
+    train.main(argv + ['trainer.max_epochs=1', f'paths.output_dir={tmp_path / "b"}'])
+    first = ep(capsys.readouterr().out)
+    train.main(argv + ['trainer.max_epochs=2', f'paths.output_dir={tmp_path / "b"}', f'ckpt_path={tmp_path / "b" / "checkpoints" / "last.ckpt"}'])
+    out = capsys.readouterr().out
+    resumed = ep(out)
+    print(whole, first, resumed)
+    assert 'resumed from' in out
+    assert len(whole) == 2 and first == whole[:1] and resumed == whole[1:], (whole, first, resumed)

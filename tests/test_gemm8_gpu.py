@@ -15,10 +15,12 @@ pytestmark = pytest.mark.gpu
 def _knobs():
     from pseldnets_amd import _lib
     _lib.set_knob('GEMM8', 1); _lib.set_knob('GEMM8_MINK', 128); _lib.set_knob('WGRAD8', 1)
+    _lib.set_knob('GEMM8P', 0)           # the eight-phase kernel is the subject of this file; the panel tests switch the panel kernel on
     yield
-    for k in ('GEMM8', 'GEMM8_MINK', 'WGRAD8', 'GEMM8W_BN', 'RESIDLN384', 'LNBWD384'):
+    for k in ('GEMM8', 'GEMM8_MINK', 'WGRAD8', 'GEMM8W_BN', 'RESIDLN384', 'LNBWD384', 'GEMM8P', 'GEMM8P_MINM'):
         _lib.set_knob(k, None)
     _lib.lib().pseld_gemm8_force_tile(0, 0)
+    _lib.lib().pseld_gemm8p_force(0, -1)
 
 
 def _kernel():
@@ -114,6 +116,56 @@ def test_repeated_launches_are_bit_identical_and_rows_do_not_depend_on_the_batch
         _lib.set_knob('GEMM8', 1)
         assert not _kernel().startswith('gemm8_kernel<')
         assert ((first.float() - y0).norm() / y0.norm()).item() < 2.5e-3
+
+
+@pytest.mark.parametrize("shape", [(1000, 1152, 384), (777, 192, 192), (3000, 1536, 384), (50000, 576, 192), (20000, 384, 384)])
+@pytest.mark.parametrize("mode,scaled", [('plain', False), ('plain', True), ('resid', False), ('resid', True), ('gelu', False), ('mulaux', False), ('mulaux', True)])
+def test_row_panel_kernel_gives_the_bits_of_the_eight_phase_kernel(dev, mode, scaled, shape):
+    """gemm8p.hip (K = 192 / 384: A rows in registers, weights streamed through LDS) against float64 AND bit for bit against gemm8.hip - the
+    launch picks between the two by M, which batch independence allows only for equal bits. Every panel height, with and without the
+    staggered epilogue, ragged last panels (rows the last waves must not store), several panels per workgroup (50 000 rows)."""
+    from pseldnets_amd import _lib
+    M, N, K = shape
+    x, w, b = _mk((M, K), 1), _mk((N, K), 2, 0.05), _mk((N,), 3, dtype=torch.float32)
+    extra = _mk((M, N), 4)
+    rps = 64
+    rs = (torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(5)) + 0.5) if scaled else None
+    if rs is not None: rs[::3] = 0.0
+    bb = None if mode == 'mulaux' else b
+    _tile(256, 256)
+    y8 = _run(dev, mode, x, w, bb, extra, rs, rps)
+    assert _kernel().startswith('gemm8_kernel<')
+    ref = _ref(mode, x, w, bb, extra, rs, rps)
+    _lib.set_knob('GEMM8P', 1); _lib.set_knob('GEMM8P_MINM', 1)
+    for mb in ((2, 3) if K == 384 else (3, 4)):
+        for stag in (0, 1):
+            _lib.lib().pseld_gemm8p_force(mb, stag)
+            yp = _run(dev, mode, x, w, bb, extra, rs, rps)
+            assert _kernel().startswith('gemm8p_kernel<'), _kernel()
+            assert torch.equal(yp, y8), (mode, scaled, shape, mb, stag, int((yp != y8).sum()))
+            for _ in range(5):
+                assert torch.equal(_run(dev, mode, x, w, bb, extra, rs, rps), yp)
+    y = yp.double().cpu()
+    rel = ((y - ref).abs().max() / ref.abs().max()).item()
+    l2 = ((y - ref).norm() / ref.norm()).item()
+    assert rel < 8e-3 and l2 < 2.5e-3
+
+
+def test_panel_kernel_takes_the_bench_size_products(dev):
+    """Routing with the panel kernel switched on (knob GEMM8P = 1; it is off by default: measured neutral in the step): K = 192 / 384 products
+    with at least 36 864 rows go to it, smaller batches and other K keep the eight-phase kernel; with the knob unset nothing goes there."""
+    from pseldnets_amd import ops, _lib
+    _lib.set_knob('GEMM8P', None); _lib.set_knob('GEMM8P_MINM', None)
+    x, w = _mk((49152, 384), 1).to(dev), _mk((1152, 384), 2, 0.05).to(dev)
+    ops.linear_fwd(x, w, None)
+    assert _kernel().startswith('gemm8_kernel<'), _kernel()
+    _lib.set_knob('GEMM8P', 1)
+    _lib.lib().pseld_gemm8p_force(0, -1)
+    _tile(0, 0)
+    for (M, N, K, panel) in ((49152, 1152, 384, True), (196608, 192, 192, True), (8192, 1152, 384, False), (49152, 384, 1536, False)):
+        x, w = _mk((M, K), 1).to(dev), _mk((N, K), 2, 0.05).to(dev)
+        ops.linear_fwd(x, w, None)
+        assert _kernel().startswith('gemm8p_kernel<' if panel else 'gemm8_kernel<'), (M, N, K, _kernel())
 
 
 def test_tile_choice_follows_the_grid_fill(dev):

@@ -112,3 +112,41 @@ def test_fused_mlp_rejects_what_it_was_not_built_for(dev):
     with pytest.raises(_lib.PseldError):
         z = torch.zeros(384, device=dev)
         ops.mlp_fwd(torch.zeros(40, 96, device=dev), z[:96], z[:96], torch.zeros(384, 96, device=dev), z, torch.zeros(96, 384, device=dev), z[:96])
+
+
+@pytest.mark.parametrize("M,C,rps", [(1000, 384, 64), (777, 192, 64), (30000, 192, 1024), (20000, 384, 256)])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_panel_fused_mlp_forward_gives_the_bits_of_the_two_launches(dev, M, C, rps, scaled):
+    """csrc/mlp8f.hip (round 6): fc1 -> GELU pair -> fc2 -> DropPath + shortcut of a C = 192 / 384 block in ONE launch (reference:
+    model_utilities.py:159-171 + htsat.py:262-264) against (i) the two pseld_gemm launches it replaces - y, h = gelu(u), g = gelu'(u) bit for
+    bit, every panel geometry, ragged last panels, dropped samples - and (ii) float64 on the same bf16 operands (h rounded to bf16 between the
+    two products, as both paths store it): rel-L2 3e-3."""
+    from pseldnets_amd import ops, _lib
+    _lib.set_knob('GEMM8P', 0)
+    g = torch.Generator().manual_seed(M + C)
+    H = 4 * C
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    xn, resid = mk(M, C).bfloat16().to(dev), mk(M, C).bfloat16().to(dev)
+    w1, b1 = mk(H, C, sc=C ** -0.5).bfloat16().to(dev), mk(H, sc=0.1).to(dev)
+    w2, b2 = mk(C, H, sc=H ** -0.5).bfloat16().to(dev), mk(C, sc=0.1).to(dev)
+    rs = None
+    if scaled:
+        rs = (torch.rand((M + rps - 1) // rps, generator=g) + 0.5)
+        rs[::3] = 0.0
+        rs = rs.to(dev)
+    h0, g0 = ops.linear_fwd(xn, w1, b1, gelu_dual=True)
+    y0 = ops.linear_fwd(h0, w2, b2, resid=resid, rowscale=rs, rows_per_scale=rps)
+    try:
+        for mb in ((2, 1) if C == 384 else (3, 2, 10)):
+            _lib.lib().pseld_mlp_panel_force(mb)
+            y1, h1, g1 = ops.mlp_panel_fwd(xn, w1, b1, w2, b2, resid, rowscale=rs, rows_per_scale=rps)
+            assert torch.equal(h1, h0) and torch.equal(g1, g0) and torch.equal(y1, y0), (M, C, scaled, mb)
+            for _ in range(3):
+                assert torch.equal(ops.mlp_panel_fwd(xn, w1, b1, w2, b2, resid, rowscale=rs, rows_per_scale=rps)[0], y1)
+    finally:
+        _lib.lib().pseld_mlp_panel_force(0)
+        _lib.set_knob('GEMM8P', None)
+    sc = rs.double().repeat_interleave(rps)[:M, None] if rs is not None else 1.0
+    hd = torch.nn.functional.gelu(xn.double() @ w1.double().t() + b1.double()).bfloat16().double()
+    ref = resid.double() + sc * (hd @ w2.double().t() + b2.double())
+    assert ((y1.double() - ref).norm() / ref.norm()).item() < 3e-3

@@ -27,6 +27,10 @@ def run(mode, x, w, b, extra, rs, rps, on, cat=True, rows=0):
     """on: False = the 128 x 192 kernels of gemm.hip; True = the eight-phase kernel, its own tile choice; 256 / 192 = that tile width;
     rows: 0 = own choice, 256 / 128 = that tile height"""
     _lib.set_knob('GEMM8', 1 if on else 0)
+    _lib.set_knob('GEMM8P', 0)
+    if on == 'p':                              # the row-panel-stationary kernel (gemm8p.hip): rows = (16-row blocks per wave or 0, stagger -1 / 0 / 1)
+        _lib.set_knob('GEMM8P', 1); _lib.set_knob('GEMM8P_MINM', 1)
+        L.pseld_gemm8p_force(rows[0], rows[1]); rows = 0
     L.pseld_gemm8_force_tile(rows, on if on in (192, 256, 384) else 0)
     _lib.set_knob('GEMM8_MINK', 128)
     if mode == 'plain': return ops.linear_fwd(x, w, b, rowscale=rs, rows_per_scale=rps)
@@ -56,7 +60,7 @@ def ref(mode, x, w, b, extra, rs, rps):
 if 'check' in what:
     torch.manual_seed(0)
     worst = 0.0
-    for (M, N, K) in ((256, 256, 128), (512, 384, 384), (1000, 1152, 384), (4096, 1536, 384), (777, 200, 192), (2048, 768, 3072),
+    for (M, N, K) in ((256, 256, 128), (512, 384, 384), (1000, 1152, 384), (4096, 1536, 384), (777, 200, 192), (50000, 576, 192), (70001, 384, 384), (2048, 768, 3072),
                       (12288, 2304, 768), (3000, 4096, 256)):
         for mode in ('plain', 'resid', 'gelu', 'mulaux'):
           for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128), (192, 64), (384, 128)):
@@ -73,6 +77,15 @@ if 'check' in what:
                 if rows in (128, 64) or bn == 384:       # every tile shape sums K in the same order: same bits
                     same = torch.equal(y8, run(mode, x, w, b, extra, rs, rps, bn, rows=256).float())
                     if not same: print(f"M={M} N={N} K={K} {mode} bn={bn}: 128-row tile differs from the 256-row tile   <-- FAIL")
+                if (bn, rows) == (256, 256) and K in (192, 384) and N % 64 == 0:      # the row-panel-stationary kernel: the same bits again
+                    for mbp in ((2, 3) if K == 384 else (3, 4)):
+                        for stag in (0, 1):
+                            yp = run(mode, x, w, b, extra, rs, rps, 'p', rows=(mbp, stag)).float()
+                            assert L.pseld_gemm_last_kernel().decode().startswith('gemm8p_kernel<'), L.pseld_gemm_last_kernel()
+                            if not torch.equal(y8, yp):
+                                bad = (y8 != yp)
+                                print(f"M={M} N={N} K={K} {mode} scaled={int(scaled)} panel mb={mbp} stag={stag}: differs from gemm8 in {int(bad.sum())} elements, rows {bad.any(1).nonzero()[:4].flatten().tolist()} cols {bad.any(0).nonzero()[:4].flatten().tolist()} max {float((y8 - yp).abs().max()):.3e}   <-- FAIL")
+                            else: print(f"M={M} N={N} K={K} {mode} scaled={int(scaled)} panel mb={mbp} stag={stag}: bit-equal to gemm8")
                 y0 = run(mode, x, w, b, extra, rs, rps, False).float()
                 r = ref(mode, x, w, b, extra, rs, rps)
                 den = r.abs().max().item()
@@ -83,7 +96,7 @@ if 'check' in what:
                 print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} bn={bn} rows={rows} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
     # race screen: the same product many times must give bit-identical results
     x = torch.randn(49152, 384, device=dev).to(dt); w = (torch.randn(1536, 384, device=dev) * 0.05).to(dt); b = torch.randn(1536, device=dev)
-    for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128), (192, 64), (384, 128)):
+    for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128), (192, 64), (384, 128), ('p', (2, 0)), ('p', (3, 0)), ('p', (2, 1)), ('p', (3, 1))):
         y = run('plain', x, w, b, None, None, 1, bn, rows=rows).clone()
         bad = 0
         for _ in range(30):
@@ -108,6 +121,8 @@ if 'square' in what:
 if 'shapes' in what:
     B = int(os.environ.get('CHUNKS', '192'))
     VARS = (((256, 256), 'r256c256'), ((192, 256), 'r256c192'), ((256, 128), 'r128c256'), ((192, 128), 'r128c192'), ((192, 64), 'p128c192x2'), ((384, 128), 'r128c384'), ((True, 0), 'auto'), ((False, 0), 'old'))
+    if os.environ.get('PANEL', '1') != '0':
+        VARS = (((256, 256), 'r256c256'), ((192, 256), 'r256c192'), ((True, 0), 'auto'), (('p', (0, 1)), 'panel'), (('p', (0, 0)), 'panel-nostag'), (('p', (2, 1)), 'panel-mb2'), (('p', (4, 1)), 'panel-mb4'))
     tot = {k: 0.0 for k, _ in VARS}
     for li, C in [(l, 96 << l) for l in map(int, os.environ.get('STAGES', '2,3').split(','))]:
         M = B * (64 >> li) ** 2
@@ -131,10 +146,13 @@ if 'shapes' in what:
             t = {}
             for rnd in range(3):
                 for v, _ in VARS:
+                    if v[0] == 'p' and (K not in (192, 384) or (v[1][0] == 2 and K != 384) or (v[1][0] == 4 and K != 192)):
+                        t.setdefault(v, []).append(float('nan')); continue
                     t.setdefault(v, []).append(timeit(lambda: one(v), 10))
             fl = 2.0 * M * N * K
-            for v in t: tot[v] += min(t[v]) * nblk
-            best = min((min(t[v]), lbl) for v, lbl in VARS[:6])[1]
-            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: " + " | ".join(f"{lbl} {min(t[v]):6.1f}" for v, lbl in VARS) + f" us | auto {fl / min(t[(True, 0)]) / 1e6:5.0f} TF | best {best}")
+            for v in t: tot[v] += (min(t[v]) if min(t[v]) == min(t[v]) else min(t[(True, 0)])) * nblk      # (a variant that does not take the shape counts as auto)
+            best = min((min(t[v]), lbl) for v, lbl in VARS if min(t[v]) == min(t[v]))[1]
+            gb = 2.0 * (M * K + N * K + M * N * (2 if mode == 'gelu' else 1) + (M * N if mode in ('resid', 'mulaux') else 0))
+            print(f"s{li} {name:10s} M={M:6d} K={K:4d} N={N:4d} {mode:6s}: " + " | ".join(f"{lbl} {min(t[v]):6.1f}" for v, lbl in VARS) + f" us | auto {fl / min(t[(True, 0)]) / 1e6:5.0f} TF | best {best} {gb / min(min(t[v]) for v, _ in VARS if min(t[v]) == min(t[v])) / 1e6:5.2f} TB/s alg")
     print("per step (blocks x (fwd + dgrad)), ms: " + " | ".join(f"{lbl} {tot[v] / 1e3:.2f}" for v, lbl in VARS))
 L.pseld_gemm8_force_tile(0, 0)
