@@ -59,17 +59,8 @@ int pseld_gemm_dgrad_lnbwd_supported(int dtype, long M, int C, int K);
 long pseld_gemm_dgrad_lnbwd_parts(long M, int C);
 int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt, const void* x, const float* gamma, const void* dres, void* dx,
                            float* partial, long M, int C, int K, int lddy, int ldwt, float eps, void* stream);
-/* Round 5: C = 384 (stage 2 of HTS-AT) is taken too - the 128 x 384 row-spanning tile of the eight-phase kernel carries the LayerNorm backward in
- * its epilogue (parts = ceil(M / 128)). Both C = 384 entry points report "supported" only with their knob set (LNBWD384 / RESIDLN384,
- * pseld_set_knob): measured on the 192-chunk step's shapes they are no faster than the two launches they replace (a persistent kernel with one
- * workgroup per CU exposes its whole epilogue), so the product keeps two launches there and the tests hold the fused path.
- * The forward counterpart: a Linear with bias, DropPath factor and residual whose epilogue is ALSO the LayerNorm that follows it (bf16, N = 384):
- *   y[M, N] = resid + s (A[M, K] . W[N, K]^T + bias),  yn[M, N] = LayerNorm(y; gamma, beta, eps)
- * (attn.proj -> norm2 and mlp.fc2 -> norm1 of the next block, htsat.py:235-262; s = rowscale[m / rows_per_scale] or 1 when NULL). yn is the
- * LayerNorm of the STORED (bf16-rounded) y: what pseld_gemm + pseld_layernorm_fwd give, in one launch. */
-int pseld_gemm_resid_ln_supported(int dtype, long M, int N, int K);
-int pseld_gemm_resid_ln(int dtype, const void* A, const void* W, const float* bias, const void* resid, const float* rowscale, int rows_per_scale,
-                        const float* gamma, const float* beta, void* y, void* yn, long M, int N, int K, int lda, int ldw, float eps, void* stream);
+/* (C = 384 variants of this epilogue and of its forward counterpart - LayerNorm in the residual epilogue, pseld_gemm_resid_ln - were built in
+ * round 5 on a 128 x 384 row-spanning tile, measured equal to the two launches they replace and removed in round 6: docs/EXPERIMENTS.md.) */
 /* Weight gradient of the same layers: dW f32[N,K] (+)= dY[Mtok,N]^T @ (gelu_on_x ? gelu(X) : X)[Mtok,K], and (when
  * dbias != NULL) the bias gradient dbias f32[N] (+)= sum_m dY[m,n] from the same pass. Split over tokens into fp32
  * slabs in `workspace`, reduced in a fixed order (bitwise reproducible). rowscale (optional, f32[Mtok / rows_per_scale]):

@@ -56,7 +56,7 @@ static inline int pseld_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 #define PSELD_KNOB_LIST(X)                                                                                                            \
     X(ATTN_HG) X(ATTN_FWD_P) X(ATTN_BWD_WGS) X(ATTN_BWD_V2) X(ALLOW_WRONG_RESULTS) X(GRU_BWD_UNITS) X(GEMM_XCD)       \
     X(GEMM_BIG) X(WGRAD_TILE) X(GEMM8) X(GEMM8_MINK) X(GEMM_DMA) X(GEMM_FWD_RING) X(GEMM_RING3) X(WGRAD_FILL) X(WGRAD_MINTOK)         \
-    X(WGRAD_RING) X(WGRAD8_MINN) X(WGRAD8) X(GEMM8_BN) X(GEMM8_BM) X(GEMM8_PACK) X(LN_EXACT) X(LNBWD384) X(RESIDLN384) X(GEMM8W_BN) X(MLP_VARIANT) X(GEMM8P) X(GEMM8P_MINM) X(GEMM8P_MODES) X(GEMM8P_K) X(GEMM8P_STAG)
+    X(WGRAD_RING) X(WGRAD8_MINN) X(WGRAD8) X(GEMM8_BN) X(GEMM8_BM) X(LN_EXACT) X(GEMM8W_BN) X(MLP_VARIANT) X(GEMM8P) X(GEMM8P_MINM) X(GEMM8P_MODES) X(GEMM8P_K) X(GEMM8P_STAG)
 enum PseldKnob {
 #define PSELD_KNOB_ENUM(n) KNOB_##n,
     PSELD_KNOB_LIST(PSELD_KNOB_ENUM)

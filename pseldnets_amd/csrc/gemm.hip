@@ -1479,13 +1479,9 @@ extern "C" int pseld_gemm(int dtype, int trans_a, int trans_b, const void* A, co
 // tile spans the row): dx[M, C] = LN'(dY[M, K] Wt[C, K]^T; x, gamma) (+ dres), i.e. pseld_gemm (input gradient through the transposed weight
 // copy Wt) + pseld_layernorm_bwd in one launch. partial: fp32 [pseld_gemm_dgrad_lnbwd_parts(M, C)][2][C], this launch's row-tile sums of
 // d(gamma) = sum dxh xh and d(beta) = sum dxh (reduce with pseld_reduce_slabs / pseld_reduce_slabs_batched, as the stand-alone kernel's).
-// C = 384 (stage 2 of HTS-AT): the 128 x 384 row-spanning tile of the eight-phase kernel with the LayerNorm backward in its epilogue (gemm8.hip,
-// G8_LNBWD); knob LNBWD384 = 0 keeps the two-launch path there (A/B)
-static bool lnbwd384(int dtype, long M, int C, int K) {
-    return dtype == PSELD_BF16 && C == 384 && K % 64 == 0 && K >= 128 && M >= 128 && M < (1L << 24) && pseld_knob(KNOB_LNBWD384, 0) != 0;
-}
+// (C = 384 - a 128 x 384 row-spanning tile of the eight-phase kernel with this epilogue - was built in round 5, measured equal to two launches
+// in the step and removed in round 6: docs/EXPERIMENTS.md.)
 extern "C" int pseld_gemm_dgrad_lnbwd_supported(int dtype, long M, int C, int K) {
-    if (lnbwd384(dtype, M, C, K)) return 1;
     return dtype == PSELD_BF16 && (C == 96 || C == 192) && K % 32 == 0 && K >= 64 && M >= 128 ? 1 : 0;
 }
 extern "C" long pseld_gemm_dgrad_lnbwd_parts(long M, int C) { return pseld_cdiv(M, C == 96 ? 256 : 128); }
@@ -1494,15 +1490,6 @@ extern "C" int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt,
     PSELD_CHECK_ARG(dY && Wt && x && gamma && dx && partial, "gemm_dgrad_lnbwd: null pointer");
     PSELD_CHECK_ARG(pseld_gemm_dgrad_lnbwd_supported(dtype, M, C, K), "gemm_dgrad_lnbwd: built for bf16, C = 96 / 192, K %% 32 == 0 (got dtype %d C %d K %d)", dtype, C, K);
     PSELD_CHECK_ARG(lddy % 8 == 0 && ldwt % 8 == 0 && M < (1L << 31), "gemm_dgrad_lnbwd: bad leading dimension / M");
-    if (lnbwd384(dtype, M, C, K)) {
-        Gemm8Desc d{};
-        d.A = dY; d.B = Wt; d.C = dx; d.resid = dres; d.M = (int)M; d.N = C; d.K = K; d.lda = lddy; d.ldb = ldwt; d.ldc = C; d.ldr = C;
-        d.rows_per_scale = 1; d.ln_mode = 2; d.ln_gamma = gamma; d.ln_x = x; d.ln_partial = partial; d.ln_ldx = C; d.ln_eps = eps;
-        PSELD_CHECK_ARG(pseld_gemm8_supported(d), "gemm_dgrad_lnbwd: C = 384 operands must be 16-byte aligned");
-        const int rc8 = pseld_gemm8_launch(d, (hipStream_t)stream);
-        g_last_gemm_kernel = pseld_gemm8_last_symbol();
-        return rc8;
-    }
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = Wt; g.C = dx; g.bias = gamma; g.resid = dres; g.aux = x; g.C2 = partial;
@@ -1528,27 +1515,6 @@ extern "C" int pseld_gemm_dgrad_lnbwd(int dtype, const void* dY, const void* Wt,
     g_last_gemm_kernel = C == 96 ? "gemm_dma_kernel<4, 1, 2, true>" : "gemm_dma_kernel<2, 2, 2, true>";
     PSELD_LAUNCH_CHECK("gemm_dgrad_lnbwd");
     return PSELD_OK;
-}
-
-// Linear + bias + DropPath + residual whose epilogue is ALSO the LayerNorm behind it (bf16, N = 384: the 128 x 384 row-spanning tile of the
-// eight-phase kernel, gemm8.hip G8_RESID_LN): y = resid + s (A W^T + bias), yn = LayerNorm(y) gamma + beta. One launch for attn.proj -> norm2
-// and for mlp.fc2 -> norm1 of the next block (htsat.py:235-262).
-extern "C" int pseld_gemm_resid_ln_supported(int dtype, long M, int N, int K) {
-    return dtype == PSELD_BF16 && N == 384 && K % 64 == 0 && K >= 128 && M >= 128 && M < (1L << 24) && pseld_knob(KNOB_RESIDLN384, 0) != 0 ? 1 : 0;
-}
-extern "C" int pseld_gemm_resid_ln(int dtype, const void* A, const void* W, const float* bias, const void* resid, const float* rowscale,
-                                   int rows_per_scale, const float* gamma, const float* beta, void* y, void* yn, long M, int N, int K, int lda,
-                                   int ldw, float eps, void* stream) {
-    PSELD_CHECK_ARG(A && W && resid && gamma && beta && y && yn, "gemm_resid_ln: null pointer");
-    PSELD_CHECK_ARG(pseld_gemm_resid_ln_supported(dtype, M, N, K), "gemm_resid_ln: built for bf16, N = 384, K %% 64 == 0 (got dtype %d N %d K %d)", dtype, N, K);
-    Gemm8Desc d{};
-    d.A = A; d.B = W; d.C = y; d.C2 = yn; d.bias = bias; d.resid = resid; d.rowscale = rowscale; d.M = (int)M; d.N = N; d.K = K; d.lda = lda;
-    d.ldb = ldw; d.ldc = N; d.ldr = N; d.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-    d.ln_mode = 1; d.ln_gamma = gamma; d.ln_beta = beta; d.ln_eps = eps;
-    PSELD_CHECK_ARG(pseld_gemm8_supported(d), "gemm_resid_ln: operands must be 16-byte aligned with leading dimensions multiples of 8");
-    const int rc8 = pseld_gemm8_launch(d, (hipStream_t)stream);
-    g_last_gemm_kernel = pseld_gemm8_last_symbol();
-    return rc8;
 }
 
 // Weight gradient dW[N,K] (fp32) = dY[Mtok,N]^T @ X[Mtok,K], optionally with GELU applied to X on load

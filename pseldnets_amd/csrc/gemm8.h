@@ -15,13 +15,6 @@ struct Gemm8Desc {
     int lda, ldb, ldc, ldr, ldaux;
     int rows_per_scale;
     int gelu_dual;
-    // LayerNorm epilogues of the 128 x 384 row-spanning tile (N <= 384, N % 96 == 0). ln_mode 1: C = resid + s (A B^T + bias), C2 = LayerNorm(C)
-    // gamma + beta (the norm BEHIND the layer). ln_mode 2: the product is the input gradient of a Linear whose input was LayerNorm(ln_x): C =
-    // LayerNorm'(A B^T; ln_x, gamma) + resid (the gradient bypassing the norm, may be null), ln_partial [ceil(M / 128)][2][N] f32 receives the
-    // per-tile partial sums of d(gamma) and d(beta). 0: none.
-    int ln_mode;
-    const float* ln_gamma; const float* ln_beta; const void* ln_x; float* ln_partial;
-    int ln_ldx; float ln_eps;
 };
 
 // 1 when the eight-phase kernel takes the product (shape / alignment / size limits), else 0

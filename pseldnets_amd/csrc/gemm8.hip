@@ -36,17 +36,11 @@ constexpr int BUF_B = 4 * HALF_B;         // one K-tile: A-h0 | A-h1 | B-h0 | B-
 constexpr int RING_B = 2 * BUF_B;         // 128 KiB
 constexpr int BIAS_FLOATS = 4672;         // the product's whole bias vector (padded to the tile grid) lives in LDS
 constexpr int LDS_B = RING_B + BIAS_FLOATS * 4;
-constexpr int LN_SCRATCH_B = 3 * 2 * 4 * 64 * 4;      // LayerNorm epilogues: three exchanges of [2 row groups][4 wave columns][64 rows] floats
-constexpr int LDS_LN_B = LDS_B + LN_SCRATCH_B;
 
-enum { G8_PLAIN = 0, G8_RESID = 1, G8_MULAUX = 2, G8_GELU_DUAL = 3,     // x SCALED (DropPath factor per token row)
-       G8_RESID_LN = 4,      // (128 x 384 tile, N = 384) residual epilogue + LayerNorm of the row it has just formed: C = y, C2 = LN(y)
-       G8_LNBWD = 5 };       // (128 x 384 tile, N = 384) input gradient whose epilogue is the backward of the LayerNorm in front of the layer
+enum { G8_PLAIN = 0, G8_RESID = 1, G8_MULAUX = 2, G8_GELU_DUAL = 3 };     // x SCALED (DropPath factor per token row)
 
 // s_waitcnt vmcnt(0) the compiler's own wait bookkeeping sees (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15)
 #define G8_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
-#define G8_FRESH_ROW(r) _Pragma("unroll") for (int k_ = 0; k_ < (int)(sizeof(r.d) / 4); ++k_) asm volatile("" : "+v"(r.d[k_]))   // (the unpacked floats of a packed row are not shared between passes)
-#define G8_OPAQUE(v) asm volatile("" : "+v"(v))       // the value is the same, the compiler no longer knows: nothing derived from it is carried across
 
 struct G8Args {
     const char* A; const char* B; bf16_t* C; bf16_t* C2;
@@ -54,10 +48,6 @@ struct G8Args {
     int M, N, K, lda, ldb, ldc, ldr, ldaux, rows_per_scale;
     float inv_rps;
     int nx, ntiles, nk;
-    // LayerNorm epilogues (G8_RESID_LN, G8_LNBWD): gamma / beta of the norm (fp32 [N]); G8_LNBWD: ln_x = the norm's INPUT rows (bf16 [M, ldx]),
-    // resid = the gradient that bypasses the norm (added to dx; may be null), ln_partial = per-tile partial sums [tile][2][N] of d(gamma), d(beta)
-    const float* ln_gamma; const float* ln_beta; const bf16_t* ln_x; float* ln_partial;
-    int ln_ldx; float ln_eps;
     unsigned long long* dbg;   // diagnostic instantiation only: s_memtime stamps per (workgroup, wave group, tile)
 };
 
@@ -117,24 +107,15 @@ __device__ __forceinline__ void g8_store_nt(bf16_t* p, const G8Piece<PD>& v) {
 // MBQ = 16-row accumulator blocks per wave and row quadrant: 4 -> 256-row tile (wave 128 rows), 2 -> 128-row tile (wave 64 rows, the A
 // half images are 64 rows = ONE LDS-DMA instruction per wave). Same K order per output element at every (NB, MBQ): the four tile
 // shapes give the same bits, so the launch may pick by grid fill (under-filled launches: the 32-chunk step, stage 3).
-// PACK (built for NB = 3, MBQ = 2: the 128 x 192 tile): the four half-tile images are packed to their real sizes (8 + 8 + 16 + 8 KB per K-tile,
-// 80 KB for the ring) and the bias comes from global memory instead of an LDS copy, so that TWO workgroups fit a CU (16 waves, <= 128
-// registers each): twice the LDS-DMA bytes in flight per CU and a second workgroup's phases under every barrier of the first.
-template <int MODE, bool SCALED, int NB, int MBQ = 4, bool DBG = false, bool PACK = false>
-__global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g) {
+// (Round 6 removed three built-and-measured-equal variants of this kernel - the 128 x 192 tile packed for two workgroups per CU, the
+//  128 x 384 row-spanning tile and its LayerNorm forward / backward epilogues: docs/EXPERIMENTS.md, rounds 4-5, has their numbers.)
+template <int MODE, bool SCALED, int NB, int MBQ = 4, bool DBG = false>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const G8Args g) {
     constexpr int WN = NB * 16, BN = 4 * WN;
-    // NB = 6 ("WIDE", MBQ = 2 only): the 128 x 384 tile - a tile spans the whole row of a C = 384 layer (stage 2 of HTS-AT), the A operand
-    // is staged once per row block instead of once per column tile, and row-wise epilogues (LayerNorm) become possible. Column quadrants
-    // of 3 + 3 blocks; images packed: A-h0 8 | A-h1 8 | B-h0 24 | B-h1 24 KB = the same 64 KB per K-tile.
-    constexpr bool WIDE = NB == 6;
-    static_assert(!WIDE || MBQ == 2, "the 384-column tile is built for 128 rows");
-    constexpr int NB0 = WIDE ? 3 : 2;            // blocks in the first column quadrant = LDS-DMA instructions per wave of B-h0 (64 NB0 rows)
+    constexpr int NB0 = 2;                       // blocks in the first column quadrant = LDS-DMA instructions per wave of B-h0 (128 rows)
     constexpr int NB1 = NB - NB0;                // ... in the second = instructions per wave of B-h1
-    constexpr int OFF_A1 = (PACK || WIDE) ? 32 * MBQ * 128 : HALF_B;        // A-h1 image (A-h0 at 0)
-    constexpr int OFF_B0 = (PACK || WIDE) ? 2 * OFF_A1 : 2 * HALF_B;
-    constexpr int OFF_B1 = (PACK || WIDE) ? OFF_B0 + NB0 * 8192 : 3 * HALF_B;
-    constexpr int BUF = (PACK || WIDE) ? OFF_B1 + NB1 * 8192 : BUF_B;       // one K-tile
-    static_assert(PACK || BUF == BUF_B, "the unpacked ring toggles its buffers by XOR");
+    constexpr int OFF_A1 = HALF_B;               // A-h1 image (A-h0 at 0)
+    constexpr int OFF_B0 = 2 * HALF_B, OFF_B1 = 3 * HALF_B;
     constexpr int BM = 64 * MBQ;                 // tile rows
     constexpr int MBN = 2 * MBQ;                 // 16-row blocks per wave
     constexpr int MA = MBQ / 2;                  // LDS-DMA instructions per wave and A half image (32 MBQ rows, 8 per instruction and wave)
@@ -152,7 +133,7 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     //  B-h1(k+1) A-h1(k+1); phase 2 for A-h1(k): B-h0(k+1) A-h0(k+1) B-h1(k+1) A-h1(k+1) B-h0(k+2))
     constexpr int VM_P4 = 2 * NB1 + 2 * MA + NB0, VM_P1 = 3 * MA + NB0 + NB1, VM_P2 = 2 * NB0 + 2 * MA + NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* bias_s = (float*)(smem + RING_B);      // (not PACK)
+    float* bias_s = (float*)(smem + RING_B);
     // (diagnostic instantiation) real-time stamps of the start-up pieces, and the end of K-tiles 0..7 of this workgroup's SECOND tile
     unsigned long long r_entry = 0, r_bias = 0, r_loop = 0, kt0 = 0, kt1 = 0, kt2 = 0, kt3 = 0, kt4 = 0, kt5 = 0, kt6 = 0, kt7 = 0;
     if constexpr (DBG) r_entry = __builtin_amdgcn_s_memrealtime();
@@ -170,24 +151,12 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     const int my_n = (chunkn - slot + per - 1) / per;
     const int first = chunk0 + slot;
 
-    if constexpr (!PACK) {
-        for (int i = tid; i < g.nx * BN; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
-        if constexpr (MODE == G8_RESID_LN || MODE == G8_LNBWD) {       // gamma | beta of the fused LayerNorm behind the bias (one column tile: N <= BN)
-            for (int i = tid; i < BN; i += 512) {
-                bias_s[BN + i] = i < g.N ? g.ln_gamma[i] : 0.f;
-                bias_s[2 * BN + i] = (i < g.N && g.ln_beta) ? g.ln_beta[i] : 0.f;
-            }
-        }
-        __syncthreads();
-    }
+    for (int i = tid; i < g.nx * BN; i += 512) bias_s[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
+    __syncthreads();
     if constexpr (DBG) r_bias = __builtin_amdgcn_s_memrealtime();
 
     // ---- fragment read addresses (buffer 0): lane reads row l15 of a 16-row block, 16-byte chunk (4 kk + q) ^ ((row >> 1) & 7) ----
-    // (LN epilogues: everything the main loop derives from the lane id is formed again behind the epilogue from `lane_m`, so that none of it
-    //  is live across the epilogue's register peak - the compiler otherwise spills these loop invariants and reloads them INSIDE the K loop,
-    //  each reload behind a vmcnt(0) that drains the LDS-DMA prefetch)
-    constexpr bool LN_EPI = MODE == G8_RESID_LN || MODE == G8_LNBWD;
-    int lane_m = lane;
+    const int lane_m = lane;
     unsigned ra0, ra1, rb0, rb1, rc0, rc1;
     auto set_frag_addrs = [&](unsigned par) {
         const int l15m = lane_m & 15, qm = lane_m >> 4, sw = (lane_m >> 1) & 7;
@@ -251,7 +220,7 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
         }
     };
     auto advance = [&]() {       // past the end of the list the cursor re-reads the last tile (nobody reads those images): the
-        ld_buf = (unsigned)BUF - ld_buf;         // vmcnt distance stays constant in the tail
+        ld_buf = (unsigned)BUF_B - ld_buf;         // vmcnt distance stays constant in the tail
         if (++ld_kt == g.nk) {
             ld_kt = 0;
             if (ld_i + 1 < my_n) { ++ld_i; set_tile(first + ld_i * per); }
@@ -263,15 +232,9 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
 
     auto init_acc = [&](int n0) {
         f32x4 b[NB];
-        if constexpr (PACK) {          // no LDS copy of the bias: this lane's 4 NB values straight from global memory (N % BN == 0 for the packed tile)
-            const float* bp = g.bias + n0 + wc * WN + 4 * NB * q;
+        const float* bp = bias_s + n0 + wc * WN + 4 * NB * q;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = g.bias ? *(const f32x4*)(bp + 4 * nb) : f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            const float* bp = bias_s + n0 + wc * WN + 4 * NB * q;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(bp + 4 * nb);
-        }
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(bp + 4 * nb);
 #pragma unroll
         for (int mb = 0; mb < MBN; ++mb)
 #pragma unroll
@@ -381,286 +344,6 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
         }
     };
 
-    // ---- LayerNorm epilogues of the 128 x 384 tile (the tile spans the row: N <= 384 = one column tile) ----------------------------------
-    // A lane holds W = 24 columns of its own rows (m0 + wr*64 + 16 mb + l15, mb < 4); the row's other columns sit in the lanes l15 + 16 q' of the
-    // same wave (two __shfl_xor) and in the other three waves of the row group (one LDS exchange: scratch [exchange][wr][wc][64 rows], a
-    // barrier - both wave groups run their epilogues side by side, so every exchange is one s_barrier all eight waves take part in).
-    [[maybe_unused]] float* const ln_red = (float*)(smem + LDS_B);
-    [[maybe_unused]] auto row_sum4 = [&](float (&v)[MBN], int xchg, int l15, int q) {      // v[mb] <- the sum over the whole row of the four rows this lane works on
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            v[mb] += __shfl_xor(v[mb], 16);
-            v[mb] += __shfl_xor(v[mb], 32);
-        }
-        float* red = ln_red + xchg * (2 * 4 * 64);
-        if (q == 0) {
-#pragma unroll
-            for (int mb = 0; mb < MBN; ++mb) red[(wr * 4 + wc) * 64 + mb * 16 + l15] = v[mb];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G8_BAR();
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            const float* r = red + wr * 4 * 64 + mb * 16 + l15;
-            v[mb] = (r[0] + r[64]) + (r[128] + r[192]);             // fixed order: every wave of the row group forms the same bits
-        }
-    };
-    // G8_RESID_LN: y = resid + s (acc) [bias in acc], C = bf16(y), C2 = bf16(LayerNorm(bf16(y)) gamma + beta) - what the stand-alone LayerNorm
-    // kernel would read and write (norm2 behind attn.proj, norm1 of the next block behind mlp.fc2: htsat.py:235,262 / model_utilities.py:166-170).
-    // The rounded y replaces the accumulators in place (registers: 96 accumulators + 48 residual pieces is the peak)
-    [[maybe_unused]] auto epilogue_ln = [&](int m0) {
-        constexpr int W = 4 * NB, HW = W / 2, PD = HW / 2;
-        typedef G8Piece<PD> piece_t;
-        int le = tid & 63;
-        asm volatile("" : "+v"(le));                                 // (the epilogue's lane-derived values are formed here, not hoisted over the K loop)
-        const int l15 = le & 15, q = le >> 4;
-        const bool isB = (l15 & 1) != 0;
-        const int rown = m0 + wr * (32 * MBQ) + l15, r1b = rown - (isB ? 1 : 0);
-        const int cown = wc * WN + W * q;                          // this lane's 24 own-row columns
-        const int cL = cown + (isB ? HW : 0);
-        const bool colok = cL < g.N, ownok = cown < g.N;           // (N % 24 == 0: strips and pieces are whole or absent)
-        const int cLc = min(cL, g.N - HW), mlast = g.M - 1;
-        float s1[MBN], s2[MBN];
-        {
-            piece_t x1[MBN], x2[MBN];
-            float sc[MBN];
-#pragma unroll
-            for (int mb = 0; mb < MBN; ++mb) {
-                sc[mb] = SCALED ? g.rowscale[div_by8(min(rown + mb * 16, mlast), g.rows_per_scale, g.inv_rps)] : 1.f;
-                x1[mb] = *(const piece_t*)(g.resid + (long)min(r1b + mb * 16, mlast) * g.ldr + cLc);
-                x2[mb] = *(const piece_t*)(g.resid + (long)min(r1b + mb * 16 + 1, mlast) * g.ldr + cLc);
-            }
-            G8_WAIT_VM0();
-#pragma unroll
-            for (int mb = 0; mb < MBN; ++mb) {
-                __builtin_amdgcn_sched_barrier(0);
-                float s = 0.f;
-                unsigned pk[W / 2];
-#pragma unroll
-                for (int c = 0; c < W; c += 2) {
-                    const int k = (c / 2) % PD;
-                    // the own row's residual dword for columns (c, c + 1): its first half sits in piece 1 of the pair's A lane, its second in piece 2 of B
-                    const unsigned got = g8_swap1(isB ? x1[mb].d[k] : x2[mb].d[k]);
-                    const unsigned xo = c < HW ? (isB ? got : x1[mb].d[k]) : (isB ? x2[mb].d[k] : got);
-                    float xa, xb, ya, yb;
-                    g8_unpack2(xo, xa, xb);
-                    const float v0 = fmaf(acc[mb][c >> 2][c & 3], sc[mb], xa), v1 = fmaf(acc[mb][(c + 1) >> 2][(c + 1) & 3], sc[mb], xb);
-                    pk[c / 2] = g8_pack2(v0, v1);
-                    g8_unpack2(pk[c / 2], ya, yb);                 // the statistics (and C2) are those of the STORED, rounded row
-                    acc[mb][c >> 2][c & 3] = ya; acc[mb][(c + 1) >> 2][(c + 1) & 3] = yb;
-                    s += ya + yb;
-                }
-                s1[mb] = ownok ? s : 0.f;
-                // y leaves here (the packed row is dead behind its stores: kept for the last phase it costs 48 registers the compiler spills)
-                piece_t y1, y2;
-#pragma unroll
-                for (int k = 0; k < PD; ++k) {
-                    const unsigned gy = g8_swap1(isB ? pk[k] : pk[PD + k]);       // A gives its second half, B its first
-                    y1.d[k] = isB ? gy : pk[k]; y2.d[k] = isB ? pk[PD + k] : gy;
-                }
-                const int r1 = r1b + mb * 16;
-                if (colok && r1 < g.M) *(piece_t*)(g.C + (long)min(r1, mlast) * g.ldc + cLc) = y1;
-                if (colok && r1 + 1 < g.M) *(piece_t*)(g.C + (long)min(r1 + 1, mlast) * g.ldc + cLc) = y2;
-            }
-        }
-        row_sum4(s1, 0, l15, q);
-        const float rN = 1.0f / (float)g.N;
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            const float mean = s1[mb] * rN;
-            float qv = 0.f;
-#pragma unroll
-            for (int c = 0; c < W; ++c) { const float dv = acc[mb][c >> 2][c & 3] - mean; qv = fmaf(dv, dv, qv); }
-            s2[mb] = ownok ? qv : 0.f;
-        }
-        row_sum4(s2, 1, l15, q);
-        const float* gam = bias_s + BN + cown;
-        const float* bet = bias_s + 2 * BN + cown;
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            __builtin_amdgcn_sched_barrier(0);
-            float mean = s1[mb] * rN, rstd = rsqrtf(s2[mb] * rN + g.ln_eps);
-            G8_OPAQUE(mean);                                         // (y - mean of the variance pass is not kept for this one: 96 registers)
-            const int r1 = r1b + mb * 16;
-            const bool ok1 = colok && r1 < g.M, ok2 = colok && r1 + 1 < g.M;
-            const long o1 = (long)min(r1, mlast) * g.ldc + cLc, o2 = (long)min(r1 + 1, mlast) * g.ldc + cLc;
-            piece_t z1, z2;
-#pragma unroll
-            for (int k = 0; k < PD; ++k) {                          // dword k of the first half / of the second half of the own row
-                const float a0 = acc[mb][(2 * k) >> 2][(2 * k) & 3], a1 = acc[mb][(2 * k + 1) >> 2][(2 * k + 1) & 3];
-                const float b0 = acc[mb][(HW + 2 * k) >> 2][(HW + 2 * k) & 3], b1 = acc[mb][(HW + 2 * k + 1) >> 2][(HW + 2 * k + 1) & 3];
-                const unsigned zlo = g8_pack2(fmaf((a0 - mean) * rstd, gam[2 * k], bet[2 * k]), fmaf((a1 - mean) * rstd, gam[2 * k + 1], bet[2 * k + 1]));
-                const unsigned zhi = g8_pack2(fmaf((b0 - mean) * rstd, gam[HW + 2 * k], bet[HW + 2 * k]), fmaf((b1 - mean) * rstd, gam[HW + 2 * k + 1], bet[HW + 2 * k + 1]));
-                const unsigned gz = g8_swap1(isB ? zlo : zhi);     // A gives its second half, B its first
-                z1.d[k] = isB ? gz : zlo; z2.d[k] = isB ? zhi : gz;
-            }
-            if (ok1) *(piece_t*)(g.C2 + o1) = z1;
-            if (ok2) *(piece_t*)(g.C2 + o2) = z2;
-        }
-    };
-    // G8_LNBWD: acc = d(LN output) of the rows (the input gradient of the Linear behind the norm). With x = the norm's input rows:
-    // xh = (x - mean) rstd, gy = acc gamma, dx = rstd (gy - mean(gy) - xh mean(gy xh)) + dres  (reference: autograd of nn.LayerNorm,
-    // htsat.py:235,262); d(gamma) += acc xh, d(beta) += acc per column -> per-tile partial sums [tile][2][N] (summed by the callers' reduction).
-    // acc is rounded to bf16 first - exactly what the two-launch path stores between the GEMM and the LayerNorm backward.
-    [[maybe_unused]] auto epilogue_lnbwd = [&](int m0, int tile) {
-        constexpr int W = 4 * NB, HW = W / 2, PD = HW / 2;
-        typedef G8Piece<PD> piece_t;
-        typedef G8Piece<W / 2> row_t;                              // a lane's 24 own-row columns: 48 bytes
-        int le = tid & 63;
-        asm volatile("" : "+v"(le));
-        const int l15 = le & 15, q = le >> 4;
-        const bool isB = (l15 & 1) != 0;
-        const int rown = m0 + wr * (32 * MBQ) + l15, r1b = rown - (isB ? 1 : 0);
-        const int cown = wc * WN + W * q;
-        const int cL = cown + (isB ? HW : 0);
-        const bool colok = cL < g.N, ownok = cown < g.N;
-        const int cLc = min(cL, g.N - HW), mlast = g.M - 1, cownc = min(cown, g.N - W);
-        row_t xr[MBN];
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) xr[mb] = *(const row_t*)(g.ln_x + (long)min(rown + mb * 16, mlast) * g.ln_ldx + cownc);
-        G8_WAIT_VM0();
-        const float rN = 1.0f / (float)g.N;
-        float s1[MBN], s2[MBN];
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < W; c += 2) { float a, b; g8_unpack2(xr[mb].d[c / 2], a, b); s += a + b; }
-            s1[mb] = ownok ? s : 0.f;
-        }
-        row_sum4(s1, 0, l15, q);
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            const float mean = s1[mb] * rN;
-            float qv = 0.f;
-            G8_FRESH_ROW(xr[mb]);
-#pragma unroll
-            for (int c = 0; c < W; c += 2) { float a, b; g8_unpack2(xr[mb].d[c / 2], a, b); a -= mean; b -= mean; qv = fmaf(a, a, fmaf(b, b, qv)); }
-            s2[mb] = ownok ? qv : 0.f;
-        }
-        row_sum4(s2, 1, l15, q);
-        const float* gam = bias_s + BN + cown;
-        float c1[MBN], c2[MBN];
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            __builtin_amdgcn_sched_barrier(0);
-            float mean = s1[mb] * rN, rstd = rsqrtf(s2[mb] * rN + g.ln_eps);
-            G8_OPAQUE(mean);                                         // (x - mean of the variance pass is not kept: formed again from the packed row)
-            const bool live = ownok && rown + mb * 16 < g.M;
-            float a1 = 0.f, a2 = 0.f;
-            G8_FRESH_ROW(xr[mb]);
-#pragma unroll
-            for (int c = 0; c < W; c += 2) {
-                float xa, xb, da, db;
-                g8_unpack2(xr[mb].d[c / 2], xa, xb);
-                g8_unpack2(g8_pack2(acc[mb][c >> 2][c & 3], acc[mb][(c + 1) >> 2][(c + 1) & 3]), da, db);
-                if (!live) { da = 0.f; db = 0.f; }
-                acc[mb][c >> 2][c & 3] = da; acc[mb][(c + 1) >> 2][(c + 1) & 3] = db;       // the rounded d(LN output) stays in the accumulators
-                const float ga = da * gam[c], gb = db * gam[c + 1];
-                a1 += ga + gb;
-                a2 = fmaf(ga, (xa - mean) * rstd, fmaf(gb, (xb - mean) * rstd, a2));
-            }
-            c1[mb] = a1; c2[mb] = a2;
-            s1[mb] = mean; s2[mb] = rstd;
-        }
-        row_sum4(c1, 2, l15, q);
-        row_sum4(c2, 0, l15, q);                                           // (the first exchange's scratch is free again: two barriers lie between)
-        // dx, row block by row block; the bypass gradient's pieces (traded layout) are fetched one row block ahead
-        piece_t rA, rB, nA, nB;
-        auto fetch_res = [&](int mb, piece_t& pa, piece_t& pb) {
-            if (g.resid) {
-                pa = *(const piece_t*)(g.resid + (long)min(r1b + mb * 16, mlast) * g.ldr + cLc);
-                pb = *(const piece_t*)(g.resid + (long)min(r1b + mb * 16 + 1, mlast) * g.ldr + cLc);
-            } else {
-#pragma unroll
-                for (int k = 0; k < PD; ++k) { pa.d[k] = 0u; pb.d[k] = 0u; }
-            }
-        };
-        fetch_res(0, rA, rB);
-#pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (mb + 1 < MBN) fetch_res(mb + 1, nA, nB);
-            const float m1 = c1[mb] * rN, m2 = c2[mb] * rN;
-            float mean = s1[mb], rstd = s2[mb];
-            G8_OPAQUE(mean); G8_OPAQUE(rstd);                       // ((x - mean) rstd of the pass before is not kept)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) G8_OPAQUE(acc[mb][nb]);   // (nor its products with gamma)
-            piece_t d1, d2;
-            G8_FRESH_ROW(xr[mb]);
-#pragma unroll
-            for (int k = 0; k < PD; ++k) {
-                float xa, xb, ra, rb;
-                g8_unpack2(xr[mb].d[k], xa, xb);
-                const unsigned lo = g8_pack2(rstd * (acc[mb][(2 * k) >> 2][(2 * k) & 3] * gam[2 * k] - m1 - (xa - mean) * rstd * m2),
-                                             rstd * (acc[mb][(2 * k + 1) >> 2][(2 * k + 1) & 3] * gam[2 * k + 1] - m1 - (xb - mean) * rstd * m2));
-                g8_unpack2(xr[mb].d[PD + k], xa, xb);
-                const unsigned hi = g8_pack2(rstd * (acc[mb][(HW + 2 * k) >> 2][(HW + 2 * k) & 3] * gam[HW + 2 * k] - m1 - (xa - mean) * rstd * m2),
-                                             rstd * (acc[mb][(HW + 2 * k + 1) >> 2][(HW + 2 * k + 1) & 3] * gam[HW + 2 * k + 1] - m1 - (xb - mean) * rstd * m2));
-                const unsigned got = g8_swap1(isB ? lo : hi);
-                unsigned e1 = isB ? got : lo, e2 = isB ? hi : got;
-                // + the bypass gradient, in the traded layout (the two-launch path adds it to the UNROUNDED dx: here dx is rounded once more first -
-                // one extra bf16 rounding of the branch gradient only, inside the tolerance of every gradient gate)
-                float a, b;
-                g8_unpack2(e1, a, b); g8_unpack2(rA.d[k], ra, rb); d1.d[k] = g.resid ? g8_pack2(a + ra, b + rb) : e1;
-                g8_unpack2(e2, a, b); g8_unpack2(rB.d[k], ra, rb); d2.d[k] = g.resid ? g8_pack2(a + ra, b + rb) : e2;
-            }
-            const int r1 = r1b + mb * 16;
-            if (colok && r1 < g.M) *(piece_t*)(g.C + (long)min(r1, mlast) * g.ldc + cLc) = d1;
-            if (colok && r1 + 1 < g.M) *(piece_t*)(g.C + (long)min(r1 + 1, mlast) * g.ldc + cLc) = d2;
-            rA = nA; rB = nB;
-        }
-        G8_WAIT_VM0();
-        // d(gamma), d(beta): the lane's 4 rows, then the 16 lanes of a DPP row (same q = same columns, l15 = rows), then the two row groups
-        // through the exchange scratch ([2 wr][4 wc][4 q][2][24] floats = its 6 KB, free behind a barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G8_BAR();                                                     // every wave is past its reads of the exchange scratch
-        float* pg = ln_red + ((wr * 4 + wc) * 4 + q) * (2 * W);
-        auto dpp_add = [](float v, auto ctrl) {
-            return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
-        };
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {                             // half the lane's columns at a time: 24 running sums beside acc and x, not 48
-            __builtin_amdgcn_sched_barrier(0);
-            float dgam[HW], dbet[HW];
-#pragma unroll
-            for (int c = 0; c < HW; ++c) { dgam[c] = 0.f; dbet[c] = 0.f; }
-#pragma unroll
-            for (int mb = 0; mb < MBN; ++mb) {
-                float mean = s1[mb], rstd = s2[mb];
-                G8_OPAQUE(mean); G8_OPAQUE(rstd);
-                G8_FRESH_ROW(xr[mb]);
-#pragma unroll
-                for (int c = 0; c < HW; c += 2) {
-                    const int cc = hf * HW + c;
-                    float xa, xb;
-                    g8_unpack2(xr[mb].d[cc / 2], xa, xb);
-                    const float da = acc[mb][cc >> 2][cc & 3], db = acc[mb][(cc + 1) >> 2][(cc + 1) & 3];
-                    dgam[c] = fmaf(da, (xa - mean) * rstd, dgam[c]); dgam[c + 1] = fmaf(db, (xb - mean) * rstd, dgam[c + 1]);
-                    dbet[c] += da; dbet[c + 1] += db;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < HW; ++c) {                          // inclusive scan over the 16 lanes of the DPP row (row_shr 1, 2, 4, 8): lane 15 holds the sum
-                float a = dgam[c], b = dbet[c];
-                a = dpp_add(a, std::integral_constant<int, 0x111>{}); b = dpp_add(b, std::integral_constant<int, 0x111>{});
-                a = dpp_add(a, std::integral_constant<int, 0x112>{}); b = dpp_add(b, std::integral_constant<int, 0x112>{});
-                a = dpp_add(a, std::integral_constant<int, 0x114>{}); b = dpp_add(b, std::integral_constant<int, 0x114>{});
-                a = dpp_add(a, std::integral_constant<int, 0x118>{}); b = dpp_add(b, std::integral_constant<int, 0x118>{});
-                if (l15 == 15) { pg[hf * HW + c] = a; pg[W + hf * HW + c] = b; }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G8_BAR();
-        if (wr == 0 && l15 < 12 && ownok) {                          // 12 lanes x 4 floats = the 24 + 24 sums of this (wave column, q): lane -> (which, 4 columns)
-            const int which = l15 / 6, c4 = (l15 % 6) * 4;
-            const float* p0 = ln_red + ((0 * 4 + wc) * 4 + q) * (2 * W) + which * W + c4;
-            const float* p1 = ln_red + ((1 * 4 + wc) * 4 + q) * (2 * W) + which * W + c4;
-            const f32x4 v = *(const f32x4*)p0 + *(const f32x4*)p1;
-            *(f32x4*)(g.ln_partial + ((long)tile * 2 + which) * g.N + cown + c4) = v;
-        }
-    };
-
 #define G8_LD_A(mq)                                                                                              \
     _Pragma("unroll") for (int mbl = 0; mbl < MBQ; ++mbl) {                                                      \
         fa[mbl][0] = *(const bf16x8*)(smem + ra0 + (mq) * OFF_A1 + mbl * 2048);                                  \
@@ -698,7 +381,6 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
     if (wr == 1) G8_BAR();                       // the stagger: waves 4-7 run one barrier behind waves 0-3
 
     const int total_kt = my_n * g.nk;
-    unsigned rdelta = (unsigned)BUF;             // (PACK) the read addresses alternate between the two K-tile buffers by +- BUF
     unsigned long long t_start = 0;
     if constexpr (DBG) { t_start = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
     for (int s = 0; s < total_kt; ++s) {
@@ -734,8 +416,7 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
         G8_BAR();
         G8_MMA(1, 0, fb0);
         G8_BAR();
-        if constexpr (PACK) { ra0 += rdelta; ra1 += rdelta; rb0 += rdelta; rb1 += rdelta; rc0 += rdelta; rc1 += rdelta; rdelta = 0u - rdelta; }
-        else { ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B; rc0 ^= BUF_B; rc1 ^= BUF_B; }
+        ra0 ^= BUF_B; ra1 ^= BUF_B; rb0 ^= BUF_B; rb1 ^= BUF_B; rc0 ^= BUF_B; rc1 ^= BUF_B;
         if constexpr (DBG) {
             if (cp_i == 1) {
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -752,16 +433,8 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
             // aux / DropPath factor) and GELU arithmetic overlap (GELU-pair product 120.6 -> 112.0 us; nothing for the plain store-only epilogue,
             // which is paced by the vector-memory path the groups share).
             if (wr == 0) G8_BAR();
-            if constexpr (MODE == G8_RESID_LN) epilogue_ln(m0c);
-            else if constexpr (MODE == G8_LNBWD) epilogue_lnbwd(m0c, T);
-            else epilogue(m0c, n0c);
+            epilogue(m0c, n0c);
             if (wr == 1) G8_BAR();
-            if constexpr (LN_EPI) {
-                lane_m = tid & 63;
-                asm volatile("" : "+v"(lane_m));
-                set_frag_addrs(((s + 1) & 1) ? (unsigned)BUF_B : 0u);
-                set_tile(first + ld_i * per);
-            }
             if constexpr (DBG) {
                 const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
                 if ((tid & 255) == 0 && cp_i < 16) {
@@ -794,19 +467,18 @@ __global__ __launch_bounds__(512, PACK ? 4 : 2) void gemm8_kernel(const G8Args g
 const char* g_gemm8_symbol = "";     // the instantiation the last launch ran, as rocprofv3 prints it (measurement aid)
 char g_gemm8_symbuf[64];
 
-constexpr int LDS_PACK_B = 2 * (2 * 32 * 2 * 128 + HALF_B + 8192);      // NB = 3, MBQ = 2 packed: 2 x 40 KB = half a CU's LDS
-template <int MODE, bool SCALED, int NB, int MBQ, bool PACK = false>
+template <int MODE, bool SCALED, int NB, int MBQ>
 int launch8(const G8Args& a, int nwg, hipStream_t stream) {
-    snprintf(g_gemm8_symbuf, sizeof g_gemm8_symbuf, "gemm8_kernel<%d, %s, %d, %d, false%s>", MODE, SCALED ? "true" : "false", NB, MBQ, PACK ? ", true" : "");
+    snprintf(g_gemm8_symbuf, sizeof g_gemm8_symbuf, "gemm8_kernel<%d, %s, %d, %d, false>", MODE, SCALED ? "true" : "false", NB, MBQ);
     g_gemm8_symbol = g_gemm8_symbuf;
-    constexpr int lds = PACK ? LDS_PACK_B : ((MODE == G8_RESID_LN || MODE == G8_LNBWD) ? LDS_LN_B : LDS_B);
+    constexpr int lds = LDS_B;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB, MBQ, false, PACK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB, MBQ, false, PACK>), dim3((unsigned)nwg), dim3(512), lds, stream, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8_kernel<MODE, SCALED, NB, MBQ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((gemm8_kernel<MODE, SCALED, NB, MBQ, false>), dim3((unsigned)nwg), dim3(512), lds, stream, a);
     PSELD_LAUNCH_CHECK("gemm8");
     return PSELD_OK;
 }
-template <int NB, int MBQ, bool PACK = false>
+template <int NB, int MBQ>
 int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t stream) {
     const bool sc = d.rowscale != nullptr;
     if constexpr (MBQ == 4) {
@@ -821,12 +493,10 @@ int launch8_mode(const Gemm8Desc& d, const G8Args& a, int nwg, hipStream_t strea
             if (!d.resid && !d.aux && !sc) return go(gemm8_kernel<G8_PLAIN, false, NB, 4, true>);
         }
     }
-    if constexpr (NB != 6) {
-        if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ, PACK>(a, nwg, stream);
-    }
-    if (d.resid) return sc ? launch8<G8_RESID, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_RESID, false, NB, MBQ, PACK>(a, nwg, stream);
-    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_MULAUX, false, NB, MBQ, PACK>(a, nwg, stream);
-    return sc ? launch8<G8_PLAIN, true, NB, MBQ, PACK>(a, nwg, stream) : launch8<G8_PLAIN, false, NB, MBQ, PACK>(a, nwg, stream);
+    if (d.gelu_dual) return launch8<G8_GELU_DUAL, false, NB, MBQ>(a, nwg, stream);
+    if (d.resid) return sc ? launch8<G8_RESID, true, NB, MBQ>(a, nwg, stream) : launch8<G8_RESID, false, NB, MBQ>(a, nwg, stream);
+    if (d.aux) return sc ? launch8<G8_MULAUX, true, NB, MBQ>(a, nwg, stream) : launch8<G8_MULAUX, false, NB, MBQ>(a, nwg, stream);
+    return sc ? launch8<G8_PLAIN, true, NB, MBQ>(a, nwg, stream) : launch8<G8_PLAIN, false, NB, MBQ>(a, nwg, stream);
 }
 
 unsigned long long* g_gemm8_dbg = nullptr;
@@ -849,15 +519,10 @@ int pseld_gemm8_supported(const Gemm8Desc& d) {
     if (d.K % 64 != 0 || d.K < 128 || d.M < 1 || d.N < 128 || d.N % 8 != 0) return 0;
     if (d.lda % 8 != 0 || d.ldb % 8 != 0 || d.ldc % 8 != 0 || (d.resid && d.ldr % 8 != 0) || (d.aux && d.ldaux % 8 != 0)) return 0;
     if ((long)d.M * d.lda * 2 >= (1L << 32) || (long)d.N * d.ldb * 2 >= (1L << 32) || d.M >= (1 << 24)) return 0;
-    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS || pseld_cdiv(d.N, 384) * 384 > BIAS_FLOATS) return 0;
+    if (pseld_cdiv(d.N, 192) * 192 > BIAS_FLOATS || pseld_cdiv(d.N, 256) * 256 > BIAS_FLOATS) return 0;
     if ((((unsigned long)d.A | (unsigned long)d.B | (unsigned long)d.C | (unsigned long)d.C2 | (unsigned long)d.resid | (unsigned long)d.aux) & 15) != 0) return 0;
     if (d.resid && d.aux) return 0;
     if (d.gelu_dual && (d.resid || d.aux || d.rowscale || !d.C2)) return 0;
-    if (d.ln_mode) {
-        if (d.N > 384 || d.N % 96 != 0 || d.gelu_dual || d.aux || !d.ln_gamma) return 0;
-        if (d.ln_mode == 1 && (!d.resid || !d.C2 || (((unsigned long)d.C2) & 15))) return 0;
-        if (d.ln_mode == 2 && (!d.ln_x || !d.ln_partial || d.rowscale || d.bias || d.ln_ldx % 8 != 0 || (((unsigned long)d.ln_x | (unsigned long)d.ln_partial) & 15))) return 0;
-    }
     return 1;
 }
 
@@ -870,15 +535,6 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     a.inv_rps = 1.0f / (float)a.rows_per_scale;
     a.nk = d.K / 64;
     a.dbg = g_gemm8_dbg;
-    a.ln_gamma = d.ln_gamma; a.ln_beta = d.ln_beta; a.ln_x = (const bf16_t*)d.ln_x; a.ln_partial = d.ln_partial; a.ln_ldx = d.ln_ldx; a.ln_eps = d.ln_eps;
-    if (d.ln_mode) {      // the row-spanning tile with a LayerNorm epilogue: one column tile, 128-row blocks
-        a.nx = 1;
-        a.ntiles = pseld_cdiv(d.M, 128);
-        int nwgl = (a.ntiles + 7) / 8 * 8;
-        if (nwgl > 256) nwgl = 256;
-        if (d.ln_mode == 1) return d.rowscale ? launch8<G8_RESID_LN, true, 6, 2>(a, nwgl, stream) : launch8<G8_RESID_LN, false, 6, 2>(a, nwgl, stream);
-        return launch8<G8_LNBWD, false, 6, 2>(a, nwgl, stream);
-    }
     // Tile shape: the cheapest of {256, 128} rows x {256, 192} columns by rounds x (bytes a workgroup stages per K-tile ~ rows + columns).
     // 192 columns need N % 192 == 0 (12-byte store pieces are whole only when the strips are); short K (<= 4 K-tiles) takes 256 columns
     // (the epilogue dominates and the 256 tile writes whole 128-byte lines per wave). A 128-row tile pays where the 256-row grid leaves
@@ -887,26 +543,6 @@ int pseld_gemm8_launch(const Gemm8Desc& d, hipStream_t stream) {
     // (knobs, common.h) and pseld_gemm8_force_tile (tools, tests) force a shape.
     const int want_bn = g_gemm8_force_bn ? g_gemm8_force_bn : pseld_knob(KNOB_GEMM8_BN, 0);
     const int want_bm = g_gemm8_force_bm ? g_gemm8_force_bm : pseld_knob(KNOB_GEMM8_BM, 0);
-    // rows = 64: the 128 x 192 tile packed for two workgroups per CU. Forced (force_tile / knob GEMM8_BM = 64), or chosen (knob GEMM8_PACK,
-    // A/B) for narrow outputs (N <= 384: one or two column tiles, the A operand dominates the traffic) with at least one full round of 512
-    bool pack = want_bm == 64;
-    if (!pack && want_bm == 0 && want_bn == 0 && pseld_knob(KNOB_GEMM8_PACK, 0) != 0 && d.N <= 384 && a.nk > 4 &&
-        (long)(d.N / 192) * pseld_cdiv(d.M, 128) >= 512) pack = true;
-    if (pack && d.N % 192 == 0 && (((unsigned long)d.bias) & 15) == 0) {
-        a.nx = d.N / 192;
-        a.ntiles = a.nx * pseld_cdiv(d.M, 128);
-        int nwg2 = (a.ntiles + 7) / 8 * 8;
-        if (nwg2 > 512) nwg2 = 512;
-        return launch8_mode<3, 2, true>(d, a, nwg2, stream);
-    }
-    // columns = 384 (force / knob): the 128 x 384 row-spanning tile (no GELU-pair epilogue; N a multiple of 96: whole 24-byte store pieces)
-    if (want_bn == 384 && d.N % 96 == 0 && !d.gelu_dual) {
-        a.nx = pseld_cdiv(d.N, 384);
-        a.ntiles = a.nx * pseld_cdiv(d.M, 128);
-        int nwg6 = (a.ntiles + 7) / 8 * 8;
-        if (nwg6 > 256) nwg6 = 256;
-        return launch8_mode<6, 2>(d, a, nwg6, stream);
-    }
     int bn = 0, bm = 0;
     double best = 0;
     for (int rows = 256; rows >= 128; rows -= 128)

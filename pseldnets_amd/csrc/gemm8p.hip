@@ -412,7 +412,7 @@ const char* pseld_gemm8p_last_symbol() { return g_gemm8p_symbol; }
 
 int pseld_gemm8p_supported(const Gemm8Desc& d) {
     if (d.K != 192 && d.K != 384) return 0;
-    if (d.N % 64 != 0 || d.N < 128 || d.N > P_BIAS_FLOATS || d.M < 1 || d.ln_mode) return 0;
+    if (d.N % 64 != 0 || d.N < 128 || d.N > P_BIAS_FLOATS || d.M < 1) return 0;
     if (d.lda % 8 != 0 || d.ldb % 8 != 0 || d.ldc % 8 != 0 || (d.resid && d.ldr % 8 != 0) || (d.aux && d.ldaux % 8 != 0)) return 0;
     if ((long)d.N * d.ldb * 2 >= (1L << 32) || d.M >= (1 << 24)) return 0;
     if ((((unsigned long)d.A | (unsigned long)d.B | (unsigned long)d.C | (unsigned long)d.C2 | (unsigned long)d.resid | (unsigned long)d.aux) & 15) != 0) return 0;

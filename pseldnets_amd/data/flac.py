@@ -46,11 +46,19 @@ def decode_flac(data, verify_md5=True):
     """bytes of a FLAC stream -> (int32 array [samples, channels], info). Frame CRCs are checked by the library, the MD5 signature here."""
     L = lib()
     info = flac_info(data)
-    cap = info['total_samples'] if info['total_samples'] > 0 else max(1, len(data) * 8)      # unknown length: no sample takes less than ~1 bit
-    out = np.empty((cap, info['channels']), dtype=np.int32)
-    n = L.pseld_flac_decode(data, len(data), out.ctypes.data_as(ctypes.c_void_p), cap)
-    if n < 0:
-        raise FlacError(L.pseld_host_last_error().decode())
+    # STREAMINFO may leave the length open (total_samples = 0: a streamed encode). The buffer then starts at what an ordinary compression
+    # ratio gives (~1 byte per sample and channel) and grows geometrically while the library reports it too small - never the len(data) * 8
+    # samples x channels of int32 a one-shot worst case would take (tens of GB for an ordinary file, ADVICE r5)
+    cap = info['total_samples'] if info['total_samples'] > 0 else max(4096, len(data) // max(1, info['channels']))
+    while True:
+        out = np.empty((cap, info['channels']), dtype=np.int32)
+        n = L.pseld_flac_decode(data, len(data), out.ctypes.data_as(ctypes.c_void_p), cap)
+        if n >= 0:
+            break
+        msg = L.pseld_host_last_error().decode()
+        if info['total_samples'] > 0 or not msg.startswith('output buffer too small') or cap >= len(data) * 8:
+            raise FlacError(msg)
+        cap = min(cap * 4, len(data) * 8)
     out = out[:n]
     if verify_md5 and info['md5'] != bytes(16):
         nbytes = (info['bits_per_sample'] + 7) // 8

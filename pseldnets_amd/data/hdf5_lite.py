@@ -29,13 +29,22 @@ class Hdf5FormatError(ValueError):
     pass
 
 
+_MAX_HEADER_BLOCKS, _MAX_HEADER_MESSAGES, _MAX_BTREE_DEPTH = 4096, 1 << 16, 64
+
+
 class _Reader:
     def __init__(self, f):
         self.f = f
         self.O = self.L = 8
         self.base = 0
+        f.seek(0, 2)
+        self.size = f.tell()
 
     def at(self, addr, n):
+        # label files are external input to a training run: every block is checked against the file before it is read (a negative or
+        # oversized length from a damaged header must raise, not allocate or hang - ADVICE r5)
+        if n < 0 or addr < 0 or self.base + addr + n > self.size:
+            raise Hdf5FormatError(f'block at {addr} (+{n}) lies outside the file ({self.size} bytes)')
         self.f.seek(self.base + addr)
         b = self.f.read(n)
         if len(b) != n:
@@ -238,7 +247,11 @@ class File(Group):
             size0 = rd.uint(head, p, szlen)
             blocks = [(addr + p + szlen, size0)]
             track = bool(flags & 4)
+            seen = 0
             while blocks:
+                seen += 1
+                if seen > _MAX_HEADER_BLOCKS or len(out) > _MAX_HEADER_MESSAGES:          # (a continuation chain that loops or never ends)
+                    raise Hdf5FormatError(f'object header at {addr}: more than {_MAX_HEADER_BLOCKS} continuation blocks / {_MAX_HEADER_MESSAGES} messages')
                 a, n = blocks.pop(0)
                 b = rd.at(a, n)
                 q = 0
@@ -258,7 +271,11 @@ class File(Group):
         nmsg = struct.unpack_from('<H', head, 2)[0]
         size = struct.unpack_from('<I', head, 8)[0]
         blocks = [(addr + 16, size)]
+        seen = 0
         while blocks and len(out) < nmsg + 64:
+            seen += 1
+            if seen > _MAX_HEADER_BLOCKS:
+                raise Hdf5FormatError(f'object header at {addr}: more than {_MAX_HEADER_BLOCKS} continuation blocks')
             a, n = blocks.pop(0)
             b = rd.at(a, n)
             q = 0
@@ -327,8 +344,12 @@ class File(Group):
         seg_size, seg = rd.uint(h, 8, rd.L), rd.uint(h, 8 + 2 * rd.L, rd.O)
         names = rd.at(seg, seg_size)
         links = {}
+        visited = set()
 
-        def walk(addr):
+        def walk(addr, depth=0):
+            if addr in visited or depth > _MAX_BTREE_DEPTH:               # (a child pointer that leads back into the tree)
+                raise Hdf5FormatError(f'group B-tree: node {addr} revisited or deeper than {_MAX_BTREE_DEPTH} levels')
+            visited.add(addr)
             b = rd.at(addr, 8 + 2 * rd.O)
             if b[:4] == b'TREE':
                 if b[4] != 0:
@@ -339,7 +360,7 @@ class File(Group):
                 for _ in range(used):
                     child = rd.uint(body, q, rd.O)
                     q += rd.O + rd.L
-                    walk(child)                             # (level > 0: further TREE nodes; level 0: symbol nodes)
+                    walk(child, depth + 1)                  # (level > 0: further TREE nodes; level 0: symbol nodes)
             elif b[:4] == b'SNOD':
                 n = struct.unpack_from('<H', b, 6)[0]
                 ent = rd.at(addr + 8, n * (2 * rd.O + 24))

@@ -344,7 +344,7 @@ class SwinEncoder:
             s1 = s2 = None
             if drop_scale is not None and self.rates[gi] > 0:
                 s1, s2 = drop_scale[gi, 0], drop_scale[gi, 1]
-            x_mid = xh2_pre = None
+            x_mid = None
             if FUSED_ATTN and FUSED_ATTN_TAIL and not self.attn_adapter and ops.swin_attn_fused_supported(x, res, heads):
                 # the whole attention half - norm1 -> qkv -> window attention -> proj -> DropPath + shortcut - in ONE kernel (csrc/swin.hip); it
                 # leaves the same saved operands as the four launches (nothing but x_mid in a no-grad forward)
@@ -370,10 +370,6 @@ class SwinEncoder:
                 a1, ad['attn'] = self._adapter_fwd(a0, b + 'attn.adapter.', resid=a0)
                 ad['a0'] = a0
                 x_mid = ops.add(x, ops.rowscale(a1, s1, L * C)) if s1 is not None else ops.add(x, a1)
-            elif not self.mlp_adapter and ops.resid_ln_supported(ao, C) and not self._mlp_fused(x, L):
-                # attn.proj + DropPath + shortcut with norm2 in the same epilogue (C = 384, knob RESIDLN384: off by default - measured)
-                x_mid, xh2_pre = ops.linear_resid_ln(ao, self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), x, a.p(b + 'norm2.weight'),
-                                                     a.p(b + 'norm2.bias'), rowscale=s1, rows_per_scale=L)
             else:
                 x_mid = ops.linear_fwd(ao, self._w(b + 'attn.proj.weight', dtype), a.p(b + 'attn.proj.bias'), resid=x,
                                        rowscale=s1, rows_per_scale=L)
@@ -387,7 +383,7 @@ class SwinEncoder:
                                          shift=shift, ad=ad))
                 x = x_out
                 continue
-            xh2 = xh2_pre if xh2_pre is not None else ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
+            xh2 = ops.layernorm_fwd(x_mid, a.p(b + 'norm2.weight'), a.p(b + 'norm2.bias'))
             if self.mlp_adapter:
                 xs, ad['mlp'] = self._adapter_fwd(xh2, b + 'mlp.adapter.')          # xs = adapter(x) (model_utilities.py:160-170)
             if GELU_DUAL and _mlp_panel(C, x_mid.shape[0]) and ops.mlp_panel_fwd_supported(xh2, 4 * C) and not self.lora:

@@ -460,25 +460,6 @@ def layernorm_bwd(dy, x, gamma, dgamma, dbeta, dres=None, merge_res=0, eps=1e-5,
     return dx
 
 
-def resid_ln_supported(x, N):
-    return bool(x.is_cuda and x.dim() == 2 and _lib.lib().pseld_gemm_resid_ln_supported(dtype_code(x), x.shape[0], N, x.shape[1]))
-
-
-def linear_resid_ln(x, w, bias, resid, gamma, beta, rowscale=None, rows_per_scale=1, eps=1e-5):
-    """y = resid + s * (x @ w^T + bias) and yn = LayerNorm(y) * gamma + beta in ONE launch (pseld_gemm_resid_ln: the 128 x 384 row-spanning
-    tile of the eight-phase kernel with the LayerNorm of the row it has just formed in its epilogue). Returns (y, yn)."""
-    _chk(x, w, bias, resid, gamma, beta, rowscale)
-    M, K = x.shape
-    N = w.shape[0]
-    assert w.shape == (N, K) and resid.shape == (M, N) and x.dtype == w.dtype == resid.dtype
-    y, yn = torch.empty_like(resid), torch.empty_like(resid)
-    rc = _lib.lib().pseld_gemm_resid_ln(dtype_code(x), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(resid), _lib.ptr(rowscale), rows_per_scale,
-                                        _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(yn), M, N, K, x.stride(0), w.stride(0), eps,
-                                        _lib.stream_ptr())
-    _lib.check(rc, "pseld_gemm_resid_ln")
-    return y, yn
-
-
 def dgrad_lnbwd_supported(dy, C):
     return bool(dy.is_cuda and dy.dim() == 2 and _lib.lib().pseld_gemm_dgrad_lnbwd_supported(dtype_code(dy), dy.shape[0], C, dy.shape[1]))
 

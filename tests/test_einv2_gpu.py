@@ -203,8 +203,8 @@ def test_train_entry_point_runs_the_einv2_networks(dev, argv, capsys, tmp_path):
 def test_train_entry_point_saves_and_resumes(dev, capsys, tmp_path):
     """The train entry writes <paths.output_dir>/checkpoints/last.ckpt at every epoch end and `ckpt_path=FILE` resumes from it (the
     reference: Lightning's ModelCheckpoint + src/train.py:49-50 `ckpt_path`): a run stopped after epoch 0 and resumed prints for epoch 1
-    exactly what the uninterrupted two-epoch run printed - weights, AdamW moments + step, StepLR epoch, the data generator and the
-    DropPath random streams all continue where they stopped."""
+    what the uninterrupted two-epoch run printed (to the run-to-run spread of the atomics in the bias-table gradients) - weights, AdamW
+    moments + step, StepLR epoch, the data generator and the DropPath random streams all continue where they stopped."""
     from pseldnets_amd import train
     argv = ['experiment=synth_maccdoa', 'model.kwargs.embed_dim=48', 'model.kwargs.depths=[2,2,2,2]', 'model.kwargs.num_heads=[2,4,8,16]',
             'model.batch_size=4', 'data.num_classes=5', 'trainer.limit_train_batches=5', 'model.optimizer.kwargs.lr=0.001', 'augment=default']
@@ -218,4 +218,8 @@ def test_train_entry_point_saves_and_resumes(dev, capsys, tmp_path):
     resumed = ep(out)
     print(whole, first, resumed)
     assert 'resumed from' in out
-    assert len(whole) == 2 and first == whole[:1] and resumed == whole[1:], (whole, first, resumed)
+    # (two runs of the same command agree to ~1e-4, not to the bit: the relative-position bias-table gradients are fp32 atomics; a resume
+    #  that dropped the weights, the AdamW moments or the data order would be off by tens of per cent)
+    val = lambda ln: float(ln.split('loss_all')[1])
+    assert len(whole) == 2 and len(first) == 1 and len(resumed) == 1 and resumed[0].startswith('epoch 1:'), (whole, first, resumed)
+    assert abs(val(first[0]) - val(whole[0])) < 2e-3 * val(whole[0]) and abs(val(resumed[0]) - val(whole[1])) < 2e-3 * val(whole[1]), (whole, first, resumed)

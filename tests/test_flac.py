@@ -99,3 +99,15 @@ def test_damaged_streams_are_errors(tmp_path):
     p.write_bytes(good)
     x, sr = F.read_flac(str(p), dtype='float32')
     assert sr == 24000 and x.dtype == np.float32 and np.array_equal(x, (pcm / 32768.0).astype(np.float32))          # sf.read(dtype='float32') scaling
+
+
+def test_unknown_length_streams_decode_without_a_worst_case_buffer():
+    """STREAMINFO with total_samples = 0 (a streamed encode): the decoder's output buffer starts small and grows (it used to be
+    len(data) * 8 samples x channels of int32); the samples and the MD5 check are those of the stream with the length filled in."""
+    F = _F()
+    pcm = _audio(40000, 4, 16, 7)
+    data = bytearray(E.encode(pcm, 24000, 16, 4096, ('fixed2', 'lpc8p12s9'), 2))
+    data[21] &= 0xF0                              # the 36-bit total-samples field: low nibble of byte 21 + bytes 22-25
+    data[22:26] = bytes(4)
+    got, info = F.decode_flac(bytes(data))
+    assert info['total_samples'] == 0 and np.array_equal(got, pcm)

@@ -17,7 +17,7 @@ def _knobs():
     _lib.set_knob('GEMM8', 1); _lib.set_knob('GEMM8_MINK', 128); _lib.set_knob('WGRAD8', 1)
     _lib.set_knob('GEMM8P', 0)           # the eight-phase kernel is the subject of this file; the panel tests switch the panel kernel on
     yield
-    for k in ('GEMM8', 'GEMM8_MINK', 'WGRAD8', 'GEMM8W_BN', 'RESIDLN384', 'LNBWD384', 'GEMM8P', 'GEMM8P_MINM'):
+    for k in ('GEMM8', 'GEMM8_MINK', 'WGRAD8', 'GEMM8W_BN', 'GEMM8P', 'GEMM8P_MINM'):
         _lib.set_knob(k, None)
     _lib.lib().pseld_gemm8_force_tile(0, 0)
     _lib.lib().pseld_gemm8p_force(0, -1)
@@ -60,8 +60,7 @@ def _run(dev, mode, x, w, b, extra, rs, rps):
 
 
 _SHAPES = [(256, 256, 128), (1000, 1152, 384), (777, 200, 192), (2048, 768, 1536), (3000, 4096, 256)]
-# (rows 64 = the 128 x 192 tile packed for two workgroups per CU: 192 columns, N a multiple of 192)
-_TILES = [(rows, bn, shp) for rows in (256, 128, 64) for bn in (256, 192) for shp in _SHAPES if rows != 64 or (bn == 192 and shp[1] % 192 == 0)]
+_TILES = [(rows, bn, shp) for rows in (256, 128) for bn in (256, 192) for shp in _SHAPES]
 
 
 @pytest.mark.parametrize("rows,bn,shape", _TILES)
@@ -95,14 +94,12 @@ def test_repeated_launches_are_bit_identical_and_rows_do_not_depend_on_the_batch
         x, w, b = _mk((M, K), 7).to(dev), _mk((N, K), 8, 0.05).to(dev), _mk((N,), 9, dtype=torch.float32).to(dev)
         fwd = (lambda xx: torch.cat(ops.linear_fwd(xx, w, b, gelu_dual=True), 1)) if gelu else (lambda xx: ops.linear_fwd(xx, w, b))
         first = None
-        for rows in (256, 128, 64):                    # 64 = the 128 x 192 tile packed for two workgroups per CU (bias from global memory)
-            for bn in (256, 192, 384):                 # 384 = the 128 x 384 row-spanning tile (no GELU-pair epilogue)
+        for rows in (256, 128):
+            for bn in (256, 192):
                 if bn == 192 and N % 192: continue
-                if rows == 64 and (bn != 192 or N % 192): continue
-                if bn == 384 and (rows != 128 or N % 96 or gelu): continue
                 _tile(rows, bn)
                 y = fwd(x).clone()
-                want = "6, 2, false>" if bn == 384 else (f"{3 if bn == 192 else 4}, {rows // 64}, false>" if rows != 64 else "3, 2, false, true>")
+                want = f"{3 if bn == 192 else 4}, {rows // 64}, false>"
                 assert _kernel().startswith('gemm8_kernel<') and _kernel().endswith(want), _kernel()
                 for _ in range(20):
                     assert torch.equal(y, fwd(x)), (M, N, K, rows, bn)
@@ -226,61 +223,3 @@ def test_grouped_weight_gradients_equal_the_single_launches(dev):
         rw = (g[0].double() * (g[4].double().repeat_interleave(rps)[:, None] if g[4] is not None else 1.0)).t() @ g[1].double()
         assert ((g[2].double() - rw).norm() / rw.norm()).item() < 1e-4
         assert ((g[2] - s[2]).norm() / s[2].norm()).item() < 1e-5 and ((g[3] - s[3]).norm() / s[3].norm()).item() < 1e-5
-
-
-# ---- LayerNorm in the epilogues of the 128 x 384 row-spanning tile (knobs RESIDLN384 / LNBWD384; off by default: measured) ----
-@pytest.mark.parametrize("M,K,scaled", [(1000, 384, True), (4096 + 77, 1536, False), (33000, 128, True)])
-def test_residual_layernorm_epilogue_equals_the_two_launch_path(dev, M, K, scaled):
-    """pseld_gemm_resid_ln (attn.proj -> norm2, mlp.fc2 -> next norm1: htsat.py:235-262): y is bit-equal to pseld_gemm's residual epilogue,
-    LayerNorm(y) within one bf16 rounding of a float64 LayerNorm of the STORED y (and of pseld_layernorm_fwd's output); ragged last row block."""
-    from pseldnets_amd import ops, _lib
-    C, L = 384, 64
-    x, w, b = _mk((M, K), 1).to(dev), _mk((C, K), 2, K ** -0.5).to(dev), _mk((C,), 3, 0.1, torch.float32).to(dev)
-    r = _mk((M, C), 4).to(dev)
-    gamma, beta = (1 + _mk((C,), 5, 0.1, torch.float32)).to(dev), _mk((C,), 6, 0.1, torch.float32).to(dev)
-    g = torch.Generator().manual_seed(7)
-    rs = ((torch.rand((M + L - 1) // L, generator=g) > 0.2).float() / 0.8).to(dev) if scaled else None
-    assert not ops.resid_ln_supported(x, C)                      # off by default
-    _lib.set_knob('RESIDLN384', 1)
-    assert ops.resid_ln_supported(x, C)
-    y1, n1 = ops.linear_resid_ln(x, w, b, r, gamma, beta, rowscale=rs, rows_per_scale=L)
-    assert _kernel().startswith('gemm8_kernel<4,')
-    y2 = ops.linear_fwd(x, w, b, resid=r, rowscale=rs, rows_per_scale=L)
-    n2 = ops.layernorm_fwd(y2, gamma, beta)
-    assert torch.equal(y1, y2)
-    ref = torch.nn.functional.layer_norm(y1.double(), (C,), gamma.double(), beta.double())
-    tol = 2.0 ** -8 * ref.abs().max().item()                     # one bf16 rounding of the largest output
-    assert (n1.double() - ref).abs().max().item() <= tol
-    assert (n1.float() - n2.float()).abs().max().item() <= 2 * tol
-    y3, n3 = ops.linear_resid_ln(x, w, b, r, gamma, beta, rowscale=rs, rows_per_scale=L)
-    assert torch.equal(y1, y3) and torch.equal(n1, n3)           # fixed-order row sums: run-to-run bit identity
-
-
-@pytest.mark.parametrize("M,K,with_res", [(1000, 1152, True), (4096 + 77, 1536, True), (33000, 128, False)])
-def test_layernorm_backward_epilogue_at_384_channels(dev, M, K, with_res):
-    """pseld_gemm_dgrad_lnbwd at C = 384 (knob LNBWD384): dx, d(gamma), d(beta) against float64 formed from the bf16-rounded Linear input gradient
-    - what the two-launch path (pseld_gemm + pseld_layernorm_bwd, test_ops_gpu.py) stores between its launches - no worse than 1.5 x that
-    path's own error (dx is rounded once more before the bypass gradient is added)."""
-    from pseldnets_amd import ops, _lib
-    C = 384
-    dy, x = _mk((M, K), 1, 0.2).to(dev), _mk((M, C), 2).to(dev)
-    w = _mk((K, C), 3, C ** -0.5).to(dev); wt = w.t().contiguous()
-    dres = _mk((M, C), 4).to(dev) if with_res else None
-    gamma = (1 + _mk((C,), 5, 0.1, torch.float32)).to(dev)
-    ga, gb = torch.zeros(2 * C, device=dev), torch.zeros(2 * C, device=dev)
-    dxh2 = ops.linear_dgrad(dy, w, wt=wt)
-    d2 = ops.layernorm_bwd(dxh2, x, gamma, ga[:C], ga[C:], dres=dres)
-    _lib.set_knob('LNBWD384', 1)
-    d1 = ops.linear_dgrad_lnbwd(dy, wt, x, gamma, gb[:C], gb[C:], dres=dres)
-    assert _kernel().startswith('gemm8_kernel<5,')
-    dxh = dxh2.double()
-    X = x.double(); mu = X.mean(1, keepdim=True); rstd = (X.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt(); xh = (X - mu) * rstd
-    gy = dxh * gamma.double()
-    ref = rstd * (gy - gy.mean(1, keepdim=True) - xh * (gy * xh).mean(1, keepdim=True)) + (dres.double() if with_res else 0)
-    e1 = ((d1.double() - ref).norm() / ref.norm()).item(); e2 = ((d2.double() - ref).norm() / ref.norm()).item()
-    assert e1 <= max(1.5 * e2, 3e-3), (e1, e2)
-    for got, want in ((gb[:C], (dxh * xh).sum(0)), (gb[C:], dxh.sum(0))):
-        assert ((got.double() - want).norm() / want.norm()).item() <= 1e-4
-    gc = torch.zeros(2 * C, device=dev)
-    d3 = ops.linear_dgrad_lnbwd(dy, wt, x, gamma, gc[:C], gc[C:], dres=dres)
-    assert torch.equal(d1, d3) and torch.equal(gb, gc)            # no atomics: bit-reproducible

@@ -91,3 +91,33 @@ def test_what_the_subset_does_not_cover_is_refused_not_misread(tmp_path):
             for fn in hf.keys():
                 for k in ('se', 'azi', 'ele'):
                     hf[f'{fn}/accdoa/{k}'][...]
+
+
+def test_damaged_files_raise_instead_of_hanging(tmp_path):
+    """Label files are external input to a training run: a truncated file, a block address / length outside the file and a group
+    B-tree whose child pointer leads back into the tree must raise Hdf5FormatError - not recurse for ever, not allocate the bogus length."""
+    H = _lib()
+    raw = bytearray(open(os.path.join(H5, 'adpit.h5'), 'rb').read())
+    # (1) truncated behind the superblock: every later block lies outside the file
+    p = tmp_path / 'cut.h5'
+    p.write_bytes(bytes(raw[:600]))
+    with pytest.raises((H.Hdf5FormatError, NotImplementedError)):
+        with H.File(str(p)) as hf:
+            list(hf.keys()); hf['mix0/adpit/se'][:]
+    # (2) a B-tree node that names itself as its first child
+    i = raw.find(b'TREE')
+    assert i > 0
+    bad = bytearray(raw)
+    O = 8
+    bad[i + 8 + 2 * O + 8: i + 8 + 2 * O + 8 + O] = i.to_bytes(O, 'little')       # child 0 (behind key 0) <- the node's own address
+    p2 = tmp_path / 'loop.h5'
+    p2.write_bytes(bytes(bad))
+    with pytest.raises(H.Hdf5FormatError):
+        with H.File(str(p2)) as hf:
+            list(hf.keys()); [list(hf[k].keys()) for k in hf.keys()]
+    # (3) the reader refuses lengths that leave the file
+    with H.File(os.path.join(H5, 'adpit.h5')) as hf:
+        with pytest.raises(H.Hdf5FormatError):
+            hf._rd.at(10, 1 << 40)
+        with pytest.raises(H.Hdf5FormatError):
+            hf._rd.at(len(raw) - 4, 16)

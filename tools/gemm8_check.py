@@ -31,7 +31,7 @@ def run(mode, x, w, b, extra, rs, rps, on, cat=True, rows=0):
     if on == 'p':                              # the row-panel-stationary kernel (gemm8p.hip): rows = (16-row blocks per wave or 0, stagger -1 / 0 / 1)
         _lib.set_knob('GEMM8P', 1); _lib.set_knob('GEMM8P_MINM', 1)
         L.pseld_gemm8p_force(rows[0], rows[1]); rows = 0
-    L.pseld_gemm8_force_tile(rows, on if on in (192, 256, 384) else 0)
+    L.pseld_gemm8_force_tile(rows, on if on in (192, 256) else 0)
     _lib.set_knob('GEMM8_MINK', 128)
     if mode == 'plain': return ops.linear_fwd(x, w, b, rowscale=rs, rows_per_scale=rps)
     if mode == 'resid': return ops.linear_fwd(x, w, b, resid=extra, rowscale=rs, rows_per_scale=rps)
@@ -63,9 +63,7 @@ if 'check' in what:
     for (M, N, K) in ((256, 256, 128), (512, 384, 384), (1000, 1152, 384), (4096, 1536, 384), (777, 200, 192), (50000, 576, 192), (70001, 384, 384), (2048, 768, 3072),
                       (12288, 2304, 768), (3000, 4096, 256)):
         for mode in ('plain', 'resid', 'gelu', 'mulaux'):
-          for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128), (192, 64), (384, 128)):
-            if rows == 64 and N % 192: continue                  # (rows 64 = the 128 x 192 tile packed for two workgroups per CU)
-            if bn == 384 and (N % 96 or mode == 'gelu'): continue   # (the 128 x 384 row-spanning tile)
+          for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128)):
             for scaled in (False, True):
                 if mode == 'gelu' and scaled: continue
                 x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
@@ -74,7 +72,7 @@ if 'check' in what:
                 rps = 64
                 rs = (torch.rand((M + rps - 1) // rps, device=dev) + 0.5) if scaled else None
                 y8 = run(mode, x, w, b, extra, rs, rps, bn, rows=rows).float()
-                if rows in (128, 64) or bn == 384:       # every tile shape sums K in the same order: same bits
+                if rows == 128:       # every tile shape sums K in the same order: same bits
                     same = torch.equal(y8, run(mode, x, w, b, extra, rs, rps, bn, rows=256).float())
                     if not same: print(f"M={M} N={N} K={K} {mode} bn={bn}: 128-row tile differs from the 256-row tile   <-- FAIL")
                 if (bn, rows) == (256, 256) and K in (192, 384) and N % 64 == 0:      # the row-panel-stationary kernel: the same bits again
@@ -96,7 +94,7 @@ if 'check' in what:
                 print(f"M={M:6d} N={N:5d} K={K:5d} {mode:6s} bn={bn} rows={rows} scaled={int(scaled)}: gemm8 max {e8:.2e} l2 {l8:.2e} | old max {e0:.2e} l2 {l0:.2e}{flag}")
     # race screen: the same product many times must give bit-identical results
     x = torch.randn(49152, 384, device=dev).to(dt); w = (torch.randn(1536, 384, device=dev) * 0.05).to(dt); b = torch.randn(1536, device=dev)
-    for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128), (192, 64), (384, 128), ('p', (2, 0)), ('p', (3, 0)), ('p', (2, 1)), ('p', (3, 1))):
+    for bn, rows in ((256, 256), (192, 256), (256, 128), (192, 128), ('p', (2, 0)), ('p', (3, 0)), ('p', (2, 1)), ('p', (3, 1))):
         y = run('plain', x, w, b, None, None, 1, bn, rows=rows).clone()
         bad = 0
         for _ in range(30):
@@ -120,7 +118,7 @@ if 'square' in what:
 
 if 'shapes' in what:
     B = int(os.environ.get('CHUNKS', '192'))
-    VARS = (((256, 256), 'r256c256'), ((192, 256), 'r256c192'), ((256, 128), 'r128c256'), ((192, 128), 'r128c192'), ((192, 64), 'p128c192x2'), ((384, 128), 'r128c384'), ((True, 0), 'auto'), ((False, 0), 'old'))
+    VARS = (((256, 256), 'r256c256'), ((192, 256), 'r256c192'), ((256, 128), 'r128c256'), ((192, 128), 'r128c192'), ((True, 0), 'auto'), ((False, 0), 'old'))
     if os.environ.get('PANEL', '1') != '0':
         VARS = (((256, 256), 'r256c256'), ((192, 256), 'r256c192'), ((True, 0), 'auto'), (('p', (0, 1)), 'panel'), (('p', (0, 0)), 'panel-nostag'), (('p', (2, 1)), 'panel-mb2'), (('p', (4, 1)), 'panel-mb4'))
     tot = {k: 0.0 for k, _ in VARS}
