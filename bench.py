@@ -178,14 +178,15 @@ class KernelTimer:
 def pmc_traffic(args, sym=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters. Counters cannot be read from inside this process: the figure is the
     one measured with rocprofv3 on this same command (separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
-    reduced per launch of one kernel symbol by tools/pmc_kernel.py and committed under profiles/r05_pmc/ - one file per symbol that has led
+    reduced per launch of one kernel symbol by tools/pmc_kernel.py and committed under profiles/r06_pmc/ (r05_pmc/ before) - one file per symbol that has led
     the step (two instantiations of the eight-phase kernel are within 2 % of each other and trade places between runs)."""
     if args.backbone != 'htsat' or args.dtype != 'bf16' or args.clips != 32 or args.chunks:
         return None
     cands = []
-    if sym:
-        cands.append(os.path.join(ROOT, 'profiles', 'r05_pmc', 'pmc_' + ''.join(c if c.isalnum() else '_' for c in sym) + '.json'))
-    cands.append(os.path.join(ROOT, 'profiles', 'r05_dominant_kernel_pmc.json'))
+    for rnd in ('r06', 'r05'):          # the newest round's passes first
+        if sym:
+            cands.append(os.path.join(ROOT, 'profiles', rnd + '_pmc', 'pmc_' + ''.join(c if c.isalnum() else '_' for c in sym) + '.json'))
+        cands.append(os.path.join(ROOT, 'profiles', rnd + '_dominant_kernel_pmc.json'))
     for path in cands:
         if os.path.exists(path):
             with open(path) as f:
@@ -578,9 +579,8 @@ def main():
         # rocprofv3 --pmc passes of this command cut at stage markers by tools/pmc_stages.py)
         st = timer.by_stage()
         st_pmc = {}
-        sp = os.path.join(ROOT, 'profiles', 'r05_stage_table.json')
-        if not os.path.exists(sp):
-            sp = os.path.join(ROOT, 'profiles', 'r04_stage_table.json')
+        sp = next((q for q in (os.path.join(ROOT, 'profiles', r + '_stage_table.json') for r in ('r06', 'r05', 'r04')) if os.path.exists(q)),
+                  os.path.join(ROOT, 'profiles', 'r04_stage_table.json'))
         if args.backbone == 'htsat' and args.dtype == 'bf16' and args.clips == 32 and not args.chunks and os.path.exists(sp):
             with open(sp) as f:
                 st_pmc = json.load(f).get('stages', {})
