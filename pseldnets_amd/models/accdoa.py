@@ -109,20 +109,25 @@ class HTSAT(HTSATNetBase):
         dy = douts[0] if isinstance(douts, (tuple, list)) else douts
         B, dt = saved['B'], self.compute_dtype
         a = self.arena
-        ops.stage('head+loss')
-        dxn = self.head.backward(dy, saved['head'], B, dt)
-        dx = self.enc.backward_final(dxn, saved['fin'])
-        hi = a.size
-        for li in reversed(range(self.enc.nl)):
-            ops.stage(f'stage{li}')
-            dx = self.enc.backward_layer(li, dx, saved['layers'][li], B)
-            if on_range_done is not None and li in (3, 2):     # buckets: {stage3+norm+head}, {stage2}, {rest}
-                lo = a.offsets[self.enc.first_param_of_layer(li)][0]
-                on_range_done(lo, hi)
-                hi = lo
-        ops.stage('front')
-        dw, db = self._bn_grads()
-        self.enc.backward_patch(dx, saved['patch'], saved['feat'], saved['mean_rstd'], dw, db, accumulate_bn=False)
+        ops.defer_stage_joins(on_range_done is None)     # no gradient range leaves before the end: one join of the weight-gradient stream, below
+        try:
+            ops.stage('head+loss')
+            dxn = self.head.backward(dy, saved['head'], B, dt)
+            dx = self.enc.backward_final(dxn, saved['fin'])
+            hi = a.size
+            for li in reversed(range(self.enc.nl)):
+                ops.stage(f'stage{li}')
+                dx = self.enc.backward_layer(li, dx, saved['layers'][li], B)
+                if on_range_done is not None and li in (3, 2):     # buckets: {stage3+norm+head}, {stage2}, {rest}
+                    lo = a.offsets[self.enc.first_param_of_layer(li)][0]
+                    on_range_done(lo, hi)
+                    hi = lo
+            ops.stage('front')
+            dw, db = self._bn_grads()
+            self.enc.backward_patch(dx, saved['patch'], saved['feat'], saved['mean_rstd'], dw, db, accumulate_bn=False)
+            ops.join_wgrads(dx.device)
+        finally:
+            ops.defer_stage_joins(False)
         if on_range_done is not None:
             on_range_done(0, hi)
 

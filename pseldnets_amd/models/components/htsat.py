@@ -445,7 +445,7 @@ class SwinEncoder:
         if self._defer is not None:
             self._defer.flush()
         ops.bias_table_grad_batched(rpb['acc'], self.arena.grad, rpb['desc'][li], self.depths[li], self.stage_dims(li)[1])
-        ops.join_wgrads(dx.device)            # the stage's weight gradients are complete before its gradient range is all-reduced
+        ops.join_wgrads(dx.device, final=False)      # the stage's weight gradients are complete before its gradient range is all-reduced (skipped without a group)
         return dx
 
     def _flush_wgroup(self):

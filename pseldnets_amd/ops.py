@@ -193,8 +193,22 @@ def linear_wgrad_side(dy, x, dw, **kw):
     st['keep'].append((dy, x, kw.get('rowscale')))
 
 
-def join_wgrads(device):
-    """The current stream waits for every weight gradient launched on the second stream so far."""
+# Without a process group nothing reads a weight gradient before the optimiser: the per-stage joins (which exist for the stage's gradient-range
+# all-reduce) are then skipped and the backward pass ends with ONE join (round 6: the dispatch timeline showed 90 us of main-queue gaps at the
+# stage joins of the single-GPU step). PSELD_WGRAD_JOIN_DEFER=0 keeps every join. Read once at import.
+_join = {'defer_env': _env_int('PSELD_WGRAD_JOIN_DEFER', '1') == 1, 'deferred': False}
+
+
+def defer_stage_joins(on):
+    """Set by the backward pass: True when no gradient range is all-reduced stage by stage (single process)."""
+    _join['deferred'] = bool(on) and _join['defer_env']
+
+
+def join_wgrads(device, final=True):
+    """The current stream waits for every weight gradient launched on the second stream so far. final=False marks a per-stage join, which is
+    skipped while defer_stage_joins(True) holds (the operands stay referenced until the final join)."""
+    if not final and _join['deferred']:
+        return
     st = _side.get(device.index) if device.type == 'cuda' else None
     if st is not None and st['keep']:
         torch.cuda.current_stream(device).wait_stream(st['stream'])
