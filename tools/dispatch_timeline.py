@@ -16,6 +16,7 @@ import csv, json, re, sys, statistics
 def load(path):
     rows = list(csv.DictReader(open(path, newline='')))
     out = []
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))            # host launch order: a step is then the same run of dispatches in every step
     for r in rows:
         out.append(dict(name=r['Kernel_Name'], q=r['Queue_Id'], s=int(r['Start_Timestamp']), e=int(r['End_Timestamp']),
                         grid=int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), vgpr=int(r['VGPR_Count']) + int(r['Accum_VGPR_Count']),
@@ -42,6 +43,11 @@ def main():
     def wall(rows, ab):
         return rows[ab[1] - 1]['e'] - rows[ab[0] - 1]['e']
     sa, sb = sa[3:], sb[3:]
+    # steady-state steps only: the most common dispatch count (the last step of a run has no next batch to prefetch features for)
+    import collections
+    for cuts in (sa, sb):
+        n = collections.Counter(b - a for a, b in cuts).most_common(1)[0][0]
+        cuts[:] = [c for c in cuts if c[1] - c[0] == n]
     ia = sorted(range(len(sa)), key=lambda i: wall(A, sa[i]))[len(sa) // 2]
     ib = sorted(range(len(sb)), key=lambda i: wall(B, sb[i]))[len(sb) // 2]
     a = A[sa[ia][0]:sa[ia][1]]
