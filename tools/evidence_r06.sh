@@ -48,7 +48,7 @@ run bench_n1_third --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 timeout 600 python3 tools/mlp8f_check.py time stamps > $O/mlp8f_time.log 2>&1; grep "two launches" $O/mlp8f_time.log
 timeout 600 python3 tools/gemm8p_stamps.py > $O/gemm8p_stamps.log 2>&1; grep -c "^==" $O/gemm8p_stamps.log
 tools/experiments/wgrad_atomic > $O/wgrad_atomic.log 2>&1; tail -2 $O/wgrad_atomic.log | cut -c1-200
-tools/experiments/membw > $O/membw.log 2>&1; grep -E "copy   U=4 +8|read   U=4 +8|one f4" $O/membw.log
+(cd tools/experiments && for b in membw last_arriver wgrad_atomic delivery_depth; do [ -x $b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o $b $b.hip; done) >/dev/null 2>&1; tools/experiments/membw > $O/membw.log 2>&1; grep -E "copy   U=4 +8|read   U=4 +8|one f4" $O/membw.log
 tools/experiments/last_arriver > $O/last_arriver.log 2>&1
 STAGES=1,2,3 python3 tools/gemm8_check.py square shapes > $O/gemm8_shapes.log 2>&1; tail -1 $O/gemm8_shapes.log
 CHUNKS=32 STAGES=1,2,3 python3 tools/gemm8_check.py shapes > $O/gemm8_shapes_chunks32.log 2>&1; tail -1 $O/gemm8_shapes_chunks32.log
