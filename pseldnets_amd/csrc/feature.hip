@@ -166,7 +166,10 @@ __device__ __forceinline__ void fft32(f32x2 (&x)[32]) {
 //    seven values arrive as two ds_read_b128 (was: five dependent LDS reads per weight, the widest filter setting the trip count
 //    of all 16 filters of its pass: 26 iterations of 25 instructions), the runs of one filter meet by two lane shuffles;
 //  * the next frame's samples are requested before the split / mel phase of the current one.
-constexpr int MEL_CAP = 12;                // bins per run
+#ifndef PSELD_MEL_CAP
+#define PSELD_MEL_CAP 12
+#endif
+constexpr int MEL_CAP = PSELD_MEL_CAP;     // bins per run
 constexpr int CAP_LD = (MEL_CAP + 1) & ~1;     // weights per run in the LDS table (pairs)
 constexpr int VBINS = 528;                 // bins per value plane (513 + the overhang of a zero-weighted run tail)
 constexpr int VI_OFF = VBINS * 16;         // byte offset of the IV plane inside a wave's region (2 * 8448 = 16896 = 2 * FFT_LDS * 8)
