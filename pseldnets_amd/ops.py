@@ -159,7 +159,10 @@ def _env_int(name, dflt):
 
 
 # second-stream weight gradients: read once at import; ops.set_wgrad_stream() switches in-process (bench.py's one-stream instrumented steps)
-_wgrad_stream = {'on': _env_int('PSELD_WGRAD_STREAM', '1') == 1, 'min_chunks': _env_int('PSELD_WGRAD_STREAM_MIN_CHUNKS', '64'),
+# (min_chunks, round 6: with a stage's weight gradients grouped into ONE launch at <= 64 chunks there are four forks per step, not fifty, and
+#  the second stream pays from 36 chunks on - 36: 5.67 / 6.04 against 6.11 / 6.10 ms, 40: 5.94 / 5.85 against 6.28, 44: 6.19 against 6.64, 48: 6.46
+#  against 6.91, 56: 7.05 against 7.47; at 32 chunks it is a wash, 5.58-5.84 against 5.66-5.67: profiles/r06_ab_runs.txt, c<chunks>_*. It was 64.)
+_wgrad_stream = {'on': _env_int('PSELD_WGRAD_STREAM', '1') == 1, 'min_chunks': _env_int('PSELD_WGRAD_STREAM_MIN_CHUNKS', '36'),
                  'prio': _env_int('PSELD_WGRAD_STREAM_PRIO', '-1')}
 
 
@@ -173,8 +176,8 @@ def set_wgrad_stream(on=None, min_chunks=None):
 
 
 def wgrad_side_enabled(device, n_chunks):
-    """The second stream pays from ~64 chunks per step on (measured: at the reference's batch of 32 the ~50 forks per step cost more
-    host time than the overlap returns); never while a hipGraph is being captured. PSELD_WGRAD_STREAM=0 disables it."""
+    """The second stream pays from 36 chunks per step on (measured, round 6; at the reference's batch of 32 it is a wash and stays off);
+    never while a hipGraph is being captured. PSELD_WGRAD_STREAM=0 disables it."""
     return (device.type == 'cuda' and _wgrad_stream['on'] and n_chunks >= _wgrad_stream['min_chunks']
             and not torch.cuda.is_current_stream_capturing())
 

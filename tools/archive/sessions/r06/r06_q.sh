@@ -1,0 +1,9 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r06; mkdir -p $O; cd $R
+run() { name=$1; shift; env "$@" 2> $O/$name.err | tail -1 > $O/$name.json; echo "$name $(python3 -c "import json;d=json.load(open('$O/$name.json'));print(d['value'],d['ms_per_step'])" 2>&1)"; }
+for ch in 36 40 44 56; do
+for rep in 1 2; do
+run c${ch}_one_stream_$rep PSELD_WGRAD_STREAM_MIN_CHUNKS=64 timeout 600 python3 bench.py --chunks $ch --steps 100 --warmup 10 --no-cpu-baseline --no-kernel-timing
+run c${ch}_side_stream_$rep PSELD_WGRAD_STREAM_MIN_CHUNKS=1 timeout 600 python3 bench.py --chunks $ch --steps 100 --warmup 10 --no-cpu-baseline --no-kernel-timing
+done
+done
