@@ -242,7 +242,8 @@ int pseld_cross_stitch_bwd(int dtype, const void* x, const void* y, const float*
 int pseld_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, float* lse, int B, int res, int C,
                           int heads, int shift, void* stream);
 long pseld_window_attn_bwd_workspace(int heads);
-/* Diagnostic only: 64 x 8 x 8 u64 s_memtime stamps (phases of the first windows of the first workgroups of the backward). */
+/* Diagnostic only: (64 x 8 x 8 + 2 x 1024) u64 - s_memtime stamps (phases of the first windows of the first workgroups of the backward), then
+   for the head_dim-24 bf16 backward the entry / exit time of every workgroup in s_memrealtime ticks (100 MHz). */
 void pseld_attn_set_debug_buffer(void* device_u64_buffer);
 int pseld_window_attn_bwd(int dtype, const void* qkv, const float* bias_table, const void* out, const float* lse,
                           const void* dout, void* dqkv, float* dbias_table, int B, int res, int C, int heads, int shift,

@@ -740,8 +740,8 @@ __device__ __forceinline__ void unpack8f(const f32x4& p, float (&v)[8]) {
 //   * row fragments are read through lane r -> LDS row swap23(r) and transposed column reads fetch column swap23(lane) (the 4-column
 //     piece index of ds_read_b64_tr_b16 is bit-swapped): every accumulator operand then sees the natural k-order and a lane's
 //     accumulator registers are 8 CONSECUTIVE head dims - dq / dk / dv go back into the tile as 16-byte pieces;
-//   * d(bias table) is binned on the fly into [4 heads][225] LDS counters by ds_add_f32 (64 per lane and window) and flushed once per
-//     workgroup onto ONE representative (key, query) pair per table index of the [heads][64][64] accumulator the callers reduce.
+//   * d(bias table): dS^T is summed in registers over the workgroup's windows (by tile class: 48 values per lane) and flushed once per
+//     workgroup with fp32 atomics onto the [heads][64][64] accumulator the callers reduce by relative position.
 // PROJ (C = 96: the four heads are the whole row): the projection's input gradient is computed in the kernel - `dout` holds d(x_mid), the
 // rows land in the dO segment by DMA like any operand, each wave turns its 24 columns into dO = (s * dY) Wproj in place (12 MFMAs against an
 // LDS image of Wproj^T, between two barriers), and the saved output O (only needed for delta) comes straight from global memory into
@@ -769,6 +769,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
 
     const int lane0 = threadIdx.x & 63, hl = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int hg = blockIdx.y;
+    // diagnostic: entry / exit of EVERY workgroup on the 100 MHz clock all XCDs share (s_memtime counters differ between XCDs)
+    const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const bool life = a.dbg && threadIdx.x == 0 && wg_lin < 1024;
+    if (life) a.dbg[4096 + 2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
     for (int i = threadIdx.x; i < HG * 225; i += 256) {
         const int hh = i / 225, idx = i - hh * 225;
         btab[i] = a.bias_table[idx * a.heads + hg * HG + hh] * LOG2E;
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
     const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 64;
     for (int wi = blockIdx.x; wi < a.n_win_total; wi += gridDim.x, ++it) {
         __syncthreads();                                  // the previous window's rows have left the tile
-        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 0] = __builtin_amdgcn_s_memtime();
+        if (stamp && it < 7) a.dbg[(blockIdx.x * 8 + it) * 8 + 0] = __builtin_amdgcn_s_memtime();
         if (threadIdx.x < 64) {
             long tk; int lb;
             window_token(a, wi, threadIdx.x, tk, lb);
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
             if (a.rowscale) { const int nw = a.res >> 3; sfac = a.rowscale[wi / (nw * nw)]; }
         }
         __syncthreads();                                  // (hipcc drains the DMA with vmcnt(0) in front of this barrier)
-        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 1] = __builtin_amdgcn_s_memtime();
+        if (stamp && it < 7) a.dbg[(blockIdx.x * 8 + it) * 8 + 1] = __builtin_amdgcn_s_memtime();
         if (PROJ) {
             // dO^T[c'][m] = Wproj^T[c'][:] . dY[m][:] for this head's 24 columns c' (rows through swap23) and both token tiles, then scaled by
             // the DropPath factor and written over the dY rows' own columns once every wave has read the rows
@@ -1010,14 +1014,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
             put(dqT[0], a.scale, pr, cq, lane >> 5);
             put(dqT[1], a.scale, 32 + pr, cq, lane >> 5);
         }
-        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 2] = __builtin_amdgcn_s_memtime();
+        if (stamp && it < 7) a.dbg[(blockIdx.x * 8 + it) * 8 + 2] = __builtin_amdgcn_s_memtime();
         __syncthreads();
-        if (stamp && it < 8) { a.dbg[(blockIdx.x * 8 + it) * 8 + 3] = __builtin_amdgcn_s_memtime(); a.dbg[(blockIdx.x * 8 + it) * 8 + 4] = a.dbg[(blockIdx.x * 8 + it) * 8 + 3]; }
+        if (stamp && it < 7) { a.dbg[(blockIdx.x * 8 + it) * 8 + 3] = __builtin_amdgcn_s_memtime(); a.dbg[(blockIdx.x * 8 + it) * 8 + 4] = a.dbg[(blockIdx.x * 8 + it) * 8 + 3]; }
         for (int sel = 0; sel < 3; ++sel)
             window_copy<bf16_t, false>(tile, STR, (bf16_t*)a.dqkv, 3 * a.C, sel * a.C + hg * GW, sel * GW, GW, toks);
-        if (stamp && it < 8) a.dbg[(blockIdx.x * 8 + it) * 8 + 5] = __builtin_amdgcn_s_memtime();
+        if (stamp && it < 7) a.dbg[(blockIdx.x * 8 + it) * 8 + 5] = __builtin_amdgcn_s_memtime();
     }
-    // flush d(bias): dbias_acc[head][key][query] += dsum (row i <-> key swap23(i), lane <-> query swap23(lane))
+    // flush d(bias): dbias_acc[head][key][query] += dsum (row i <-> key swap23(i), lane <-> query swap23(lane)): 48 fire-and-forget atomics per
+    // lane. Their drain (every workgroup of a head group hits the same 4 096 words: 10 us of the stage-2 launch, 22 us of 60 at stage 3 when
+    // the launch runs alone, tools/attn_life.py) is memory-system time, not CU time: in the step the next kernels' workgroups take the CUs
+    // meanwhile. Round 6 tried folding the 3 072 values of a head to its 225 table sums in the workgroup first (LDS layout + two passes,
+    // 2.4 us of issue time per workgroup, 13x fewer atomics, spread over the pairs of each index): alone 60.1 -> 46.9 / 89.3 -> 85.0 /
+    // 162.7 -> 165.7 us at stages 3 / 2 / 1, in the step 17.92 -> 17.97 ms and 5.58 -> 5.69 ms at 32 chunks: not kept (docs/EXPERIMENTS.md).
     {
         const int r = lane0 & 31, h2 = lane0 >> 5, pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
         float* dst = a.dbias_acc + (long)(hg * HG + hl) * 4096;
@@ -1029,6 +1038,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd24_kernel(AttnArgs a) {
                 atomicAdd(dst + (kt * 32 + 16 * (e >> 3) + 8 * h2 + (e & 7)) * 64 + qt * 32 + pr, dsum[y][e]);
         }
     }
+    if (life) { __builtin_amdgcn_s_waitcnt(0); a.dbg[4096 + 2 * wg_lin + 1] = __builtin_amdgcn_s_memrealtime(); }
 }
 constexpr size_t BWD24_LDS = 64 * 976 + 4 * 225 * 4 + 64 * 4 * 4 + 64 * 8 + 65 * 4 + 12;
 constexpr size_t BWD24P_LDS = 64 * 784 + 4 * 225 * 4 + 64 * 4 * 4 + 64 * 8 + 65 * 4 + 12 + 16 + 96 * 208;

@@ -11,11 +11,11 @@ for li, (C, heads) in enumerate(((96, 4), (192, 8), (384, 16), (768, 32))):
     bt = torch.randn(225, heads, device=dev) * 0.1
     fn = lambda: ops.window_attn_fwd(qkv, bt, B, res, heads, 0)
     fn(); fn(); torch.cuda.synchronize()
-    dbg = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(64 * 8 * 8 + 2048, dtype=torch.int64, device=dev)
     L.pseld_attn_set_debug_buffer(dbg.data_ptr())
     fn(); torch.cuda.synchronize()
     L.pseld_attn_set_debug_buffer(None)
-    d = dbg.view(64, 8, 8).double().cpu()
+    d = dbg[:4096].view(64, 8, 8).double().cpu()
     d = d[:, 1:]                                   # skip the first window of each workgroup (cold)
     ok = (d[..., 0] > 0) & (d[..., 5] > 0)
     ph = [(d[..., i + 1] - d[..., i])[ok].median().item() for i in range(5)]
