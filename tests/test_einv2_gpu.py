@@ -207,7 +207,7 @@ def test_train_entry_point_saves_and_resumes(dev, capsys, tmp_path):
     moments + step, StepLR epoch, the data generator and the DropPath random streams all continue where they stopped."""
     from pseldnets_amd import train
     argv = ['experiment=synth_maccdoa', 'model.kwargs.embed_dim=48', 'model.kwargs.depths=[2,2,2,2]', 'model.kwargs.num_heads=[2,4,8,16]',
-            'model.batch_size=4', 'data.num_classes=5', 'trainer.limit_train_batches=5', 'model.optimizer.kwargs.lr=0.001', 'augment=default']
+            'model.batch_size=4', 'data.num_classes=5', 'trainer.limit_train_batches=5', 'model.optimizer.kwargs.lr=0.0001', 'augment=default']
     ep = lambda out: [ln.split('  lr')[0] for ln in out.splitlines() if ln.startswith('epoch')]
     train.main(argv + ['trainer.max_epochs=2', f'paths.output_dir={tmp_path / "a"}'])
     whole = ep(capsys.readouterr().out)
@@ -218,8 +218,10 @@ def test_train_entry_point_saves_and_resumes(dev, capsys, tmp_path):
     resumed = ep(out)
     print(whole, first, resumed)
     assert 'resumed from' in out
-    # (two runs of the same command agree to ~1e-4, not to the bit: the relative-position bias-table gradients are fp32 atomics; a resume
-    #  that dropped the weights, the AdamW moments or the data order would be off by tens of per cent)
+    # (two runs of the same command do not agree to the bit: the relative-position bias-table gradients are fp32 atomics. Measured over five
+    #  runs, tools/archive/sessions/r06/resume_spread.py: epoch 0 identical to five digits, epoch 1 0.06130 .. 0.06134 = 6.5e-4 relative at this
+    #  learning rate - at lr 1e-3 the ten steps amplify it to 2.5e-3 and the test was flaky at its old 2e-3 gate. A resume that dropped the
+    #  weights would double the epoch-1 loss; lost AdamW moments or a different data order move it by per cents)
     val = lambda ln: float(ln.split('loss_all')[1])
     assert len(whole) == 2 and len(first) == 1 and len(resumed) == 1 and resumed[0].startswith('epoch 1:'), (whole, first, resumed)
-    assert abs(val(first[0]) - val(whole[0])) < 2e-3 * val(whole[0]) and abs(val(resumed[0]) - val(whole[1])) < 2e-3 * val(whole[1]), (whole, first, resumed)
+    assert abs(val(first[0]) - val(whole[0])) < 5e-3 * val(whole[0]) and abs(val(resumed[0]) - val(whole[1])) < 5e-3 * val(whole[1]), (whole, first, resumed)
